@@ -1,0 +1,131 @@
+"""CPU-only: pins the oracle (Python big-int <-> C restatement <-> closed forms <-> reference constants)."""
+import numpy as np
+import pytest
+
+from oracle import bn254 as O
+from oracle import c_oracle as CO
+
+R, Q = O.R_MOD, O.Q_MOD
+
+
+def fr(vals):
+    return O.ints_to_limbs(vals, R)
+
+
+def test_constants():
+    # SURVEY §8c values, re-derived in oracle/bn254.py; G1 generator (1,2) on y^2=x^3+3
+    assert O.g1_is_on_curve(O.G1_GEN)
+    assert pow(O.ROOT_OF_UNITY, 1 << 28, R) == 1 and pow(O.ROOT_OF_UNITY, 1 << 27, R) != 1
+    assert O.DELTA == 0x09226B6E22C6F0CA64EC26AAD4C86E715B5F898E5E963F25870E56BBE533E9A2
+    # Montgomery R mod r / mod q as stored in memory by halo2curves
+    assert O.ints_to_limbs([1], R)[0].tolist() == [0xAC96341C4FFFFFFB, 0x36FC76959F60CD29, 0x666EA36F7879462E, 0x0E0A77C19A07DF2F]
+    assert O.ints_to_limbs([1], Q)[0].tolist() == [0xD35D438DC58F0D9D, 0x0A78EB28F5C70B3D, 0x666EA36F7879462C, 0x0E0A77C19A07DF2F]
+
+
+def test_c_field_ops_vs_python():
+    a = O.random_scalars(257, 1) + [0, 1, R - 1]
+    b = O.random_scalars(257, 2) + [R - 1, R - 1, R - 1]
+    A, B = fr(a), fr(b)
+    assert O.limbs_to_ints(CO.fr_mul(A, B), R) == [x * y % R for x, y in zip(a, b)]
+    assert O.limbs_to_ints(CO.fr_add(A, B), R) == [(x + y) % R for x, y in zip(a, b)]
+    assert O.limbs_to_ints(CO.fr_sub(A, B), R) == [(x - y) % R for x, y in zip(a, b)]
+    assert O.limbs_to_ints(CO.fr_batch_invert(A), R) == O.batch_invert(a)
+    aq = [x % Q for x in a]
+    assert O.limbs_to_ints(CO.fq_mul(O.ints_to_limbs(aq, Q), O.ints_to_limbs(aq, Q)), Q) == [x * x % Q for x in aq]
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8])
+def test_fft_python_vs_definition_vs_c(log_n):
+    n = 1 << log_n
+    a = O.random_scalars(n, 10 + log_n)
+    w = O.omega_for(log_n)
+    ref = O.dft_quadratic(a, w)
+    assert O.best_fft(a, w, log_n) == ref
+    got = CO.best_fft(fr(a), log_n, fr([w]))
+    assert O.limbs_to_ints(got, R) == ref
+    back = CO.ifft(got, log_n, fr([w]))
+    assert O.limbs_to_ints(back, R) == a
+    assert O.ifft(ref, w, log_n) == a
+
+
+def test_fft_threads_and_horner():
+    log_n = 13
+    a = O.random_scalars(1 << log_n, 5)
+    w = O.omega_for(log_n)
+    g1 = CO.best_fft(fr(a), log_n, fr([w]), threads=1)
+    g4 = CO.best_fft(fr(a), log_n, fr([w]), threads=4)
+    assert np.array_equal(g1, g4)
+    got = O.limbs_to_ints(g1, R)
+    for j in (0, 1, 77, (1 << log_n) - 1):
+        assert got[j] == O.eval_polynomial(a, pow(w, j, R))
+        assert O.limbs_to_ints(CO.fr_eval_polynomial(fr(a), fr([pow(w, j, R)])), R)[0] == got[j]
+
+
+def test_coset_extension_roundtrip():
+    k, ek = 5, 7
+    a = O.random_scalars(1 << k, 3)
+    ext = O.coeff_to_extended(a, k, ek)
+    # definition: evaluations of a(X) on zeta * <omega_ext>  (zeta^(i mod 3) == zeta^i since zeta^3 = 1)
+    we = O.omega_for(ek)
+    for j in (0, 1, 9, 127):
+        assert ext[j] == O.eval_polynomial(a, O.ZETA * pow(we, j, R) % R)
+    cext = CO.coeff_to_extended(fr(a), k, ek, fr([we]), fr([O.ZETA]))
+    assert O.limbs_to_ints(cext, R) == ext
+    back = O.extended_to_coeff(ext, ek)
+    assert back[: 1 << k] == a and all(v == 0 for v in back[1 << k:])
+    cback = CO.extended_to_coeff(cext, ek, fr([we]), fr([O.ZETA]))
+    assert O.limbs_to_ints(cback, R) == back
+
+
+def test_g1_and_msm_small():
+    G = O.G1_GEN
+    P5 = O.g1_mul(G, 5)
+    assert O.g1_is_on_curve(P5)
+    assert O.g1_add(O.g1_mul(G, 2), O.g1_mul(G, 3)) == P5
+    assert O.g1_add(P5, O.g1_neg(P5)) is None
+    cg = CO.g1_mul(O.points_to_limbs([G]), fr([5]))
+    assert O.limbs_to_points(cg) == [P5]
+    assert CO.g1_is_on_curve(cg)
+    for n in (1, 3, 5, 33, 200):
+        s = O.random_scalars(n, n)
+        pts = [O.g1_mul(G, k) for k in O.random_scalars(n, 1000 + n)]
+        want = O.msm_naive(s, pts)
+        assert O.multiexp_serial(s, pts) == want
+        for th in (1, 3):
+            got = CO.best_multiexp(fr(s), O.points_to_limbs(pts), threads=th)
+            assert O.limbs_to_points(got) == [want]
+
+
+def test_msm_known_dlog_and_edge_cases():
+    n, k0, d = 1000, 12345, 77
+    bases = CO.known_dlog_bases(n, fr([k0]), fr([d]))
+    pts = O.limbs_to_points(bases)
+    assert pts[:5] == O.known_dlog_bases(5, k0, d)
+    s = O.circuit_like_scalars(n, 9)
+    expect = O.g1_mul(O.G1_GEN, sum(si * (k0 + i * d) for i, si in enumerate(s)) % R)
+    assert O.limbs_to_points(CO.best_multiexp(fr(s), bases, threads=2)) == [expect]
+    # reference edge cases: halo2-ecc/src/bn254/tests/msm_sum_infinity.rs:16-69 (sum = identity, P+P, dups)
+    P = O.g1_mul(O.G1_GEN, 0xDEADBEEF)
+    cases = [
+        ([1, 1, R - 2], [P, P, P], None),
+        ([1, 1, R - 1], [P, P, O.g1_add(P, P)], None),
+        ([1, 1, 1, R - 1], [P, P, P, O.g1_mul(P, 3)], None),
+        ([1, 1, 1, R - 1], [O.G1_GEN] * 3 + [O.g1_mul(O.G1_GEN, 3)], None),
+        ([R - 1, R - 1, 1, 1], [P, P, P, O.g1_add(P, P)], P),
+    ]
+    for sc, bs, want in cases:
+        assert O.msm_naive(sc, bs) == want
+        assert O.multiexp_serial(sc, bs) == want
+        assert O.limbs_to_points(CO.best_multiexp(fr(sc), O.points_to_limbs(bs))) == [want]
+
+
+def test_misc_poly_ops():
+    a = O.random_scalars(50, 4)
+    b = 987654321
+    q = O.kate_division(a, b)
+    assert O.limbs_to_ints(CO.fr_kate_division(fr(a), fr([b])), R) == q
+    # (X - b) * q(X) + f(b) == f(X) at a random point
+    x = 31337
+    assert ((x - b) * O.eval_polynomial(q, x) + O.eval_polynomial(a, b)) % R == O.eval_polynomial(a, x)
+    num, den = O.random_scalars(20, 6), O.random_scalars(20, 7)
+    assert O.limbs_to_ints(CO.fr_grand_product(fr(num), fr(den)), R) == O.grand_product(num, den)
