@@ -1,0 +1,416 @@
+// C ABI of libh2hip (declared in include/h2hip.h): context, memory, timers, and the host-buffer / device-
+// pointer entry points that route to the kernels in ntt.hip, msm.hip and fr_ops.hip.
+#include <stdarg.h>
+
+#include "internal.h"
+
+namespace h2 {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ws_reserve(h2hip_ctx *ctx, int slot, size_t bytes, void **out) {
+    DevBuf &b = ctx->ws[slot];
+    if (bytes == 0) bytes = 256;
+    if (b.cap < bytes) {
+        if (b.p) {
+            H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+            H2_HIPCHK(hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        size_t cap = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;   // 1 MiB granules
+        hipError_t e = hipMalloc(&b.p, cap);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) for workspace slot %d failed: %s", cap, slot, hipGetErrorString(e));
+            b.p = nullptr;
+            return H2HIP_ERR_NOMEM;
+        }
+        b.cap = cap;
+    }
+    *out = b.p;
+    return H2HIP_OK;
+}
+
+static hipEvent_t get_event(h2hip_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void prof_begin(h2hip_ctx *ctx, const char *name) {
+    if (!ctx->profiling) return;
+    hipEvent_t a = get_event(ctx), b = get_event(ctx);
+    if (!a || !b) return;
+    hipEventRecord(a, ctx->stream);
+    ctx->pending.push_back({name, {a, b}});
+}
+void prof_end(h2hip_ctx *ctx) {
+    if (!ctx->profiling || ctx->pending.empty()) return;
+    hipEventRecord(ctx->pending.back().second.second, ctx->stream);
+}
+static void prof_collect(h2hip_ctx *ctx) {
+    if (ctx->pending.empty()) return;
+    hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            KernelStat &s = ctx->stats[p.first];
+            s.total_ms += ms;
+            s.launches += 1;
+        }
+        ctx->event_pool.push_back(p.second.first);
+        ctx->event_pool.push_back(p.second.second);
+    }
+    ctx->pending.clear();
+}
+
+__global__ void point_finish_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        XYZZ p = in[0];
+        if (jac) jac[0] = xyzz_to_jacobian(p);
+        if (aff) aff[0] = xyzz_to_affine(p);
+    }
+}
+
+}  // namespace h2
+
+using namespace h2;
+
+extern "C" {
+
+const char *h2hip_last_error(void) { return g_err; }
+int h2hip_version(void) { return 100; }
+
+int h2hip_device_count(int *count) {
+    H2_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return H2HIP_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return H2HIP_OK;
+}
+
+int h2hip_init(int device, void *hip_stream, h2hip_ctx **out) {
+    H2_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device available (libh2hip has no CPU fallback)");
+        return H2HIP_ERR_NO_DEVICE;
+    }
+    H2_REQUIRE(device >= 0 && device < n, "device index out of range");
+    H2_HIPCHK(hipSetDevice(device));
+    h2hip_ctx *ctx = new h2hip_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete ctx;
+            return H2HIP_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return H2HIP_OK;
+}
+
+void h2hip_destroy(h2hip_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->ws)
+        if (b.p) hipFree(b.p);
+    for (auto &t : ctx->twiddles) {
+        hipFree(t.t1);
+        hipFree(t.t2);
+    }
+    for (auto &p : ctx->pending) {
+        hipEventDestroy(p.second.first);
+        hipEventDestroy(p.second.second);
+    }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int h2hip_sync(h2hip_ctx *ctx) {
+    H2_REQUIRE(ctx, "ctx is NULL");
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+
+static int *param_slot(h2hip_ctx *ctx, const char *name) {
+    if (!strcmp(name, "msm_window_bits")) return &ctx->msm_window_bits;
+    if (!strcmp(name, "msm_chunk")) return &ctx->msm_chunk;
+    if (!strcmp(name, "msm_chunk2")) return &ctx->msm_chunk2;
+    if (!strcmp(name, "msm_seg")) return &ctx->msm_seg;
+    if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
+    return nullptr;
+}
+int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
+    H2_REQUIRE(ctx && name, "NULL argument");
+    int *p = param_slot(ctx, name);
+    H2_REQUIRE(p, "unknown parameter name");
+    if (p == &ctx->msm_window_bits) H2_REQUIRE(value == 0 || (value >= 2 && value <= 23), "msm_window_bits must be 0 or 2..23");
+    if (p == &ctx->msm_chunk) H2_REQUIRE(value >= 2 && value <= 4096, "msm_chunk must be 2..4096");
+    if (p == &ctx->msm_chunk2) H2_REQUIRE(value >= 4 && value <= 4096, "msm_chunk2 must be 4..4096");
+    if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
+    if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
+    *p = value;
+    return H2HIP_OK;
+}
+int h2hip_get_param(h2hip_ctx *ctx, const char *name, int *value) {
+    H2_REQUIRE(ctx && name && value, "NULL argument");
+    int *p = param_slot(ctx, name);
+    H2_REQUIRE(p, "unknown parameter name");
+    *value = *p;
+    return H2HIP_OK;
+}
+
+int h2hip_malloc(h2hip_ctx *ctx, size_t bytes, void **dptr) {
+    H2_REQUIRE(ctx && dptr, "NULL argument");
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 256);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return H2HIP_ERR_NOMEM;
+    }
+    return H2HIP_OK;
+}
+int h2hip_free(h2hip_ctx *ctx, void *dptr) {
+    H2_REQUIRE(ctx, "ctx is NULL");
+    if (!dptr) return H2HIP_OK;
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    H2_HIPCHK(hipFree(dptr));
+    return H2HIP_OK;
+}
+int h2hip_upload(h2hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    H2_REQUIRE(ctx && (bytes == 0 || (dst_dev && src_host)), "NULL argument");
+    if (!bytes) return H2HIP_OK;
+    H2_HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+int h2hip_download(h2hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    H2_REQUIRE(ctx && (bytes == 0 || (dst_host && src_dev)), "NULL argument");
+    if (!bytes) return H2HIP_OK;
+    H2_HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+
+// ------------------------------------------------------------------ profiling
+int h2hip_profile_enable(h2hip_ctx *ctx, int on) {
+    H2_REQUIRE(ctx, "ctx is NULL");
+    prof_collect(ctx);
+    ctx->profiling = on != 0;
+    return H2HIP_OK;
+}
+int h2hip_profile_reset(h2hip_ctx *ctx) {
+    H2_REQUIRE(ctx, "ctx is NULL");
+    prof_collect(ctx);
+    ctx->stats.clear();
+    return H2HIP_OK;
+}
+int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches) {
+    H2_REQUIRE(ctx && prefix, "NULL argument");
+    prof_collect(ctx);
+    double ms = 0;
+    uint64_t cnt = 0;
+    size_t len = strlen(prefix);
+    for (auto &kv : ctx->stats)
+        if (kv.first.compare(0, len, prefix) == 0) {
+            ms += kv.second.total_ms;
+            cnt += kv.second.launches;
+        }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = cnt;
+    return H2HIP_OK;
+}
+static thread_local hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
+int h2hip_timer_start(h2hip_ctx *ctx) {
+    H2_REQUIRE(ctx, "ctx is NULL");
+    if (!g_t0) {
+        H2_HIPCHK(hipEventCreate(&g_t0));
+        H2_HIPCHK(hipEventCreate(&g_t1));
+    }
+    H2_HIPCHK(hipEventRecord(g_t0, ctx->stream));
+    return H2HIP_OK;
+}
+int h2hip_timer_stop(h2hip_ctx *ctx, double *elapsed_ms) {
+    H2_REQUIRE(ctx && elapsed_ms && g_t0, "timer not started");
+    H2_HIPCHK(hipEventRecord(g_t1, ctx->stream));
+    H2_HIPCHK(hipEventSynchronize(g_t1));
+    float ms = 0;
+    H2_HIPCHK(hipEventElapsedTime(&ms, g_t0, g_t1));
+    *elapsed_ms = ms;
+    return H2HIP_OK;
+}
+
+// ------------------------------------------------------------------ MSM
+static int bases_create(h2hip_ctx *ctx, const void *src, bool src_on_device, size_t n, uint32_t flags, h2hip_bases **out) {
+    H2_REQUIRE(ctx && out && (n == 0 || src), "NULL argument");
+    H2_REQUIRE((flags & ~H2HIP_BASES_PRECOMPUTE) == 0, "unknown flags");
+    H2_REQUIRE(!(flags & H2HIP_BASES_PRECOMPUTE), "H2HIP_BASES_PRECOMPUTE is not available in this build");
+    h2hip_bases *b = new h2hip_bases();
+    b->n = n;
+    hipError_t e = hipMalloc((void **)&b->pts, sizeof(G1Affine) * (n ? n : 1));
+    if (e != hipSuccess) {
+        set_error("hipMalloc for %zu bases failed: %s", n, hipGetErrorString(e));
+        delete b;
+        return H2HIP_ERR_NOMEM;
+    }
+    if (n) {
+        e = hipMemcpyAsync(b->pts, src, sizeof(G1Affine) * n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("copying bases failed: %s", hipGetErrorString(e));
+            hipFree(b->pts);
+            delete b;
+            return H2HIP_ERR_HIP;
+        }
+    }
+    *out = b;
+    return H2HIP_OK;
+}
+int h2hip_bases_upload(h2hip_ctx *ctx, const void *g1_affine_host, size_t n, uint32_t flags, h2hip_bases **out) {
+    return bases_create(ctx, g1_affine_host, false, n, flags, out);
+}
+int h2hip_bases_from_device(h2hip_ctx *ctx, const void *g1_affine_dev, size_t n, uint32_t flags, h2hip_bases **out) {
+    return bases_create(ctx, g1_affine_dev, true, n, flags, out);
+}
+void h2hip_bases_free(h2hip_ctx *ctx, h2hip_bases *bases) {
+    if (!bases) return;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (bases->pts) hipFree(bases->pts);
+    delete bases;
+}
+size_t h2hip_bases_len(const h2hip_bases *bases) { return bases ? bases->n : 0; }
+
+int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_dev, size_t n, int point_format, void *out_host) {
+    H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_dev), "NULL argument");
+    H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
+    char *outbuf = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, 1024, (void **)&outbuf));
+    XYZZ *acc = (XYZZ *)outbuf;
+    G1Jac *jac = (G1Jac *)(outbuf + 256);
+    G1Affine *aff = (G1Affine *)(outbuf + 512);
+    H2_CHK(msm_run(ctx, bases, (const Fr *)scalars_dev, n, acc));
+    const bool affine = point_format == H2HIP_POINT_AFFINE;
+    prof_begin(ctx, "point_finish_kernel");
+    hipLaunchKernelGGL(point_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const XYZZ *)acc, affine ? (G1Jac *)nullptr : jac,
+                       affine ? aff : (G1Affine *)nullptr);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_HIPCHK(hipMemcpyAsync(out_host, affine ? (void *)aff : (void *)jac, affine ? sizeof(G1Affine) : sizeof(G1Jac), hipMemcpyDeviceToHost,
+                             ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host) {
+    H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_host), "NULL argument");
+    Fr *stage = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_STAGE, sizeof(Fr) * n, (void **)&stage));
+    if (n) H2_HIPCHK(hipMemcpyAsync(stage, scalars_host, sizeof(Fr) * n, hipMemcpyHostToDevice, ctx->stream));
+    return h2hip_msm_g1_dev(ctx, bases, stage, n, point_format, out_host);
+}
+
+// ------------------------------------------------------------------ NTT family
+static Fr load_fr(const void *p) {
+    Fr r;
+    memcpy(&r, p, sizeof(Fr));
+    return r;
+}
+static int stage_in(h2hip_ctx *ctx, const void *host, size_t elems, Fr **dev) {
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_STAGE, sizeof(Fr) * elems, (void **)dev));
+    H2_HIPCHK(hipMemcpyAsync(*dev, host, sizeof(Fr) * elems, hipMemcpyHostToDevice, ctx->stream));
+    return H2HIP_OK;
+}
+static int stage_out(h2hip_ctx *ctx, void *host, const Fr *dev, size_t elems) {
+    H2_HIPCHK(hipMemcpyAsync(host, dev, sizeof(Fr) * elems, hipMemcpyDeviceToHost, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+
+int h2hip_best_fft_dev(h2hip_ctx *ctx, void *a_dev, const void *omega, uint32_t log_n) {
+    H2_REQUIRE(ctx && a_dev && omega, "NULL argument");
+    return ntt_run(ctx, (Fr *)a_dev, log_n, load_fr(omega), nullptr, 0, nullptr, nullptr);
+}
+int h2hip_best_fft(h2hip_ctx *ctx, void *a_host, const void *omega, uint32_t log_n) {
+    H2_REQUIRE(ctx && a_host && omega && log_n <= 28, "bad argument");
+    Fr *d = nullptr;
+    H2_CHK(stage_in(ctx, a_host, (size_t)1 << log_n, &d));
+    H2_CHK(h2hip_best_fft_dev(ctx, d, omega, log_n));
+    return stage_out(ctx, a_host, d, (size_t)1 << log_n);
+}
+int h2hip_ifft_dev(h2hip_ctx *ctx, void *a_dev, const void *omega_inv, uint32_t log_n, const void *divisor) {
+    H2_REQUIRE(ctx && a_dev && omega_inv && divisor, "NULL argument");
+    Fr d = load_fr(divisor);
+    Fr out3[3] = {d, d, d};
+    return ntt_run(ctx, (Fr *)a_dev, log_n, load_fr(omega_inv), nullptr, 0, nullptr, out3);
+}
+int h2hip_ifft(h2hip_ctx *ctx, void *a_host, const void *omega_inv, uint32_t log_n, const void *divisor) {
+    H2_REQUIRE(ctx && a_host && omega_inv && divisor && log_n <= 28, "bad argument");
+    Fr *d = nullptr;
+    H2_CHK(stage_in(ctx, a_host, (size_t)1 << log_n, &d));
+    H2_CHK(h2hip_ifft_dev(ctx, d, omega_inv, log_n, divisor));
+    return stage_out(ctx, a_host, d, (size_t)1 << log_n);
+}
+int h2hip_coeff_to_extended_dev(h2hip_ctx *ctx, const void *coeffs_dev, uint32_t k, void *out_dev, uint32_t ext_k, const void *ext_omega,
+                                const void *zeta) {
+    H2_REQUIRE(ctx && coeffs_dev && out_dev && ext_omega && zeta, "NULL argument");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    H2_REQUIRE(coeffs_dev != out_dev || k == ext_k, "coeffs and out must not alias");
+    Fr z = load_fr(zeta);
+    Fr in3[3] = {Fr::one(), z, fe_mul(z, z)};
+    return ntt_run(ctx, (Fr *)out_dev, ext_k, load_fr(ext_omega), (const Fr *)coeffs_dev, (uint64_t)1 << k, in3, nullptr);
+}
+int h2hip_coeff_to_extended(h2hip_ctx *ctx, const void *coeffs_host, uint32_t k, void *out_host, uint32_t ext_k, const void *ext_omega,
+                            const void *zeta) {
+    H2_REQUIRE(ctx && coeffs_host && out_host && ext_omega && zeta, "NULL argument");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    Fr *d = nullptr;
+    const size_t n = (size_t)1 << k, ne = (size_t)1 << ext_k;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_STAGE, sizeof(Fr) * (n + ne), (void **)&d));
+    H2_HIPCHK(hipMemcpyAsync(d, coeffs_host, sizeof(Fr) * n, hipMemcpyHostToDevice, ctx->stream));
+    H2_CHK(h2hip_coeff_to_extended_dev(ctx, d, k, d + n, ext_k, ext_omega, zeta));
+    return stage_out(ctx, out_host, d + n, ne);
+}
+int h2hip_extended_to_coeff_dev(h2hip_ctx *ctx, void *a_dev, uint32_t ext_k, const void *ext_omega_inv, const void *ext_divisor,
+                                const void *zeta_inv) {
+    H2_REQUIRE(ctx && a_dev && ext_omega_inv && ext_divisor && zeta_inv, "NULL argument");
+    Fr d = load_fr(ext_divisor), zi = load_fr(zeta_inv);
+    Fr out3[3] = {d, fe_mul(d, zi), fe_mul(d, fe_mul(zi, zi))};
+    return ntt_run(ctx, (Fr *)a_dev, ext_k, load_fr(ext_omega_inv), nullptr, 0, nullptr, out3);
+}
+int h2hip_extended_to_coeff(h2hip_ctx *ctx, void *a_host, uint32_t ext_k, const void *ext_omega_inv, const void *ext_divisor,
+                            const void *zeta_inv) {
+    H2_REQUIRE(ctx && a_host && ext_omega_inv && ext_divisor && zeta_inv && ext_k <= 28, "bad argument");
+    Fr *d = nullptr;
+    H2_CHK(stage_in(ctx, a_host, (size_t)1 << ext_k, &d));
+    H2_CHK(h2hip_extended_to_coeff_dev(ctx, d, ext_k, ext_omega_inv, ext_divisor, zeta_inv));
+    return stage_out(ctx, a_host, d, (size_t)1 << ext_k);
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// libh2hip internals shared by the translation units (context, workspace, error plumbing, kernel timers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/h2hip.h"
+#include "ec.cuh"
+
+namespace h2 {
+
+void set_error(const char *fmt, ...);
+
+#define H2_HIPCHK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            h2::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__));     \
+            return H2HIP_ERR_HIP;                                                                    \
+        }                                                                                            \
+    } while (0)
+
+#define H2_CHK(expr)                      \
+    do {                                  \
+        int r__ = (expr);                 \
+        if (r__ != H2HIP_OK) return r__;  \
+    } while (0)
+
+#define H2_REQUIRE(cond, msg)                                        \
+    do {                                                             \
+        if (!(cond)) {                                               \
+            h2::set_error("%s: invalid argument: %s", __func__, msg); \
+            return H2HIP_ERR_INVALID;                                \
+        }                                                            \
+    } while (0)
+
+// growable device scratch buffer owned by the context
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct TwiddleSet {   // omega^i tables for one (log_n, omega)
+    uint32_t log_n = 0, lo_bits = 0;
+    Fr omega;
+    Fr *t1 = nullptr;   // omega^i,            i < 2^lo_bits
+    Fr *t2 = nullptr;   // omega^(i<<lo_bits), i < 2^(log_n-lo_bits)
+};
+
+struct KernelStat {
+    double total_ms = 0;
+    uint64_t launches = 0;
+};
+
+}  // namespace h2
+
+struct h2hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    // scratch
+    enum { WS_NTT = 0, WS_DIGITS, WS_COUNTS, WS_OFFSETS, WS_CURSOR, WS_SKEY, WS_SVAL, WS_BUCKETS, WS_PKEY0, WS_PVAL0, WS_PKEY1,
+           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_COUNT };
+    h2::DevBuf ws[WS_COUNT];
+    std::vector<h2::TwiddleSet> twiddles;
+    // tuning knobs (h2hip_set_param)
+    int msm_window_bits = 0;   // 0 = auto
+    int msm_chunk = 32;        // level-1 entries per lane
+    int msm_chunk2 = 8;        // level>=2 entries per lane
+    int msm_seg = 8;           // buckets per running-sum segment
+    int ntt_tile_bits = 10;
+    // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled
+    bool profiling = false;
+    std::map<std::string, h2::KernelStat> stats;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+struct h2hip_bases {
+    h2::G1Affine *pts = nullptr;   // [tables][n] affine, Montgomery
+    size_t n = 0;
+    uint32_t window_bits = 0;      // precomputed mode: window the table was built for
+    uint32_t tables = 1;           // 1 = plain; W = precomputed 2^(c*w) multiples
+};
+
+namespace h2 {
+int ws_reserve(h2hip_ctx *ctx, int slot, size_t bytes, void **out);
+
+// RAII-less kernel timer: prof_begin/prof_end bracket one launch with events when ctx->profiling.
+void prof_begin(h2hip_ctx *ctx, const char *name);
+void prof_end(h2hip_ctx *ctx);
+
+// implemented in ntt.hip / msm.hip / fr_ops.hip, all on device pointers
+int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in_override, uint64_t in_len, const Fr *in_scale3,
+            const Fr *out_scale3);
+int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
+}  // namespace h2

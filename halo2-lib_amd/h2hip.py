@@ -1,0 +1,292 @@
+"""ctypes binding of libh2hip's C ABI (include/h2hip.h).  Host arrays are numpy uint64: field elements
+(n,4), affine points (n,8), Jacobian points (n,12), all Montgomery limbs exactly as halo2curves stores them."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+POINT_JACOBIAN = 0
+POINT_AFFINE = 1
+BASES_PLAIN = 0
+BASES_PRECOMPUTE = 1
+
+_vp, _sz, _u32, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+_PROTOS = {
+    "h2hip_last_error": (C.c_char_p, []),
+    "h2hip_version": (_int, []),
+    "h2hip_device_count": (_int, [C.POINTER(_int)]),
+    "h2hip_init": (_int, [_int, _vp, C.POINTER(_vp)]),
+    "h2hip_destroy": (None, [_vp]),
+    "h2hip_sync": (_int, [_vp]),
+    "h2hip_set_param": (_int, [_vp, C.c_char_p, _int]),
+    "h2hip_get_param": (_int, [_vp, C.c_char_p, C.POINTER(_int)]),
+    "h2hip_malloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "h2hip_free": (_int, [_vp, _vp]),
+    "h2hip_upload": (_int, [_vp, _vp, _vp, _sz]),
+    "h2hip_download": (_int, [_vp, _vp, _vp, _sz]),
+    "h2hip_profile_enable": (_int, [_vp, _int]),
+    "h2hip_profile_reset": (_int, [_vp]),
+    "h2hip_profile_get": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "h2hip_timer_start": (_int, [_vp]),
+    "h2hip_timer_stop": (_int, [_vp, C.POINTER(C.c_double)]),
+    "h2hip_bases_upload": (_int, [_vp, _vp, _sz, _u32, C.POINTER(_vp)]),
+    "h2hip_bases_from_device": (_int, [_vp, _vp, _sz, _u32, C.POINTER(_vp)]),
+    "h2hip_bases_free": (None, [_vp, _vp]),
+    "h2hip_bases_len": (_sz, [_vp]),
+    "h2hip_msm_g1": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "h2hip_msm_g1_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "h2hip_best_fft": (_int, [_vp, _vp, _vp, _u32]),
+    "h2hip_best_fft_dev": (_int, [_vp, _vp, _vp, _u32]),
+    "h2hip_ifft": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "h2hip_ifft_dev": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "h2hip_coeff_to_extended": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp]),
+    "h2hip_coeff_to_extended_dev": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp]),
+    "h2hip_extended_to_coeff": (_int, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    "h2hip_extended_to_coeff_dev": (_int, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    "h2hip_fr_add_batch_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "h2hip_fr_sub_batch_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "h2hip_fr_mul_batch_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "h2hip_fr_mul_add_batch_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _sz]),
+    "h2hip_bench_modmul": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+# symbols added by later translation units register themselves here (see fr_ops section below)
+EXPORTED_SYMBOLS = list(_PROTOS)
+
+
+class H2HipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libh2hip error {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "csrc", "libh2hip.so")
+
+
+_LIBS = {}
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libh2hip.so and attach prototypes.  Fails loudly when the HIP extension has not been built."""
+    path = os.path.abspath(path or library_path())
+    if path in _LIBS:
+        return _LIBS[path]
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'); "
+            "halo2-lib_amd has no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)   # AttributeError here = the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIBS[path] = lib
+    return lib
+
+
+def _fe(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, 4)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_vp)
+
+
+class Bases:
+    """Resident G1Affine bases (an SRS column: ParamsKZG.g or .g_lagrange)."""
+
+    def __init__(self, ctx: "Context", handle: int, n: int):
+        self.ctx, self.handle, self.n = ctx, handle, n
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.h2hip_bases_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __len__(self):
+        return self.n
+
+
+class Context:
+    """One per GPU/process; serialises work on one HIP stream (optionally a caller-provided hipStream_t,
+    e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        h = _vp()
+        self.handle = None
+        self._chk(self.lib.h2hip_init(device, _vp(stream) if stream else None, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    # -- plumbing
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise H2HipError(rc, self.lib.h2hip_last_error().decode(errors="replace"))
+
+    def close(self):
+        if self.handle:
+            self.lib.h2hip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self.lib.h2hip_sync(self.handle))
+
+    def set_param(self, name: str, value: int):
+        self._chk(self.lib.h2hip_set_param(self.handle, name.encode(), int(value)))
+
+    def get_param(self, name: str) -> int:
+        v = _int()
+        self._chk(self.lib.h2hip_get_param(self.handle, name.encode(), C.byref(v)))
+        return v.value
+
+    # -- device memory
+    def malloc(self, nbytes: int) -> int:
+        p = _vp()
+        self._chk(self.lib.h2hip_malloc(self.handle, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, dptr: int):
+        self._chk(self.lib.h2hip_free(self.handle, _vp(dptr)))
+
+    def upload(self, dptr: int, host: np.ndarray):
+        host = np.ascontiguousarray(host)
+        self._chk(self.lib.h2hip_upload(self.handle, _vp(dptr), _ptr(host), host.nbytes))
+
+    def to_device(self, host: np.ndarray) -> int:
+        host = np.ascontiguousarray(host)
+        d = self.malloc(host.nbytes)
+        self.upload(d, host)
+        return d
+
+    def download(self, dptr: int, shape, dtype=np.uint64) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self._chk(self.lib.h2hip_download(self.handle, _ptr(out), _vp(dptr), out.nbytes))
+        return out
+
+    # -- profiling / timing
+    def profile_enable(self, on: bool = True):
+        self._chk(self.lib.h2hip_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.lib.h2hip_profile_reset(self.handle))
+
+    def profile_get(self, prefix: str):
+        ms, cnt = C.c_double(), C.c_uint64()
+        self._chk(self.lib.h2hip_profile_get(self.handle, prefix.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def timer_start(self):
+        self._chk(self.lib.h2hip_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_double()
+        self._chk(self.lib.h2hip_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    # -- MSM (arithmetic::best_multiexp)
+    def bases_upload(self, points: np.ndarray, flags: int = BASES_PLAIN) -> Bases:
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+        h = _vp()
+        self._chk(self.lib.h2hip_bases_upload(self.handle, _ptr(pts), len(pts), flags, C.byref(h)))
+        return Bases(self, h, len(pts))
+
+    def bases_from_device(self, dptr: int, n: int, flags: int = BASES_PLAIN) -> Bases:
+        h = _vp()
+        self._chk(self.lib.h2hip_bases_from_device(self.handle, _vp(dptr), n, flags, C.byref(h)))
+        return Bases(self, h, n)
+
+    def msm(self, bases: Bases, scalars: np.ndarray, point_format: int = POINT_AFFINE) -> np.ndarray:
+        s = _fe(scalars)
+        out = np.zeros((1, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
+        self._chk(self.lib.h2hip_msm_g1(self.handle, bases.handle, _ptr(s), len(s), point_format, _ptr(out)))
+        return out
+
+    def msm_dev(self, bases: Bases, scalars_dptr: int, n: int, point_format: int = POINT_JACOBIAN) -> np.ndarray:
+        out = np.zeros((1, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
+        self._chk(self.lib.h2hip_msm_g1_dev(self.handle, bases.handle, _vp(scalars_dptr), n, point_format, _ptr(out)))
+        return out
+
+    # -- NTT family (arithmetic::best_fft, EvaluationDomain::*)
+    def best_fft(self, a: np.ndarray, omega: np.ndarray, log_n: int) -> np.ndarray:
+        a = _fe(a).copy()
+        assert len(a) == 1 << log_n
+        self._chk(self.lib.h2hip_best_fft(self.handle, _ptr(a), _ptr(_fe(omega)), log_n))
+        return a
+
+    def best_fft_dev(self, dptr: int, omega: np.ndarray, log_n: int):
+        self._chk(self.lib.h2hip_best_fft_dev(self.handle, _vp(dptr), _ptr(_fe(omega)), log_n))
+
+    def ifft(self, a: np.ndarray, omega_inv: np.ndarray, log_n: int, divisor: np.ndarray) -> np.ndarray:
+        a = _fe(a).copy()
+        self._chk(self.lib.h2hip_ifft(self.handle, _ptr(a), _ptr(_fe(omega_inv)), log_n, _ptr(_fe(divisor))))
+        return a
+
+    def ifft_dev(self, dptr: int, omega_inv: np.ndarray, log_n: int, divisor: np.ndarray):
+        self._chk(self.lib.h2hip_ifft_dev(self.handle, _vp(dptr), _ptr(_fe(omega_inv)), log_n, _ptr(_fe(divisor))))
+
+    def coeff_to_extended(self, coeffs: np.ndarray, k: int, ext_k: int, ext_omega: np.ndarray, zeta: np.ndarray) -> np.ndarray:
+        a = _fe(coeffs)
+        assert len(a) == 1 << k
+        out = np.empty((1 << ext_k, 4), dtype=np.uint64)
+        self._chk(self.lib.h2hip_coeff_to_extended(self.handle, _ptr(a), k, _ptr(out), ext_k, _ptr(_fe(ext_omega)), _ptr(_fe(zeta))))
+        return out
+
+    def coeff_to_extended_dev(self, coeffs_dptr: int, k: int, out_dptr: int, ext_k: int, ext_omega: np.ndarray, zeta: np.ndarray):
+        self._chk(self.lib.h2hip_coeff_to_extended_dev(self.handle, _vp(coeffs_dptr), k, _vp(out_dptr), ext_k, _ptr(_fe(ext_omega)), _ptr(_fe(zeta))))
+
+    def extended_to_coeff(self, a: np.ndarray, ext_k: int, ext_omega_inv: np.ndarray, ext_divisor: np.ndarray, zeta_inv: np.ndarray) -> np.ndarray:
+        a = _fe(a).copy()
+        self._chk(self.lib.h2hip_extended_to_coeff(self.handle, _ptr(a), ext_k, _ptr(_fe(ext_omega_inv)), _ptr(_fe(ext_divisor)), _ptr(_fe(zeta_inv))))
+        return a
+
+    def extended_to_coeff_dev(self, dptr: int, ext_k: int, ext_omega_inv: np.ndarray, ext_divisor: np.ndarray, zeta_inv: np.ndarray):
+        self._chk(self.lib.h2hip_extended_to_coeff_dev(self.handle, _vp(dptr), ext_k, _ptr(_fe(ext_omega_inv)), _ptr(_fe(ext_divisor)), _ptr(_fe(zeta_inv))))
+
+    # -- K8 witness-column batches (device pointers)
+    def _binop(self, fn, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        a, b = _fe(a), _fe(b)
+        assert a.shape == b.shape
+        da, db = self.to_device(a), self.to_device(b)
+        try:
+            self._chk(fn(self.handle, _vp(da), _vp(da), _vp(db), len(a)))
+            return self.download(da, a.shape)
+        finally:
+            self.free(da)
+            self.free(db)
+
+    def fr_add(self, a, b):
+        return self._binop(self.lib.h2hip_fr_add_batch_dev, a, b)
+
+    def fr_sub(self, a, b):
+        return self._binop(self.lib.h2hip_fr_sub_batch_dev, a, b)
+
+    def fr_mul(self, a, b):
+        return self._binop(self.lib.h2hip_fr_mul_batch_dev, a, b)
+
+    def fr_mul_add(self, a, b, c):
+        a, b, c = _fe(a), _fe(b), _fe(c)
+        da, db, dc = self.to_device(a), self.to_device(b), self.to_device(c)
+        try:
+            self._chk(self.lib.h2hip_fr_mul_add_batch_dev(self.handle, _vp(da), _vp(da), _vp(db), _vp(dc), len(a)))
+            return self.download(da, a.shape)
+        finally:
+            for d in (da, db, dc):
+                self.free(d)
+
+    def bench_modmul(self, blocks: int = 4096, iters: int = 512, chains: int = 1):
+        """returns (elapsed_ms, modmuls) of the multiplier probe kernel"""
+        ms, mm = C.c_double(), C.c_double()
+        self._chk(self.lib.h2hip_bench_modmul(self.handle, blocks, iters, chains, C.byref(ms), C.byref(mm)))
+        return ms.value, mm.value

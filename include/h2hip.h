@@ -1,0 +1,124 @@
+/*
+ * libh2hip — C ABI of the MI355X (gfx950) prover backend for halo2-lib's proving hot path.
+ *
+ * This is the drop-in boundary: a `halo2_proofs`-compatible Rust crate selected through
+ * halo2-lib's existing backend seam (reference halo2-base/src/lib.rs:25-28, the `halo2_base::halo2_proofs`
+ * re-export toggled by a cargo feature exactly like `cuda`) binds these symbols where upstream
+ * halo2-axiom 0.5.3 calls its CPU kernels.  INTEGRATION.md shows the `extern "C"` block and the call sites.
+ *
+ * Data formats (bit-identical to halo2curves' in-memory types; reference halo2-base/src/utils/mod.rs:28-38,
+ * 342-377 and halo2-ecc/benches/msm.rs:62):
+ *   Fr / Fq      4 x u64 little-endian limbs, MONTGOMERY form (R = 2^256)          32 B
+ *   G1Affine     { Fq x; Fq y }, identity = all-zero bytes                         64 B
+ *   G1 (curve)   { Fq x; Fq y; Fq z } Jacobian, identity has z = 0                 96 B
+ *
+ * Conventions: every function returns H2HIP_OK (0) or a negative H2HIP_ERR_* code and never throws or
+ * aborts; h2hip_last_error() returns a thread-local message.  Host buffers stay caller-owned.  A context
+ * serialises its work on one HIP stream; use it from one thread at a time (the reference calls
+ * create_proof from a single thread, halo2-base/src/utils/testing.rs:32-50).  There is NO CPU fallback:
+ * without a usable HIP device h2hip_init fails with H2HIP_ERR_NO_DEVICE.
+ *
+ * Functions ending in `_dev` take device pointers (from h2hip_malloc, or any HIP allocation on the
+ * context's device, e.g. a torch tensor's data_ptr) so polynomials can stay resident in HBM between calls;
+ * the un-suffixed forms stage host buffers through the context's stream.
+ */
+#ifndef H2HIP_H
+#define H2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2HIP_OK 0
+#define H2HIP_ERR_INVALID (-1)   /* bad argument (message says which) */
+#define H2HIP_ERR_HIP (-2)       /* HIP runtime / kernel launch failure */
+#define H2HIP_ERR_NOMEM (-3)
+#define H2HIP_ERR_NO_DEVICE (-4)
+
+#define H2HIP_POINT_JACOBIAN 0   /* 96 B, what best_multiexp returns (C::Curve) */
+#define H2HIP_POINT_AFFINE 1     /* 64 B, normalised on the device (one field inversion) */
+
+#define H2HIP_BASES_PLAIN 0u
+#define H2HIP_BASES_PRECOMPUTE 1u /* also store 2^(c*w)*P_i for every window: fixed-base (SRS) fast path */
+
+typedef struct h2hip_ctx h2hip_ctx;
+typedef struct h2hip_bases h2hip_bases;
+
+/* ---- context ------------------------------------------------------------------------------------- */
+const char *h2hip_last_error(void);
+int h2hip_version(void);
+int h2hip_device_count(int *count);
+/* hip_stream: an existing hipStream_t to run on (NULL: the context creates its own). */
+int h2hip_init(int device, void *hip_stream, h2hip_ctx **out);
+void h2hip_destroy(h2hip_ctx *ctx);
+int h2hip_sync(h2hip_ctx *ctx);
+/* tuning knobs: "msm_window_bits" (0 = auto), "msm_chunk", "msm_chunk2", "msm_seg", "ntt_tile_bits" */
+int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value);
+int h2hip_get_param(h2hip_ctx *ctx, const char *name, int *value);
+
+/* ---- device memory (for callers without a HIP runtime of their own, e.g. the Rust shim) ----------- */
+int h2hip_malloc(h2hip_ctx *ctx, size_t bytes, void **dptr);
+int h2hip_free(h2hip_ctx *ctx, void *dptr);
+int h2hip_upload(h2hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* synchronous */
+int h2hip_download(h2hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* synchronous */
+
+/* ---- per-kernel timing (HIP events on the context's stream around every launch) ------------------- */
+int h2hip_profile_enable(h2hip_ctx *ctx, int on);
+int h2hip_profile_reset(h2hip_ctx *ctx);
+/* total milliseconds and launch count accumulated for kernels whose name starts with `prefix` */
+int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);
+/* bracket an arbitrary region with events on the context's stream (bench.py's timed region) */
+int h2hip_timer_start(h2hip_ctx *ctx);
+int h2hip_timer_stop(h2hip_ctx *ctx, double *elapsed_ms);
+
+/* ---- K1: multi-scalar multiplication  (replaces arithmetic::best_multiexp [UPSTREAM], reached from the
+ *      reference via ParamsKZG::commit / commit_lagrange inside create_proof,
+ *      halo2-base/src/utils/testing.rs:40-47) ------------------------------------------------------- */
+/* Upload n G1Affine bases once (the SRS `g` or `g_lagrange` of ParamsKZG, reference
+ * halo2-base/src/utils/mod.rs:401-443); they stay resident in HBM. */
+int h2hip_bases_upload(h2hip_ctx *ctx, const void *g1_affine_host, size_t n, uint32_t flags, h2hip_bases **out);
+int h2hip_bases_from_device(h2hip_ctx *ctx, const void *g1_affine_dev, size_t n, uint32_t flags, h2hip_bases **out);
+void h2hip_bases_free(h2hip_ctx *ctx, h2hip_bases *bases);
+size_t h2hip_bases_len(const h2hip_bases *bases);
+/* out = sum_{i<n} scalars[i] * bases[i];  n <= h2hip_bases_len.  point_format selects 96 B Jacobian or 64 B affine. */
+int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host);
+int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_dev, size_t n, int point_format, void *out_host);
+
+/* ---- K2/K3: NTT family  (replaces arithmetic::best_fft and EvaluationDomain::{ifft, coeff_to_extended,
+ *      extended_to_coeff} [UPSTREAM]) ------------------------------------------------ */
+/* in-place, natural order in and out, no scaling:  a[k] <- sum_j a[j] * omega^(jk),  len(a) = 2^log_n */
+int h2hip_best_fft(h2hip_ctx *ctx, void *a_host, const void *omega, uint32_t log_n);
+int h2hip_best_fft_dev(h2hip_ctx *ctx, void *a_dev, const void *omega, uint32_t log_n);
+/* EvaluationDomain::ifft: best_fft with omega_inv, then every element times `divisor` (= 2^-log_n) */
+int h2hip_ifft(h2hip_ctx *ctx, void *a_host, const void *omega_inv, uint32_t log_n, const void *divisor);
+int h2hip_ifft_dev(h2hip_ctx *ctx, void *a_dev, const void *omega_inv, uint32_t log_n, const void *divisor);
+/* EvaluationDomain::coeff_to_extended: out[0..2^ext_k) = NTT_{ext_omega}( coeffs[i] * zeta^(i mod 3), zero padded ) */
+int h2hip_coeff_to_extended(h2hip_ctx *ctx, const void *coeffs_host, uint32_t k, void *out_host, uint32_t ext_k, const void *ext_omega,
+                            const void *zeta);
+int h2hip_coeff_to_extended_dev(h2hip_ctx *ctx, const void *coeffs_dev, uint32_t k, void *out_dev, uint32_t ext_k,
+                                const void *ext_omega, const void *zeta);
+/* EvaluationDomain::extended_to_coeff (without the final truncation, which is a length change on the
+ * caller's Vec): in-place iNTT with ext_omega_inv, times ext_divisor, times [1, zeta_inv, zeta_inv^2][i mod 3]
+ * (zeta_inv = zeta^2 because zeta^3 = 1) */
+int h2hip_extended_to_coeff(h2hip_ctx *ctx, void *a_host, uint32_t ext_k, const void *ext_omega_inv, const void *ext_divisor,
+                            const void *zeta_inv);
+int h2hip_extended_to_coeff_dev(h2hip_ctx *ctx, void *a_dev, uint32_t ext_k, const void *ext_omega_inv, const void *ext_divisor,
+                                const void *zeta_inv);
+
+/* ---- K8: witness-column F_r batches (halo2-base GateInstructions add/sub/mul/mul_add on column values,
+ *      reference halo2-base/src/gates/flex_gate/mod.rs:158-277); out may alias an input ----------------- */
+int h2hip_fr_add_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, const void *b_dev, size_t n);
+int h2hip_fr_sub_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, const void *b_dev, size_t n);
+int h2hip_fr_mul_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, const void *b_dev, size_t n);
+int h2hip_fr_mul_add_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, const void *b_dev, const void *c_dev, size_t n);
+
+/* ---- diagnostics: 254-bit Montgomery multiplier throughput (the integer roofline bench.py quotes) ------ */
+int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H2HIP_H */

@@ -1,0 +1,185 @@
+// TEST INFRASTRUCTURE ONLY — a host-side stand-in for <hip/hip_runtime.h>.
+//
+// Compiling halo2-lib_amd/csrc/*.hip with `clang++ -x c++ -I tests/emu` runs the *same kernel source* on
+// the CPU (one fiber per GPU thread, __syncthreads = yield-to-next-fiber, blocks spread over OS threads).
+// It exists so that index math, carry handling and sort/scan/segment logic can be debugged in the
+// GPU-less build container before GPU minutes are spent.  It is never built by __graft_entry__.build(),
+// never loaded by the product (`halo2-lib_amd/`), and the library it produces (tests/emu/libh2hip_emu.so)
+// is only opened explicitly by tests/test_emu_*.py.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+#include <atomic>
+#include <chrono>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __constant__ static const
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+
+namespace hipemu {
+inline thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+struct Worker {
+    std::vector<ucontext_t> ctx;
+    std::vector<char *> stacks;
+    std::vector<char> done;
+    ucontext_t main_ctx;
+    int cur = 0;
+    std::function<void()> body;
+    std::vector<char> dyn_smem;
+    ~Worker() { for (char *p : stacks) free(p); }
+};
+inline thread_local Worker *t_worker = nullptr;
+inline void fiber_entry() {
+    Worker *w = t_worker;
+    w->body();
+    w->done[w->cur] = 1;
+    swapcontext(&w->ctx[w->cur], &w->main_ctx);
+}
+constexpr size_t kStack = 256 * 1024;
+inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
+    if (w.ctx.size() < nthreads) {
+        size_t old = w.ctx.size();
+        w.ctx.resize(nthreads);
+        w.stacks.resize(nthreads, nullptr);
+        w.done.resize(nthreads);
+        for (size_t i = old; i < nthreads; ++i) w.stacks[i] = (char *)malloc(kStack);
+    }
+    for (unsigned i = 0; i < nthreads; ++i) {
+        getcontext(&w.ctx[i]);
+        w.ctx[i].uc_stack.ss_sp = w.stacks[i];
+        w.ctx[i].uc_stack.ss_size = kStack;
+        w.ctx[i].uc_link = &w.main_ctx;
+        makecontext(&w.ctx[i], (void (*)())fiber_entry, 0);
+        w.done[i] = 0;
+    }
+    unsigned remaining = nthreads;
+    while (remaining) {
+        for (unsigned i = 0; i < nthreads; ++i) {
+            if (w.done[i]) continue;
+            w.cur = (int)i;
+            t_threadIdx = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
+            swapcontext(&w.main_ctx, &w.ctx[i]);
+            if (w.done[i]) --remaining;
+        }
+    }
+}
+inline void *dyn_smem_ptr() { return t_worker->dyn_smem.data(); }
+inline void syncthreads() {
+    Worker *w = t_worker;
+    swapcontext(&w->ctx[w->cur], &w->main_ctx);
+    // resumed: restore threadIdx (set by scheduler before swap)
+}
+}  // namespace hipemu
+
+#define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)hipemu::dyn_smem_ptr();
+#define threadIdx (hipemu::t_threadIdx)
+#define blockIdx (hipemu::t_blockIdx)
+#define blockDim (hipemu::t_blockDim)
+#define gridDim (hipemu::t_gridDim)
+inline void __syncthreads() { hipemu::syncthreads(); }
+inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+
+template <class T> inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <class T> inline T atomicMax(T *p, T v) {
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+inline unsigned __brev(unsigned x) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+
+// ---------------------------------------------------------------- runtime API subset
+typedef int hipError_t;
+typedef struct hipemu_stream *hipStream_t;
+struct hipemu_event { std::chrono::steady_clock::time_point t; };
+typedef hipemu_event *hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamNonBlocking = 1, hipEventDefault = 0 };
+struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchName[64]; size_t totalGlobalMem; };
+inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+    memset(p, 0, sizeof(*p));
+    p->multiProcessorCount = 8;
+    strcpy(p->name, "hipemu-cpu");
+    strcpy(p->gcnArchName, "emu");
+    p->totalGlobalMem = (size_t)8 << 30;
+    return hipSuccess;
+}
+inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
+inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+
+template <class K, class... A>
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t /*stream*/, A... args) {
+    unsigned nblocks = grid.x * grid.y * grid.z, nthreads = block.x * block.y * block.z;
+    if (!nblocks || !nthreads) return;
+    unsigned nworkers = std::min<unsigned>(nblocks, std::max(1u, std::thread::hardware_concurrency()));
+    std::atomic<unsigned> next{0};
+    auto work = [&]() {
+        static thread_local hipemu::Worker worker;
+        hipemu::t_worker = &worker;
+        hipemu::t_blockDim = block;
+        hipemu::t_gridDim = grid;
+        worker.body = [&]() { kernel(args...); };
+        if (worker.dyn_smem.size() < shmem + 64) worker.dyn_smem.resize(shmem + 64);
+        for (;;) {
+            unsigned b = next.fetch_add(1);
+            if (b >= nblocks) break;
+            hipemu::t_blockIdx = dim3(b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y));
+            hipemu::run_block(worker, nthreads, block);
+        }
+    };
+    if (nworkers == 1) { work(); return; }
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nworkers; ++i) th.emplace_back(work);
+    for (auto &t : th) t.join();
+}

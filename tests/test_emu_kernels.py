@@ -1,0 +1,111 @@
+"""CPU-only: runs the product's *kernel sources* through the host emulation shim (tests/emu/) against the
+oracle, so index math / carries / sort / segmented accumulation are exercised in the GPU-less container.
+This is NOT the product path (the product only ever loads the hipcc-built libh2hip.so)."""
+import numpy as np
+import pytest
+
+import halo2_lib_amd as H
+from oracle import bn254 as O
+from oracle import c_oracle as CO
+from tests.emu_util import emu_context
+from tests.util import R, circuit_like_fr, domain_consts, fr, jac_to_affine_ints, rand_fr
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = emu_context()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 9, 10, 11, 13, 15])
+def test_ntt_matches_oracle(ctx, log_n):
+    a = rand_fr(1 << log_n, log_n)
+    w, winv, div = domain_consts(log_n)
+    got = ctx.best_fft(a, w, log_n)
+    assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=4))
+    assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
+
+
+@pytest.mark.parametrize("tile", [4, 6, 8])
+def test_ntt_small_tiles_force_many_passes(ctx, tile):
+    ctx.set_param("ntt_tile_bits", tile)
+    try:
+        for log_n in (7, 12):
+            a = rand_fr(1 << log_n, 3)
+            w, _, _ = domain_consts(log_n)
+            assert np.array_equal(ctx.best_fft(a, w, log_n), CO.best_fft(a, log_n, w))
+    finally:
+        ctx.set_param("ntt_tile_bits", 10)
+
+
+@pytest.mark.parametrize("k,ek", [(0, 2), (3, 5), (9, 11), (12, 14)])
+def test_coset_extension(ctx, k, ek):
+    a = rand_fr(1 << k, k)
+    we, weinv, ediv = domain_consts(ek)
+    z, zinv = fr([O.ZETA]), fr([O.ZETA * O.ZETA % R])
+    ext = ctx.coeff_to_extended(a, k, ek, we, z)
+    assert np.array_equal(ext, CO.coeff_to_extended(a, k, ek, we, z, threads=4))
+    back = ctx.extended_to_coeff(ext, ek, weinv, ediv, zinv)
+    assert np.array_equal(back[: 1 << k], a) and not back[1 << k:].any()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 257, 3000])
+@pytest.mark.parametrize("kind", ["uniform", "circuit"])
+def test_msm_matches_oracle(ctx, n, kind):
+    bases = CO.known_dlog_bases(n, fr([777 + n]), fr([13]))
+    s = rand_fr(n, n) if kind == "uniform" else circuit_like_fr(n, n)
+    b = ctx.bases_upload(bases)
+    want = CO.best_multiexp(s, bases, threads=4)
+    assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), want)
+    assert [jac_to_affine_ints(ctx.msm(b, s, H.POINT_JACOBIAN))] == O.limbs_to_points(want)
+    b.free()
+
+
+@pytest.mark.parametrize("c,k1,k2,seg", [(4, 2, 4, 1), (5, 4, 4, 2), (9, 16, 8, 8), (13, 32, 8, 16)])
+def test_msm_parameter_sweep(ctx, c, k1, k2, seg):
+    n = 1500
+    bases = CO.known_dlog_bases(n, fr([5]), fr([3]))
+    b = ctx.bases_upload(bases)
+    for name, v in (("msm_window_bits", c), ("msm_chunk", k1), ("msm_chunk2", k2), ("msm_seg", seg)):
+        ctx.set_param(name, v)
+    try:
+        for s in (rand_fr(n, c), circuit_like_fr(n, c)):
+            assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=4))
+    finally:
+        for name, v in (("msm_window_bits", 0), ("msm_chunk", 32), ("msm_chunk2", 8), ("msm_seg", 8)):
+            ctx.set_param(name, v)
+        b.free()
+
+
+def test_msm_reference_edge_cases(ctx):
+    # halo2-ecc/src/bn254/tests/msm_sum_infinity.rs:16-69 (+ identity base, zero scalars, n = 0, prefix of bases)
+    P = O.g1_mul(O.G1_GEN, 0xDEADBEEF)
+    cases = [
+        ([1, 1, R - 2], [P, P, P]),
+        ([1, 1, R - 1], [P, P, O.g1_add(P, P)]),
+        ([1, 1, 1, R - 1], [P, P, P, O.g1_mul(P, 3)]),
+        ([1, 1, 1, R - 1], [O.G1_GEN] * 3 + [O.g1_mul(O.G1_GEN, 3)]),
+        ([R - 1, R - 1, 1, 1], [P, P, P, O.g1_add(P, P)]),
+        ([5, 7], [None, P]),
+        ([0, 0], [P, P]),
+        ([R - 1], [P]),
+    ]
+    for sc, bs in cases:
+        b = ctx.bases_upload(O.points_to_limbs(bs))
+        assert O.limbs_to_points(ctx.msm(b, fr(sc), H.POINT_AFFINE)) == [O.msm_naive(sc, bs)]
+        b.free()
+    b = ctx.bases_upload(O.points_to_limbs([P, P, P]))
+    assert O.limbs_to_points(ctx.msm(b, np.zeros((0, 4), dtype=np.uint64), H.POINT_AFFINE)) == [None]
+    assert O.limbs_to_points(ctx.msm(b, fr([2, 3]), H.POINT_AFFINE)) == [O.g1_mul(P, 5)]
+    with pytest.raises(H.H2HipError):
+        ctx.msm(b, fr([1, 2, 3, 4]), H.POINT_AFFINE)   # more scalars than bases
+    b.free()
+
+
+def test_fr_batches(ctx):
+    a, b, c = rand_fr(700, 1), rand_fr(700, 2), rand_fr(700, 3)
+    assert np.array_equal(ctx.fr_mul(a, b), CO.fr_mul(a, b))
+    assert np.array_equal(ctx.fr_add(a, b), CO.fr_add(a, b))
+    assert np.array_equal(ctx.fr_sub(a, b), CO.fr_sub(a, b))
+    assert np.array_equal(ctx.fr_mul_add(a, b, c), CO.fr_add(CO.fr_mul(a, b), c))

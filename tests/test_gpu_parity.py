@@ -1,0 +1,127 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, must be
+bit-exact against the CPU oracle on the same seeded inputs; at BASELINE sizes also via closed forms."""
+import numpy as np
+import pytest
+
+import halo2_lib_amd as H
+from oracle import bn254 as O
+from oracle import c_oracle as CO
+from tests.util import R, circuit_like_fr, domain_consts, fr, jac_to_affine_ints, rand_fr
+
+pytestmark = pytest.mark.gpu
+NT = 16   # oracle threads
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = H.Context(device=0)   # the hipcc-built libh2hip.so on a real GPU; raises otherwise
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 4, 9, 10, 11, 14, 16, 19, 20, 22])
+def test_ntt_bit_exact(ctx, log_n):
+    a = rand_fr(1 << log_n, log_n)
+    w, winv, div = domain_consts(log_n)
+    got = ctx.best_fft(a, w, log_n)
+    assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=NT))
+    assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
+
+
+def test_ntt_22_properties(ctx):
+    # config #3 size: linearity + Horner spot checks (size-independent properties)
+    log_n = 22
+    n = 1 << log_n
+    a, b = rand_fr(n, 1), rand_fr(n, 2)
+    w, _, _ = domain_consts(log_n)
+    fa, fb = ctx.best_fft(a, w, log_n), ctx.best_fft(b, w, log_n)
+    fab = ctx.best_fft(CO.fr_add(a, b), w, log_n)
+    assert np.array_equal(fab, CO.fr_add(fa, fb))
+    wi = O.omega_for(log_n)
+    for j in (0, 1, 123457, n - 1):
+        assert np.array_equal(fa[j:j + 1], CO.fr_eval_polynomial(a, fr([pow(wi, j, R)])))
+
+
+@pytest.mark.parametrize("k,ek", [(0, 2), (5, 7), (12, 14), (17, 19), (19, 21)])
+def test_coset_extension(ctx, k, ek):
+    a = rand_fr(1 << k, k)
+    we, weinv, ediv = domain_consts(ek)
+    z, zinv = fr([O.ZETA]), fr([O.ZETA * O.ZETA % R])
+    ext = ctx.coeff_to_extended(a, k, ek, we, z)
+    assert np.array_equal(ext, CO.coeff_to_extended(a, k, ek, we, z, threads=NT))
+    back = ctx.extended_to_coeff(ext, ek, weinv, ediv, zinv)
+    assert np.array_equal(back[: 1 << k], a) and not back[1 << k:].any()
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 1000, 1 << 14, (1 << 16) + 3])
+@pytest.mark.parametrize("kind", ["uniform", "circuit"])
+def test_msm_bit_exact(ctx, n, kind):
+    bases = CO.known_dlog_bases(n, fr([777 + n]), fr([13]))
+    s = rand_fr(n, n) if kind == "uniform" else circuit_like_fr(n, n)
+    b = ctx.bases_upload(bases)
+    want = CO.best_multiexp(s, bases, threads=NT)
+    assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), want)
+    assert [jac_to_affine_ints(ctx.msm(b, s, H.POINT_JACOBIAN))] == O.limbs_to_points(want)
+    b.free()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "circuit"])
+def test_msm_2_20_bit_exact_and_closed_form(ctx, kind):
+    # config #2: 2^20 points.  Checked against the C oracle AND the known-dlog closed form
+    # sum_i s_i*(k0+i*d) * G  (SURVEY §8c), which does not depend on any MSM implementation.
+    n, k0, d = 1 << 20, 987654321, 31
+    bases = CO.known_dlog_bases(n, fr([k0]), fr([d]))
+    s = rand_fr(n, 7) if kind == "uniform" else circuit_like_fr(n, 7)
+    b = ctx.bases_upload(bases)
+    got = ctx.msm(b, s, H.POINT_AFFINE)
+    assert np.array_equal(got, CO.best_multiexp(s, bases, threads=NT))
+    si = O.limbs_to_ints(s, R)
+    total = sum(v * (k0 + i * d) for i, v in enumerate(si)) % R
+    assert O.limbs_to_points(got) == [O.g1_mul(O.G1_GEN, total)]
+    # device-resident scalars give the same answer (the bench path)
+    ds = ctx.to_device(s)
+    assert [jac_to_affine_ints(ctx.msm_dev(b, ds, n, H.POINT_JACOBIAN))] == O.limbs_to_points(got)
+    ctx.free(ds)
+    b.free()
+
+
+def test_msm_reference_edge_cases(ctx):
+    P = O.g1_mul(O.G1_GEN, 0xDEADBEEF)
+    cases = [
+        ([1, 1, R - 2], [P, P, P]),
+        ([1, 1, R - 1], [P, P, O.g1_add(P, P)]),
+        ([1, 1, 1, R - 1], [P, P, P, O.g1_mul(P, 3)]),
+        ([1, 1, 1, R - 1], [O.G1_GEN] * 3 + [O.g1_mul(O.G1_GEN, 3)]),
+        ([R - 1, R - 1, 1, 1], [P, P, P, O.g1_add(P, P)]),
+        ([5, 7], [None, P]),
+        ([0, 0], [P, P]),
+        ([R - 1], [P]),
+    ]
+    for sc, bs in cases:
+        b = ctx.bases_upload(O.points_to_limbs(bs))
+        assert O.limbs_to_points(ctx.msm(b, fr(sc), H.POINT_AFFINE)) == [O.msm_naive(sc, bs)]
+        b.free()
+    b = ctx.bases_upload(O.points_to_limbs([P, P, P]))
+    assert O.limbs_to_points(ctx.msm(b, np.zeros((0, 4), dtype=np.uint64), H.POINT_AFFINE)) == [None]
+    with pytest.raises(H.H2HipError):
+        ctx.msm(b, fr([1, 2, 3, 4]), H.POINT_AFFINE)
+    b.free()
+
+
+def test_msm_many_duplicates_and_single_bucket(ctx):
+    # all scalars equal, all bases equal: every entry lands in the same buckets and every add is a doubling
+    n = 5000
+    P = O.g1_mul(O.G1_GEN, 424242)
+    bases = np.repeat(O.points_to_limbs([P]), n, axis=0)
+    s = np.repeat(fr([0x1234567]), n, axis=0)
+    b = ctx.bases_upload(bases)
+    assert O.limbs_to_points(ctx.msm(b, s, H.POINT_AFFINE)) == [O.g1_mul(P, 0x1234567 * n)]
+    b.free()
+
+
+def test_fr_batches(ctx):
+    a, b, c = rand_fr(100003, 1), rand_fr(100003, 2), rand_fr(100003, 3)
+    assert np.array_equal(ctx.fr_mul(a, b), CO.fr_mul(a, b))
+    assert np.array_equal(ctx.fr_add(a, b), CO.fr_add(a, b))
+    assert np.array_equal(ctx.fr_sub(a, b), CO.fr_sub(a, b))
+    assert np.array_equal(ctx.fr_mul_add(a, b, c), CO.fr_add(CO.fr_mul(a, b), c))
