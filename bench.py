@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""
+bench.py — headline benchmark of the MI355X prover backend (contract: see the task statement).
+
+Workload (BASELINE.json configs[1]): one step = one 2^20-point BN254 G1 Pippenger MSM
+(`h2hip_msm_g1_dev`: scalars and bases already resident in HBM, the Jacobian result is returned to the
+host like arithmetic::best_multiexp returns C::Curve).  Synthetic data: uniformly random scalars; bases
+are 4096 distinct curve points (built here in pure Python) tiled with random signs to 2^20.
+
+  value      = G1-adds/s over the whole job, with the add count defined by SURVEY.md §8d:
+               adds(n) = n*W + 2*W*2^(c-1) for the window the kernel actually used (c, W reported).
+  roofline   = dominant kernel (msm_accum_kernel<affine>) — algorithmic bytes 96 B/pair x n per launch
+               over its mean duration, measured with HIP events on the context's stream inside the timed
+               region; `roofline_int` adds the binding roof: Montgomery multiplies/s vs. the chip's measured
+               254-bit multiplier peak (h2hip_bench_modmul on the same GPU, same run).
+  cpu_baseline = oracle/ restatement of best_multiexp ("port") on the box's own host cores, rank 0, N=1 only.
+
+Multi-GPU (`--gpus N` under torch.distributed.run): point-range sharding — every rank owns a
+2^20-point slice of an N*2^20-point MSM (weak scaling), computes its partial on its own GPU, partials are
+all-gathered over RCCL (96 B each) and summed on every rank's GPU (RCCL has no group-law reduction).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+# ---------------------------------------------------------------- synthetic inputs (no oracle involved)
+def _g1_add(P, S):
+    (x1, y1), (x2, y2) = P, S
+    if x1 == x2:
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, Q) % Q
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, Q) % Q
+    x3 = (lam * lam - x1 - x2) % Q
+    return (x3, (lam * (x1 - x3) - y1) % Q)
+
+
+def _limbs(vals, p):
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for i, v in enumerate(vals):
+        v = (v << 256) % p   # Montgomery form
+        out[i] = [(v >> (64 * k)) & mask for k in range(4)]
+    return out
+
+
+def synthetic_bases(n: int, seed: int) -> np.ndarray:
+    """n valid G1Affine points: 4096 distinct multiples of G=(1,2) tiled with random signs."""
+    m = min(n, 4096)
+    pts, P = [], (1, 2)
+    step = _g1_add(_g1_add((1, 2), (1, 2)), (1, 2))   # 3G
+    for _ in range(m):
+        pts.append(P)
+        P = _g1_add(P, step)
+    xs = _limbs([p[0] for p in pts], Q)
+    ys = _limbs([p[1] for p in pts], Q)
+    ysn = _limbs([(-p[1]) % Q for p in pts], Q)
+    g = np.random.default_rng(seed)
+    idx = g.integers(0, m, size=n)
+    sign = g.integers(0, 2, size=n).astype(bool)
+    out = np.empty((n, 8), dtype=np.uint64)
+    out[:, :4] = xs[idx]
+    out[:, 4:] = np.where(sign[:, None], ysn[idx], ys[idx])
+    return out
+
+
+def synthetic_scalars(n: int, seed: int) -> np.ndarray:
+    """uniform random valid F_r elements (raw Montgomery limbs, value < 2^252 < r)."""
+    g = np.random.default_rng(seed)
+    a = g.integers(0, 2**63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + g.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    return a
+
+
+def window_for(ctx, n):
+    c = ctx.get_param("msm_window_bits")
+    if c == 0:   # mirror of pick_window() in msm.hip
+        best, best_cost = 4, float("inf")
+        for cc in range(4, 21):
+            W = (255 + cc - 1) // cc
+            cost = W * (10.0 * n + 28.0 * (1 << (cc - 1)) + 400.0 * cc)
+            if cost < best_cost:
+                best, best_cost = cc, cost
+        c = best
+    return c, (255 + c - 1) // c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import halo2_lib_amd as H
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n = 1 << args.log_n
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = H.Context(device=local_rank, stream=stream)
+    # each rank owns its own slice of the (world * n)-point MSM
+    bases_h = synthetic_bases(n, seed=1000 + rank)
+    scal_h = synthetic_scalars(n, seed=2000 + rank)
+    bases = ctx.bases_upload(bases_h)
+    scal_d = torch.from_numpy(scal_h.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+
+    from halo2_lib_amd.multi_gpu import sharded_msm
+
+    def step():
+        # partial MSM on this rank's slice; N>1: all-gather of 96 B partials over RCCL + on-GPU sum
+        return sharded_msm(ctx, bases, scal_d.data_ptr(), n, device=dev if world > 1 else None)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    if rank == 0:
+        c, W = window_for(ctx, n)
+        adds_per_msm = n * W + 2 * W * (1 << (c - 1))
+        units = world * args.steps * adds_per_msm
+        ms_per_step = elapsed / args.steps * 1e3
+        # dominant kernel, timed with HIP events on the launch stream inside the timed region
+        k_ms, k_cnt = ctx.profile_get("msm_accum_kernel<affine>")
+        k_avg_s = (k_ms / max(k_cnt, 1)) * 1e-3
+        alg_bytes = 96.0 * n
+        achieved_gbs = alg_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        breakdown = {}
+        for name in ("msm_digits", "scan", "msm_hist", "msm_scatter", "msm_accum_kernel<affine>", "msm_accum_kernel<xyzz>", "msm_merge",
+                     "msm_seg", "msm_winsum", "msm_fold", "point_finish"):
+            ms, cnt = ctx.profile_get(name)
+            if cnt:
+                breakdown[name] = round(ms / args.steps, 4)
+        mm_ms, mm_n = ctx.bench_modmul(16384, 256, 2)
+        modmul_peak = mm_n / (mm_ms * 1e-3)
+        alg_modmul = 10.0 * n * W   # XYZZ mixed add = 8M + 2S per (scalar, window) pair
+        out = {
+            "metric": "MSM G1-adds/sec (2^%d-point BN254 G1 Pippenger MSM; create_proof's dominant kernel, k=19 ECDSA shape = 12 such MSMs of 2^19)" % args.log_n,
+            "value": units / elapsed,
+            "unit": "G1-adds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8 (254-bit Montgomery integers)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 2^%d-point BN254 G1 MSM, uniform random scalars, bases resident in HBM" % args.log_n,
+                       "points_per_gpu": n, "window_bits": c, "windows": W, "adds_per_msm": adds_per_msm,
+                       "sharding": "point-range, one 2^%d slice per GPU, all-gather of 96 B partials" % args.log_n},
+            "pairs_per_sec": world * args.steps * n / elapsed,
+            "kernel_ms_per_msm": breakdown,
+            "roofline": {"bound": "hbm", "kernel": "msm_accum_kernel<affine>", "achieved": achieved_gbs, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved_gbs / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": k_avg_s * 1e3, "launches": int(k_cnt)},
+            "roofline_int": {"bound": "int32-multiplier (v_mad_u64_u32)", "kernel": "msm_accum_kernel<affine>",
+                             "achieved": alg_modmul / k_avg_s if k_avg_s > 0 else 0.0, "peak": modmul_peak, "unit": "modmul/s",
+                             "frac": (alg_modmul / k_avg_s / modmul_peak) if k_avg_s > 0 else 0.0,
+                             "note": "peak = h2hip_bench_modmul measured in this run; algorithmic modmuls = 10*n*W"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(bases_h, scal_h, adds_per_msm)
+        print(json.dumps(out), flush=True)
+    bases.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(bases_h, scal_h, adds_per_msm):
+    """oracle/ restatement of upstream best_multiexp (thread-chunked multiexp_serial), all host cores."""
+    from oracle import c_oracle as CO
+
+    cores = os.cpu_count() or 1
+    try:
+        lib = CO.lib(native=True)
+    except Exception:
+        lib = CO.lib()
+    n = len(scal_h)
+    CO.best_multiexp(scal_h[:4096], bases_h[:4096], threads=cores, l=lib)   # warm up
+    reps, t_total = 0, 0.0
+    while t_total < 5.0 and reps < 20:
+        t0 = time.perf_counter()
+        CO.best_multiexp(scal_h, bases_h, threads=cores, l=lib)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    per = t_total / reps
+    return {"value": adds_per_msm / per, "unit": "G1-adds/s", "cores": cores, "kind": "port",
+            "sample": "full 2^%d-point MSM x %d reps (%.3f s each), C restatement of best_multiexp (chunk = n/threads, c = ceil(ln chunk)); "
+                      "value uses the SAME adds-per-MSM constant as the GPU line so the ratio equals the pairs/s ratio" % (int(np.log2(n)), reps, per),
+            "pairs_per_sec": n / per, "seconds_per_msm": per}
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,34 @@ __global__ void point_finish_kernel(const XYZZ *__restrict__ in, G1Jac *__restri
     }
 }
 
+// sum of n Jacobian points (multi-GPU partial results): one workgroup, strided accumulate + LDS tree
+__global__ __launch_bounds__(64) void jac_sum_kernel(const G1Jac *__restrict__ pts, uint32_t n, XYZZ *__restrict__ out) {
+    __shared__ XYZZ sh[64];
+    uint32_t tid = threadIdx.x;
+    XYZZ acc = XYZZ::identity();
+    for (uint32_t i = tid; i < n; i += 64) {
+        G1Jac p = pts[i];
+        if (p.z.is_zero()) continue;
+        XYZZ q;
+        q.x = p.x;
+        q.y = p.y;
+        q.zz = fe_sqr(p.z);
+        q.zzz = fe_mul(q.zz, p.z);
+        xyzz_add(acc, q);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        if (tid < d) {
+            XYZZ a = sh[tid];
+            xyzz_add(a, sh[tid + d]);
+            sh[tid] = a;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = sh[0];
+}
+
 }  // namespace h2
 
 using namespace h2;
@@ -308,15 +336,27 @@ void h2hip_bases_free(h2hip_ctx *ctx, h2hip_bases *bases) {
 }
 size_t h2hip_bases_len(const h2hip_bases *bases) { return bases ? bases->n : 0; }
 
+static int finish_point(h2hip_ctx *ctx, char *outbuf, int point_format, void *out_host);
 int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_dev, size_t n, int point_format, void *out_host) {
     H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_dev), "NULL argument");
     H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
     char *outbuf = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, 1024, (void **)&outbuf));
+    H2_CHK(msm_run(ctx, bases, (const Fr *)scalars_dev, n, (XYZZ *)outbuf));
+    return finish_point(ctx, outbuf, point_format, out_host);
+}
+int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host) {
+    H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_host), "NULL argument");
+    Fr *stage = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_STAGE, sizeof(Fr) * n, (void **)&stage));
+    if (n) H2_HIPCHK(hipMemcpyAsync(stage, scalars_host, sizeof(Fr) * n, hipMemcpyHostToDevice, ctx->stream));
+    return h2hip_msm_g1_dev(ctx, bases, stage, n, point_format, out_host);
+}
+
+static int finish_point(h2hip_ctx *ctx, char *outbuf, int point_format, void *out_host) {
     XYZZ *acc = (XYZZ *)outbuf;
     G1Jac *jac = (G1Jac *)(outbuf + 256);
     G1Affine *aff = (G1Affine *)(outbuf + 512);
-    H2_CHK(msm_run(ctx, bases, (const Fr *)scalars_dev, n, acc));
     const bool affine = point_format == H2HIP_POINT_AFFINE;
     prof_begin(ctx, "point_finish_kernel");
     hipLaunchKernelGGL(point_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const XYZZ *)acc, affine ? (G1Jac *)nullptr : jac,
@@ -328,12 +368,18 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
     return H2HIP_OK;
 }
-int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host) {
-    H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_host), "NULL argument");
-    Fr *stage = nullptr;
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_STAGE, sizeof(Fr) * n, (void **)&stage));
-    if (n) H2_HIPCHK(hipMemcpyAsync(stage, scalars_host, sizeof(Fr) * n, hipMemcpyHostToDevice, ctx->stream));
-    return h2hip_msm_g1_dev(ctx, bases, stage, n, point_format, out_host);
+
+int h2hip_g1_sum_jacobian_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, int point_format, void *out_host) {
+    H2_REQUIRE(ctx && out_host && (n == 0 || points_dev), "NULL argument");
+    H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
+    H2_REQUIRE(n < (1u << 24), "too many points");
+    char *outbuf = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, 1024, (void **)&outbuf));
+    prof_begin(ctx, "jac_sum_kernel");
+    hipLaunchKernelGGL(jac_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, (const G1Jac *)points_dev, (uint32_t)n, (XYZZ *)outbuf);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return finish_point(ctx, outbuf, point_format, out_host);
 }
 
 // ------------------------------------------------------------------ NTT family

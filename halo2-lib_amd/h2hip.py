@@ -39,6 +39,7 @@ _PROTOS = {
     "h2hip_bases_len": (_sz, [_vp]),
     "h2hip_msm_g1": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "h2hip_msm_g1_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "h2hip_g1_sum_jacobian_dev": (_int, [_vp, _vp, _sz, _int, _vp]),
     "h2hip_best_fft": (_int, [_vp, _vp, _vp, _u32]),
     "h2hip_best_fft_dev": (_int, [_vp, _vp, _vp, _u32]),
     "h2hip_ifft": (_int, [_vp, _vp, _vp, _u32, _vp]),
@@ -216,6 +217,11 @@ class Context:
     def msm_dev(self, bases: Bases, scalars_dptr: int, n: int, point_format: int = POINT_JACOBIAN) -> np.ndarray:
         out = np.zeros((1, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
         self._chk(self.lib.h2hip_msm_g1_dev(self.handle, bases.handle, _vp(scalars_dptr), n, point_format, _ptr(out)))
+        return out
+
+    def g1_sum_jacobian_dev(self, points_dptr: int, n: int, point_format: int = POINT_JACOBIAN) -> np.ndarray:
+        out = np.zeros((1, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
+        self._chk(self.lib.h2hip_g1_sum_jacobian_dev(self.handle, _vp(points_dptr), n, point_format, _ptr(out)))
         return out
 
     # -- NTT family (arithmetic::best_fft, EvaluationDomain::*)

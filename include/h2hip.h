@@ -87,6 +87,10 @@ size_t h2hip_bases_len(const h2hip_bases *bases);
 int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host);
 int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_dev, size_t n, int point_format, void *out_host);
 
+/* Sum of n Jacobian points resident on the device (multi-GPU: the all-gathered per-GPU partial MSM results;
+ * RCCL has no group-law reduction). */
+int h2hip_g1_sum_jacobian_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, int point_format, void *out_host);
+
 /* ---- K2/K3: NTT family  (replaces arithmetic::best_fft and EvaluationDomain::{ifft, coeff_to_extended,
  *      extended_to_coeff} [UPSTREAM]) ------------------------------------------------ */
 /* in-place, natural order in and out, no scaling:  a[k] <- sum_j a[j] * omega^(jk),  len(a) = 2^log_n */

@@ -1,0 +1,73 @@
+"""CPU-only, world_size 2 over gloo: the multi-GPU point-range sharding (halo2-lib_amd/multi_gpu.py) with the
+emulated kernels standing in for the GPU.  Every rank must return the full MSM."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import halo2_lib_amd as H
+        from halo2_lib_amd.multi_gpu import columns_for_rank, shard_range, sharded_msm
+        from oracle import c_oracle as CO
+        from tests.emu_util import emu_context
+        from tests.util import circuit_like_fr, fr, jac_to_affine_ints, rand_fr
+        from oracle import bn254 as O
+
+        ctx = emu_context()
+        bases = CO.known_dlog_bases(n, fr([99]), fr([5]))
+        scal = np.concatenate([rand_fr(n // 2, 1), circuit_like_fr(n - n // 2, 2)])
+        lo, hi = shard_range(n, rank, world)
+        b = ctx.bases_upload(bases[lo:hi])
+        ds = ctx.to_device(scal[lo:hi])
+        got = sharded_msm(ctx, b, ds, hi - lo)
+        want = CO.best_multiexp(scal, bases, threads=2)
+        ok = [jac_to_affine_ints(got)] == O.limbs_to_points(want)
+        got_aff = sharded_msm(ctx, b, ds, hi - lo, point_format=H.POINT_AFFINE)
+        ok = ok and np.array_equal(got_aff, want)
+        cols = columns_for_rank(7, rank, world)
+        q.put((rank, ok, cols))
+        ctx.free(ds)
+        b.free()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_msm_world2():
+    from tests.emu_util import emu_context
+
+    emu_context().close()   # build the emulated library once, before forking workers
+    world, n = 2, 777
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
+    assert sorted(res[0][2] + res[1][2]) == list(range(7))
+
+
+def test_shard_range_covers_everything():
+    from halo2_lib_amd.multi_gpu import shard_range
+
+    for n in (0, 1, 7, 8, 1 << 20):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
