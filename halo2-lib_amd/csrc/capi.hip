@@ -300,7 +300,6 @@ int h2hip_timer_stop(h2hip_ctx *ctx, double *elapsed_ms) {
 static int bases_create(h2hip_ctx *ctx, const void *src, bool src_on_device, size_t n, uint32_t flags, h2hip_bases **out) {
     H2_REQUIRE(ctx && out && (n == 0 || src), "NULL argument");
     H2_REQUIRE((flags & ~H2HIP_BASES_PRECOMPUTE) == 0, "unknown flags");
-    H2_REQUIRE(!(flags & H2HIP_BASES_PRECOMPUTE), "H2HIP_BASES_PRECOMPUTE is not available in this build");
     h2hip_bases *b = new h2hip_bases();
     b->n = n;
     hipError_t e = hipMalloc((void **)&b->pts, sizeof(G1Affine) * (n ? n : 1));
@@ -317,6 +316,14 @@ static int bases_create(h2hip_ctx *ctx, const void *src, bool src_on_device, siz
             hipFree(b->pts);
             delete b;
             return H2HIP_ERR_HIP;
+        }
+    }
+    if ((flags & H2HIP_BASES_PRECOMPUTE) && n) {
+        int rc = msm_build_table(ctx, b);
+        if (rc != H2HIP_OK) {
+            hipFree(b->pts);
+            delete b;
+            return rc;
         }
     }
     *out = b;

@@ -98,5 +98,6 @@ void prof_end(h2hip_ctx *ctx);
 // implemented in ntt.hip / msm.hip / fr_ops.hip, all on device pointers
 int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in_override, uint64_t in_len, const Fr *in_scale3,
             const Fr *out_scale3);
+int msm_build_table(h2hip_ctx *ctx, h2hip_bases *bases);
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
 }  // namespace h2

@@ -4,27 +4,34 @@
 // /root/reference/halo2-base/src/utils/testing.rs:40-47; SURVEY.md §3.2 K1].
 //
 // The result (one group element) is unique, so the algorithm is free to differ from the CPU one:
-//   1. msm_digits    one lane per scalar: Montgomery -> canonical, signed c-bit digits, histogram (atomics)
-//   2. scan          exclusive prefix sum of the histogram -> bucket offsets
-//   3. msm_scatter   counting sort: (bucket key, base index | sign) pairs grouped by bucket
-//   4. msm_accum     *distribution-oblivious* bucket accumulation: every lane owns K consecutive sorted
-//                    entries (perfect balance for uniform and for 0/1-heavy circuit columns alike), adds
-//                    them in XYZZ coordinates, writes complete interior runs straight to their bucket and
-//                    hands its first/last (possibly shared) runs to the next level as (key, XYZZ) partials;
-//                    levels repeat on the partial list until one lane remains.  No atomics on points.
-//   5. msm_seg/winsum/fold   per-window running sums sum_j j*B_j over short segments (+ small scalar
-//                    multiple), tree sum per window, 2^(c*w) fold.
-// Bases stay resident in HBM (h2hip_bases); signs are applied by negating y on load.
+//   1. msm_digits     one lane per scalar: Montgomery -> canonical, signed c-bit digits -> digits[w][i]
+//   2. msm_hist       counting sort without global atomics: workgroup (w, g) histograms chunk g of window w
+//                     in a *full-window* LDS histogram (2^15 x u32 = 128 KiB of the CU's 160 KiB).  Window w is
+//                     pinned to XCD (w mod 8) so its sorted segment and cursors live in one L2.
+//   3. msm_hist_scan  per (window, bucket) exclusive prefix over chunks + bucket totals; global scan -> offsets
+//   4. msm_scatter    workgroup (w, g) loads its cursors into LDS, ranks entries with LDS atomics, writes
+//                     (base index | sign) into bucket order
+//   5. msm_accum      *distribution-oblivious* bucket accumulation: every lane owns K consecutive sorted
+//                     entries (perfect balance for uniform and for 0/1-heavy circuit columns alike), walks the
+//                     offsets table for bucket boundaries, adds in XYZZ, writes complete interior runs to
+//                     their bucket and emits its first/last (possibly shared) runs as (key, XYZZ) partials
+//   6. msm_merge      block-level segmented scan over the sorted partial list (early exit once no lane merges);
+//                     runs closed inside a block go to buckets, block-crossing runs to the next, 128x shorter level
+//   7. msm_presum/seg/winsum/fold   bucket reduction: per-window sum_j j*B_j over short segments (+ small
+//                     scalar multiple), tree sum per window, 2^(c*w) fold (skipped for precomputed bases)
+// Bases stay resident in HBM (h2hip_bases); with H2HIP_BASES_PRECOMPUTE the table also holds 2^(c*w)*P_i for
+// every window (16x the memory — sized for 288 GB HBM), so all windows share one bucket set per index and the
+// serial 2^(c*w) fold disappears.  Signs are applied by negating y on load.
 #include "internal.h"
 
 namespace h2 {
 
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t MAX_LDS_BUCKETS = 1u << 15;   // 128 KiB of u32 counters
 
-// ------------------------------------------------------------------ 1. digits + histogram
+// ------------------------------------------------------------------ 1. digits
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr *__restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                                                         uint32_t *__restrict__ digits, uint32_t *__restrict__ counts,
-                                                         uint32_t keys_per_window) {
+                                                         uint32_t *__restrict__ digits) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s = fe_from_mont(scalars[i]);
@@ -45,11 +52,53 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr *__restrict__ 
         uint32_t d = neg ? (1u << c) - v : v;
         carry = neg;
         digits[(size_t)w * n + i] = d | (neg << 31);
-        if (d) atomicAdd(&counts[w * keys_per_window + d - 1], 1u);
     }
 }
 
-// ------------------------------------------------------------------ 2. exclusive scan of u32 (3 kernels)
+// workgroup -> (window, chunk): window w lives on XCD (w mod 8) (blocks are dealt round-robin to XCDs)
+__device__ __forceinline__ void block_to_window_chunk(uint32_t L, uint32_t G, uint32_t &w, uint32_t &g) {
+    uint32_t x = L & 7u, q = L >> 3;
+    w = x + 8u * (q / G);
+    g = q % G;
+}
+
+// ------------------------------------------------------------------ 2. per-(window, chunk) LDS histogram
+__global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
+                                                        uint32_t G, uint32_t chunk, uint32_t *__restrict__ bhist) {
+    __shared__ uint32_t hist[MAX_LDS_BUCKETS];
+    uint32_t w, g;
+    block_to_window_chunk(blockIdx.x, G, w, g);
+    if (w >= W) return;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) hist[b] = 0;
+    __syncthreads();
+    uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t *dw = digits + (size_t)w * n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        uint32_t d = dw[i] & 0x7fffffffu;
+        if (d) atomicAdd(&hist[d - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t *out = bhist + ((size_t)w * G + g) * B;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) out[b] = hist[b];
+}
+
+// ------------------------------------------------------------------ 3. prefix over chunks per (window, bucket)
+__global__ __launch_bounds__(256) void msm_hist_scan_kernel(uint32_t *__restrict__ bhist, uint32_t W, uint32_t B, uint32_t G,
+                                                            uint32_t *__restrict__ counts) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W * B) return;
+    uint32_t w = t / B, b = t - w * B;
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        size_t idx = ((size_t)w * G + g) * B + b;
+        uint32_t v = bhist[idx];
+        bhist[idx] = run;
+        run += v;
+    }
+    counts[t] = run;
+}
+
+// exclusive scan of u32 (3 kernels)
 constexpr uint32_t SCAN_TILE = 1024;   // 256 lanes x 4
 __global__ __launch_bounds__(256) void scan_tile_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                         uint32_t *__restrict__ tile_sums, uint32_t n) {
@@ -117,86 +166,148 @@ static int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out,
     return H2HIP_OK;
 }
 
-// ------------------------------------------------------------------ 3. counting-sort scatter
-__global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W,
-                                                          uint32_t keys_per_window, uint32_t precomp,
-                                                          const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
-                                                          uint32_t *__restrict__ skey, uint32_t *__restrict__ sval) {
-    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)n * W) return;
-    uint32_t dv = digits[g];
-    uint32_t d = dv & 0x7fffffffu;
-    if (!d) return;
-    uint32_t w = (uint32_t)(g / n), i = (uint32_t)(g - (size_t)w * n);
-    uint32_t key = w * keys_per_window + d - 1;
-    uint32_t pos = offsets[key] + atomicAdd(&cursor[key], 1u);
-    skey[pos] = key;
-    sval[pos] = (precomp ? (uint32_t)g : i) | (dv & 0x80000000u);
+// ------------------------------------------------------------------ 4. scatter with LDS cursors
+__global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
+                                                           uint32_t G, uint32_t chunk, uint32_t table_stride,
+                                                           const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ bhist,
+                                                           uint32_t *__restrict__ sval) {
+    __shared__ uint32_t cursor[MAX_LDS_BUCKETS];
+    uint32_t w, g;
+    block_to_window_chunk(blockIdx.x, G, w, g);
+    if (w >= W) return;
+    const uint32_t *off_w = offsets + (size_t)w * B;
+    const uint32_t *bh = bhist + ((size_t)w * G + g) * B;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) cursor[b] = off_w[b] + bh[b];
+    __syncthreads();
+    uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t *dw = digits + (size_t)w * n;
+    const uint32_t idx_base = w * table_stride;   // precomputed bases: window w reads table level w
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        uint32_t dv = dw[i], d = dv & 0x7fffffffu;
+        if (!d) continue;
+        uint32_t pos = atomicAdd(&cursor[d - 1], 1u);
+        sval[pos] = (idx_base + i) | (dv & 0x80000000u);
+    }
 }
 
-// ------------------------------------------------------------------ 4. chunked bucket accumulation
-// AFFINE = true : level 1, vals = (base index | sign<<31), entries added with the mixed XYZZ+affine formula
-// AFFINE = false: level >= 2, vals = XYZZ partial sums
-template <bool AFFINE>
-__global__ __launch_bounds__(256) void msm_accum_kernel(const uint32_t *__restrict__ keys, const void *__restrict__ vals_,
-                                                        const G1Affine *__restrict__ bases, const uint32_t *__restrict__ total_ptr,
-                                                        uint32_t total_fixed, uint32_t K, XYZZ *__restrict__ buckets,
-                                                        uint32_t *__restrict__ out_keys, XYZZ *__restrict__ out_vals,
-                                                        uint32_t nthreads, uint32_t final_level) {
+// ------------------------------------------------------------------ 5. chunked bucket accumulation
+// largest k in [lo, nkeys) with offsets[k] <= e   (offsets has nkeys+1 entries, e < offsets[nkeys])
+__device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offsets, uint32_t lo, uint32_t nkeys, uint32_t e) {
+    uint32_t hi = nkeys;
+    while (hi - lo > 1) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (offsets[mid] <= e) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
+                                                        const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
+                                                        XYZZ *__restrict__ buckets, uint32_t *__restrict__ out_keys,
+                                                        XYZZ *__restrict__ out_vals, uint32_t nthreads) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nthreads) return;
-    const uint32_t total = total_ptr ? *total_ptr : total_fixed;
-    uint64_t start = (uint64_t)t * K, end = start + K;
-    if (end > total) end = total;
-    uint32_t cur = KEY_INVALID, hk = KEY_INVALID, tk = KEY_INVALID;
+    const uint32_t total = offsets[nkeys];
+    uint64_t start64 = (uint64_t)t * K;
+    if (start64 >= total) {
+        out_keys[2 * (size_t)t] = KEY_INVALID;
+        out_keys[2 * (size_t)t + 1] = KEY_INVALID;
+        return;
+    }
+    uint32_t start = (uint32_t)start64, end = (start64 + K > total) ? total : start + K;
+    uint32_t cur = find_key(offsets, 0, nkeys, start);
+    uint32_t next = offsets[cur + 1];
+    uint32_t hk = KEY_INVALID;
     bool first = true;
     XYZZ acc = XYZZ::identity();
-    for (uint64_t e = start; e < end; ++e) {
-        uint32_t k = keys[e];
-        if (k == KEY_INVALID) continue;
-        if (k != cur) {
-            if (cur != KEY_INVALID) {
-                if (first && !final_level) {
-                    out_vals[2 * (size_t)t] = acc;
-                    hk = cur;
-                } else {
-                    buckets[cur] = acc;
-                }
+    for (uint32_t e = start; e < end; ++e) {
+        if (e >= next) {   // bucket boundary: close the run
+            if (first) {
+                out_vals[2 * (size_t)t] = acc;
+                hk = cur;
                 first = false;
+            } else {
+                buckets[cur] = acc;
             }
-            cur = k;
             acc = XYZZ::identity();
+            cur = (offsets[cur + 2] > e) ? cur + 1 : find_key(offsets, cur + 1, nkeys, e);
+            next = offsets[cur + 1];
         }
-        if (AFFINE) {
-            uint32_t v = ((const uint32_t *)vals_)[e];
-            G1Affine p = bases[v & 0x7fffffffu];
-            if (!p.is_identity()) {
-                if (v >> 31) p.y = fe_neg(p.y);
-                xyzz_add_affine(acc, p.x, p.y);
-            }
-        } else {
-            XYZZ p = ((const XYZZ *)vals_)[e];
-            xyzz_add(acc, p);
+        uint32_t v = sval[e];
+        G1Affine p = bases[v & 0x7fffffffu];
+        if (!p.is_identity()) {
+            if (v >> 31) p.y = fe_neg(p.y);
+            xyzz_add_affine(acc, p.x, p.y);
         }
     }
-    if (cur != KEY_INVALID) {
-        if (final_level) {
-            buckets[cur] = acc;
-        } else if (first) {
-            out_vals[2 * (size_t)t] = acc;
-            hk = cur;
-        } else {
-            out_vals[2 * (size_t)t + 1] = acc;
-            tk = cur;
-        }
-    }
-    if (!final_level) {
+    // the list handed to msm_merge is sorted and hole-free: a single-run chunk emits (key, sum), (key, identity)
+    if (first) {
+        out_vals[2 * (size_t)t] = acc;
+        out_vals[2 * (size_t)t + 1] = XYZZ::identity();
+        out_keys[2 * (size_t)t] = cur;
+    } else {
+        out_vals[2 * (size_t)t + 1] = acc;
         out_keys[2 * (size_t)t] = hk;
-        out_keys[2 * (size_t)t + 1] = tk;
+    }
+    out_keys[2 * (size_t)t + 1] = cur;
+}
+
+// ------------------------------------------------------------------ 6. segmented merge of the partial list
+// One slot per lane, 256 slots per workgroup.  keys are non-decreasing; KEY_INVALID only at the tail.
+// Runs closed inside the workgroup (checked against the neighbouring workgroups' boundary keys) are written
+// to buckets (identity totals are skipped: buckets start zeroed = identity, which also makes the filler slots
+// harmless); the (at most two) runs that cross a workgroup boundary go to slots 2*blk, 2*blk+1 of the next level.
+__global__ __launch_bounds__(256) void msm_merge_kernel(const uint32_t *__restrict__ kin, const XYZZ *__restrict__ vin, uint32_t len,
+                                                        XYZZ *__restrict__ buckets, uint32_t *__restrict__ kout,
+                                                        XYZZ *__restrict__ vout, uint32_t final_level) {
+    __shared__ XYZZ sv[256];
+    __shared__ uint32_t sk[256];
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x;
+    const uint32_t i = blk * 256 + tid;
+    const uint32_t key = i < len ? kin[i] : KEY_INVALID;
+    XYZZ val = XYZZ::identity();
+    if (key != KEY_INVALID) val = vin[i];
+    sk[tid] = key;
+    sv[tid] = val;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const bool m = tid >= d && key != KEY_INVALID && sk[tid - d] == key;
+        XYZZ other = XYZZ::identity();
+        if (m) other = sv[tid - d];
+        if (!__syncthreads_or(m ? 1 : 0)) break;   // also orders this step's LDS reads before its writes
+        if (m) {
+            xyzz_add(val, other);
+            sv[tid] = val;
+        }
+        __syncthreads();
+    }
+    const uint32_t first_key = sk[0], last_key = sk[255];
+    if (!final_level && tid == 0) {   // default filler slots keep the next level sorted and hole-free
+        kout[2 * (size_t)blk] = first_key;
+        vout[2 * (size_t)blk] = XYZZ::identity();
+        kout[2 * (size_t)blk + 1] = last_key;
+        if (last_key != KEY_INVALID) vout[2 * (size_t)blk + 1] = XYZZ::identity();
+    }
+    __syncthreads();
+    if (key == KEY_INVALID) return;
+    const bool in_block_end = (tid == 255) || (sk[tid + 1] != key);
+    if (!in_block_end) return;
+    bool left_closed = true, right_closed = true;
+    if (!final_level) {
+        if (key == first_key && blk > 0) left_closed = kin[blk * 256 - 1] != key;
+        if (tid == 255) right_closed = (i + 1 >= len) || (kin[i + 1] != key);
+    }
+    if (left_closed && right_closed) {
+        if (!val.is_identity()) buckets[key] = val;
+    } else if (key == first_key) {
+        vout[2 * (size_t)blk] = val;   // slot 2*blk+1 keeps the (last_key == key, identity) filler if this is also the last run
+    } else {
+        vout[2 * (size_t)blk + 1] = val;
     }
 }
 
-// ------------------------------------------------------------------ 5. bucket reduction
+// ------------------------------------------------------------------ 7. bucket reduction
 __device__ __forceinline__ XYZZ xyzz_small_mul(const XYZZ &p, uint32_t k) {
     XYZZ r = XYZZ::identity();
     for (int bit = 31 - __clz(k | 1u); bit >= 0; --bit) {
@@ -204,6 +315,14 @@ __device__ __forceinline__ XYZZ xyzz_small_mul(const XYZZ &p, uint32_t k) {
         if ((k >> bit) & 1u) xyzz_add(r, p);
     }
     return r;
+}
+// precomputed bases: all windows carry weight 1, so fold them per bucket index first: out[b] = sum_w buckets[w][b]
+__global__ __launch_bounds__(64) void msm_presum_kernel(const XYZZ *__restrict__ buckets, XYZZ *__restrict__ out, uint32_t B, uint32_t W) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    XYZZ acc = buckets[b];
+    for (uint32_t w = 1; w < W; ++w) xyzz_add(acc, buckets[(size_t)w * B + b]);
+    out[b] = acc;
 }
 // one lane per segment of L buckets: sum_{b in seg} (b+1) * bucket[b]
 __global__ __launch_bounds__(64) void msm_seg_kernel(const XYZZ *__restrict__ buckets, XYZZ *__restrict__ seg_out, uint32_t B, uint32_t L,
@@ -260,11 +379,52 @@ __global__ __launch_bounds__(64) void msm_fold_kernel(const XYZZ *__restrict__ w
     if (tid == 0) out[0] = sh[0];
 }
 
-// ------------------------------------------------------------------ host driver
+// ------------------------------------------------------------------ precomputed tables (H2HIP_BASES_PRECOMPUTE)
+// level w holds 2^(c*w) * P_i.  Step 1: Jacobian doublings of the previous level; step 2: batch normalisation
+// (Montgomery's trick over runs of NORM_RUN points, one Fermat inversion per run).
+constexpr uint32_t NORM_RUN = 32;
+__global__ __launch_bounds__(256) void table_double_kernel(const G1Affine *__restrict__ prev, G1Jac *__restrict__ tmp, uint32_t n, uint32_t c) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine p = prev[i];
+    XYZZ a = XYZZ::from_affine(p);
+    for (uint32_t k = 0; k < c; ++k) a = xyzz_double(a);
+    tmp[i] = xyzz_to_jacobian(a);
+}
+__global__ __launch_bounds__(64) void table_normalize_kernel(const G1Jac *__restrict__ tmp, Fq *__restrict__ prefix, G1Affine *__restrict__ out,
+                                                             uint32_t n) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t lo = r * NORM_RUN;
+    if (lo >= n) return;
+    uint32_t hi = lo + NORM_RUN < n ? lo + NORM_RUN : n;
+    Fq acc = Fq::one();
+    for (uint32_t i = lo; i < hi; ++i) {
+        prefix[i] = acc;
+        Fq z = tmp[i].z;
+        if (!z.is_zero()) acc = fe_mul(acc, z);
+    }
+    acc = fe_inv(acc);
+    for (uint32_t i = hi; i-- > lo;) {
+        G1Jac p = tmp[i];
+        G1Affine a;
+        if (p.z.is_zero()) {
+            a.x = Fq::zero();
+            a.y = Fq::zero();
+        } else {
+            Fq zi = fe_mul(acc, prefix[i]);
+            acc = fe_mul(acc, p.z);
+            Fq zi2 = fe_sqr(zi);
+            a.x = fe_mul(p.x, zi2);
+            a.y = fe_mul(p.y, fe_mul(zi2, zi));
+        }
+        out[i] = a;
+    }
+}
+
 static uint32_t pick_window(size_t n) {
     uint32_t best = 4;
     double best_cost = 1e300;
-    for (uint32_t c = 4; c <= 20; ++c) {
+    for (uint32_t c = 4; c <= 16; ++c) {
         double W = (double)((255 + c - 1) / c);
         double cost = W * (10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + 400.0 * c);
         if (cost < best_cost) {
@@ -275,6 +435,45 @@ static uint32_t pick_window(size_t n) {
     return best;
 }
 
+// builds levels 1..W-1 of a precomputed table in place (level 0 = the uploaded bases)
+int msm_build_table(h2hip_ctx *ctx, h2hip_bases *b) {
+    const uint32_t c = ctx->msm_window_bits ? (uint32_t)ctx->msm_window_bits : pick_window(b->n);
+    H2_REQUIRE(c >= 2 && c <= 16, "window bits out of range for precomputed bases");
+    const uint32_t W = (255 + c - 1) / c;
+    H2_REQUIRE((uint64_t)b->n * W < (1ull << 31), "precomputed table too large for 31-bit indices");
+    G1Affine *table = nullptr;
+    hipError_t e = hipMalloc((void **)&table, sizeof(G1Affine) * b->n * W);
+    if (e != hipSuccess) {
+        set_error("hipMalloc for precomputed table (%zu points x %u windows) failed: %s", b->n, W, hipGetErrorString(e));
+        return H2HIP_ERR_NOMEM;
+    }
+    H2_HIPCHK(hipMemcpyAsync(table, b->pts, sizeof(G1Affine) * b->n, hipMemcpyDeviceToDevice, ctx->stream));
+    G1Jac *tmp = nullptr;
+    Fq *prefix = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP1, sizeof(G1Jac) * b->n, (void **)&tmp));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, sizeof(Fq) * b->n, (void **)&prefix));
+    const uint32_t n = (uint32_t)b->n;
+    for (uint32_t w = 1; w < W; ++w) {
+        prof_begin(ctx, "table_double_kernel");
+        hipLaunchKernelGGL(table_double_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const G1Affine *)(table + (size_t)(w - 1) * n),
+                           tmp, n, c);
+        prof_end(ctx);
+        uint32_t runs = (n + NORM_RUN - 1) / NORM_RUN;
+        prof_begin(ctx, "table_normalize_kernel");
+        hipLaunchKernelGGL(table_normalize_kernel, dim3((runs + 63) / 64), dim3(64), 0, ctx->stream, (const G1Jac *)tmp, prefix,
+                           table + (size_t)w * n, n);
+        prof_end(ctx);
+        H2_HIPCHK(hipGetLastError());
+    }
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    H2_HIPCHK(hipFree(b->pts));
+    b->pts = table;
+    b->tables = W;
+    b->window_bits = c;
+    return H2HIP_OK;
+}
+
+// ------------------------------------------------------------------ host driver
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(n < (1u << 27), "n too large for 32-bit entry indices");
@@ -285,82 +484,94 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     }
     const bool precomp = bases->tables > 1;
     const uint32_t c = precomp ? bases->window_bits : (ctx->msm_window_bits ? (uint32_t)ctx->msm_window_bits : pick_window(n));
-    H2_REQUIRE(c >= 2 && c <= 23, "window bits out of range");
+    H2_REQUIRE(c >= 2 && c <= 16, "window bits must be 2..16 (a window's bucket histogram lives in LDS)");
     const uint32_t W = (255 + c - 1) / c;
+    H2_REQUIRE(W <= 64, "too many windows");
     H2_REQUIRE(!precomp || bases->tables >= W, "precomputed table has too few windows");
-    H2_REQUIRE(!precomp || n == bases->n, "precomputed bases require n == table size");
     const uint32_t B = 1u << (c - 1);
-    const uint32_t Wr = precomp ? 1 : W;            // windows present in the bucket array
-    const uint32_t nkeys = Wr * B;
-    const uint32_t kpw = precomp ? 0 : B;           // key stride per window
+    const uint32_t nkeys = W * B;
     const uint64_t emax = (uint64_t)n * W;
     H2_REQUIRE(emax < 0xFFFFFFF0ull, "n*W overflows 32 bits");
-    const uint32_t K1 = (uint32_t)ctx->msm_chunk, K2 = (uint32_t)ctx->msm_chunk2;
+    const uint32_t K1 = (uint32_t)ctx->msm_chunk;
     uint32_t L = (uint32_t)ctx->msm_seg;
     if (L > B) L = B;
+    // chunking of the counting sort: about 32 chunks per window, 4Ki..64Ki scalars each
+    uint32_t chunk = (uint32_t)((n + 31) / 32);
+    if (chunk < 4096) chunk = 4096;
+    if (chunk > 65536) chunk = 65536;
+    const uint32_t G = (uint32_t)((n + chunk - 1) / chunk);
+    const uint32_t sort_grid = 8 * G * ((W + 7) / 8);
 
-    uint32_t *digits, *counts, *offsets, *cursor, *skey, *sval, *pkey[2];
-    XYZZ *buckets, *pval[2], *seg, *win;
+    uint32_t *digits, *bhist, *counts, *offsets, *sval, *pkey[2];
+    XYZZ *buckets, *pval[2], *seg, *win, *presum = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_DIGITS, sizeof(uint32_t) * emax, (void **)&digits));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * (nkeys + 1), (void **)&counts));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * (nkeys + 1), (void **)&offsets));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * nkeys, (void **)&cursor));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SKEY, sizeof(uint32_t) * emax, (void **)&skey));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * (nkeys + 2), (void **)&offsets));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SVAL, sizeof(uint32_t) * emax, (void **)&sval));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(XYZZ) * nkeys, (void **)&buckets));
     const uint32_t T1 = (uint32_t)((emax + K1 - 1) / K1);
-    const uint32_t T2 = (2 * T1 + K2 - 1) / K2;
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY0, sizeof(uint32_t) * 2 * (size_t)T1, (void **)&pkey[0]));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL0, sizeof(XYZZ) * 2 * (size_t)T1, (void **)&pval[0]));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY1, sizeof(uint32_t) * 2 * (size_t)T2, (void **)&pkey[1]));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ) * 2 * (size_t)T2, (void **)&pval[1]));
+    const uint32_t len1 = 2 * T1, blocks1 = (len1 + 255) / 256;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY0, sizeof(uint32_t) * (size_t)len1, (void **)&pkey[0]));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL0, sizeof(XYZZ) * (size_t)len1, (void **)&pval[0]));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY1, sizeof(uint32_t) * 2 * (size_t)blocks1, (void **)&pkey[1]));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ) * 2 * (size_t)blocks1, (void **)&pval[1]));
+    const uint32_t Wr = precomp ? 1 : W;   // windows left after the optional per-index presum
     const uint32_t nseg = Wr * (B / L);
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(XYZZ) * nseg, (void **)&seg));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(XYZZ) * 64, (void **)&win));
-    H2_REQUIRE(Wr <= 64, "too many windows");
+    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ) * B, (void **)&presum));
 
-    H2_HIPCHK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * (nkeys + 1), st));
-    H2_HIPCHK(hipMemsetAsync(cursor, 0, sizeof(uint32_t) * nkeys, st));
+    H2_HIPCHK(hipMemsetAsync(counts + nkeys, 0, sizeof(uint32_t), st));
+    H2_HIPCHK(hipMemsetAsync(offsets + nkeys + 1, 0xff, sizeof(uint32_t), st));   // sentinel read by the boundary walk
     H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ) * nkeys, st));
 
     prof_begin(ctx, "msm_digits_kernel");
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, scalars, (uint32_t)n, c, W, digits, counts, kpw);
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, scalars, (uint32_t)n, c, W, digits);
+    prof_end(ctx);
+    prof_begin(ctx, "msm_hist_kernel");
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(1024), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
+    prof_end(ctx);
+    prof_begin(ctx, "msm_hist_scan_kernel");
+    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, bhist, W, B, G, counts);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     H2_CHK(exclusive_scan_u32(ctx, counts, offsets, nkeys + 1));
     prof_begin(ctx, "msm_scatter_kernel");
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3((uint32_t)((emax + 255) / 256)), dim3(256), 0, st, (const uint32_t *)digits, (uint32_t)n, W,
-                       kpw, precomp ? 1u : 0u, (const uint32_t *)offsets, cursor, skey, sval);
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(sort_grid), dim3(1024), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk,
+                       precomp ? (uint32_t)bases->n : 0u, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
 
-    // level 1 over the sorted entries (true count lives on the device: offsets[nkeys])
-    prof_begin(ctx, "msm_accum_kernel<affine>");
-    hipLaunchKernelGGL(msm_accum_kernel<true>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)skey, (const void *)sval,
-                       (const G1Affine *)bases->pts, (const uint32_t *)(offsets + nkeys), 0u, K1, buckets, pkey[0], pval[0], T1, 0u);
+    prof_begin(ctx, "msm_accum_kernel");
+    hipLaunchKernelGGL(msm_accum_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts,
+                       (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    uint32_t len = 2 * T1;
+    uint32_t len = len1;
     int src = 0;
-    while (len > K2) {
-        uint32_t T = (len + K2 - 1) / K2;
-        prof_begin(ctx, "msm_accum_kernel<xyzz>");
-        hipLaunchKernelGGL(msm_accum_kernel<false>, dim3((T + 255) / 256), dim3(256), 0, st, (const uint32_t *)pkey[src],
-                           (const void *)pval[src], (const G1Affine *)nullptr, (const uint32_t *)nullptr, len, K2, buckets, pkey[src ^ 1],
-                           pval[src ^ 1], T, 0u);
+    for (;;) {
+        const uint32_t blocks = (len + 255) / 256;
+        const uint32_t final_level = blocks == 1 ? 1u : 0u;
+        prof_begin(ctx, "msm_merge_kernel");
+        hipLaunchKernelGGL(msm_merge_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *)pkey[src], (const XYZZ *)pval[src], len, buckets,
+                           pkey[src ^ 1], pval[src ^ 1], final_level);
         prof_end(ctx);
         H2_HIPCHK(hipGetLastError());
-        len = 2 * T;
+        if (final_level) break;
+        len = 2 * blocks;
         src ^= 1;
     }
-    prof_begin(ctx, "msm_accum_kernel<xyzz>");
-    hipLaunchKernelGGL(msm_accum_kernel<false>, dim3(1), dim3(64), 0, st, (const uint32_t *)pkey[src], (const void *)pval[src],
-                       (const G1Affine *)nullptr, (const uint32_t *)nullptr, len, len, buckets, pkey[src ^ 1], pval[src ^ 1], 1u, 1u);
-    prof_end(ctx);
-    H2_HIPCHK(hipGetLastError());
 
+    const XYZZ *red_in = buckets;
+    if (precomp) {
+        prof_begin(ctx, "msm_presum_kernel");
+        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const XYZZ *)buckets, presum, B, W);
+        prof_end(ctx);
+        red_in = presum;
+    }
     prof_begin(ctx, "msm_seg_kernel");
-    hipLaunchKernelGGL(msm_seg_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, (const XYZZ *)buckets, seg, B, L, nseg);
+    hipLaunchKernelGGL(msm_seg_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, red_in, seg, B, L, nseg);
     prof_end(ctx);
     prof_begin(ctx, "msm_winsum_kernel");
     hipLaunchKernelGGL(msm_winsum_kernel, dim3(Wr), dim3(256), 0, st, (const XYZZ *)seg, win, B / L);

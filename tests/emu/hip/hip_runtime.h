@@ -45,6 +45,8 @@ struct Worker {
     int cur = 0;
     std::function<void()> body;
     std::vector<char> dyn_smem;
+    std::vector<int> or_calls;
+    int or_val[3] = {0, 0, 0};
     ~Worker() { for (char *p : stacks) free(p); }
 };
 inline thread_local Worker *t_worker = nullptr;
@@ -71,6 +73,8 @@ inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
         makecontext(&w.ctx[i], (void (*)())fiber_entry, 0);
         w.done[i] = 0;
     }
+    w.or_calls.assign(nthreads, 0);
+    w.or_val[0] = w.or_val[1] = w.or_val[2] = 0;
     unsigned remaining = nthreads;
     while (remaining) {
         for (unsigned i = 0; i < nthreads; ++i) {
@@ -96,6 +100,15 @@ inline void syncthreads() {
 #define blockDim (hipemu::t_blockDim)
 #define gridDim (hipemu::t_gridDim)
 inline void __syncthreads() { hipemu::syncthreads(); }
+inline int __syncthreads_or(int pred) {
+    hipemu::Worker *w = hipemu::t_worker;
+    int k = w->or_calls[w->cur]++;
+    w->or_val[k % 3] |= (pred != 0);
+    hipemu::syncthreads();
+    int r = w->or_val[k % 3];
+    w->or_val[(k + 2) % 3] = 0;
+    return r;
+}
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 template <class T> inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

@@ -109,3 +109,42 @@ def test_fr_batches(ctx):
     assert np.array_equal(ctx.fr_add(a, b), CO.fr_add(a, b))
     assert np.array_equal(ctx.fr_sub(a, b), CO.fr_sub(a, b))
     assert np.array_equal(ctx.fr_mul_add(a, b, c), CO.fr_add(CO.fr_mul(a, b), c))
+
+
+def test_msm_multi_chunk_sort_and_deep_merge(ctx):
+    # n > 4096 gives several counting-sort chunks per window (G > 1); msm_chunk=2 makes the partial list long
+    # enough for three merge levels; the skewed half produces runs that span many workgroups.
+    n = 9000
+    bases = CO.known_dlog_bases(n, fr([11]), fr([7]))
+    s = np.concatenate([rand_fr(n // 2, 5), circuit_like_fr(n - n // 2, 6)])
+    b = ctx.bases_upload(bases)
+    ctx.set_param("msm_window_bits", 12)
+    ctx.set_param("msm_chunk", 2)
+    try:
+        assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=8))
+    finally:
+        ctx.set_param("msm_window_bits", 0)
+        ctx.set_param("msm_chunk", 32)
+        b.free()
+
+
+@pytest.mark.parametrize("c", [0, 5, 11])
+def test_msm_precomputed_bases(ctx, c):
+    # H2HIP_BASES_PRECOMPUTE: table of 2^(c*w) multiples, shared bucket set, no window fold
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    n = 700
+    P = O.g1_mul(O.G1_GEN, 99)
+    pts = O.limbs_to_points(CO.known_dlog_bases(n - 3, fr([3]), fr([9]))) + [None, P, P]   # identity + duplicate bases
+    bases = O.points_to_limbs(pts)
+    ctx.set_param("msm_window_bits", c)
+    try:
+        b = ctx.bases_upload(bases, BASES_PRECOMPUTE)
+        for s in (rand_fr(n, c), circuit_like_fr(n, c + 1)):
+            assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=4))
+        # a prefix of the table still works (n < table size)
+        s = rand_fr(100, 3)
+        assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases[:100], threads=2))
+        b.free()
+    finally:
+        ctx.set_param("msm_window_bits", 0)

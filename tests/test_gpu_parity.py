@@ -125,3 +125,32 @@ def test_fr_batches(ctx):
     assert np.array_equal(ctx.fr_add(a, b), CO.fr_add(a, b))
     assert np.array_equal(ctx.fr_sub(a, b), CO.fr_sub(a, b))
     assert np.array_equal(ctx.fr_mul_add(a, b, c), CO.fr_add(CO.fr_mul(a, b), c))
+
+
+@pytest.mark.parametrize("n", [700, 1 << 16])
+def test_msm_precomputed_bases(ctx, n):
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    P = O.g1_mul(O.G1_GEN, 99)
+    pts = CO.known_dlog_bases(n - 3, fr([3]), fr([9]))
+    bases = np.concatenate([pts, O.points_to_limbs([None, P, P])])
+    b = ctx.bases_upload(bases, BASES_PRECOMPUTE)
+    for s in (rand_fr(n, 1), circuit_like_fr(n, 2)):
+        assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=NT))
+    s = rand_fr(100, 3)
+    assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases[:100], threads=2))
+    b.free()
+
+
+def test_msm_2_20_precomputed_closed_form(ctx):
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    n, k0, d = 1 << 20, 123456789, 17
+    bases = CO.known_dlog_bases(n, fr([k0]), fr([d]))
+    b = ctx.bases_upload(bases, BASES_PRECOMPUTE)
+    for seed, s in ((1, rand_fr(n, 11)), (2, circuit_like_fr(n, 12))):
+        got = ctx.msm(b, s, H.POINT_AFFINE)
+        si = O.limbs_to_ints(s, R)
+        total = sum(v * (k0 + i * d) for i, v in enumerate(si)) % R
+        assert O.limbs_to_points(got) == [O.g1_mul(O.G1_GEN, total)]
+    b.free()

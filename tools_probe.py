@@ -33,18 +33,19 @@ for log_n in (16, 19, 20, 22):
     for _ in range(5): ctx.best_fft_dev(d, w, log_n)
     res[f"ntt_{log_n}_ms"] = ctx.timer_stop() / 5
     ctx.free(d)
-for kind in ("uniform", "circuit"):
+for kind in ("uniform", "circuit", "uniform_pre", "circuit_pre"):
     for log_n in (16, 18, 20):
         n = 1 << log_n
         t = time.time(); bases = CO.known_dlog_bases(n, fr([5]), fr([3])); tb = time.time() - t
-        s = rand_fr(n, 1) if kind == "uniform" else circuit_like_fr(n, 1)
-        b = ctx.bases_upload(bases); ds = ctx.to_device(s)
+        s = rand_fr(n, 1) if kind.startswith("uniform") else circuit_like_fr(n, 1)
+        t = time.time(); b = ctx.bases_upload(bases, 1 if kind.endswith("_pre") else 0); res[f"upload_{kind}_{log_n}_s"] = time.time() - t
+        ds = ctx.to_device(s)
         ctx.msm_dev(b, ds, n)
         ctx.profile_reset()
         ctx.timer_start()
         for _ in range(3): ctx.msm_dev(b, ds, n)
         res[f"msm_{kind}_{log_n}_ms"] = ctx.timer_stop() / 3
-        for name in ("msm_digits", "scan", "msm_scatter", "msm_accum_kernel<affine>", "msm_accum_kernel<xyzz>", "msm_seg", "msm_winsum", "msm_fold", "point_finish"):
+        for name in ("msm_digits", "msm_hist_kernel", "msm_hist_scan", "scan_kernels", "msm_scatter", "msm_accum_kernel", "msm_merge", "msm_presum", "msm_seg", "msm_winsum", "msm_fold", "point_finish"):
             ms, cnt = ctx.profile_get(name)
             res[f"msm_{kind}_{log_n}_{name}_ms_per_msm"] = ms / 3
         ctx.free(ds); b.free()
