@@ -46,6 +46,283 @@ __global__ __launch_bounds__(256) void modmul_bench_kernel(Fr *__restrict__ io, 
     io[i] = acc;
 }
 
+
+// ------------------------------------------------------------------ K4: BatchInvert (0 -> 0)
+// Montgomery's trick over strided runs: lane t owns a[t], a[t+T], a[t+2T], ... (coalesced), one Fermat
+// inversion per lane.  [UPSTREAM ff::BatchInvert / halo2 batch_invert_assigned; denominators come from
+// reference halo2-base/src/gates/flex_gate/mod.rs:677-681,791-795]
+__global__ __launch_bounds__(256) void fr_batch_invert_kernel(Fr *__restrict__ a, Fr *__restrict__ scratch, size_t n) {
+    const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Fr acc = Fr::one();
+    size_t last = t;
+    for (size_t i = t; i < n; i += T) {
+        Fr v = a[i];
+        scratch[i] = acc;
+        if (!v.is_zero()) acc = fe_mul(acc, v);
+        last = i;
+    }
+    Fr inv = fe_inv(acc);
+    for (size_t i = last;; i -= T) {
+        Fr v = a[i];
+        if (!v.is_zero()) {
+            a[i] = fe_mul(inv, scratch[i]);
+            inv = fe_mul(inv, v);
+        }
+        if (i < T) break;
+    }
+}
+
+// ------------------------------------------------------------------ K5: prefix product (grand product core)
+// inclusive prefix product over tiles of 256 lanes x SCAN_J consecutive elements
+constexpr uint32_t SCAN_J = 8;
+__global__ __launch_bounds__(256) void fr_prefix_prod_tile_kernel(const Fr *__restrict__ in, Fr *__restrict__ out, Fr *__restrict__ tile_prod,
+                                                                  size_t n) {
+    __shared__ Fr sh[256];
+    const uint32_t tid = threadIdx.x;
+    const size_t base = ((size_t)blockIdx.x * 256 + tid) * SCAN_J;
+    Fr acc = Fr::one();
+    for (uint32_t k = 0; k < SCAN_J; ++k)
+        if (base + k < n) acc = fe_mul(acc, in[base + k]);
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        Fr o = Fr::one();
+        if (tid >= d) o = sh[tid - d];
+        __syncthreads();
+        if (tid >= d) sh[tid] = fe_mul(sh[tid], o);
+        __syncthreads();
+    }
+    Fr run = tid ? sh[tid - 1] : Fr::one();   // exclusive prefix of this lane inside the tile
+    for (uint32_t k = 0; k < SCAN_J; ++k)
+        if (base + k < n) {
+            run = fe_mul(run, in[base + k]);
+            out[base + k] = run;
+        }
+    if (tid == 255) tile_prod[blockIdx.x] = sh[255];
+}
+// exclusive prefix product of the tile totals, one workgroup (tiles <= 1024 * per)
+__global__ __launch_bounds__(1024) void fr_prefix_prod_sums_kernel(Fr *__restrict__ tile_prod, uint32_t ntiles) {
+    __shared__ Fr sh[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (ntiles + 1023) / 1024, lo = tid * per, hi = lo + per < ntiles ? lo + per : ntiles;
+    Fr acc = Fr::one();
+    for (uint32_t k = lo; k < hi; ++k) acc = fe_mul(acc, tile_prod[k]);
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        Fr o = Fr::one();
+        if (tid >= d) o = sh[tid - d];
+        __syncthreads();
+        if (tid >= d) sh[tid] = fe_mul(sh[tid], o);
+        __syncthreads();
+    }
+    Fr run = tid ? sh[tid - 1] : Fr::one();
+    for (uint32_t k = lo; k < hi; ++k) {
+        Fr t = tile_prod[k];
+        tile_prod[k] = run;
+        run = fe_mul(run, t);
+    }
+}
+__global__ __launch_bounds__(256) void fr_prefix_prod_apply_kernel(Fr *__restrict__ out, const Fr *__restrict__ tile_excl, size_t n) {
+    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_J;
+    if (blockIdx.x == 0) return;
+    Fr m = tile_excl[blockIdx.x];
+    for (uint32_t k = 0; k < SCAN_J; ++k)
+        if (base + k < n) out[base + k] = fe_mul(out[base + k], m);
+}
+// z[0] = 1 (written by the host wrapper), t[i] = num[i] * den_inv[i]
+__global__ __launch_bounds__(256) void fr_set_one_kernel(Fr *__restrict__ z) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) z[0] = Fr::one();
+}
+
+// ------------------------------------------------------------------ K7: eval_polynomial / kate_division
+struct PowTable {
+    Fr p[24];
+};
+// stage 1: each workgroup evaluates its 256*EVAL_J coefficients relative to its first one:
+// lane Horner over EVAL_J coefficients, then a tree with x^(EVAL_J * 2^l)
+constexpr uint32_t EVAL_J = 8;
+__global__ __launch_bounds__(256) void fr_eval_tile_kernel(const Fr *__restrict__ coeffs, size_t n, Fr x, PowTable pw, Fr *__restrict__ tile_val) {
+    __shared__ Fr sh[256];
+    const uint32_t tid = threadIdx.x;
+    const size_t base = ((size_t)blockIdx.x * 256 + tid) * EVAL_J;
+    Fr acc = Fr::zero();
+    for (int k = EVAL_J - 1; k >= 0; --k) {
+        acc = fe_mul(acc, x);
+        if (base + k < n) acc = fe_add(acc, coeffs[base + k]);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t d = 1, l = 0; d < 256; d <<= 1, ++l) {
+        if ((tid & (2 * d - 1)) == 0) sh[tid] = fe_add(sh[tid], fe_mul(sh[tid + d], pw.p[l]));   // p[l] = x^(EVAL_J*2^l)
+        __syncthreads();
+    }
+    if (tid == 0) tile_val[blockIdx.x] = sh[0];
+}
+// stage 2: one workgroup combines the tile values: sum_b tile_val[b] * X^b with X = x^(256*EVAL_J) = pw.p[8]
+__global__ __launch_bounds__(256) void fr_eval_final_kernel(const Fr *__restrict__ tile_val, uint32_t ntiles, PowTable pw, Fr *__restrict__ out) {
+    __shared__ Fr sh[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (ntiles + 255) / 256, lo = tid * per;
+    const Fr X = pw.p[8];
+    Fr acc = Fr::zero();
+    for (int k = (int)per - 1; k >= 0; --k) {
+        acc = fe_mul(acc, X);
+        if (lo + k < ntiles) acc = fe_add(acc, tile_val[lo + k]);
+    }
+    // lane value must be scaled by X^(per*tid): tree with Y^(2^l), Y = X^per
+    sh[tid] = acc;
+    __syncthreads();
+    Fr Y = fe_pow_u64(X, per);
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        if ((tid & (2 * d - 1)) == 0) sh[tid] = fe_add(sh[tid], fe_mul(sh[tid + d], Y));
+        Y = fe_sqr(Y);
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = sh[0];
+}
+
+// kate_division: q[m] = sum_{j>m} c_j b^(j-m-1), m = 0..n-2  (suffix Horner).  Stage 1 computes every
+// workgroup's head H = sum_{j in tile} c_j b^(j-lo); stage 2 turns heads into carries
+// carry[blk] = sum_{blk'>blk} H[blk'] * (b^TILE)^(blk'-blk-1); stage 3 replays the tile with its carry.
+constexpr uint32_t KATE_J = 8, KATE_TILE = 256 * KATE_J;
+__device__ __forceinline__ Fr kate_tile_scan(const Fr *__restrict__ c, size_t n, size_t lo, Fr b, const PowTable &pw, Fr *sh, Fr carry_in,
+                                             Fr *__restrict__ q) {
+    // returns the tile head; when q != nullptr also writes the quotient coefficients of this tile
+    const uint32_t tid = threadIdx.x;
+    const size_t base = lo + (size_t)tid * KATE_J;
+    Fr h = Fr::zero();
+    for (int k = KATE_J - 1; k >= 0; --k) {
+        h = fe_mul(h, b);
+        if (base + k < n) h = fe_add(h, c[base + k]);
+    }
+    sh[tid] = h;
+    __syncthreads();
+    // inclusive suffix scan: I_t = h_t + b^J * I_{t+1}
+    for (uint32_t d = 1, l = 0; d < 256; d <<= 1, ++l) {
+        Fr o = Fr::zero();
+        if (tid + d < 256) o = sh[tid + d];
+        __syncthreads();
+        if (tid + d < 256) sh[tid] = fe_add(sh[tid], fe_mul(o, pw.p[l]));   // p[l] = b^(J*2^l)
+        __syncthreads();
+    }
+    Fr head = sh[0];
+    if (q) {
+        // carry into this lane = I_{t+1} + b^(J*(255-t)) * carry_in
+        Fr car = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
+        car = fe_add(car, fe_mul(fe_pow_u64(pw.p[0], 255 - tid), carry_in));
+        Fr tmp = car;
+        for (int k = KATE_J - 1; k >= 0; --k) {
+            if (base + k < n) {
+                tmp = fe_add(c[base + k], fe_mul(tmp, b));
+                if (base + k >= 1) q[base + k - 1] = tmp;
+            }
+        }
+    }
+    return head;
+}
+__global__ __launch_bounds__(256) void fr_kate_heads_kernel(const Fr *__restrict__ c, size_t n, Fr b, PowTable pw, Fr *__restrict__ heads) {
+    __shared__ Fr sh[256];
+    Fr h = kate_tile_scan(c, n, (size_t)blockIdx.x * KATE_TILE, b, pw, sh, Fr::zero(), nullptr);
+    if (threadIdx.x == 0) heads[blockIdx.x] = h;
+}
+// carry[blk] = sum_{blk'>blk} H[blk'] * B^(blk'-blk-1), B = b^TILE = pw.p[8]: one workgroup, lane-serial runs of
+// `per` tiles + a suffix scan across lanes
+__global__ __launch_bounds__(256) void fr_kate_carry_kernel(const Fr *__restrict__ heads, Fr *__restrict__ carry, uint32_t ntiles, PowTable pw) {
+    __shared__ Fr sh[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (ntiles + 255) / 256, lo = tid * per;
+    const Fr B = pw.p[8];
+    Fr h = Fr::zero();
+    for (int k = (int)per - 1; k >= 0; --k) {
+        h = fe_mul(h, B);
+        if (lo + k < ntiles) h = fe_add(h, heads[lo + k]);
+    }
+    sh[tid] = h;
+    __syncthreads();
+    Fr Y = fe_pow_u64(B, per);
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        Fr o = Fr::zero();
+        if (tid + d < 256) o = sh[tid + d];
+        __syncthreads();
+        if (tid + d < 256) sh[tid] = fe_add(sh[tid], fe_mul(o, Y));
+        Y = fe_sqr(Y);
+        __syncthreads();
+    }
+    Fr car = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
+    for (int k = (int)per - 1; k >= 0; --k) {
+        if (lo + k < ntiles) {
+            carry[lo + k] = car;
+            car = fe_add(heads[lo + k], fe_mul(car, B));
+        }
+    }
+}
+__global__ __launch_bounds__(256) void fr_kate_apply_kernel(const Fr *__restrict__ c, size_t n, Fr b, PowTable pw, const Fr *__restrict__ carry,
+                                                            Fr *__restrict__ q) {
+    __shared__ Fr sh[256];
+    kate_tile_scan(c, n, (size_t)blockIdx.x * KATE_TILE, b, pw, sh, carry[blockIdx.x], q);
+}
+
+// ------------------------------------------------------------------ K8: Poseidon permutation batches
+// One lane per instance, textbook rounds (ARK, x^5, MDS) with the caller's spec — algebraically equal to
+// halo2-base's optimised PoseidonState::permutation (reference halo2-base/src/poseidon/hasher/state.rs:35-83,
+// absorb rule :124-160: inputs added to s[1..], a padding 1 after the last input when fewer than RATE).
+template <int T>
+__global__ __launch_bounds__(256) void poseidon_permute_kernel(Fr *__restrict__ states, const Fr *__restrict__ inputs, uint32_t num_inputs,
+                                                               size_t n, const Fr *__restrict__ rc, const Fr *__restrict__ mds, uint32_t r_f,
+                                                               uint32_t r_p) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) s[k] = states[i * T + k];
+#pragma unroll
+    for (int k = 0; k < T - 1; ++k) {
+        if ((uint32_t)k < num_inputs) s[k + 1] = fe_add(s[k + 1], inputs[i * num_inputs + k]);
+        else if ((uint32_t)k == num_inputs) s[k + 1] = fe_add(s[k + 1], Fr::one());
+    }
+    const uint32_t half = r_f / 2;
+    for (uint32_t r = 0; r < r_f + r_p; ++r) {
+        const bool full = r < half || r >= half + r_p;
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            Fr v = fe_add(s[k], rc[r * T + k]);
+            if (full || k == 0) {
+                Fr v2 = fe_sqr(v);
+                v = fe_mul(v, fe_sqr(v2));
+            }
+            s[k] = v;
+        }
+        Fr o[T];
+#pragma unroll
+        for (int a = 0; a < T; ++a) {
+            Fr acc = fe_mul(mds[a * T], s[0]);
+#pragma unroll
+            for (int b = 1; b < T; ++b) acc = fe_add(acc, fe_mul(mds[a * T + b], s[b]));
+            o[a] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < T; ++k) s[k] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < T; ++k) states[i * T + k] = s[k];
+}
+
+// ------------------------------------------------------------------ K6: halo2-base gate term of the quotient
+// acc[i] = acc[i]*y + q[i] * (a[i] + a[i+s]*a[i+2s] - a[i+3s])  on the extended domain (indices mod n_ext,
+// s = 2^(ext_k-k) = one row): the single custom gate of halo2-base, q*(a + b*c - d) at rotations 0..3
+// (reference halo2-base/src/gates/flex_gate/mod.rs:80-91), folded into h's numerator by powers of y.
+__global__ __launch_bounds__(256) void quotient_flex_gate_kernel(Fr *__restrict__ acc, const Fr *__restrict__ q, const Fr *__restrict__ a,
+                                                                 size_t n_ext, uint32_t rot_step, Fr y) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = n_ext - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ext; i += stride) {
+        Fr a0 = a[i], a1 = a[(i + rot_step) & mask], a2 = a[(i + 2 * (size_t)rot_step) & mask], a3 = a[(i + 3 * (size_t)rot_step) & mask];
+        Fr g = fe_mul(q[i], fe_sub(fe_add(a0, fe_mul(a1, a2)), a3));
+        acc[i] = fe_add(fe_mul(acc[i], y), g);
+    }
+}
+
 static uint32_t grid_for(h2hip_ctx *ctx, size_t n) {
     size_t blocks = (n + 255) / 256, cap = (size_t)ctx->num_cus * 8;
     if (blocks > cap) blocks = cap;
@@ -79,6 +356,158 @@ int h2hip_fr_mul_add_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const v
     prof_begin(ctx, "fr_mul_add_kernel");
     hipLaunchKernelGGL(fr_mul_add_kernel, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (Fr *)out, (const Fr *)a, (const Fr *)b,
                        (const Fr *)c, n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+
+// ------------------------------------------------------------------ K4 / K5
+int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a, size_t n) {
+    H2_REQUIRE(ctx && (n == 0 || a), "NULL argument");
+    if (!n) return H2HIP_OK;
+    Fr *scratch = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP1, sizeof(Fr) * n, (void **)&scratch));
+    size_t lanes = (n + 31) / 32;   // ~32 elements per lane
+    uint32_t blocks = (uint32_t)((lanes + 255) / 256);
+    prof_begin(ctx, "fr_batch_invert_kernel");
+    hipLaunchKernelGGL(fr_batch_invert_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (Fr *)a, scratch, n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+static int prefix_product_inplace(h2hip_ctx *ctx, const Fr *in, Fr *out, size_t n) {
+    const uint32_t tile = 256 * SCAN_J;
+    uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
+    Fr *tp = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, sizeof(Fr) * (ntiles + 1), (void **)&tp));
+    prof_begin(ctx, "fr_prefix_prod_kernels");
+    hipLaunchKernelGGL(fr_prefix_prod_tile_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, in, out, tp, n);
+    hipLaunchKernelGGL(fr_prefix_prod_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, tp, ntiles);
+    hipLaunchKernelGGL(fr_prefix_prod_apply_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, out, (const Fr *)tp, n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+int h2hip_fr_prefix_product_dev(h2hip_ctx *ctx, void *out, const void *in, size_t n) {
+    H2_REQUIRE(ctx && (n == 0 || (out && in)), "NULL argument");
+    if (!n) return H2HIP_OK;
+    return prefix_product_inplace(ctx, (const Fr *)in, (Fr *)out, n);
+}
+// z[0] = 1, z[i+1] = z[i] * num[i] / den[i], i < n  (z has n+1 elements; 0 denominators count as 0^-1 := 0)
+int h2hip_fr_grand_product_dev(h2hip_ctx *ctx, void *z, const void *num, const void *den, size_t n) {
+    H2_REQUIRE(ctx && z && (n == 0 || (num && den)), "NULL argument");
+    Fr *zz = (Fr *)z;
+    hipLaunchKernelGGL(fr_set_one_kernel, dim3(1), dim3(64), 0, ctx->stream, zz);
+    if (!n) return H2HIP_OK;
+    Fr *t = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(Fr) * n, (void **)&t));
+    H2_HIPCHK(hipMemcpyAsync(t, den, sizeof(Fr) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    H2_CHK(h2hip_fr_batch_invert_dev(ctx, t, n));
+    H2_CHK(binop(ctx, OP_MUL, t, t, num, n));
+    return prefix_product_inplace(ctx, t, zz + 1, n);
+}
+
+// ------------------------------------------------------------------ K7
+static void pow_table(const Fr &x, uint32_t j, PowTable &pw) {
+    // p[l] = x^(j*2^l) for l = 0..23
+    Fr v = fe_pow_u64(x, j);
+    for (int l = 0; l < 24; ++l) {
+        pw.p[l] = v;
+        v = fe_sqr(v);
+    }
+}
+int h2hip_fr_eval_polynomial_dev(h2hip_ctx *ctx, const void *coeffs, size_t n, const void *x, void *out_host) {
+    H2_REQUIRE(ctx && out_host && x && (n == 0 || coeffs), "NULL argument");
+    Fr xv;
+    memcpy(&xv, x, sizeof(Fr));
+    const uint32_t tile = 256 * EVAL_J;
+    uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
+    if (!ntiles) ntiles = 1;
+    PowTable pw;
+    pow_table(xv, EVAL_J, pw);   // p[8] = x^(EVAL_J*256) = x^tile
+    Fr *tv = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, sizeof(Fr) * (ntiles + 1), (void **)&tv));
+    prof_begin(ctx, "fr_eval_kernels");
+    hipLaunchKernelGGL(fr_eval_tile_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, xv, pw, tv);
+    hipLaunchKernelGGL(fr_eval_final_kernel, dim3(1), dim3(256), 0, ctx->stream, (const Fr *)tv, ntiles, pw, tv + ntiles);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_HIPCHK(hipMemcpyAsync(out_host, tv + ntiles, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+// q[0..n-1) = (f(X) - f(b)) / (X - b)   [UPSTREAM arithmetic::kate_division]
+int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *b) {
+    H2_REQUIRE(ctx && b && n >= 1 && coeffs && (n == 1 || q), "bad argument");
+    H2_REQUIRE(q != coeffs, "q must not alias coeffs");
+    if (n == 1) return H2HIP_OK;
+    Fr bv;
+    memcpy(&bv, b, sizeof(Fr));
+    uint32_t ntiles = (uint32_t)((n + KATE_TILE - 1) / KATE_TILE);
+    PowTable pw;
+    pow_table(bv, KATE_J, pw);   // p[8] = b^KATE_TILE
+    Fr *heads = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, sizeof(Fr) * 2 * (ntiles + 1), (void **)&heads));
+    Fr *carry = heads + ntiles + 1;
+    prof_begin(ctx, "fr_kate_kernels");
+    hipLaunchKernelGGL(fr_kate_heads_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, bv, pw, heads);
+    hipLaunchKernelGGL(fr_kate_carry_kernel, dim3(1), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles, pw);
+    hipLaunchKernelGGL(fr_kate_apply_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, bv, pw, (const Fr *)carry, (Fr *)q);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+// ------------------------------------------------------------------ K8 Poseidon
+int h2hip_poseidon_set_spec(h2hip_ctx *ctx, uint32_t t, uint32_t r_f, uint32_t r_p, const void *round_constants, const void *mds) {
+    H2_REQUIRE(ctx && round_constants && mds, "NULL argument");
+    H2_REQUIRE(t == 3 || t == 5, "state width t must be 3 or 5");
+    H2_REQUIRE(r_f >= 2 && (r_f % 2) == 0 && r_f <= 16 && r_p <= 256, "round numbers out of range");
+    size_t nrc = (size_t)(r_f + r_p) * t, nm = (size_t)t * t;
+    Fr *buf = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_POSEIDON, sizeof(Fr) * (nrc + nm), (void **)&buf));
+    H2_HIPCHK(hipMemcpyAsync(buf, round_constants, sizeof(Fr) * nrc, hipMemcpyHostToDevice, ctx->stream));
+    H2_HIPCHK(hipMemcpyAsync(buf + nrc, mds, sizeof(Fr) * nm, hipMemcpyHostToDevice, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->pos_t = t;
+    ctx->pos_rf = r_f;
+    ctx->pos_rp = r_p;
+    return H2HIP_OK;
+}
+int h2hip_poseidon_permute_batch_dev(h2hip_ctx *ctx, void *states, const void *inputs, uint32_t num_inputs, size_t n) {
+    H2_REQUIRE(ctx && (n == 0 || states), "NULL argument");
+    H2_REQUIRE(ctx->pos_t != 0, "call h2hip_poseidon_set_spec first");
+    H2_REQUIRE(num_inputs < ctx->pos_t, "num_inputs must be <= RATE = t-1");
+    H2_REQUIRE(num_inputs == 0 || inputs || n == 0, "inputs is NULL");
+    if (!n) return H2HIP_OK;
+    const Fr *rc = (const Fr *)ctx->ws[h2hip_ctx::WS_POSEIDON].p;
+    const Fr *mds = rc + (size_t)(ctx->pos_rf + ctx->pos_rp) * ctx->pos_t;
+    dim3 g((uint32_t)((n + 255) / 256)), blk(256);
+    prof_begin(ctx, "poseidon_permute_kernel");
+    if (ctx->pos_t == 3)
+        hipLaunchKernelGGL(poseidon_permute_kernel<3>, g, blk, 0, ctx->stream, (Fr *)states, (const Fr *)inputs, num_inputs, n, rc, mds, ctx->pos_rf,
+                           ctx->pos_rp);
+    else
+        hipLaunchKernelGGL(poseidon_permute_kernel<5>, g, blk, 0, ctx->stream, (Fr *)states, (const Fr *)inputs, num_inputs, n, rc, mds, ctx->pos_rf,
+                           ctx->pos_rp);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+// ------------------------------------------------------------------ K6 (halo2-base gate term)
+int h2hip_quotient_flex_gate_dev(h2hip_ctx *ctx, void *acc, const void *q, const void *a, uint32_t ext_k, uint32_t k, const void *y) {
+    H2_REQUIRE(ctx && acc && q && a && y, "NULL argument");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    H2_REQUIRE(acc != a && acc != q, "acc must not alias an input");
+    Fr yv;
+    memcpy(&yv, y, sizeof(Fr));
+    size_t n_ext = (size_t)1 << ext_k;
+    prof_begin(ctx, "quotient_flex_gate_kernel");
+    hipLaunchKernelGGL(quotient_flex_gate_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)acc, (const Fr *)q, (const Fr *)a, n_ext,
+                       1u << (ext_k - k), yv);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;

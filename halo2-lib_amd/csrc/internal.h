@@ -65,15 +65,16 @@ struct h2hip_ctx {
     int num_cus = 256;
     // scratch
     enum { WS_NTT = 0, WS_DIGITS, WS_COUNTS, WS_OFFSETS, WS_CURSOR, WS_SKEY, WS_SVAL, WS_BUCKETS, WS_PKEY0, WS_PVAL0, WS_PKEY1,
-           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_COUNT };
+           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_POSEIDON, WS_COUNT };
     h2::DevBuf ws[WS_COUNT];
     std::vector<h2::TwiddleSet> twiddles;
     // tuning knobs (h2hip_set_param)
     int msm_window_bits = 0;   // 0 = auto
     int msm_chunk = 32;        // level-1 entries per lane
     int msm_chunk2 = 8;        // level>=2 entries per lane
-    int msm_seg = 8;           // buckets per running-sum segment
+    int msm_seg = 4;           // buckets per running-sum segment
     int ntt_tile_bits = 10;
+    uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]
     // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled
     bool profiling = false;
     std::map<std::string, h2::KernelStat> stats;

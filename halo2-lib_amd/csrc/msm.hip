@@ -317,12 +317,17 @@ __device__ __forceinline__ XYZZ xyzz_small_mul(const XYZZ &p, uint32_t k) {
     return r;
 }
 // precomputed bases: all windows carry weight 1, so fold them per bucket index first: out[b] = sum_w buckets[w][b]
-__global__ __launch_bounds__(64) void msm_presum_kernel(const XYZZ *__restrict__ buckets, XYZZ *__restrict__ out, uint32_t B, uint32_t W) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    XYZZ acc = buckets[b];
-    for (uint32_t w = 1; w < W; ++w) xyzz_add(acc, buckets[(size_t)w * B + b]);
-    out[b] = acc;
+// (rows = number of windows of `in`, summed in groups of `group`; launched twice: W -> ceil(W/4) -> 1 rows)
+__global__ __launch_bounds__(64) void msm_presum_kernel(const XYZZ *__restrict__ in, XYZZ *__restrict__ out, uint32_t B, uint32_t rows,
+                                                        uint32_t group) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t groups = (rows + group - 1) / group;
+    if (t >= B * groups) return;
+    uint32_t gi = t / B, b = t - gi * B;
+    uint32_t w0 = gi * group, w1 = w0 + group < rows ? w0 + group : rows;
+    XYZZ acc = in[(size_t)w0 * B + b];
+    for (uint32_t w = w0 + 1; w < w1; ++w) xyzz_add(acc, in[(size_t)w * B + b]);
+    out[(size_t)gi * B + b] = acc;
 }
 // one lane per segment of L buckets: sum_{b in seg} (b+1) * bucket[b]
 __global__ __launch_bounds__(64) void msm_seg_kernel(const XYZZ *__restrict__ buckets, XYZZ *__restrict__ seg_out, uint32_t B, uint32_t L,
@@ -340,14 +345,14 @@ __global__ __launch_bounds__(64) void msm_seg_kernel(const XYZZ *__restrict__ bu
     seg_out[g] = acc;
 }
 // one workgroup per window: tree sum of its segment results
-__global__ __launch_bounds__(256) void msm_winsum_kernel(const XYZZ *__restrict__ seg, XYZZ *__restrict__ win_out, uint32_t per) {
-    __shared__ XYZZ sh[256];
+__global__ __launch_bounds__(1024) void msm_winsum_kernel(const XYZZ *__restrict__ seg, XYZZ *__restrict__ win_out, uint32_t per) {
+    __shared__ XYZZ sh[1024];
     uint32_t tid = threadIdx.x, w = blockIdx.x;
     XYZZ acc = XYZZ::identity();
-    for (uint32_t i = tid; i < per; i += 256) xyzz_add(acc, seg[(size_t)w * per + i]);
+    for (uint32_t i = tid; i < per; i += 1024) xyzz_add(acc, seg[(size_t)w * per + i]);
     sh[tid] = acc;
     __syncthreads();
-    for (uint32_t d = 128; d >= 1; d >>= 1) {
+    for (uint32_t d = 512; d >= 1; d >>= 1) {
         if (tid < d) {
             XYZZ a = sh[tid];
             xyzz_add(a, sh[tid + d]);
@@ -520,7 +525,8 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     const uint32_t nseg = Wr * (B / L);
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(XYZZ) * nseg, (void **)&seg));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(XYZZ) * 64, (void **)&win));
-    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ) * B, (void **)&presum));
+    const uint32_t pre_rows = (W + 3) / 4;
+    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ) * B * (pre_rows + 1), (void **)&presum));
 
     H2_HIPCHK(hipMemsetAsync(counts + nkeys, 0, sizeof(uint32_t), st));
     H2_HIPCHK(hipMemsetAsync(offsets + nkeys + 1, 0xff, sizeof(uint32_t), st));   // sentinel read by the boundary walk
@@ -566,7 +572,8 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     const XYZZ *red_in = buckets;
     if (precomp) {
         prof_begin(ctx, "msm_presum_kernel");
-        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const XYZZ *)buckets, presum, B, W);
+        hipLaunchKernelGGL(msm_presum_kernel, dim3((B * pre_rows + 63) / 64), dim3(64), 0, st, (const XYZZ *)buckets, presum + B, B, W, 4u);
+        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const XYZZ *)(presum + B), presum, B, pre_rows, pre_rows);
         prof_end(ctx);
         red_in = presum;
     }
@@ -574,7 +581,7 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     hipLaunchKernelGGL(msm_seg_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, red_in, seg, B, L, nseg);
     prof_end(ctx);
     prof_begin(ctx, "msm_winsum_kernel");
-    hipLaunchKernelGGL(msm_winsum_kernel, dim3(Wr), dim3(256), 0, st, (const XYZZ *)seg, win, B / L);
+    hipLaunchKernelGGL(msm_winsum_kernel, dim3(Wr), dim3(1024), 0, st, (const XYZZ *)seg, win, B / L);
     prof_end(ctx);
     prof_begin(ctx, "msm_fold_kernel");
     hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ *)win, Wr, c, out);

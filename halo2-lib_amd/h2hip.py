@@ -52,6 +52,14 @@ _PROTOS = {
     "h2hip_fr_sub_batch_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "h2hip_fr_mul_batch_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "h2hip_fr_mul_add_batch_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _sz]),
+    "h2hip_fr_batch_invert_dev": (_int, [_vp, _vp, _sz]),
+    "h2hip_fr_prefix_product_dev": (_int, [_vp, _vp, _vp, _sz]),
+    "h2hip_fr_grand_product_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "h2hip_fr_eval_polynomial_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "h2hip_fr_kate_division_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "h2hip_quotient_flex_gate_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
+    "h2hip_poseidon_permute_batch_dev": (_int, [_vp, _vp, _vp, _u32, _sz]),
     "h2hip_bench_modmul": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 # symbols added by later translation units register themselves here (see fr_ops section below)
@@ -296,3 +304,86 @@ class Context:
         ms, mm = C.c_double(), C.c_double()
         self._chk(self.lib.h2hip_bench_modmul(self.handle, blocks, iters, chains, C.byref(ms), C.byref(mm)))
         return ms.value, mm.value
+
+    # -- K4/K5/K7 (host-array conveniences over the _dev entry points)
+    def fr_batch_invert(self, a: np.ndarray) -> np.ndarray:
+        a = _fe(a)
+        d = self.to_device(a)
+        try:
+            self._chk(self.lib.h2hip_fr_batch_invert_dev(self.handle, _vp(d), len(a)))
+            return self.download(d, a.shape)
+        finally:
+            self.free(d)
+
+    def fr_prefix_product(self, a: np.ndarray) -> np.ndarray:
+        a = _fe(a)
+        d, o = self.to_device(a), self.malloc(max(a.nbytes, 32))
+        try:
+            self._chk(self.lib.h2hip_fr_prefix_product_dev(self.handle, _vp(o), _vp(d), len(a)))
+            return self.download(o, a.shape)
+        finally:
+            self.free(d)
+            self.free(o)
+
+    def fr_grand_product(self, num: np.ndarray, den: np.ndarray) -> np.ndarray:
+        num, den = _fe(num), _fe(den)
+        dn, dd, z = self.to_device(num), self.to_device(den), self.malloc(32 * (len(num) + 1))
+        try:
+            self._chk(self.lib.h2hip_fr_grand_product_dev(self.handle, _vp(z), _vp(dn), _vp(dd), len(num)))
+            return self.download(z, (len(num) + 1, 4))
+        finally:
+            for d in (dn, dd, z):
+                self.free(d)
+
+    def fr_eval_polynomial(self, coeffs: np.ndarray, x: np.ndarray) -> np.ndarray:
+        c = _fe(coeffs)
+        d = self.to_device(c) if len(c) else self.malloc(32)
+        out = np.zeros((1, 4), dtype=np.uint64)
+        try:
+            self._chk(self.lib.h2hip_fr_eval_polynomial_dev(self.handle, _vp(d), len(c), _ptr(_fe(x)), _ptr(out)))
+            return out
+        finally:
+            self.free(d)
+
+    def fr_kate_division(self, coeffs: np.ndarray, b: np.ndarray) -> np.ndarray:
+        c = _fe(coeffs)
+        d, q = self.to_device(c), self.malloc(32 * max(len(c) - 1, 1))
+        try:
+            self._chk(self.lib.h2hip_fr_kate_division_dev(self.handle, _vp(q), _vp(d), len(c), _ptr(_fe(b))))
+            return self.download(q, (len(c) - 1, 4))
+        finally:
+            self.free(d)
+            self.free(q)
+
+    def quotient_flex_gate(self, acc: np.ndarray, q: np.ndarray, a: np.ndarray, ext_k: int, k: int, y: np.ndarray) -> np.ndarray:
+        acc, q, a = _fe(acc), _fe(q), _fe(a)
+        da, dq, dv = self.to_device(acc), self.to_device(q), self.to_device(a)
+        try:
+            self._chk(self.lib.h2hip_quotient_flex_gate_dev(self.handle, _vp(da), _vp(dq), _vp(dv), ext_k, k, _ptr(_fe(y))))
+            return self.download(da, acc.shape)
+        finally:
+            for d in (da, dq, dv):
+                self.free(d)
+
+    # -- K8 Poseidon
+    def poseidon_set_spec(self, t: int, r_f: int, r_p: int, round_constants: np.ndarray, mds: np.ndarray):
+        rc, m = _fe(round_constants), _fe(mds)
+        assert len(rc) == (r_f + r_p) * t and len(m) == t * t
+        self._chk(self.lib.h2hip_poseidon_set_spec(self.handle, t, r_f, r_p, _ptr(rc), _ptr(m)))
+        self._pos_t = t
+
+    def poseidon_permute(self, states: np.ndarray, inputs: Optional[np.ndarray] = None) -> np.ndarray:
+        """states: (n, t, 4); inputs: (n, m, 4) with m <= t-1 or None"""
+        t = self._pos_t
+        st = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, t, 4)
+        n = len(st)
+        m = 0 if inputs is None else np.asarray(inputs).reshape(n, -1, 4).shape[1]
+        ds = self.to_device(st)
+        di = self.to_device(np.ascontiguousarray(inputs, dtype=np.uint64)) if m else None
+        try:
+            self._chk(self.lib.h2hip_poseidon_permute_batch_dev(self.handle, _vp(ds), _vp(di) if di else None, m, n))
+            return self.download(ds, st.shape)
+        finally:
+            self.free(ds)
+            if di:
+                self.free(di)

@@ -119,6 +119,35 @@ int h2hip_fr_sub_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, con
 int h2hip_fr_mul_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, const void *b_dev, size_t n);
 int h2hip_fr_mul_add_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, const void *b_dev, const void *c_dev, size_t n);
 
+/* ---- K4: BatchInvert, in place, 0 -> 0 (ff::BatchInvert / batch_invert_assigned [UPSTREAM]; the deferred
+ *      denominators come from reference halo2-base/src/gates/flex_gate/mod.rs:677-681,791-795) ---------- */
+int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a_dev, size_t n);
+
+/* ---- K5: permutation / lookup grand products: out[i] = prod_{j<=i} in[j], and
+ *      z[0] = 1, z[i+1] = z[i]*num[i]/den[i] (z has n+1 elements) ---------------------------------------- */
+int h2hip_fr_prefix_product_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, size_t n);
+int h2hip_fr_grand_product_dev(h2hip_ctx *ctx, void *z_dev, const void *num_dev, const void *den_dev, size_t n);
+
+/* ---- K7: arithmetic::eval_polynomial and arithmetic::kate_division [UPSTREAM] ------------------------- */
+int h2hip_fr_eval_polynomial_dev(h2hip_ctx *ctx, const void *coeffs_dev, size_t n, const void *x, void *out_host);
+/* q[0..n-1) = (f(X) - f(b)) / (X - b); q_dev must not alias coeffs_dev */
+int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_dev, size_t n, const void *b);
+
+/* ---- K6: the halo2-base custom gate's term of the quotient numerator on the extended domain:
+ *      acc[i] = acc[i]*y + q[i]*(a[i] + a[i+s]*a[i+2s] - a[i+3s]), s = 2^(ext_k-k)
+ *      (gate q*(a+b*c-d) at rotations 0..3, reference halo2-base/src/gates/flex_gate/mod.rs:80-91) ----- */
+int h2hip_quotient_flex_gate_dev(h2hip_ctx *ctx, void *acc_dev, const void *q_dev, const void *a_dev, uint32_t ext_k, uint32_t k,
+                                 const void *y);
+
+/* ---- K8: Poseidon permutation batches (halo2-base PoseidonState::permutation, reference
+ *      halo2-base/src/poseidon/hasher/state.rs:35-83,124-160).  The caller supplies the spec its
+ *      OptimizedPoseidonSpec was derived from (hasher/spec.rs:88-175): (r_f+r_p)*t round constants and
+ *      the t x t MDS matrix (row major), Montgomery limbs; t in {3, 5}.  states: n x t elements, updated
+ *      in place; inputs: n x num_inputs elements (num_inputs <= t-1) added to s[1..] with the padding 1
+ *      after the last input when num_inputs < t-1. -------------------------------------------------------- */
+int h2hip_poseidon_set_spec(h2hip_ctx *ctx, uint32_t t, uint32_t r_f, uint32_t r_p, const void *round_constants, const void *mds);
+int h2hip_poseidon_permute_batch_dev(h2hip_ctx *ctx, void *states_dev, const void *inputs_dev, uint32_t num_inputs, size_t n);
+
 /* ---- diagnostics: 254-bit Montgomery multiplier throughput (the integer roofline bench.py quotes) ------ */
 int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);
 

@@ -148,3 +148,58 @@ def test_msm_precomputed_bases(ctx, c):
         b.free()
     finally:
         ctx.set_param("msm_window_bits", 0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 257, 5000])
+def test_batch_invert_and_grand_product(ctx, n):
+    a = rand_fr(n, n)
+    if n > 2:
+        a[1] = 0   # 0 -> 0
+        a[n - 1] = 0
+    assert np.array_equal(ctx.fr_batch_invert(a), CO.fr_batch_invert(a))
+    num, den = rand_fr(n, n + 1), rand_fr(n, n + 2)
+    assert np.array_equal(ctx.fr_grand_product(num, den), CO.fr_grand_product(num, den))
+    pp = ctx.fr_prefix_product(num)
+    assert np.array_equal(pp, CO.fr_grand_product(num, np.repeat(fr([1]), n, axis=0))[1:])
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 2048, 2049, 20000])
+def test_eval_polynomial_and_kate_division(ctx, n):
+    c = rand_fr(n, n)
+    x = rand_fr(1, 99)
+    assert np.array_equal(ctx.fr_eval_polynomial(c, x), CO.fr_eval_polynomial(c, x))
+    if n >= 2:
+        assert np.array_equal(ctx.fr_kate_division(c, x), CO.fr_kate_division(c, x))
+
+
+@pytest.mark.parametrize("t,r_p", [(3, 57), (5, 60)])
+def test_poseidon_batch_matches_reference_kat(ctx, t, r_p):
+    from oracle.poseidon import Spec
+
+    spec = Spec(t, 8, r_p)
+    ctx.poseidon_set_spec(t, 8, r_p, fr([c for row in spec.constants for c in row]), fr([m for row in spec.mds for m in row]))
+    # the reference's golden vector (halo2-base/src/poseidon/hasher/tests/state.rs:29-33,55-61) as instance 0
+    states = [list(range(t))] + [O.random_scalars(t, 100 + i) for i in range(70)]
+    inputs = [[0] * (t - 1)] + [O.random_scalars(t - 1, 200 + i) for i in range(70)]
+    got = ctx.poseidon_permute(np.stack([fr(s) for s in states]), np.stack([fr(i) for i in inputs]))
+    want = [spec.absorb_and_permute(s, i) for s, i in zip(states, inputs)]
+    assert [O.limbs_to_ints(g, R) for g in got] == want
+    kat3 = [7853200120776062878684798364095072458815029376092732009249414926327459813530,
+            7142104613055408817911962100316808866448378443474503659992478482890339429929,
+            6549537674122432311777789598043107870002137484850126429160507761192163713804]
+    if t == 3:
+        assert O.limbs_to_ints(got[0], R) == kat3
+    # fewer inputs than RATE: padding 1 after the last input
+    got1 = ctx.poseidon_permute(np.stack([fr(s) for s in states[:5]]), np.stack([fr(i[:1]) for i in inputs[:5]]))
+    assert [O.limbs_to_ints(g, R) for g in got1] == [spec.absorb_and_permute(s, i[:1]) for s, i in zip(states[:5], inputs[:5])]
+
+
+def test_quotient_flex_gate(ctx):
+    k, ek = 6, 8
+    ne, step = 1 << ek, 1 << (ek - k)
+    acc, q, a, y = rand_fr(ne, 1), rand_fr(ne, 2), rand_fr(ne, 3), rand_fr(1, 4)
+    got = ctx.quotient_flex_gate(acc, q, a, ek, k, y)
+    rot = lambda v, r: np.roll(v, -r * step, axis=0)
+    gate = CO.fr_mul(q, CO.fr_sub(CO.fr_add(a, CO.fr_mul(rot(a, 1), rot(a, 2))), rot(a, 3)))
+    want = CO.fr_add(CO.fr_mul(acc, np.repeat(y, ne, axis=0)), gate)
+    assert np.array_equal(got, want)

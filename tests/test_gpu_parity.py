@@ -154,3 +154,48 @@ def test_msm_2_20_precomputed_closed_form(ctx):
         total = sum(v * (k0 + i * d) for i, v in enumerate(si)) % R
         assert O.limbs_to_points(got) == [O.g1_mul(O.G1_GEN, total)]
     b.free()
+
+
+@pytest.mark.parametrize("n", [1, 257, 1 << 19])
+def test_batch_invert_and_grand_product(ctx, n):
+    a = rand_fr(n, n)
+    if n > 2:
+        a[1] = 0
+        a[n - 1] = 0
+    assert np.array_equal(ctx.fr_batch_invert(a), CO.fr_batch_invert(a))
+    num, den = rand_fr(n, n + 1), rand_fr(n, n + 2)
+    assert np.array_equal(ctx.fr_grand_product(num, den), CO.fr_grand_product(num, den))
+
+
+@pytest.mark.parametrize("n", [1, 2049, 1 << 19, (1 << 21) + 5])
+def test_eval_polynomial_and_kate_division(ctx, n):
+    c = rand_fr(n, n)
+    x = rand_fr(1, 99)
+    assert np.array_equal(ctx.fr_eval_polynomial(c, x), CO.fr_eval_polynomial(c, x))
+    if n >= 2:
+        assert np.array_equal(ctx.fr_kate_division(c, x), CO.fr_kate_division(c, x))
+
+
+@pytest.mark.parametrize("t,r_p", [(3, 57), (5, 60)])
+def test_poseidon_batch(ctx, t, r_p):
+    from oracle.poseidon import Spec
+
+    spec = Spec(t, 8, r_p)
+    ctx.poseidon_set_spec(t, 8, r_p, fr([c for row in spec.constants for c in row]), fr([m for row in spec.mds for m in row]))
+    n = 300
+    states = [list(range(t))] + [O.random_scalars(t, 100 + i) for i in range(n - 1)]
+    inputs = [[0] * (t - 1)] + [O.random_scalars(t - 1, 900 + i) for i in range(n - 1)]
+    got = ctx.poseidon_permute(np.stack([fr(s) for s in states]), np.stack([fr(i) for i in inputs]))
+    assert [O.limbs_to_ints(g, R) for g in got] == [spec.absorb_and_permute(s, i) for s, i in zip(states, inputs)]
+    if t == 3:   # reference golden vector, halo2-base/src/poseidon/hasher/tests/state.rs:29-33
+        assert O.limbs_to_ints(got[0], R)[0] == 7853200120776062878684798364095072458815029376092732009249414926327459813530
+
+
+def test_quotient_flex_gate(ctx):
+    k, ek = 12, 14
+    ne, step = 1 << ek, 1 << (ek - k)
+    acc, q, a, y = rand_fr(ne, 1), rand_fr(ne, 2), rand_fr(ne, 3), rand_fr(1, 4)
+    got = ctx.quotient_flex_gate(acc, q, a, ek, k, y)
+    rot = lambda v, r: np.roll(v, -r * step, axis=0)
+    gate = CO.fr_mul(q, CO.fr_sub(CO.fr_add(a, CO.fr_mul(rot(a, 1), rot(a, 2))), rot(a, 3)))
+    assert np.array_equal(got, CO.fr_add(CO.fr_mul(acc, np.repeat(y, ne, axis=0)), gate))

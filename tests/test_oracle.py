@@ -129,3 +129,35 @@ def test_misc_poly_ops():
     assert ((x - b) * O.eval_polynomial(q, x) + O.eval_polynomial(a, b)) % R == O.eval_polynomial(a, x)
     num, den = O.random_scalars(20, 6), O.random_scalars(20, 7)
     assert O.limbs_to_ints(CO.fr_grand_product(fr(num), fr(den)), R) == O.grand_product(num, den)
+
+
+def test_poseidon_pinned_by_reference_golden_vectors():
+    """The reference's own KATs (halo2-base/src/poseidon/hasher/tests/state.rs:29-33,55-61 and
+    tests/mod.rs:14-30): pins the oracle's F_r arithmetic and the Poseidon oracle itself."""
+    from oracle.poseidon import Spec
+
+    s3 = Spec(3, 8, 57)
+    assert s3.mds == [
+        [7511745149465107256748700652201246547602992235352608707588321460060273774987,
+         10370080108974718697676803824769673834027675643658433702224577712625900127200,
+         19705173408229649878903981084052839426532978878058043055305024233888854471533],
+        [18732019378264290557468133440468564866454307626475683536618613112504878618481,
+         20870176810702568768751421378473869562658540583882454726129544628203806653987,
+         7266061498423634438633389053804536045105766754026813321943009179476902321146],
+        [9131299761947733513298312097611845208338517739621853568979632113419485819303,
+         10595341252162738537912664445405114076324478519622938027420701542910180337937,
+         11597556804922396090267472882856054602429588299176362916247939723151043581408],
+    ]
+    assert s3.absorb_and_permute([0, 1, 2], [0, 0]) == [
+        7853200120776062878684798364095072458815029376092732009249414926327459813530,
+        7142104613055408817911962100316808866448378443474503659992478482890339429929,
+        6549537674122432311777789598043107870002137484850126429160507761192163713804,
+    ]
+    s5 = Spec(5, 8, 60)
+    assert s5.absorb_and_permute([0, 1, 2, 3, 4], [0, 0, 0, 0]) == [
+        18821383157269793795438455681495246036402687001665670618754263018637548127333,
+        7817711165059374331357136443537800893307845083525445872661165200086166013245,
+        16733335996448830230979566039396561240864200624113062088822991822580465420551,
+        6644334865470350789317807668685953492649391266180911382577082600917830417726,
+        3372108894677221197912083238087960099443657816445944159266857514496320565191,
+    ]
