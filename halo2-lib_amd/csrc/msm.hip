@@ -426,6 +426,19 @@ __global__ __launch_bounds__(64) void table_normalize_kernel(const G1Jac *__rest
     }
 }
 
+// Jacobian -> affine for n points (tmp is read, out written; they may not alias)
+int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_t n) {
+    Fq *prefix = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, sizeof(Fq) * (size_t)(n ? n : 1), (void **)&prefix));
+    uint32_t runs = (n + NORM_RUN - 1) / NORM_RUN;
+    if (!runs) return H2HIP_OK;
+    prof_begin(ctx, "table_normalize_kernel");
+    hipLaunchKernelGGL(table_normalize_kernel, dim3((runs + 63) / 64), dim3(64), 0, ctx->stream, tmp, prefix, out, n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
 static uint32_t pick_window(size_t n) {
     uint32_t best = 4;
     double best_cost = 1e300;
@@ -454,21 +467,15 @@ int msm_build_table(h2hip_ctx *ctx, h2hip_bases *b) {
     }
     H2_HIPCHK(hipMemcpyAsync(table, b->pts, sizeof(G1Affine) * b->n, hipMemcpyDeviceToDevice, ctx->stream));
     G1Jac *tmp = nullptr;
-    Fq *prefix = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP1, sizeof(G1Jac) * b->n, (void **)&tmp));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, sizeof(Fq) * b->n, (void **)&prefix));
     const uint32_t n = (uint32_t)b->n;
     for (uint32_t w = 1; w < W; ++w) {
         prof_begin(ctx, "table_double_kernel");
         hipLaunchKernelGGL(table_double_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const G1Affine *)(table + (size_t)(w - 1) * n),
                            tmp, n, c);
         prof_end(ctx);
-        uint32_t runs = (n + NORM_RUN - 1) / NORM_RUN;
-        prof_begin(ctx, "table_normalize_kernel");
-        hipLaunchKernelGGL(table_normalize_kernel, dim3((runs + 63) / 64), dim3(64), 0, ctx->stream, (const G1Jac *)tmp, prefix,
-                           table + (size_t)w * n, n);
-        prof_end(ctx);
         H2_HIPCHK(hipGetLastError());
+        H2_CHK(batch_normalize_jac(ctx, tmp, table + (size_t)w * n, n));
     }
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
     H2_HIPCHK(hipFree(b->pts));

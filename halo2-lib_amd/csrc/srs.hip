@@ -1,0 +1,183 @@
+// KZG SRS generation on the GPU — the device side of ParamsKZG::<Bn256>::setup(k, rng) [UPSTREAM
+// halo2-axiom 0.5.3 poly::kzg::commitment; reached from the reference at halo2-base/src/utils/mod.rs:439-443
+// (gen_srs) and halo2-base/benches/mul.rs:39]:
+//     g[i]          = s^i * G1                                   (monomial basis)
+//     g_lagrange[i] = L_i(s) * G1,  L_i(s) = (s^n - 1)/n * w^i / (s - w^i)   (Lagrange basis, no group FFT needed
+//                                                                             because s is known at setup)
+// Both are batches of fixed-base scalar multiplications: an 8-bit window table of the base (32 x 255 affine
+// points) is built once, then every lane does <= 32 mixed XYZZ additions and the batch is normalised.
+// The G2 half of the SRS (g2, s*g2) is verifier-side and not on the prover path.
+#include "internal.h"
+
+namespace h2 {
+
+constexpr uint32_t FB_WIN = 8, FB_WINDOWS = 32, FB_PER = 255;
+
+__device__ __forceinline__ XYZZ xyzz_small_mul_affine(const G1Affine &p, uint32_t k) {
+    XYZZ r = XYZZ::identity();
+    if (p.is_identity()) return r;
+    for (int bit = 31 - __clz(k | 1u); bit >= 0; --bit) {
+        r = xyzz_double(r);
+        if ((k >> bit) & 1u) xyzz_add_affine(r, p.x, p.y);
+    }
+    return r;
+}
+// lane w: Q_w = 2^(8w) * P
+__global__ __launch_bounds__(64) void fb_window_bases_kernel(G1Affine base, G1Jac *__restrict__ out) {
+    uint32_t w = threadIdx.x;
+    if (w >= FB_WINDOWS) return;
+    XYZZ a = XYZZ::from_affine(base);
+    for (uint32_t i = 0; i < FB_WIN * w; ++i) a = xyzz_double(a);
+    out[w] = xyzz_to_jacobian(a);
+}
+// lane (w, d): T[w][d] = (d+1) * Q_w
+__global__ __launch_bounds__(256) void fb_table_kernel(const G1Affine *__restrict__ qw, G1Jac *__restrict__ out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= FB_WINDOWS * FB_PER) return;
+    uint32_t w = t / FB_PER, d = t - w * FB_PER;
+    out[t] = xyzz_to_jacobian(xyzz_small_mul_affine(qw[w], d + 1));
+}
+__global__ __launch_bounds__(256) void fb_mul_kernel(const G1Affine *__restrict__ table, const Fr *__restrict__ scalars, uint32_t n,
+                                                     G1Jac *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = fe_from_mont(scalars[i]);
+    XYZZ acc = XYZZ::identity();
+#pragma unroll
+    for (int limb = 0; limb < 8; ++limb) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint32_t d = (s.l[limb] >> (8 * b)) & 0xffu;
+            if (d) {
+                G1Affine p = table[(limb * 4 + b) * FB_PER + d - 1];
+                if (!p.is_identity()) xyzz_add_affine(acc, p.x, p.y);
+            }
+        }
+    }
+    out[i] = xyzz_to_jacobian(acc);
+}
+
+// scalars for ParamsKZG::setup: mono[i] = s^i ; den[i] = s - w^i ; num[i] = mult * w^i, mult = (s^n-1)/n
+__global__ __launch_bounds__(256) void kzg_setup_scalars_kernel(Fr s, Fr omega, Fr mult, uint32_t n, Fr *__restrict__ mono, Fr *__restrict__ num,
+                                                                Fr *__restrict__ den) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    mono[i] = fe_pow_u64(s, i);
+    Fr wi = fe_pow_u64(omega, i);
+    num[i] = fe_mul(mult, wi);
+    den[i] = fe_sub(s, wi);
+}
+
+static int fixed_base_table(h2hip_ctx *ctx, const G1Affine &base, G1Affine **table_out) {
+    const uint32_t total = FB_WINDOWS * FB_PER;
+    char *buf = nullptr;
+    // layout: [Jac tmp: total] [affine Q_w: 32] [affine table: total]
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_FBTABLE, sizeof(G1Jac) * total + sizeof(G1Affine) * (FB_WINDOWS + total), (void **)&buf));
+    G1Jac *jtmp = (G1Jac *)buf;
+    G1Affine *qw = (G1Affine *)(buf + sizeof(G1Jac) * total);
+    G1Affine *table = qw + FB_WINDOWS;
+    prof_begin(ctx, "fb_table_kernels");
+    hipLaunchKernelGGL(fb_window_bases_kernel, dim3(1), dim3(64), 0, ctx->stream, base, jtmp);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_CHK(batch_normalize_jac(ctx, jtmp, qw, FB_WINDOWS));
+    prof_begin(ctx, "fb_table_kernels");
+    hipLaunchKernelGGL(fb_table_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, (const G1Affine *)qw, jtmp);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_CHK(batch_normalize_jac(ctx, jtmp, table, total));
+    *table_out = table;
+    return H2HIP_OK;
+}
+
+static int fixed_base_mul(h2hip_ctx *ctx, const G1Affine *table, const Fr *scalars, uint32_t n, G1Affine *out) {
+    G1Jac *jtmp = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP1, sizeof(G1Jac) * (size_t)(n ? n : 1), (void **)&jtmp));
+    if (!n) return H2HIP_OK;
+    prof_begin(ctx, "fb_mul_kernel");
+    hipLaunchKernelGGL(fb_mul_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, table, scalars, n, jtmp);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return batch_normalize_jac(ctx, jtmp, out, n);
+}
+
+}  // namespace h2
+
+using namespace h2;
+
+extern "C" {
+
+// out[i] = scalars[i] * base   (device arrays; base is a host G1Affine)
+int h2hip_g1_fixed_base_mul_batch_dev(h2hip_ctx *ctx, const void *base_affine, const void *scalars_dev, size_t n, void *out_affine_dev) {
+    H2_REQUIRE(ctx && base_affine && (n == 0 || (scalars_dev && out_affine_dev)), "NULL argument");
+    H2_REQUIRE(n < (1u << 31), "n too large");
+    G1Affine base;
+    memcpy(&base, base_affine, sizeof(base));
+    G1Affine *table = nullptr;
+    H2_CHK(fixed_base_table(ctx, base, &table));
+    return fixed_base_mul(ctx, table, (const Fr *)scalars_dev, (uint32_t)n, (G1Affine *)out_affine_dev);
+}
+
+int h2hip_params_kzg_setup(h2hip_ctx *ctx, uint32_t k, const void *s_fr, uint32_t flags, h2hip_bases **g_out, h2hip_bases **g_lagrange_out) {
+    H2_REQUIRE(ctx && s_fr && g_out && g_lagrange_out, "NULL argument");
+    H2_REQUIRE(k <= 26, "k too large");
+    const uint32_t n = 1u << k;
+    Fr s;
+    memcpy(&s, s_fr, sizeof(Fr));
+    // domain constants on the host (a handful of field operations)
+    // ROOT_OF_UNITY = 7^((r-1)/2^28), canonical 0x03ddb9f5166d18b798865ea93dd31f743215cf6dd39329c8d34f1ed960c37c9c
+    Fr rou_canon = {{0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du, 0x3dd31f74u, 0x98865ea9u, 0x166d18b7u, 0x03ddb9f5u}};
+    Fr omega = fe_to_mont(rou_canon);
+    for (uint32_t i = k; i < 28; ++i) omega = fe_sqr(omega);
+    Fr sn = fe_pow_u64(s, n);
+    Fr n_fr = Fr::zero();
+    n_fr.l[0] = n;
+    Fr mult = fe_mul(fe_sub(sn, Fr::one()), fe_inv(fe_to_mont(n_fr)));
+    // s must not be an n-th root of unity (then some L_i has a pole); the real setup samples s at random
+    H2_REQUIRE(!fe_sub(sn, Fr::one()).is_zero(), "s is an n-th root of unity");
+
+    Fr *mono = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(Fr) * 3 * (size_t)n, (void **)&mono));
+    Fr *num = mono + n, *den = num + n;
+    prof_begin(ctx, "kzg_setup_scalars_kernel");
+    hipLaunchKernelGGL(kzg_setup_scalars_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, s, omega, mult, n, mono, num, den);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_CHK(h2hip_fr_batch_invert_dev(ctx, den, n));
+    H2_CHK(h2hip_fr_mul_batch_dev(ctx, num, num, den, n));   // num[i] = L_i(s)
+
+    G1Affine gen;   // G1 generator (1, 2)
+    Fq one_c = Fq::zero(), two_c = Fq::zero();
+    one_c.l[0] = 1;
+    two_c.l[0] = 2;
+    gen.x = fe_to_mont(one_c);
+    gen.y = fe_to_mont(two_c);
+    G1Affine *table = nullptr;
+    H2_CHK(fixed_base_table(ctx, gen, &table));
+    G1Affine *pts = nullptr;
+    H2_HIPCHK(hipMalloc((void **)&pts, sizeof(G1Affine) * 2 * (size_t)n));
+    int rc = fixed_base_mul(ctx, table, mono, n, pts);
+    if (rc == H2HIP_OK) rc = fixed_base_mul(ctx, table, num, n, pts + n);
+    if (rc == H2HIP_OK) rc = h2hip_bases_from_device(ctx, pts, n, flags, g_out);
+    if (rc == H2HIP_OK) {
+        rc = h2hip_bases_from_device(ctx, pts + n, n, flags, g_lagrange_out);
+        if (rc != H2HIP_OK) {
+            h2hip_bases_free(ctx, *g_out);
+            *g_out = nullptr;
+        }
+    }
+    hipStreamSynchronize(ctx->stream);
+    hipFree(pts);
+    return rc;
+}
+
+// copies the (level-0) affine points of a resident base set back to the host
+int h2hip_bases_download(h2hip_ctx *ctx, const h2hip_bases *bases, void *out_host) {
+    H2_REQUIRE(ctx && bases && out_host, "NULL argument");
+    if (!bases->n) return H2HIP_OK;
+    H2_HIPCHK(hipMemcpyAsync(out_host, bases->pts, sizeof(G1Affine) * bases->n, hipMemcpyDeviceToHost, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+
+}  // extern "C"

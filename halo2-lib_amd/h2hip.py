@@ -39,6 +39,9 @@ _PROTOS = {
     "h2hip_bases_len": (_sz, [_vp]),
     "h2hip_msm_g1": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "h2hip_msm_g1_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "h2hip_params_kzg_setup": (_int, [_vp, _u32, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp)]),
+    "h2hip_g1_fixed_base_mul_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "h2hip_bases_download": (_int, [_vp, _vp, _vp]),
     "h2hip_g1_sum_jacobian_dev": (_int, [_vp, _vp, _sz, _int, _vp]),
     "h2hip_best_fft": (_int, [_vp, _vp, _vp, _u32]),
     "h2hip_best_fft_dev": (_int, [_vp, _vp, _vp, _u32]),
@@ -225,6 +228,28 @@ class Context:
     def msm_dev(self, bases: Bases, scalars_dptr: int, n: int, point_format: int = POINT_JACOBIAN) -> np.ndarray:
         out = np.zeros((1, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
         self._chk(self.lib.h2hip_msm_g1_dev(self.handle, bases.handle, _vp(scalars_dptr), n, point_format, _ptr(out)))
+        return out
+
+    def params_kzg_setup(self, k: int, s: np.ndarray, flags: int = BASES_PLAIN):
+        """(g, g_lagrange) resident base sets of ParamsKZG::setup(k) for the toxic-waste scalar s"""
+        g, gl = _vp(), _vp()
+        self._chk(self.lib.h2hip_params_kzg_setup(self.handle, k, _ptr(_fe(s)), flags, C.byref(g), C.byref(gl)))
+        return Bases(self, g, 1 << k), Bases(self, gl, 1 << k)
+
+    def g1_fixed_base_mul(self, base: np.ndarray, scalars: np.ndarray) -> np.ndarray:
+        s = _fe(scalars)
+        b = np.ascontiguousarray(base, dtype=np.uint64).reshape(1, 8)
+        ds, do = self.to_device(s), self.malloc(64 * max(len(s), 1))
+        try:
+            self._chk(self.lib.h2hip_g1_fixed_base_mul_batch_dev(self.handle, _ptr(b), _vp(ds), len(s), _vp(do)))
+            return self.download(do, (len(s), 8))
+        finally:
+            self.free(ds)
+            self.free(do)
+
+    def bases_download(self, bases: Bases) -> np.ndarray:
+        out = np.empty((bases.n, 8), dtype=np.uint64)
+        self._chk(self.lib.h2hip_bases_download(self.handle, bases.handle, _ptr(out)))
         return out
 
     def g1_sum_jacobian_dev(self, points_dptr: int, n: int, point_format: int = POINT_JACOBIAN) -> np.ndarray:

@@ -87,6 +87,16 @@ size_t h2hip_bases_len(const h2hip_bases *bases);
 int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host);
 int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_dev, size_t n, int point_format, void *out_host);
 
+/* ---- a2: KZG SRS (ParamsKZG::<Bn256>::setup [UPSTREAM]; reference gen_srs halo2-base/src/utils/mod.rs:439-443,
+ *      halo2-base/benches/mul.rs:39).  g[i] = s^i*G1 and g_lagrange[i] = L_i(s)*G1 for i < 2^k are generated on
+ *      the GPU (fixed-base window tables) and stay resident as two base sets; `flags` as in h2hip_bases_upload.
+ *      The G2 half (g2, s*g2) is verifier-side and stays with the host library. --------------------------- */
+int h2hip_params_kzg_setup(h2hip_ctx *ctx, uint32_t k, const void *s_fr, uint32_t flags, h2hip_bases **g_out, h2hip_bases **g_lagrange_out);
+/* out[i] = scalars[i] * base for a fixed G1Affine base (host pointer); scalars and out are device arrays */
+int h2hip_g1_fixed_base_mul_batch_dev(h2hip_ctx *ctx, const void *base_affine, const void *scalars_dev, size_t n, void *out_affine_dev);
+/* copy the resident affine points back to the host (n x 64 B) — ParamsKZG::write / tests */
+int h2hip_bases_download(h2hip_ctx *ctx, const h2hip_bases *bases, void *out_host);
+
 /* Sum of n Jacobian points resident on the device (multi-GPU: the all-gathered per-GPU partial MSM results;
  * RCCL has no group-law reduction). */
 int h2hip_g1_sum_jacobian_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, int point_format, void *out_host);

@@ -1,0 +1,94 @@
+"""The host-side mirror of the halo2_proofs names (halo2-lib_amd/halo2_proofs.py): emulated kernels on CPU,
+the real library on the GPU (same test bodies)."""
+import os
+
+import numpy as np
+import pytest
+
+import halo2_lib_amd as H
+from halo2_lib_amd import halo2_proofs as HP
+from oracle import bn254 as O
+from oracle import c_oracle as CO
+from tests.util import R, fr, rand_fr
+
+
+def _run_all(ctx, k, tmp_path):
+    n = 1 << k
+    # EvaluationDomain for the k=19-ECDSA-shaped circuit: degree 5 -> quotient degree 4 -> extended_k = k + 2
+    dom = HP.EvaluationDomain(ctx, 5, k)
+    assert dom.extended_k == k + 2 and dom.quotient_poly_degree == 4
+    assert HP.EvaluationDomain(ctx, 4, k).extended_k == k + 2   # degree 4 -> 3n -> also k + 2
+    vals = rand_fr(n, 1)
+    coeffs = dom.lagrange_to_coeff(vals)
+    assert np.array_equal(coeffs, CO.ifft(vals, k, dom.omega, threads=4))
+    ext = dom.coeff_to_extended(coeffs)
+    assert np.array_equal(ext, CO.coeff_to_extended(coeffs, k, k + 2, dom.extended_omega, dom.g_coset, threads=4))
+    back = dom.extended_to_coeff(ext)
+    assert len(back) == 4 * n and np.array_equal(back[:n], coeffs) and not back[n:].any()
+    # arithmetic::*
+    w = dom.omega
+    assert np.array_equal(HP.best_fft(ctx, coeffs, w, k), vals)
+    x = rand_fr(1, 5)
+    assert np.array_equal(HP.eval_polynomial(ctx, coeffs, x), CO.fr_eval_polynomial(coeffs, x))
+    assert np.array_equal(HP.kate_division(ctx, coeffs, x), CO.fr_kate_division(coeffs, x))
+    with pytest.raises(AssertionError):
+        HP.best_fft(ctx, coeffs[:-1], w, k)
+    # ParamsKZG: commit_lagrange(values) == commit(coeffs) == p(s)*G  (closed form for SRS-shaped bases)
+    s = 0x1234567890ABCDEF1234567890ABCDEF
+    for pre in (False, True):
+        params = HP.ParamsKZG.setup(ctx, k, s, precompute=pre)
+        c1 = params.commit_lagrange(vals, H.POINT_AFFINE)
+        c2 = params.commit(coeffs, H.POINT_AFFINE)
+        assert np.array_equal(c1, c2)
+        ps = O.eval_polynomial(O.limbs_to_ints(coeffs, R), s)
+        assert O.limbs_to_points(c1) == [O.g1_mul(O.G1_GEN, ps)]
+        # best_multiexp mirror + its length assertion
+        assert np.array_equal(HP.best_multiexp(ctx, coeffs, params.g, H.POINT_AFFINE), c2)
+        with pytest.raises(AssertionError):
+            HP.best_multiexp(ctx, coeffs[:-1], params.g)
+        # shorter polynomial commits against a prefix of the bases
+        short = params.commit(coeffs[: n // 2], H.POINT_AFFINE)
+        assert np.array_equal(short, CO.best_multiexp(coeffs[: n // 2], ctx.bases_download(params.g)[: n // 2], threads=4))
+        if not pre:
+            path = os.path.join(tmp_path, "kzg_bn254_%d.srs" % k)
+            params.write(path)
+            again = HP.ParamsKZG.read(ctx, path, precompute=False)
+            assert again.k == k
+            assert np.array_equal(ctx.bases_download(again.g_lagrange), ctx.bases_download(params.g_lagrange))
+            assert np.array_equal(again.commit_lagrange(vals, H.POINT_AFFINE), c1)
+            again.free()
+        params.free()
+
+
+def test_host_mirror_emulated(tmp_path):
+    from tests.emu_util import emu_context
+
+    ctx = emu_context()
+    _run_all(ctx, 7, str(tmp_path))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_host_mirror_gpu(tmp_path):
+    ctx = H.Context(0)
+    _run_all(ctx, 14, str(tmp_path))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_params_kzg_setup_k16_matches_oracle():
+    ctx = H.Context(0)
+    k, s = 16, 0xDEADBEEFCAFEBABE1234
+    params = HP.ParamsKZG.setup(ctx, k, s, precompute=False)
+    g = ctx.bases_download(params.g)
+    n = 1 << k
+    # g[i] = s^i G: spot-check against the oracle's scalar multiplication, and every point is on the curve
+    for i in (0, 1, 2, 777, n - 1):
+        assert O.limbs_to_points(g[i:i + 1]) == [O.g1_mul(O.G1_GEN, pow(s, i, R))]
+    gl = ctx.bases_download(params.g_lagrange)
+    w = O.omega_for(k)
+    for i in (0, 1, 4097, n - 1):
+        li = (pow(s, n, R) - 1) * pow(n, -1, R) * pow(w, i, R) * pow(s - pow(w, i, R), -1, R) % R
+        assert O.limbs_to_points(gl[i:i + 1]) == [O.g1_mul(O.G1_GEN, li)]
+    params.free()
+    ctx.close()
