@@ -1,0 +1,248 @@
+// C++ host-side mirror of the `halo2_proofs` names on the proving hot path, over libh2hip's C ABI
+// (include/h2hip.h).  The reference's host language is Rust (no toolchain in this image), so this header plays the
+// role of the `halo2-axiom-hip` shim crate described in INTEGRATION.md: same names, argument meaning and error
+// behaviour as upstream halo2-axiom 0.5.3 [UPSTREAM], reached from the reference at
+//   halo2-base/src/utils/testing.rs:8-22,40-47   (create_proof / ParamsKZG / transcript imports)
+//   halo2-base/src/utils/mod.rs:401-443          (gen_srs / read_params)
+// Only constants (a few field elements per domain) are computed on the host; all bulk arithmetic is on the GPU.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/h2hip.h"
+
+namespace halo2_proofs {
+
+struct Fr {
+    uint64_t l[4];
+    bool operator==(const Fr &o) const { return memcmp(l, o.l, 32) == 0; }
+};
+struct Fq {
+    uint64_t l[4];
+};
+struct G1Affine {
+    Fq x, y;
+    bool operator==(const G1Affine &o) const { return memcmp(this, &o, 64) == 0; }
+};
+struct G1 {   // Jacobian, identity z = 0  (C::Curve)
+    Fq x, y, z;
+};
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc) {
+    if (rc != H2HIP_OK) throw Error(rc, std::string("libh2hip: ") + h2hip_last_error());
+}
+
+// ---- host-side F_r for domain constants only (Montgomery, 4 x u64) ---------------------------------------
+namespace host_fr {
+typedef unsigned __int128 u128;
+static const uint64_t MOD[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static const uint64_t INV = 0xc2e1f593efffffffULL;
+static const Fr R1 = {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}};
+static const Fr R2 = {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}};
+inline Fr mul(const Fr &a, const Fr &b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 4; ++j) {
+            c += (u128)a.l[j] * b.l[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        uint64_t m = t[0] * INV;
+        c = ((u128)m * MOD[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) {
+            c += (u128)m * MOD[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    Fr r = {{t[0], t[1], t[2], t[3]}};
+    bool ge = t[4] != 0;
+    if (!ge) {
+        ge = true;
+        for (int i = 3; i >= 0; --i) {
+            if (r.l[i] != MOD[i]) {
+                ge = r.l[i] > MOD[i];
+                break;
+            }
+        }
+    }
+    if (ge) {
+        u128 br = 0;
+        for (int i = 0; i < 4; ++i) {
+            u128 d = (u128)r.l[i] - MOD[i] - br;
+            r.l[i] = (uint64_t)d;
+            br = (d >> 64) & 1;
+        }
+    }
+    return r;
+}
+inline Fr from_u64(uint64_t v) { return mul(Fr{{v, 0, 0, 0}}, R2); }
+inline Fr from_canonical(const uint64_t v[4]) { return mul(Fr{{v[0], v[1], v[2], v[3]}}, R2); }
+inline Fr pow(const Fr &a, const uint64_t e[4]) {
+    Fr acc = R1, base = a;
+    for (int i = 0; i < 256; ++i) {
+        if ((e[i >> 6] >> (i & 63)) & 1) acc = mul(acc, base);
+        base = mul(base, base);
+    }
+    return acc;
+}
+inline Fr inv(const Fr &a) {
+    uint64_t e[4] = {MOD[0] - 2, MOD[1], MOD[2], MOD[3]};
+    return pow(a, e);
+}
+static const uint64_t ROOT_OF_UNITY[4] = {0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL};
+static const uint64_t ZETA[4] = {0xb8ca0b2d36636f23ULL, 0xcc37a73fec2bc5e9ULL, 0x048b6e193fd84104ULL, 0x30644e72e131a029ULL};
+}  // namespace host_fr
+
+// ---- backend context (one per GPU) ----------------------------------------------------------------------
+class Backend {
+  public:
+    explicit Backend(int device = 0, void *hip_stream = nullptr) { check(h2hip_init(device, hip_stream, &ctx_)); }
+    ~Backend() { h2hip_destroy(ctx_); }
+    Backend(const Backend &) = delete;
+    Backend &operator=(const Backend &) = delete;
+    h2hip_ctx *raw() const { return ctx_; }
+
+  private:
+    h2hip_ctx *ctx_ = nullptr;
+};
+
+class Bases {   // resident G1Affine bases (an SRS column)
+  public:
+    Bases(Backend &b, const std::vector<G1Affine> &pts, bool precompute = false) : be_(&b) {
+        check(h2hip_bases_upload(b.raw(), pts.data(), pts.size(), precompute ? H2HIP_BASES_PRECOMPUTE : H2HIP_BASES_PLAIN, &h_));
+    }
+    Bases(Backend &b, h2hip_bases *h) : be_(&b), h_(h) {}
+    Bases(Bases &&o) noexcept : be_(o.be_), h_(o.h_) { o.h_ = nullptr; }
+    Bases(const Bases &) = delete;
+    ~Bases() {
+        if (h_) h2hip_bases_free(be_->raw(), h_);
+    }
+    size_t len() const { return h2hip_bases_len(h_); }
+    h2hip_bases *raw() const { return h_; }
+    std::vector<G1Affine> download() const {
+        std::vector<G1Affine> out(len());
+        check(h2hip_bases_download(be_->raw(), h_, out.data()));
+        return out;
+    }
+
+  private:
+    Backend *be_;
+    h2hip_bases *h_ = nullptr;
+};
+
+namespace arithmetic {
+// best_multiexp(coeffs, bases) -> C::Curve; panics (throws) like upstream's assert_eq!(coeffs.len(), bases.len())
+inline G1 best_multiexp(Backend &b, const std::vector<Fr> &coeffs, const Bases &bases) {
+    if (coeffs.size() != bases.len()) throw Error(H2HIP_ERR_INVALID, "assertion failed: coeffs.len() == bases.len()");
+    G1 out;
+    check(h2hip_msm_g1(b.raw(), bases.raw(), coeffs.data(), coeffs.size(), H2HIP_POINT_JACOBIAN, &out));
+    return out;
+}
+inline void best_fft(Backend &b, std::vector<Fr> &a, const Fr &omega, uint32_t log_n) {
+    if (a.size() != ((size_t)1 << log_n)) throw Error(H2HIP_ERR_INVALID, "assertion failed: a.len() == 1 << log_n");
+    check(h2hip_best_fft(b.raw(), a.data(), &omega, log_n));
+}
+}  // namespace arithmetic
+
+namespace poly {
+// EvaluationDomain::new(j, k)   
+class EvaluationDomain {
+  public:
+    EvaluationDomain(Backend &b, uint32_t j, uint32_t k) : be_(&b), k_(k), quotient_poly_degree_(j - 1) {
+        using namespace host_fr;
+        extended_k_ = k;
+        while (((uint64_t)1 << extended_k_) < ((uint64_t)1 << k) * quotient_poly_degree_) ++extended_k_;
+        if (extended_k_ > 28) throw Error(H2HIP_ERR_INVALID, "extended_k exceeds the 2-adicity of F_r");
+        Fr root = from_canonical(ROOT_OF_UNITY);
+        extended_omega_ = root;
+        for (uint32_t i = extended_k_; i < 28; ++i) extended_omega_ = mul(extended_omega_, extended_omega_);
+        omega_ = extended_omega_;
+        for (uint32_t i = k; i < extended_k_; ++i) omega_ = mul(omega_, omega_);
+        omega_inv_ = inv(omega_);
+        extended_omega_inv_ = inv(extended_omega_);
+        g_coset_ = from_canonical(ZETA);
+        g_coset_inv_ = mul(g_coset_, g_coset_);
+        ifft_divisor_ = inv(from_u64((uint64_t)1 << k));
+        extended_ifft_divisor_ = inv(from_u64((uint64_t)1 << extended_k_));
+    }
+    uint32_t k() const { return k_; }
+    uint32_t extended_k() const { return extended_k_; }
+    size_t extended_len() const { return (size_t)1 << extended_k_; }
+    const Fr &get_omega() const { return omega_; }
+    const Fr &get_extended_omega() const { return extended_omega_; }
+    void lagrange_to_coeff(std::vector<Fr> &a) const {
+        expect(a.size() == ((size_t)1 << k_));
+        check(h2hip_ifft(be_->raw(), a.data(), &omega_inv_, k_, &ifft_divisor_));
+    }
+    std::vector<Fr> coeff_to_extended(const std::vector<Fr> &a) const {
+        expect(a.size() == ((size_t)1 << k_));
+        std::vector<Fr> out(extended_len());
+        check(h2hip_coeff_to_extended(be_->raw(), a.data(), k_, out.data(), extended_k_, &extended_omega_, &g_coset_));
+        return out;
+    }
+    // in place, then truncated to n*(j-1) coefficients like upstream
+    void extended_to_coeff(std::vector<Fr> &a) const {
+        expect(a.size() == extended_len());
+        check(h2hip_extended_to_coeff(be_->raw(), a.data(), extended_k_, &extended_omega_inv_, &extended_ifft_divisor_, &g_coset_inv_));
+        a.resize(((size_t)1 << k_) * quotient_poly_degree_);
+    }
+
+  private:
+    static void expect(bool c) {
+        if (!c) throw Error(H2HIP_ERR_INVALID, "assertion failed: polynomial length does not match the domain");
+    }
+    Backend *be_;
+    uint32_t k_, extended_k_;
+    uint64_t quotient_poly_degree_;
+    Fr omega_, omega_inv_, extended_omega_, extended_omega_inv_, g_coset_, g_coset_inv_, ifft_divisor_, extended_ifft_divisor_;
+};
+
+namespace kzg {
+// the prover half of ParamsKZG<Bn256>: g and g_lagrange resident in HBM
+class ParamsKZG {
+  public:
+    // ParamsKZG::setup(k, rng) with the toxic waste s drawn by the caller's RNG (stays on the host side)
+    static ParamsKZG setup(Backend &b, uint32_t k, const Fr &s, bool precompute = true) {
+        h2hip_bases *g = nullptr, *gl = nullptr;
+        check(h2hip_params_kzg_setup(b.raw(), k, &s, precompute ? H2HIP_BASES_PRECOMPUTE : H2HIP_BASES_PLAIN, &g, &gl));
+        return ParamsKZG(b, k, Bases(b, g), Bases(b, gl));
+    }
+    uint32_t k() const { return k_; }
+    uint64_t n() const { return (uint64_t)1 << k_; }
+    G1 commit(const std::vector<Fr> &coeffs) const { return msm(g_, coeffs); }
+    G1 commit_lagrange(const std::vector<Fr> &values) const { return msm(g_lagrange_, values); }
+    const Bases &get_g() const { return g_; }
+    const Bases &get_g_lagrange() const { return g_lagrange_; }
+
+  private:
+    ParamsKZG(Backend &b, uint32_t k, Bases g, Bases gl) : be_(&b), k_(k), g_(std::move(g)), g_lagrange_(std::move(gl)) {}
+    G1 msm(const Bases &bases, const std::vector<Fr> &v) const {
+        if (v.size() > bases.len()) throw Error(H2HIP_ERR_INVALID, "assertion failed: bases.len() >= size");
+        G1 out;
+        check(h2hip_msm_g1(be_->raw(), bases.raw(), v.data(), v.size(), H2HIP_POINT_JACOBIAN, &out));
+        return out;
+    }
+    Backend *be_;
+    uint32_t k_;
+    Bases g_, g_lagrange_;
+};
+}  // namespace kzg
+}  // namespace poly
+}  // namespace halo2_proofs
