@@ -84,6 +84,14 @@ __global__ void point_finish_kernel(const XYZZ *__restrict__ in, G1Jac *__restri
     }
 }
 
+__global__ void point_finish_slot_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff, uint32_t slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        XYZZ p = in[0];
+        if (jac) jac[slot] = xyzz_to_jacobian(p);
+        if (aff) aff[slot] = xyzz_to_affine(p);
+    }
+}
+
 // sum of n Jacobian points (multi-GPU partial results): one workgroup, strided accumulate + LDS tree
 __global__ __launch_bounds__(64) void jac_sum_kernel(const G1Jac *__restrict__ pts, uint32_t n, XYZZ *__restrict__ out) {
     __shared__ XYZZ sh[64];
@@ -179,6 +187,12 @@ void h2hip_destroy(h2hip_ctx *ctx) {
         hipEventDestroy(p.second.second);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
+    for (int l = 0; l < 2; ++l)
+        if (ctx->lane[l]) {
+            h2hip_destroy(ctx->lane[l]);
+            hipEventDestroy(ctx->lane_ev[l]);
+        }
+    if (ctx->fork_ev) hipEventDestroy(ctx->fork_ev);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -352,6 +366,65 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
     H2_CHK(msm_run(ctx, bases, (const Fr *)scalars_dev, n, (XYZZ *)outbuf));
     return finish_point(ctx, outbuf, point_format, out_host);
 }
+// Several independent MSMs over the same bases (e.g. the h(X) pieces, or all advice columns of a phase): MSM j runs
+// on lane j mod 2 — a child context with its own stream and scratch — so the latency-bound tail of one MSM (merge,
+// bucket reduction) overlaps the multiplier-bound accumulation of the next.
+int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count, int point_format,
+                           void *out_host) {
+    H2_REQUIRE(ctx && bases && (count == 0 || (scalars_dev && out_host)), "NULL argument");
+    H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
+    if (!count) return H2HIP_OK;
+    const bool affine = point_format == H2HIP_POINT_AFFINE;
+    const size_t psz = affine ? sizeof(G1Affine) : sizeof(G1Jac);
+    for (int l = 0; l < 2; ++l) {
+        if (!ctx->lane[l]) {
+            h2hip_ctx *c = nullptr;
+            H2_CHK(h2hip_init(ctx->device, nullptr, &c));
+            c->msm_window_bits = ctx->msm_window_bits;
+            ctx->lane[l] = c;
+            H2_HIPCHK(hipEventCreate(&ctx->lane_ev[l]));
+        }
+        h2hip_ctx *c = ctx->lane[l];
+        c->msm_chunk = ctx->msm_chunk;
+        c->msm_seg = ctx->msm_seg;
+        c->msm_window_bits = ctx->msm_window_bits;
+        c->profiling = ctx->profiling;
+    }
+    if (!ctx->fork_ev) H2_HIPCHK(hipEventCreate(&ctx->fork_ev));
+    char *results = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH, psz * count, (void **)&results));
+    H2_HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));   // inputs produced on the caller's stream are ready after this
+    for (int l = 0; l < 2; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->fork_ev, 0));
+    for (size_t j = 0; j < count; ++j) {
+        h2hip_ctx *c = ctx->lane[j & 1];
+        H2_REQUIRE(n == 0 || scalars_dev[j], "NULL scalar column");
+        char *outbuf = nullptr;
+        H2_CHK(ws_reserve(c, h2hip_ctx::WS_OUT, 1024, (void **)&outbuf));
+        H2_CHK(msm_run(c, bases, (const Fr *)scalars_dev[j], n, (XYZZ *)outbuf));
+        prof_begin(c, "point_finish_kernel");
+        hipLaunchKernelGGL(point_finish_slot_kernel, dim3(1), dim3(64), 0, c->stream, (const XYZZ *)outbuf, affine ? (G1Jac *)nullptr : (G1Jac *)results,
+                           affine ? (G1Affine *)results : (G1Affine *)nullptr, (uint32_t)j);
+        prof_end(c);
+        H2_HIPCHK(hipGetLastError());
+    }
+    for (int l = 0; l < 2; ++l) {
+        H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));
+        H2_HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
+    }
+    H2_HIPCHK(hipMemcpyAsync(out_host, results, psz * count, hipMemcpyDeviceToHost, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling)   // fold the lanes' kernel timers into the parent's table
+        for (int l = 0; l < 2; ++l) {
+            prof_collect(ctx->lane[l]);
+            for (auto &kv : ctx->lane[l]->stats) {
+                ctx->stats[kv.first].total_ms += kv.second.total_ms;
+                ctx->stats[kv.first].launches += kv.second.launches;
+            }
+            ctx->lane[l]->stats.clear();
+        }
+    return H2HIP_OK;
+}
+
 int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host) {
     H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_host), "NULL argument");
     Fr *stage = nullptr;

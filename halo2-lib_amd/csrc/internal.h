@@ -65,7 +65,7 @@ struct h2hip_ctx {
     int num_cus = 256;
     // scratch
     enum { WS_NTT = 0, WS_DIGITS, WS_COUNTS, WS_OFFSETS, WS_CURSOR, WS_SKEY, WS_SVAL, WS_BUCKETS, WS_PKEY0, WS_PVAL0, WS_PKEY1,
-           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_POSEIDON, WS_FBTABLE, WS_COUNT };
+           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_POSEIDON, WS_FBTABLE, WS_BATCH, WS_COUNT };
     h2::DevBuf ws[WS_COUNT];
     std::vector<h2::TwiddleSet> twiddles;
     // tuning knobs (h2hip_set_param)
@@ -80,6 +80,10 @@ struct h2hip_ctx {
     std::map<std::string, h2::KernelStat> stats;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
     std::vector<hipEvent_t> event_pool;
+    // batch lanes (h2hip_msm_g1_batch_dev): child contexts with their own stream + scratch
+    h2hip_ctx *lane[2] = {nullptr, nullptr};
+    hipEvent_t lane_ev[2] = {nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr;
 };
 
 struct h2hip_bases {

@@ -39,6 +39,7 @@ _PROTOS = {
     "h2hip_bases_len": (_sz, [_vp]),
     "h2hip_msm_g1": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "h2hip_msm_g1_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "h2hip_msm_g1_batch_dev": (_int, [_vp, _vp, C.POINTER(_vp), _sz, _sz, _int, _vp]),
     "h2hip_params_kzg_setup": (_int, [_vp, _u32, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp)]),
     "h2hip_g1_fixed_base_mul_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_bases_download": (_int, [_vp, _vp, _vp]),
@@ -255,6 +256,14 @@ class Context:
     def g1_sum_jacobian_dev(self, points_dptr: int, n: int, point_format: int = POINT_JACOBIAN) -> np.ndarray:
         out = np.zeros((1, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
         self._chk(self.lib.h2hip_g1_sum_jacobian_dev(self.handle, _vp(points_dptr), n, point_format, _ptr(out)))
+        return out
+
+    def msm_batch_dev(self, bases: Bases, scalar_dptrs, n: int, point_format: int = POINT_JACOBIAN) -> np.ndarray:
+        """several independent MSMs over the same bases, pipelined over two streams; returns (count, 8|12)"""
+        count = len(scalar_dptrs)
+        arr = (_vp * count)(*[_vp(int(p)) for p in scalar_dptrs])
+        out = np.zeros((count, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
+        self._chk(self.lib.h2hip_msm_g1_batch_dev(self.handle, bases.handle, arr, n, count, point_format, _ptr(out)))
         return out
 
     # -- NTT family (arithmetic::best_fft, EvaluationDomain::*)

@@ -47,3 +47,30 @@ def sharded_msm(ctx: Context, bases: Bases, scalars_dptr: int, n_local: int, gro
     if device is not None:
         torch.cuda.current_stream(device).synchronize()
     return ctx.g1_sum_jacobian_dev(allp.data_ptr(), world, point_format)
+
+
+def sharded_msm_batch(ctx: Context, bases: Bases, scalar_dptrs, n_local: int, group=None, device=None) -> np.ndarray:
+    """`len(scalar_dptrs)` independent MSMs (e.g. all columns of a phase) over this rank's slice, pipelined on two
+    streams; ONE all-gather carries all the partials (count x 96 B per rank); every rank returns all full results
+    as a (count, 12) Jacobian array."""
+    import torch
+    import torch.distributed as dist
+
+    count = len(scalar_dptrs)
+    parts = ctx.msm_batch_dev(bases, scalar_dptrs, n_local, POINT_JACOBIAN)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return parts
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(parts.view(np.int64).copy()).reshape(1, count, 12)
+    if device is not None:
+        t = t.to(device)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t, group=group)
+    allp = torch.cat(gathered, dim=0).permute(1, 0, 2).contiguous()   # (count, world, 12)
+    if device is not None:
+        torch.cuda.current_stream(device).synchronize()
+    out = np.zeros((count, 12), dtype=np.uint64)
+    stride = world * 12 * 8
+    for j in range(count):
+        out[j] = ctx.g1_sum_jacobian_dev(allp.data_ptr() + j * stride, world, POINT_JACOBIAN)[0]
+    return out

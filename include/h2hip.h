@@ -87,6 +87,12 @@ size_t h2hip_bases_len(const h2hip_bases *bases);
 int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host);
 int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_dev, size_t n, int point_format, void *out_host);
 
+/* `count` independent MSMs over the same bases (all advice columns of a phase, the pieces of h(X), ...).
+ * scalars_dev: host array of `count` device pointers, n scalars each; out_host: `count` points.  The MSMs are
+ * pipelined over two internal streams so that one MSM's latency-bound tail overlaps the next one's accumulation. */
+int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count,
+                           int point_format, void *out_host);
+
 /* ---- a2: KZG SRS (ParamsKZG::<Bn256>::setup [UPSTREAM]; reference gen_srs halo2-base/src/utils/mod.rs:439-443,
  *      halo2-base/benches/mul.rs:39).  g[i] = s^i*G1 and g_lagrange[i] = L_i(s)*G1 for i < 2^k are generated on
  *      the GPU (fixed-base window tables) and stay resident as two base sets; `flags` as in h2hip_bases_upload.

@@ -18,7 +18,7 @@ def _worker(rank, world, port, n, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import halo2_lib_amd as H
-        from halo2_lib_amd.multi_gpu import columns_for_rank, shard_range, sharded_msm
+        from halo2_lib_amd.multi_gpu import columns_for_rank, shard_range, sharded_msm, sharded_msm_batch
         from oracle import c_oracle as CO
         from tests.emu_util import emu_context
         from tests.util import circuit_like_fr, fr, jac_to_affine_ints, rand_fr
@@ -35,6 +35,12 @@ def _worker(rank, world, port, n, q):
         ok = [jac_to_affine_ints(got)] == O.limbs_to_points(want)
         got_aff = sharded_msm(ctx, b, ds, hi - lo, point_format=H.POINT_AFFINE)
         ok = ok and np.array_equal(got_aff, want)
+        scal2 = rand_fr(n, 77)
+        ds2 = ctx.to_device(scal2[lo:hi])
+        gotb = sharded_msm_batch(ctx, b, [ds, ds2, ds], hi - lo)
+        want2 = CO.best_multiexp(scal2, bases, threads=2)
+        ok = ok and [jac_to_affine_ints(gotb[j]) for j in range(3)] == O.limbs_to_points(np.concatenate([want, want2, want]))
+        ctx.free(ds2)
         cols = columns_for_rank(7, rank, world)
         q.put((rank, ok, cols))
         ctx.free(ds)

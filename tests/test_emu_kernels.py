@@ -203,3 +203,19 @@ def test_quotient_flex_gate(ctx):
     gate = CO.fr_mul(q, CO.fr_sub(CO.fr_add(a, CO.fr_mul(rot(a, 1), rot(a, 2))), rot(a, 3)))
     want = CO.fr_add(CO.fr_mul(acc, np.repeat(y, ne, axis=0)), gate)
     assert np.array_equal(got, want)
+
+
+def test_msm_batch_pipelined(ctx):
+    n = 600
+    bases = CO.known_dlog_bases(n, fr([21]), fr([4]))
+    b = ctx.bases_upload(bases)
+    cols = [rand_fr(n, 1), circuit_like_fr(n, 2), rand_fr(n, 3), np.zeros((n, 4), dtype=np.uint64), rand_fr(n, 5)]
+    dptrs = [ctx.to_device(c) for c in cols]
+    got = ctx.msm_batch_dev(b, dptrs, n, H.POINT_AFFINE)
+    for j, c in enumerate(cols):
+        assert np.array_equal(got[j:j + 1], CO.best_multiexp(c, bases, threads=2))
+    gotj = ctx.msm_batch_dev(b, dptrs[:2], n, H.POINT_JACOBIAN)
+    assert [jac_to_affine_ints(gotj[0])] == O.limbs_to_points(got[0:1])
+    for d in dptrs:
+        ctx.free(d)
+    b.free()

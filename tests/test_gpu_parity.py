@@ -199,3 +199,18 @@ def test_quotient_flex_gate(ctx):
     rot = lambda v, r: np.roll(v, -r * step, axis=0)
     gate = CO.fr_mul(q, CO.fr_sub(CO.fr_add(a, CO.fr_mul(rot(a, 1), rot(a, 2))), rot(a, 3)))
     assert np.array_equal(got, CO.fr_add(CO.fr_mul(acc, np.repeat(y, ne, axis=0)), gate))
+
+
+def test_msm_batch_pipelined(ctx):
+    n = 1 << 16
+    bases = CO.known_dlog_bases(n, fr([21]), fr([4]))
+    for flags in (0, 1):
+        b = ctx.bases_upload(bases, flags)
+        cols = [rand_fr(n, 1), circuit_like_fr(n, 2), rand_fr(n, 3), np.zeros((n, 4), dtype=np.uint64), rand_fr(n, 5)]
+        dptrs = [ctx.to_device(c) for c in cols]
+        got = ctx.msm_batch_dev(b, dptrs, n, H.POINT_AFFINE)
+        for j, c in enumerate(cols):
+            assert np.array_equal(got[j:j + 1], CO.best_multiexp(c, bases, threads=NT))
+        for d in dptrs:
+            ctx.free(d)
+        b.free()
