@@ -332,8 +332,8 @@ static int bases_create(h2hip_ctx *ctx, const void *src, bool src_on_device, siz
             return H2HIP_ERR_HIP;
         }
     }
-    if ((flags & H2HIP_BASES_PRECOMPUTE) && n) {
-        int rc = msm_build_table(ctx, b);
+    {
+        int rc = msm_prepare_bases(ctx, b, (flags & H2HIP_BASES_PRECOMPUTE) != 0);
         if (rc != H2HIP_OK) {
             hipFree(b->pts);
             delete b;
@@ -353,6 +353,7 @@ void h2hip_bases_free(h2hip_ctx *ctx, h2hip_bases *bases) {
     if (!bases) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (bases->pts) hipFree(bases->pts);
+    if (bases->pts29) hipFree(bases->pts29);
     delete bases;
 }
 size_t h2hip_bases_len(const h2hip_bases *bases) { return bases ? bases->n : 0; }

@@ -1,0 +1,214 @@
+// BN254 F_q in an UNSATURATED 9 x 29-bit representation for the MSM's point arithmetic on CDNA4.
+//
+// Why: with saturated 8 x 32-bit limbs (field.cuh) a Montgomery product is 128+8 multiplies but ~370 further VALU
+// slots of carry chains, zero-extension moves and VCC-hazard nops — on gfx950 the multiplies are only ~40 % of its
+// issue time.  With 29-bit limbs the 81 partial products of a row-less schoolbook product (and the 81 of the
+// interleaved Montgomery reduction) accumulate straight into 64-bit column registers with v_mad_u64_u32 and no
+// carry handling at all (9*2^60 + 9*2^58 < 2^64): 171 multiplies + ~57 other instructions, measured 1.745e11
+// products/s vs 1.27e11 saturated on MI355X (profiles/r01_modmul_repr.md).
+//
+// Value semantics: an Fq29 holds an integer v = sum l[i]*2^(29 i) that represents the field element
+// v * 2^-261 mod q (Montgomery radix R' = 2^261) and is only WEAKLY reduced: 0 <= v < X*q for a small bound X that
+// every routine documents.  "Normalised" (N) means l[i] < 2^29 for i < 8.  Rules:
+//   f29_mul / f29_sqr   inputs: limbs <= 2^30 (N, or one lazy add of two N values), X_a*X_b <= 169 ;
+//                       output: N, value < (1 + X_a*X_b/169.3) q
+//   f29_add             lazy limb-wise sum (no carries)          f29_norm  carry propagation -> N
+//   f29_sub<K>          a - b + K*q, requires b N and b < K*q, a limbs <= 2^30; output N, value < a + K*q
+// Zero tests compare against the multiples of q inside the documented range.  The bounds used by the point formulas
+// (ec29.cuh) close with X < 5.25 q, Y < 3.3 q, ZZ,ZZZ < 1.3 q.  The emulated build (tests/emu) asserts every limb bound.
+#pragma once
+#include "field.cuh"
+
+#ifdef H2_HIPEMU
+#include <assert.h>
+#define H2_ASSERT29(c) assert(c)
+#else
+#define H2_ASSERT29(c) ((void)0)
+#endif
+
+namespace h2 {
+
+namespace k29 {
+#include "fq29_constants.inc"
+}
+
+constexpr uint32_t MASK29 = (1u << 29) - 1;
+
+struct Fq29 {
+    uint32_t l[9];
+    H2_HD static Fq29 zero() {
+        Fq29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = 0;
+        return r;
+    }
+    H2_HD static Fq29 one() {   // 2^261 mod q
+        Fq29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = k29::one29(i);
+        return r;
+    }
+    H2_HD bool is_zero_exact() const {   // the integer 0 (only ever assigned, never computed from non-zero elements)
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o |= l[i];
+        return o == 0;
+    }
+};
+
+H2_HD Fq29 f29_norm(const Fq29 &a) {
+    Fq29 r;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = a.l[i] + carry;
+        r.l[i] = v & MASK29;
+        carry = v >> 29;
+    }
+    r.l[8] = a.l[8] + carry;
+    return r;
+}
+H2_HD Fq29 f29_add(const Fq29 &a, const Fq29 &b) {   // lazy
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+
+#define H2_SUBK_LIMB(K, i) ((K) == 2 ? k29::sub2p29(i) : (K) == 3 ? k29::sub3p29(i) : (K) == 4 ? k29::sub4p29(i) : (K) == 6 ? k29::sub6p29(i) : k29::sub8p29(i))
+// a - b + K*q, normalised.  b must be N and < K*q.
+template <int K>
+H2_HD Fq29 f29_sub(const Fq29 &a, const Fq29 &b) {
+    static_assert(K == 2 || K == 3 || K == 4 || K == 6 || K == 8, "no constant for this K");
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        H2_ASSERT29(i == 8 || b.l[i] <= MASK29);
+        H2_ASSERT29(H2_SUBK_LIMB(K, i) >= b.l[i]);
+        r.l[i] = a.l[i] + (H2_SUBK_LIMB(K, i) - b.l[i]);
+    }
+    return f29_norm(r);
+}
+template <int K>
+H2_HD Fq29 f29_neg(const Fq29 &b) {   // K*q - b
+    return f29_sub<K>(Fq29::zero(), b);
+}
+
+// Montgomery reduction of 18 column sums (radix 2^29) -> normalised 9 limbs
+H2_HD Fq29 f29_reduce_columns(uint64_t (&c)[18]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        uint32_t m = ((uint32_t)c[k] * k29::INV29) & MASK29;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) c[k + j] += (uint64_t)m * k29::p29(j);
+        c[k + 1] += c[k] >> 29;
+    }
+    Fq29 r;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint64_t v = c[9 + k] + carry;
+        r.l[k] = (uint32_t)v & MASK29;
+        carry = v >> 29;
+    }
+    uint64_t top = c[17] + carry;
+    H2_ASSERT29(top < (1ull << 29));
+    r.l[8] = (uint32_t)top;
+    return r;
+}
+H2_HD Fq29 f29_mul(const Fq29 &a, const Fq29 &b) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        H2_ASSERT29(a.l[i] <= (1u << 30) && b.l[i] <= (1u << 30));
+#pragma unroll
+        for (int j = 0; j < 9; ++j) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+    return f29_reduce_columns(c);
+}
+H2_HD Fq29 f29_sqr(const Fq29 &a) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) c[k] = 0;
+    uint32_t a2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        H2_ASSERT29(a.l[i] <= (1u << 30));
+        a2[i] = a.l[i] << 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        c[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+        for (int j = i + 1; j < 9; ++j) c[i + j] += (uint64_t)a.l[i] * a2[j];
+    }
+    return f29_reduce_columns(c);
+}
+
+// a == k*q for some 0 <= k <= KMAX ?   (a must be N; use when a < (KMAX+1)*q)
+#define H2_MULK_LIMB(k, i) ((k) == 0 ? 0u : (k) == 1 ? k29::mul1p29(i) : (k) == 2 ? k29::mul2p29(i) : (k) == 3 ? k29::mul3p29(i) : (k) == 4 ? k29::mul4p29(i) : (k) == 5 ? k29::mul5p29(i) : (k) == 6 ? k29::mul6p29(i) : (k) == 7 ? k29::mul7p29(i) : k29::mul8p29(i))
+template <int KMAX>
+H2_HD bool f29_is_zero_mod_q(const Fq29 &a) {
+    static_assert(KMAX <= 8, "range too large");
+    bool cand = false;
+#pragma unroll
+    for (int k = 0; k <= KMAX; ++k) cand |= (a.l[0] == H2_MULK_LIMB(k, 0));
+    if (!cand) return false;
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k <= KMAX; ++k) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d |= a.l[i] ^ H2_MULK_LIMB(k, i);
+        hit |= (d == 0);
+    }
+    return hit;
+}
+
+// saturated Montgomery (R = 2^256, canonical < q)  ->  unsaturated (R' = 2^261), N, value < 1.01 q
+H2_HD Fq29 f29_from_sat(const Fq &s) {
+    Fq29 t;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int bit = 29 * i, w = bit >> 5, off = bit & 31;
+        uint64_t lo = w < 8 ? s.l[w] : 0, hi = (w + 1) < 8 ? s.l[w + 1] : 0;
+        t.l[i] = (uint32_t)(((hi << 32) | lo) >> off) & MASK29;
+    }
+    Fq29 k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k.l[i] = k29::conv_in29(i);
+    return f29_mul(t, k);
+}
+// unsaturated (any documented bound) -> saturated Montgomery R = 2^256, canonical
+H2_HD Fq f29_to_sat(const Fq29 &v) {
+    Fq29 k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k.l[i] = k29::conv_out29(i);
+    Fq29 t = f29_mul(v, k);   // N, < 1.04 q  -> at most one subtraction of q
+    uint32_t d[9], borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint32_t x = t.l[i] - k29::p29(i) - borrow;
+        borrow = (x >> 31) & 1u;            // limbs are < 2^29, so a wrap sets the top bit
+        d[i] = i < 8 ? (x & MASK29) : x;
+    }
+    uint32_t r[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r[i] = borrow ? t.l[i] : d[i];
+    Fq out;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        // word w covers bits [32w, 32w+32): limbs floor(32w/29) and the next one
+        const int lo_limb = (32 * w) / 29, off = 32 * w - 29 * lo_limb;
+        uint64_t v = (uint64_t)r[lo_limb] >> off;
+        int have = 29 - off;
+        if (lo_limb + 1 < 9) v |= (uint64_t)r[lo_limb + 1] << have;
+        if (have + 29 < 32 && lo_limb + 2 < 9) v |= (uint64_t)r[lo_limb + 2] << (have + 29);
+        out.l[w] = (uint32_t)v;
+    }
+    return out;
+}
+
+}  // namespace h2

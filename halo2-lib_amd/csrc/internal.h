@@ -86,8 +86,12 @@ struct h2hip_ctx {
     hipEvent_t fork_ev = nullptr;
 };
 
+namespace h2 {
+struct G1Affine29;
+}
 struct h2hip_bases {
-    h2::G1Affine *pts = nullptr;   // [tables][n] affine, Montgomery
+    h2::G1Affine *pts = nullptr;      // [n] affine, saturated Montgomery limbs (as uploaded; h2hip_bases_download)
+    h2::G1Affine29 *pts29 = nullptr;  // [tables][n] the same points in the unsaturated layout the MSM kernels read
     size_t n = 0;
     uint32_t window_bits = 0;      // precomputed mode: window the table was built for
     uint32_t tables = 1;           // 1 = plain; W = precomputed 2^(c*w) multiples
@@ -104,6 +108,6 @@ void prof_end(h2hip_ctx *ctx);
 int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in_override, uint64_t in_len, const Fr *in_scale3,
             const Fr *out_scale3);
 int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_t n);
-int msm_build_table(h2hip_ctx *ctx, h2hip_bases *bases);
+int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *bases, bool precompute);
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
 }  // namespace h2

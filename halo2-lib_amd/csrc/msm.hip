@@ -23,6 +23,7 @@
 // every window (16x the memory — sized for 288 GB HBM), so all windows share one bucket set per index and the
 // serial 2^(c*w) fold disappears.  Signs are applied by negating y on load.
 #include "internal.h"
+#include "ec29.cuh"
 
 namespace h2 {
 
@@ -202,10 +203,10 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offset
     return lo;
 }
 
-__global__ __launch_bounds__(256) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
+__global__ __launch_bounds__(256) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine29 *__restrict__ bases,
                                                         const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
-                                                        XYZZ *__restrict__ buckets, uint32_t *__restrict__ out_keys,
-                                                        XYZZ *__restrict__ out_vals, uint32_t nthreads) {
+                                                        XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
+                                                        XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nthreads) return;
     const uint32_t total = offsets[nkeys];
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void msm_accum_kernel(const uint32_t *__restri
     uint32_t next = offsets[cur + 1];
     uint32_t hk = KEY_INVALID;
     bool first = true;
-    XYZZ acc = XYZZ::identity();
+    XYZZ29 acc = XYZZ29::identity();
     for (uint32_t e = start; e < end; ++e) {
         if (e >= next) {   // bucket boundary: close the run
             if (first) {
@@ -230,21 +231,18 @@ __global__ __launch_bounds__(256) void msm_accum_kernel(const uint32_t *__restri
             } else {
                 buckets[cur] = acc;
             }
-            acc = XYZZ::identity();
+            acc = XYZZ29::identity();
             cur = (offsets[cur + 2] > e) ? cur + 1 : find_key(offsets, cur + 1, nkeys, e);
             next = offsets[cur + 1];
         }
         uint32_t v = sval[e];
-        G1Affine p = bases[v & 0x7fffffffu];
-        if (!p.is_identity()) {
-            if (v >> 31) p.y = fe_neg(p.y);
-            xyzz_add_affine(acc, p.x, p.y);
-        }
+        G1Affine29 p = bases[v & 0x7fffffffu];
+        if (!p.is_identity()) xyzz29_add_affine(acc, p.x, p.y, (v >> 31) != 0);
     }
     // the list handed to msm_merge is sorted and hole-free: a single-run chunk emits (key, sum), (key, identity)
     if (first) {
         out_vals[2 * (size_t)t] = acc;
-        out_vals[2 * (size_t)t + 1] = XYZZ::identity();
+        out_vals[2 * (size_t)t + 1] = XYZZ29::identity();
         out_keys[2 * (size_t)t] = cur;
     } else {
         out_vals[2 * (size_t)t + 1] = acc;
@@ -258,26 +256,26 @@ __global__ __launch_bounds__(256) void msm_accum_kernel(const uint32_t *__restri
 // Runs closed inside the workgroup (checked against the neighbouring workgroups' boundary keys) are written
 // to buckets (identity totals are skipped: buckets start zeroed = identity, which also makes the filler slots
 // harmless); the (at most two) runs that cross a workgroup boundary go to slots 2*blk, 2*blk+1 of the next level.
-__global__ __launch_bounds__(256) void msm_merge_kernel(const uint32_t *__restrict__ kin, const XYZZ *__restrict__ vin, uint32_t len,
-                                                        XYZZ *__restrict__ buckets, uint32_t *__restrict__ kout,
-                                                        XYZZ *__restrict__ vout, uint32_t final_level) {
-    __shared__ XYZZ sv[256];
+__global__ __launch_bounds__(256) void msm_merge_kernel(const uint32_t *__restrict__ kin, const XYZZ29 *__restrict__ vin, uint32_t len,
+                                                        XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ kout,
+                                                        XYZZ29 *__restrict__ vout, uint32_t final_level) {
+    __shared__ XYZZ29 sv[256];
     __shared__ uint32_t sk[256];
     const uint32_t tid = threadIdx.x, blk = blockIdx.x;
     const uint32_t i = blk * 256 + tid;
     const uint32_t key = i < len ? kin[i] : KEY_INVALID;
-    XYZZ val = XYZZ::identity();
+    XYZZ29 val = XYZZ29::identity();
     if (key != KEY_INVALID) val = vin[i];
     sk[tid] = key;
     sv[tid] = val;
     __syncthreads();
     for (uint32_t d = 1; d < 256; d <<= 1) {
         const bool m = tid >= d && key != KEY_INVALID && sk[tid - d] == key;
-        XYZZ other = XYZZ::identity();
+        XYZZ29 other = XYZZ29::identity();
         if (m) other = sv[tid - d];
         if (!__syncthreads_or(m ? 1 : 0)) break;   // also orders this step's LDS reads before its writes
         if (m) {
-            xyzz_add(val, other);
+            xyzz29_add(val, other);
             sv[tid] = val;
         }
         __syncthreads();
@@ -285,9 +283,9 @@ __global__ __launch_bounds__(256) void msm_merge_kernel(const uint32_t *__restri
     const uint32_t first_key = sk[0], last_key = sk[255];
     if (!final_level && tid == 0) {   // default filler slots keep the next level sorted and hole-free
         kout[2 * (size_t)blk] = first_key;
-        vout[2 * (size_t)blk] = XYZZ::identity();
+        vout[2 * (size_t)blk] = XYZZ29::identity();
         kout[2 * (size_t)blk + 1] = last_key;
-        if (last_key != KEY_INVALID) vout[2 * (size_t)blk + 1] = XYZZ::identity();
+        if (last_key != KEY_INVALID) vout[2 * (size_t)blk + 1] = XYZZ29::identity();
     }
     __syncthreads();
     if (key == KEY_INVALID) return;
@@ -308,54 +306,54 @@ __global__ __launch_bounds__(256) void msm_merge_kernel(const uint32_t *__restri
 }
 
 // ------------------------------------------------------------------ 7. bucket reduction
-__device__ __forceinline__ XYZZ xyzz_small_mul(const XYZZ &p, uint32_t k) {
-    XYZZ r = XYZZ::identity();
+__device__ __forceinline__ XYZZ29 xyzz_small_mul(const XYZZ29 &p, uint32_t k) {
+    XYZZ29 r = XYZZ29::identity();
     for (int bit = 31 - __clz(k | 1u); bit >= 0; --bit) {
-        r = xyzz_double(r);
-        if ((k >> bit) & 1u) xyzz_add(r, p);
+        r = xyzz29_double(r);
+        if ((k >> bit) & 1u) xyzz29_add(r, p);
     }
     return r;
 }
 // precomputed bases: all windows carry weight 1, so fold them per bucket index first: out[b] = sum_w buckets[w][b]
 // (rows = number of windows of `in`, summed in groups of `group`; launched twice: W -> ceil(W/4) -> 1 rows)
-__global__ __launch_bounds__(64) void msm_presum_kernel(const XYZZ *__restrict__ in, XYZZ *__restrict__ out, uint32_t B, uint32_t rows,
+__global__ __launch_bounds__(64) void msm_presum_kernel(const XYZZ29 *__restrict__ in, XYZZ29 *__restrict__ out, uint32_t B, uint32_t rows,
                                                         uint32_t group) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t groups = (rows + group - 1) / group;
     if (t >= B * groups) return;
     uint32_t gi = t / B, b = t - gi * B;
     uint32_t w0 = gi * group, w1 = w0 + group < rows ? w0 + group : rows;
-    XYZZ acc = in[(size_t)w0 * B + b];
-    for (uint32_t w = w0 + 1; w < w1; ++w) xyzz_add(acc, in[(size_t)w * B + b]);
+    XYZZ29 acc = in[(size_t)w0 * B + b];
+    for (uint32_t w = w0 + 1; w < w1; ++w) xyzz29_add(acc, in[(size_t)w * B + b]);
     out[(size_t)gi * B + b] = acc;
 }
 // one lane per segment of L buckets: sum_{b in seg} (b+1) * bucket[b]
-__global__ __launch_bounds__(64) void msm_seg_kernel(const XYZZ *__restrict__ buckets, XYZZ *__restrict__ seg_out, uint32_t B, uint32_t L,
+__global__ __launch_bounds__(64) void msm_seg_kernel(const XYZZ29 *__restrict__ buckets, XYZZ29 *__restrict__ seg_out, uint32_t B, uint32_t L,
                                                      uint32_t nseg_total) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nseg_total) return;
     uint32_t per = B / L, w = g / per, lo = (g - w * per) * L;
-    const XYZZ *bw = buckets + (size_t)w * B;
-    XYZZ run = XYZZ::identity(), acc = XYZZ::identity();
+    const XYZZ29 *bw = buckets + (size_t)w * B;
+    XYZZ29 run = XYZZ29::identity(), acc = XYZZ29::identity();
     for (int b = (int)(lo + L) - 1; b >= (int)lo; --b) {
-        xyzz_add(run, bw[b]);
-        xyzz_add(acc, run);
+        xyzz29_add(run, bw[b]);
+        xyzz29_add(acc, run);
     }
-    if (lo) xyzz_add(acc, xyzz_small_mul(run, lo));
+    if (lo) xyzz29_add(acc, xyzz_small_mul(run, lo));
     seg_out[g] = acc;
 }
 // one workgroup per window: tree sum of its segment results
-__global__ __launch_bounds__(1024) void msm_winsum_kernel(const XYZZ *__restrict__ seg, XYZZ *__restrict__ win_out, uint32_t per) {
-    __shared__ XYZZ sh[1024];
+__global__ __launch_bounds__(1024) void msm_winsum_kernel(const XYZZ29 *__restrict__ seg, XYZZ29 *__restrict__ win_out, uint32_t per) {
+    __shared__ XYZZ29 sh[1024];
     uint32_t tid = threadIdx.x, w = blockIdx.x;
-    XYZZ acc = XYZZ::identity();
-    for (uint32_t i = tid; i < per; i += 1024) xyzz_add(acc, seg[(size_t)w * per + i]);
+    XYZZ29 acc = XYZZ29::identity();
+    for (uint32_t i = tid; i < per; i += 1024) xyzz29_add(acc, seg[(size_t)w * per + i]);
     sh[tid] = acc;
     __syncthreads();
     for (uint32_t d = 512; d >= 1; d >>= 1) {
         if (tid < d) {
-            XYZZ a = sh[tid];
-            xyzz_add(a, sh[tid + d]);
+            XYZZ29 a = sh[tid];
+            xyzz29_add(a, sh[tid + d]);
             sh[tid] = a;
         }
         __syncthreads();
@@ -363,25 +361,25 @@ __global__ __launch_bounds__(1024) void msm_winsum_kernel(const XYZZ *__restrict
     if (tid == 0) win_out[w] = sh[0];
 }
 // out = sum_w 2^(c*w) * win[w]   (Wr <= 64 windows, one lane each, then a tree)
-__global__ __launch_bounds__(64) void msm_fold_kernel(const XYZZ *__restrict__ win, uint32_t Wr, uint32_t c, XYZZ *__restrict__ out) {
-    __shared__ XYZZ sh[64];
+__global__ __launch_bounds__(64) void msm_fold_kernel(const XYZZ29 *__restrict__ win, uint32_t Wr, uint32_t c, XYZZ *__restrict__ out) {
+    __shared__ XYZZ29 sh[64];
     uint32_t tid = threadIdx.x;
-    XYZZ p = XYZZ::identity();
+    XYZZ29 p = XYZZ29::identity();
     if (tid < Wr) {
         p = win[tid];
-        for (uint32_t i = 0; i < c * tid; ++i) p = xyzz_double(p);
+        for (uint32_t i = 0; i < c * tid; ++i) p = xyzz29_double(p);
     }
     sh[tid] = p;
     __syncthreads();
     for (uint32_t d = 32; d >= 1; d >>= 1) {
         if (tid < d) {
-            XYZZ a = sh[tid];
-            xyzz_add(a, sh[tid + d]);
+            XYZZ29 a = sh[tid];
+            xyzz29_add(a, sh[tid + d]);
             sh[tid] = a;
         }
         __syncthreads();
     }
-    if (tid == 0) out[0] = sh[0];
+    if (tid == 0) out[0] = xyzz29_to_sat(sh[0]);   // back to saturated canonical limbs for the C ABI
 }
 
 // ------------------------------------------------------------------ precomputed tables (H2HIP_BASES_PRECOMPUTE)
@@ -439,6 +437,12 @@ int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_
     return H2HIP_OK;
 }
 
+// saturated affine table -> unsaturated 29-bit layout used by msm_accum_kernel
+__global__ __launch_bounds__(256) void bases_to_29_kernel(const G1Affine *__restrict__ in, G1Affine29 *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = g1affine29_from_sat(in[i]);
+}
+
 static uint32_t pick_window(size_t n) {
     uint32_t best = 4;
     double best_cost = 1e300;
@@ -453,33 +457,57 @@ static uint32_t pick_window(size_t n) {
     return best;
 }
 
-// builds levels 1..W-1 of a precomputed table in place (level 0 = the uploaded bases)
-int msm_build_table(h2hip_ctx *ctx, h2hip_bases *b) {
-    const uint32_t c = ctx->msm_window_bits ? (uint32_t)ctx->msm_window_bits : pick_window(b->n);
-    H2_REQUIRE(c >= 2 && c <= 16, "window bits out of range for precomputed bases");
-    const uint32_t W = (255 + c - 1) / c;
-    H2_REQUIRE((uint64_t)b->n * W < (1ull << 31), "precomputed table too large for 31-bit indices");
-    G1Affine *table = nullptr;
-    hipError_t e = hipMalloc((void **)&table, sizeof(G1Affine) * b->n * W);
+// (re)builds bases->pts29, the unsaturated copy every MSM reads; with `precompute` it holds W levels
+// 2^(c*w) * P_i (level w at offset w*n), built level by level in saturated arithmetic and converted.
+int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *b, bool precompute) {
+    const uint32_t n = (uint32_t)b->n;
+    uint32_t c = 0, W = 1;
+    if (precompute && n) {
+        c = ctx->msm_window_bits ? (uint32_t)ctx->msm_window_bits : pick_window(b->n);
+        H2_REQUIRE(c >= 2 && c <= 16, "window bits out of range for precomputed bases");
+        W = (255 + c - 1) / c;
+        H2_REQUIRE((uint64_t)b->n * W < (1ull << 31), "precomputed table too large for 31-bit indices");
+    }
+    G1Affine29 *t29 = nullptr;
+    hipError_t e = hipMalloc((void **)&t29, sizeof(G1Affine29) * (size_t)(n ? n : 1) * W);
     if (e != hipSuccess) {
-        set_error("hipMalloc for precomputed table (%zu points x %u windows) failed: %s", b->n, W, hipGetErrorString(e));
+        set_error("hipMalloc for %zu bases x %u windows failed: %s", b->n, W, hipGetErrorString(e));
         return H2HIP_ERR_NOMEM;
     }
-    H2_HIPCHK(hipMemcpyAsync(table, b->pts, sizeof(G1Affine) * b->n, hipMemcpyDeviceToDevice, ctx->stream));
-    G1Jac *tmp = nullptr;
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP1, sizeof(G1Jac) * b->n, (void **)&tmp));
-    const uint32_t n = (uint32_t)b->n;
-    for (uint32_t w = 1; w < W; ++w) {
-        prof_begin(ctx, "table_double_kernel");
-        hipLaunchKernelGGL(table_double_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const G1Affine *)(table + (size_t)(w - 1) * n),
-                           tmp, n, c);
+    auto convert = [&](const G1Affine *src, uint32_t level) -> int {
+        if (!n) return H2HIP_OK;
+        prof_begin(ctx, "bases_to_29_kernel");
+        hipLaunchKernelGGL(bases_to_29_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, t29 + (size_t)level * n, (size_t)n);
         prof_end(ctx);
         H2_HIPCHK(hipGetLastError());
-        H2_CHK(batch_normalize_jac(ctx, tmp, table + (size_t)w * n, n));
+        return H2HIP_OK;
+    };
+    int rc = convert(b->pts, 0);
+    if (rc == H2HIP_OK && W > 1) {
+        G1Jac *tmp = nullptr;
+        G1Affine *lvl[2] = {nullptr, nullptr};
+        rc = ws_reserve(ctx, h2hip_ctx::WS_TMP1, sizeof(G1Jac) * b->n, (void **)&tmp);
+        if (rc == H2HIP_OK) rc = ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(G1Affine) * 2 * b->n, (void **)&lvl[0]);
+        lvl[1] = lvl[0] + b->n;
+        const G1Affine *prev = b->pts;
+        for (uint32_t w = 1; rc == H2HIP_OK && w < W; ++w) {
+            G1Affine *cur = lvl[w & 1];
+            prof_begin(ctx, "table_double_kernel");
+            hipLaunchKernelGGL(table_double_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, prev, tmp, n, c);
+            prof_end(ctx);
+            if (hipGetLastError() != hipSuccess) rc = H2HIP_ERR_HIP;
+            if (rc == H2HIP_OK) rc = batch_normalize_jac(ctx, tmp, cur, n);
+            if (rc == H2HIP_OK) rc = convert(cur, w);
+            prev = cur;
+        }
     }
-    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
-    H2_HIPCHK(hipFree(b->pts));
-    b->pts = table;
+    if (rc == H2HIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = H2HIP_ERR_HIP;
+    if (rc != H2HIP_OK) {
+        hipFree(t29);
+        return rc;
+    }
+    if (b->pts29) hipFree(b->pts29);
+    b->pts29 = t29;
     b->tables = W;
     b->window_bits = c;
     return H2HIP_OK;
@@ -488,6 +516,7 @@ int msm_build_table(h2hip_ctx *ctx, h2hip_bases *b) {
 // ------------------------------------------------------------------ host driver
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
+    H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
     H2_REQUIRE(n < (1u << 27), "n too large for 32-bit entry indices");
     hipStream_t st = ctx->stream;
     if (n == 0) {
@@ -515,29 +544,29 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     const uint32_t sort_grid = 8 * G * ((W + 7) / 8);
 
     uint32_t *digits, *bhist, *counts, *offsets, *sval, *pkey[2];
-    XYZZ *buckets, *pval[2], *seg, *win, *presum = nullptr;
+    XYZZ29 *buckets, *pval[2], *seg, *win, *presum = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_DIGITS, sizeof(uint32_t) * emax, (void **)&digits));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * (nkeys + 1), (void **)&counts));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * (nkeys + 2), (void **)&offsets));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SVAL, sizeof(uint32_t) * emax, (void **)&sval));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(XYZZ) * nkeys, (void **)&buckets));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(XYZZ29) * nkeys, (void **)&buckets));
     const uint32_t T1 = (uint32_t)((emax + K1 - 1) / K1);
     const uint32_t len1 = 2 * T1, blocks1 = (len1 + 255) / 256;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY0, sizeof(uint32_t) * (size_t)len1, (void **)&pkey[0]));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL0, sizeof(XYZZ) * (size_t)len1, (void **)&pval[0]));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL0, sizeof(XYZZ29) * (size_t)len1, (void **)&pval[0]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY1, sizeof(uint32_t) * 2 * (size_t)blocks1, (void **)&pkey[1]));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ) * 2 * (size_t)blocks1, (void **)&pval[1]));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ29) * 2 * (size_t)blocks1, (void **)&pval[1]));
     const uint32_t Wr = precomp ? 1 : W;   // windows left after the optional per-index presum
     const uint32_t nseg = Wr * (B / L);
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(XYZZ) * nseg, (void **)&seg));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(XYZZ) * 64, (void **)&win));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(XYZZ29) * nseg, (void **)&seg));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(XYZZ29) * 64, (void **)&win));
     const uint32_t pre_rows = (W + 3) / 4;
-    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ) * B * (pre_rows + 1), (void **)&presum));
+    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ29) * B * (pre_rows + 1), (void **)&presum));
 
     H2_HIPCHK(hipMemsetAsync(counts + nkeys, 0, sizeof(uint32_t), st));
     H2_HIPCHK(hipMemsetAsync(offsets + nkeys + 1, 0xff, sizeof(uint32_t), st));   // sentinel read by the boundary walk
-    H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ) * nkeys, st));
+    H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
 
     prof_begin(ctx, "msm_digits_kernel");
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, scalars, (uint32_t)n, c, W, digits);
@@ -557,7 +586,7 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     H2_HIPCHK(hipGetLastError());
 
     prof_begin(ctx, "msm_accum_kernel");
-    hipLaunchKernelGGL(msm_accum_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts,
+    hipLaunchKernelGGL(msm_accum_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine29 *)bases->pts29,
                        (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
@@ -567,7 +596,7 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
         const uint32_t blocks = (len + 255) / 256;
         const uint32_t final_level = blocks == 1 ? 1u : 0u;
         prof_begin(ctx, "msm_merge_kernel");
-        hipLaunchKernelGGL(msm_merge_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *)pkey[src], (const XYZZ *)pval[src], len, buckets,
+        hipLaunchKernelGGL(msm_merge_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *)pkey[src], (const XYZZ29 *)pval[src], len, buckets,
                            pkey[src ^ 1], pval[src ^ 1], final_level);
         prof_end(ctx);
         H2_HIPCHK(hipGetLastError());
@@ -576,11 +605,11 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
         src ^= 1;
     }
 
-    const XYZZ *red_in = buckets;
+    const XYZZ29 *red_in = buckets;
     if (precomp) {
         prof_begin(ctx, "msm_presum_kernel");
-        hipLaunchKernelGGL(msm_presum_kernel, dim3((B * pre_rows + 63) / 64), dim3(64), 0, st, (const XYZZ *)buckets, presum + B, B, W, 4u);
-        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const XYZZ *)(presum + B), presum, B, pre_rows, pre_rows);
+        hipLaunchKernelGGL(msm_presum_kernel, dim3((B * pre_rows + 63) / 64), dim3(64), 0, st, (const XYZZ29 *)buckets, presum + B, B, W, 4u);
+        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const XYZZ29 *)(presum + B), presum, B, pre_rows, pre_rows);
         prof_end(ctx);
         red_in = presum;
     }
@@ -588,10 +617,10 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     hipLaunchKernelGGL(msm_seg_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, red_in, seg, B, L, nseg);
     prof_end(ctx);
     prof_begin(ctx, "msm_winsum_kernel");
-    hipLaunchKernelGGL(msm_winsum_kernel, dim3(Wr), dim3(1024), 0, st, (const XYZZ *)seg, win, B / L);
+    hipLaunchKernelGGL(msm_winsum_kernel, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, B / L);
     prof_end(ctx);
     prof_begin(ctx, "msm_fold_kernel");
-    hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ *)win, Wr, c, out);
+    hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ29 *)win, Wr, c, out);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;

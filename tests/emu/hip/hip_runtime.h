@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 
+#define H2_HIPEMU 1
 #define __global__
 #define __device__
 #define __host__
