@@ -209,6 +209,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_chunk2")) return &ctx->msm_chunk2;
     if (!strcmp(name, "msm_seg")) return &ctx->msm_seg;
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
+    if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
     return nullptr;
 }
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
@@ -216,9 +217,10 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     int *p = param_slot(ctx, name);
     H2_REQUIRE(p, "unknown parameter name");
     if (p == &ctx->msm_window_bits) H2_REQUIRE(value == 0 || (value >= 2 && value <= 23), "msm_window_bits must be 0 or 2..23");
-    if (p == &ctx->msm_chunk) H2_REQUIRE(value >= 2 && value <= 4096, "msm_chunk must be 2..4096");
+    if (p == &ctx->msm_chunk) H2_REQUIRE(value == 0 || (value >= 2 && value <= 4096), "msm_chunk must be 0 (auto) or 2..4096");
     if (p == &ctx->msm_chunk2) H2_REQUIRE(value >= 4 && value <= 4096, "msm_chunk2 must be 4..4096");
     if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
+    if (p == &ctx->msm_accum_variant) H2_REQUIRE(value == 3 || value == 4, "msm_accum_variant must be 3 or 4");
     if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
     *p = value;
     return H2HIP_OK;
@@ -388,6 +390,7 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
         h2hip_ctx *c = ctx->lane[l];
         c->msm_chunk = ctx->msm_chunk;
         c->msm_seg = ctx->msm_seg;
+        c->msm_accum_variant = ctx->msm_accum_variant;
         c->msm_window_bits = ctx->msm_window_bits;
         c->profiling = ctx->profiling;
     }

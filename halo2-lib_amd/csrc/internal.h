@@ -70,10 +70,11 @@ struct h2hip_ctx {
     std::vector<h2::TwiddleSet> twiddles;
     // tuning knobs (h2hip_set_param)
     int msm_window_bits = 0;   // 0 = auto
-    int msm_chunk = 32;        // level-1 entries per lane
+    int msm_chunk = 0;         // level-1 entries per lane (0 = auto: 8..64, keeping >= 4 waves per SIMD)
     int msm_chunk2 = 8;        // level>=2 entries per lane
-    int msm_seg = 4;           // buckets per running-sum segment
+    int msm_seg = 8;           // buckets per running-sum segment
     int ntt_tile_bits = 10;
+    int msm_accum_variant = 3;   // min waves/SIMD the accumulate kernel is compiled for (3 or 4)
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]
     // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled
     bool profiling = false;

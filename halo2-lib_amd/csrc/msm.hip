@@ -203,7 +203,8 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offset
     return lo;
 }
 
-__global__ __launch_bounds__(256) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine29 *__restrict__ bases,
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine29 *__restrict__ bases,
                                                         const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
                                                         XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
                                                         XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
@@ -533,7 +534,11 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     const uint32_t nkeys = W * B;
     const uint64_t emax = (uint64_t)n * W;
     H2_REQUIRE(emax < 0xFFFFFFF0ull, "n*W overflows 32 bits");
-    const uint32_t K1 = (uint32_t)ctx->msm_chunk;
+    uint32_t K1 = (uint32_t)ctx->msm_chunk;
+    if (K1 == 0) {   // auto: as long as possible (fewer partials to merge) while the grid still fills 4 waves per SIMD
+        uint64_t k = emax / 262144;
+        K1 = k < 8 ? 8u : k > 64 ? 64u : (uint32_t)k;
+    }
     uint32_t L = (uint32_t)ctx->msm_seg;
     if (L > B) L = B;
     // chunking of the counting sort: about 32 chunks per window, 4Ki..64Ki scalars each
@@ -586,8 +591,12 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     H2_HIPCHK(hipGetLastError());
 
     prof_begin(ctx, "msm_accum_kernel");
-    hipLaunchKernelGGL(msm_accum_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine29 *)bases->pts29,
-                       (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+    if (ctx->msm_accum_variant == 4)
+        hipLaunchKernelGGL(msm_accum_kernel<4>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine29 *)bases->pts29,
+                           (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+    else
+        hipLaunchKernelGGL(msm_accum_kernel<3>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine29 *)bases->pts29,
+                           (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     uint32_t len = len1;

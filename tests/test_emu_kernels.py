@@ -73,7 +73,7 @@ def test_msm_parameter_sweep(ctx, c, k1, k2, seg):
         for s in (rand_fr(n, c), circuit_like_fr(n, c)):
             assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=4))
     finally:
-        for name, v in (("msm_window_bits", 0), ("msm_chunk", 32), ("msm_chunk2", 8), ("msm_seg", 8)):
+        for name, v in (("msm_window_bits", 0), ("msm_chunk", 0), ("msm_chunk2", 8), ("msm_seg", 8)):
             ctx.set_param(name, v)
         b.free()
 
@@ -124,7 +124,7 @@ def test_msm_multi_chunk_sort_and_deep_merge(ctx):
         assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=8))
     finally:
         ctx.set_param("msm_window_bits", 0)
-        ctx.set_param("msm_chunk", 32)
+        ctx.set_param("msm_chunk", 0)
         b.free()
 
 

@@ -9,11 +9,11 @@ n = 1 << 20
 bases_h = synthetic_bases(n, 1); s = synthetic_scalars(n, 2)
 ds = ctx.to_device(s)
 res = {}
-for pre in (1, 0):
+for pre in (1,):
     b = ctx.bases_upload(bases_h, pre)
-    for k1 in (24, 32, 48, 64):
-        for seg in (2, 4, 8):
-            ctx.set_param("msm_chunk", k1); ctx.set_param("msm_seg", seg)
+    for k1, seg, var in ((32, 8, 3), (32, 8, 4), (64, 8, 3), (64, 8, 4), (64, 16, 3), (96, 8, 3), (128, 8, 3)):
+        if True:
+            ctx.set_param("msm_chunk", k1); ctx.set_param("msm_seg", seg); ctx.set_param("msm_accum_variant", var)
             ctx.msm_dev(b, ds, n)
             ctx.profile_enable(True); ctx.profile_reset()
             ctx.timer_start()
@@ -21,8 +21,8 @@ for pre in (1, 0):
             ms = ctx.timer_stop() / 5
             parts = {nm: round(ctx.profile_get(nm)[0] / 5, 3) for nm in ("msm_scatter", "msm_accum_kernel", "msm_merge", "msm_presum", "msm_seg", "msm_winsum", "msm_fold")}
             ctx.profile_enable(False)
-            res[f"pre{pre}_k{k1}_seg{seg}"] = {"ms": round(ms, 3), **parts}
-            print(f"pre{pre}_k{k1}_seg{seg}", round(ms, 3), parts, flush=True)
+            res[f"pre{pre}_k{k1}_seg{seg}_v{var}"] = {"ms": round(ms, 3), **parts}
+            print(f"pre{pre}_k{k1}_seg{seg}_v{var}", round(ms, 3), parts, flush=True)
     b.free()
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/sweep.json", "w"), indent=1)
