@@ -28,24 +28,23 @@
 
 namespace h2 {
 
-namespace k29 {
-#include "fq29_constants.inc"
-}
+#include "fq29_constants.inc"   // struct Q29P (G1 coordinate field), struct R29P (scalar field)
 
 constexpr uint32_t MASK29 = (1u << 29) - 1;
 
-struct Fq29 {
+template <class P>
+struct F29 {
     uint32_t l[9];
-    H2_HD static Fq29 zero() {
-        Fq29 r;
+    H2_HD static F29 zero() {
+        F29 r;
 #pragma unroll
         for (int i = 0; i < 9; ++i) r.l[i] = 0;
         return r;
     }
-    H2_HD static Fq29 one() {   // 2^261 mod q
-        Fq29 r;
+    H2_HD static F29 one() {   // 2^261 mod p
+        F29 r;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) r.l[i] = k29::one29(i);
+        for (int i = 0; i < 9; ++i) r.l[i] = P::one(i);
         return r;
     }
     H2_HD bool is_zero_exact() const {   // the integer 0 (only ever assigned, never computed from non-zero elements)
@@ -56,8 +55,12 @@ struct Fq29 {
     }
 };
 
-H2_HD Fq29 f29_norm(const Fq29 &a) {
-    Fq29 r;
+using Fq29 = F29<Q29P>;
+using Fr29 = F29<R29P>;
+
+template <class P>
+H2_HD F29<P> f29_norm(const F29<P> &a) {
+    F29<P> r;
     uint32_t carry = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -68,19 +71,20 @@ H2_HD Fq29 f29_norm(const Fq29 &a) {
     r.l[8] = a.l[8] + carry;
     return r;
 }
-H2_HD Fq29 f29_add(const Fq29 &a, const Fq29 &b) {   // lazy
-    Fq29 r;
+template <class P>
+H2_HD F29<P> f29_add(const F29<P> &a, const F29<P> &b) {   // lazy
+    F29<P> r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
     return r;
 }
 
-#define H2_SUBK_LIMB(K, i) ((K) == 2 ? k29::sub2p29(i) : (K) == 3 ? k29::sub3p29(i) : (K) == 4 ? k29::sub4p29(i) : (K) == 6 ? k29::sub6p29(i) : k29::sub8p29(i))
+#define H2_SUBK_LIMB(K, i) ((K) == 2 ? P::sub2p(i) : (K) == 3 ? P::sub3p(i) : (K) == 4 ? P::sub4p(i) : (K) == 6 ? P::sub6p(i) : P::sub8p(i))
 // a - b + K*q, normalised.  b must be N and < K*q.
-template <int K>
-H2_HD Fq29 f29_sub(const Fq29 &a, const Fq29 &b) {
+template <int K, class P>
+H2_HD F29<P> f29_sub(const F29<P> &a, const F29<P> &b) {
     static_assert(K == 2 || K == 3 || K == 4 || K == 6 || K == 8, "no constant for this K");
-    Fq29 r;
+    F29<P> r;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         H2_ASSERT29(i == 8 || b.l[i] <= MASK29);
@@ -89,21 +93,22 @@ H2_HD Fq29 f29_sub(const Fq29 &a, const Fq29 &b) {
     }
     return f29_norm(r);
 }
-template <int K>
-H2_HD Fq29 f29_neg(const Fq29 &b) {   // K*q - b
-    return f29_sub<K>(Fq29::zero(), b);
+template <int K, class P>
+H2_HD F29<P> f29_neg(const F29<P> &b) {   // K*p - b
+    return f29_sub<K>(F29<P>::zero(), b);
 }
 
 // Montgomery reduction of 18 column sums (radix 2^29) -> normalised 9 limbs
-H2_HD Fq29 f29_reduce_columns(uint64_t (&c)[18]) {
+template <class P>
+H2_HD F29<P> f29_reduce_columns(uint64_t (&c)[18]) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        uint32_t m = ((uint32_t)c[k] * k29::INV29) & MASK29;
+        uint32_t m = ((uint32_t)c[k] * P::INV) & MASK29;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) c[k + j] += (uint64_t)m * k29::p29(j);
+        for (int j = 0; j < 9; ++j) c[k + j] += (uint64_t)m * P::p(j);
         c[k + 1] += c[k] >> 29;
     }
-    Fq29 r;
+    F29<P> r;
     uint64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -116,7 +121,8 @@ H2_HD Fq29 f29_reduce_columns(uint64_t (&c)[18]) {
     r.l[8] = (uint32_t)top;
     return r;
 }
-H2_HD Fq29 f29_mul(const Fq29 &a, const Fq29 &b) {
+template <class P>
+H2_HD F29<P> f29_mul(const F29<P> &a, const F29<P> &b) {
     uint64_t c[18];
 #pragma unroll
     for (int k = 0; k < 18; ++k) c[k] = 0;
@@ -126,9 +132,10 @@ H2_HD Fq29 f29_mul(const Fq29 &a, const Fq29 &b) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) c[i + j] += (uint64_t)a.l[i] * b.l[j];
     }
-    return f29_reduce_columns(c);
+    return f29_reduce_columns<P>(c);
 }
-H2_HD Fq29 f29_sqr(const Fq29 &a) {
+template <class P>
+H2_HD F29<P> f29_sqr(const F29<P> &a) {
     uint64_t c[18];
 #pragma unroll
     for (int k = 0; k < 18; ++k) c[k] = 0;
@@ -144,13 +151,13 @@ H2_HD Fq29 f29_sqr(const Fq29 &a) {
 #pragma unroll
         for (int j = i + 1; j < 9; ++j) c[i + j] += (uint64_t)a.l[i] * a2[j];
     }
-    return f29_reduce_columns(c);
+    return f29_reduce_columns<P>(c);
 }
 
 // a == k*q for some 0 <= k <= KMAX ?   (a must be N; use when a < (KMAX+1)*q)
-#define H2_MULK_LIMB(k, i) ((k) == 0 ? 0u : (k) == 1 ? k29::mul1p29(i) : (k) == 2 ? k29::mul2p29(i) : (k) == 3 ? k29::mul3p29(i) : (k) == 4 ? k29::mul4p29(i) : (k) == 5 ? k29::mul5p29(i) : (k) == 6 ? k29::mul6p29(i) : (k) == 7 ? k29::mul7p29(i) : k29::mul8p29(i))
-template <int KMAX>
-H2_HD bool f29_is_zero_mod_q(const Fq29 &a) {
+#define H2_MULK_LIMB(k, i) ((k) == 0 ? 0u : (k) == 1 ? P::mul1p(i) : (k) == 2 ? P::mul2p(i) : (k) == 3 ? P::mul3p(i) : (k) == 4 ? P::mul4p(i) : (k) == 5 ? P::mul5p(i) : (k) == 6 ? P::mul6p(i) : (k) == 7 ? P::mul7p(i) : P::mul8p(i))
+template <int KMAX, class P>
+H2_HD bool f29_is_zero_mod_q(const F29<P> &a) {
     static_assert(KMAX <= 8, "range too large");
     bool cand = false;
 #pragma unroll
@@ -168,39 +175,35 @@ H2_HD bool f29_is_zero_mod_q(const Fq29 &a) {
 }
 
 // saturated Montgomery (R = 2^256, canonical < q)  ->  unsaturated (R' = 2^261), N, value < 1.01 q
-H2_HD Fq29 f29_from_sat(const Fq &s) {
-    Fq29 t;
+// raw limb split of a saturated element (no domain change: the integer is unchanged)
+template <class P, class PS>
+H2_HD F29<P> f29_split(const Fe<PS> &s) {
+    F29<P> t;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int bit = 29 * i, w = bit >> 5, off = bit & 31;
         uint64_t lo = w < 8 ? s.l[w] : 0, hi = (w + 1) < 8 ? s.l[w + 1] : 0;
         t.l[i] = (uint32_t)(((hi << 32) | lo) >> off) & MASK29;
     }
-    Fq29 k;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) k.l[i] = k29::conv_in29(i);
-    return f29_mul(t, k);
+    return t;
 }
-// unsaturated (any documented bound) -> saturated Montgomery R = 2^256, canonical
-H2_HD Fq f29_to_sat(const Fq29 &v) {
-    Fq29 k;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) k.l[i] = k29::conv_out29(i);
-    Fq29 t = f29_mul(v, k);   // N, < 1.04 q  -> at most one subtraction of q
+// N value < 2p (any integer below 2p) -> canonical (< p) saturated limbs
+template <class PS, class P>
+H2_HD Fe<PS> f29_pack_canonical(const F29<P> &t) {
     uint32_t d[9], borrow = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        uint32_t x = t.l[i] - k29::p29(i) - borrow;
+        uint32_t x = t.l[i] - P::p(i) - borrow;
         borrow = (x >> 31) & 1u;            // limbs are < 2^29, so a wrap sets the top bit
         d[i] = i < 8 ? (x & MASK29) : x;
     }
     uint32_t r[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) r[i] = borrow ? t.l[i] : d[i];
-    Fq out;
+    Fe<PS> out;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
-        // word w covers bits [32w, 32w+32): limbs floor(32w/29) and the next one
+        // word w covers bits [32w, 32w+32): limbs floor(32w/29) and the next one or two
         const int lo_limb = (32 * w) / 29, off = 32 * w - 29 * lo_limb;
         uint64_t v = (uint64_t)r[lo_limb] >> off;
         int have = 29 - off;
@@ -209,6 +212,20 @@ H2_HD Fq f29_to_sat(const Fq29 &v) {
         out.l[w] = (uint32_t)v;
     }
     return out;
+}
+
+H2_HD Fq29 f29_from_sat(const Fq &s) {
+    Fq29 k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k.l[i] = Q29P::conv_in(i);
+    return f29_mul(f29_split<Q29P>(s), k);
+}
+// unsaturated (any documented bound) -> saturated Montgomery R = 2^256, canonical
+H2_HD Fq f29_to_sat(const Fq29 &v) {
+    Fq29 k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k.l[i] = Q29P::conv_out(i);
+    return f29_pack_canonical<FqP>(f29_mul(v, k));   // the product is N and < 1.04 q: at most one subtraction of q
 }
 
 }  // namespace h2

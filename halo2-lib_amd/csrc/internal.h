@@ -47,8 +47,8 @@ struct DevBuf {
 struct TwiddleSet {   // omega^i tables for one (log_n, omega)
     uint32_t log_n = 0, lo_bits = 0;
     Fr omega;
-    Fr *t1 = nullptr;   // omega^i,            i < 2^lo_bits
-    Fr *t2 = nullptr;   // omega^(i<<lo_bits), i < 2^(log_n-lo_bits)
+    void *t1 = nullptr;   // omega^i,            i < 2^lo_bits          (Fr29, R' = 2^261 Montgomery form)
+    void *t2 = nullptr;   // omega^(i<<lo_bits), i < 2^(log_n-lo_bits)
 };
 
 struct KernelStat {
