@@ -181,6 +181,8 @@ void h2hip_destroy(h2hip_ctx *ctx) {
     for (auto &t : ctx->twiddles) {
         hipFree(t.t1);
         hipFree(t.t2);
+        for (int k = 0; k < 4; ++k)
+            if (t.direct[k]) hipFree(t.direct[k]);
     }
     for (auto &p : ctx->pending) {
         hipEventDestroy(p.second.first);
@@ -210,6 +212,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_seg")) return &ctx->msm_seg;
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
     if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
+    if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     return nullptr;
 }
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {

@@ -49,6 +49,8 @@ struct TwiddleSet {   // omega^i tables for one (log_n, omega)
     Fr omega;
     void *t1 = nullptr;   // omega^i,            i < 2^lo_bits          (Fr29, R' = 2^261 Montgomery form)
     void *t2 = nullptr;   // omega^(i<<lo_bits), i < 2^(log_n-lo_bits)
+    void *direct[4] = {nullptr, nullptr, nullptr, nullptr};   // per-stride direct tables omega^(t << log_s) for later passes
+    uint32_t direct_log_s[4] = {0, 0, 0, 0};
 };
 
 struct KernelStat {
@@ -74,6 +76,7 @@ struct h2hip_ctx {
     int msm_chunk2 = 8;        // level>=2 entries per lane
     int msm_seg = 8;           // buckets per running-sum segment
     int ntt_tile_bits = 10;
+    int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_accum_variant = 3;   // min waves/SIMD the accumulate kernel is compiled for (3 or 4)
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]
     // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled

@@ -18,6 +18,13 @@
 
 namespace h2 {
 
+// LDS / table element: 9 limbs padded to 48 B so that it moves as three 16-byte accesses (ds_read_b128 /
+// global_load_dwordx4); a 12-word stride is bank-conflict free for 16-lane b128 groups
+struct alignas(16) Fr29L {
+    Fr29 v;
+    uint32_t pad[3];
+};
+
 struct NttScale {
     Fr in3[3];
     Fr out3[3];
@@ -31,103 +38,147 @@ __device__ __forceinline__ Fr29 fr29_from_sat(const Fr &s) {
     return f29_mul(f29_split<R29P>(s), k);
 }
 
-__global__ void ntt_twiddle_kernel(Fr29 *t1, Fr29 *t2, Fr omega, uint32_t lo_bits, uint32_t hi_count) {
+__global__ void ntt_twiddle_kernel(Fr29L *t1, Fr29L *t2, Fr omega, uint32_t lo_bits, uint32_t hi_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t lo_count = 1u << lo_bits;
-    if (i < lo_count) t1[i] = fr29_from_sat(fe_pow_u64(omega, (uint64_t)i));
-    if (i < hi_count) t2[i] = fr29_from_sat(fe_pow_u64(omega, (uint64_t)i << lo_bits));
+    if (i < lo_count) t1[i].v = fr29_from_sat(fe_pow_u64(omega, (uint64_t)i));
+    if (i < hi_count) t2[i].v = fr29_from_sat(fe_pow_u64(omega, (uint64_t)i << lo_bits));
 }
 
-__device__ __forceinline__ Fr29 tw_lookup(const Fr29 *__restrict__ t1, const Fr29 *__restrict__ t2, uint32_t lo_bits, uint64_t e) {
+__device__ __forceinline__ Fr29 tw_lookup(const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits, uint64_t e) {
     uint32_t lo = (uint32_t)(e & ((1ull << lo_bits) - 1));
     uint32_t hi = (uint32_t)(e >> lo_bits);
-    return f29_mul(t2[hi], t1[lo]);
+    return f29_mul(t2[hi].v, t1[lo].v);
 }
 
 __device__ __forceinline__ uint32_t bitrev_m(uint32_t x, uint32_t m) { return m ? (__brev(x) >> (32 - m)) : 0; }
 
-// One pass; grid = number of tiles, block = 256.  Data moves through HBM as saturated canonical Montgomery limbs
-// (the caller's format); inside the workgroup it lives in LDS as unsaturated 9 x 29-bit limbs (36 B, a 9-word stride
-// is bank-conflict free), where the integer value*2^256 is kept, only weakly reduced.  Stage twiddles and inter-pass
-// twiddles are stored in the R' = 2^261 Montgomery form, so mont29(x, w) keeps the integer's 2^256 scaling and no
-// conversion multiply is ever needed.  Butterflies are decimation-in-time (t = w*b; a + t, a - t + 2r): the bound of
-// a lane's value grows by at most 2r per stage (<= 21 r after 10 stages) instead of doubling.
+// One pass; persistent 256-thread workgroups loop over tiles (grid = min(#tiles, 3 per CU)).  Data moves through HBM as
+// saturated canonical Montgomery limbs (the caller's format); inside the workgroup it lives in LDS as unsaturated
+// 9 x 29-bit limbs (36 B: a 9-word stride is bank-conflict free), where the integer value*2^256 is kept, only weakly
+// reduced.  Stage twiddles and inter-pass twiddles are stored in the R' = 2^261 Montgomery form, so mont29(x, w)
+// keeps the integer's 2^256 scaling and no conversion multiply is ever needed.  Butterflies are decimation-in-time
+// (t = w*b; a + t, a - t + 2r), two stages per LDS round trip with four elements per lane in registers: a value's
+// bound grows by at most 2r per stage (<= 21 r after 10 stages) instead of doubling.  While a tile is being
+// transformed, the lane's share of the NEXT tile is already in flight from HBM into registers.
+constexpr uint32_t NTT_EPT = 4;   // elements per lane per tile (tile <= 1024 elements)
 __global__ __launch_bounds__(256) void ntt_pass_kernel(const Fr *__restrict__ x, Fr *__restrict__ y, uint32_t log_n, uint32_t m,
-                                                       uint32_t log_s, uint32_t cb, const Fr29 *__restrict__ t1,
-                                                       const Fr29 *__restrict__ t2, uint32_t lo_bits, uint64_t in_len, int in_mul,
-                                                       int out_mul, NttScale sc) {
-    HIP_DYNAMIC_SHARED(Fr29, lds)
+                                                       uint32_t log_s, uint32_t cb, const Fr29L *__restrict__ t1,
+                                                       const Fr29L *__restrict__ t2, uint32_t lo_bits, const Fr29L *__restrict__ tdirect,
+                                                       uint64_t in_len, int in_mul, int out_mul, NttScale sc, int debug_skip) {
+    HIP_DYNAMIC_SHARED(Fr29L, lds)
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << m, C = 1u << cb;
     const uint32_t elems = R << cb;
-    Fr29 *tw_s = lds + elems;                           // omega_R^k, k < R/2
+    Fr29L *tw_s = lds + elems;                          // omega_R^k, k < R/2
+    Fr29L *scale_s = tw_s + (R >> 1) + 1;               // [0..3) input scales, [3..6) output scales (R' form)
     const uint64_t rows_stride = 1ull << (log_n - m);   // N/R
-    const uint64_t j0 = (uint64_t)blockIdx.x << cb;
+    const uint32_t ntiles = 1u << (log_n - m - cb);
+    const bool has_tw = (log_s + m) < log_n;            // the last pass has j - q == 0 everywhere
+    const uint64_t smask = (1ull << log_s) - 1;
 
-    for (uint32_t k = tid; k < (R >> 1); k += 256) tw_s[k] = tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m));
+    for (uint32_t k = tid; k < (R >> 1); k += 256) tw_s[k].v = tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m));
+    if (tid < 3 && in_mul) scale_s[tid].v = fr29_from_sat(sc.in3[tid]);
+    if (tid >= 3 && tid < 6 && out_mul) scale_s[tid].v = fr29_from_sat(sc.out3[tid - 3]);
 
-    Fr29 in3[3];
-    if (in_mul) {
+    Fr pre[NTT_EPT];
+    auto fetch = [&](uint32_t tile) {
+        const uint64_t j0 = (uint64_t)tile << cb;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) in3[k] = fr29_from_sat(sc.in3[k]);
-    }
-    for (uint32_t e = tid; e < elems; e += 256) {
-        uint32_t t = e >> cb, c = e & (C - 1);
-        uint64_t idx = j0 + c + (uint64_t)t * rows_stride;
-        Fr29 v = Fr29::zero();
-        if (idx < in_len) {
-            v = f29_split<R29P>(x[idx]);
-            if (in_mul) {
-                uint32_t r3 = (uint32_t)(idx % 3);
-                v = f29_mul(v, r3 == 0 ? in3[0] : r3 == 1 ? in3[1] : in3[2]);
+        for (uint32_t k = 0; k < NTT_EPT; ++k) {
+            uint32_t e = tid + 256 * k;
+            uint64_t idx = j0 + (e & (C - 1)) + (uint64_t)(e >> cb) * rows_stride;
+            pre[k] = (e < elems && idx < in_len) ? x[idx] : Fr::zero();
+        }
+    };
+    uint32_t tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    __syncthreads();   // tw_s / scale_s visible
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const uint64_t j0 = (uint64_t)tile << cb;
+#pragma unroll
+        for (uint32_t k = 0; k < NTT_EPT; ++k) {
+            uint32_t e = tid + 256 * k;
+            if (e < elems) {
+                uint32_t t = e >> cb, c = e & (C - 1);
+                Fr29 v = f29_split<R29P>(pre[k]);
+                if (in_mul) {
+                    uint64_t idx = j0 + c + (uint64_t)t * rows_stride;
+                    v = f29_mul(v, scale_s[idx % 3].v);   // zero padding stays zero
+                }
+                lds[(bitrev_m(t, m) << cb) + c].v = v;   // DIT: bit-reversed rows in, natural rows out
             }
         }
-        lds[(bitrev_m(t, m) << cb) + c] = v;   // DIT: bit-reversed rows in, natural rows out
-    }
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);   // next tile's loads overlap this tile's arithmetic
 
-    for (uint32_t st = 0; st < m; ++st) {
-        const uint32_t h = 1u << st;
+        uint32_t st = (debug_skip & 1) ? m : 0;
+        if ((m & 1) && !(debug_skip & 1)) {   // odd number of stages: one radix-2 stage (twiddle 1), then radix-4 rounds
+            __syncthreads();
+            for (uint32_t b = tid; b < (elems >> 1); b += 256) {
+                uint32_t c = b & (C - 1), p = b >> cb;
+                uint32_t e0 = ((p << 1) << cb) + c, e1 = e0 + C;
+                Fr29 a = lds[e0].v, t = lds[e1].v;
+                lds[e0].v = f29_norm(f29_add(a, t));
+                lds[e1].v = f29_sub<2>(a, t);
+            }
+            st = 1;
+        }
+        for (; st < m; st += 2) {
+            const uint32_t h = 1u << st;
+            __syncthreads();
+            for (uint32_t g = tid; g < (elems >> 2); g += 256) {
+                uint32_t c = g & (C - 1), p = g >> cb;
+                uint32_t i = p & (h - 1), blk = p >> st;
+                uint32_t e0 = (((blk << (st + 2)) + i) << cb) + c, stride = h << cb;
+                Fr29 x0 = lds[e0].v, x1 = lds[e0 + stride].v, x2 = lds[e0 + 2 * stride].v, x3 = lds[e0 + 3 * stride].v;
+                if (st) {   // stage st: omega_{2h}^i (for st == 0 it is 1)
+                    Fr29 w1 = tw_s[i << (m - 1 - st)].v;
+                    x1 = f29_mul(x1, w1);
+                    x3 = f29_mul(x3, w1);
+                }
+                Fr29 y0 = f29_norm(f29_add(x0, x1)), y1 = f29_sub<2>(x0, x1);
+                Fr29 y2 = f29_norm(f29_add(x2, x3)), y3 = f29_sub<2>(x2, x3);
+                // stage st+1 (half = 2h): omega_{4h}^i and omega_{4h}^(i+h)
+                y2 = f29_mul(y2, tw_s[i << (m - 2 - st)].v);
+                y3 = f29_mul(y3, tw_s[(i + h) << (m - 2 - st)].v);
+                lds[e0].v = f29_norm(f29_add(y0, y2));
+                lds[e0 + 2 * stride].v = f29_sub<2>(y0, y2);
+                lds[e0 + stride].v = f29_norm(f29_add(y1, y3));
+                lds[e0 + 3 * stride].v = f29_sub<2>(y1, y3);
+            }
+        }
         __syncthreads();
-        for (uint32_t b = tid; b < (elems >> 1); b += 256) {
-            uint32_t c = b & (C - 1), p = b >> cb;
-            uint32_t i = p & (h - 1), blk = p >> st;
-            uint32_t e0 = (((blk << (st + 1)) + i) << cb) + c, e1 = e0 + (h << cb);
-            Fr29 a = lds[e0], bb = lds[e1];
-            Fr29 t = st ? f29_mul(bb, tw_s[i << (m - 1 - st)]) : bb;   // omega_{2h}^i = omega_R^(i * R/(2h)); stage 0: w = 1
-            if (!st) t = f29_norm(t);
-            lds[e0] = f29_norm(f29_add(a, t));
-            lds[e1] = f29_sub<2>(a, t);
-        }
-    }
-    __syncthreads();
 
-    const bool has_tw = (log_s + m) < log_n;   // the last pass has j - q == 0 everywhere
-    const uint64_t smask = (1ull << log_s) - 1;
-    Fr29 out3[3];
-    if (out_mul) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) out3[k] = fr29_from_sat(sc.out3[k]);
-    }
-    for (uint32_t e = tid; e < elems; e += 256) {
-        uint32_t u, c;
-        if (log_s == 0) {   // first pass: output (j0+c)*R + u is contiguous in u
-            c = e >> m;
-            u = e & (R - 1);
-        } else {            // later passes: contiguous in q (i.e. in c)
-            u = e >> cb;
-            c = e & (C - 1);
+        for (uint32_t e = tid; e < elems; e += 256) {
+            uint32_t u, c;
+            if (log_s == 0) {   // first pass: output (j0+c)*R + u is contiguous in u
+                c = e >> m;
+                u = e & (R - 1);
+            } else {            // later passes: contiguous in q (i.e. in c)
+                u = e >> cb;
+                c = e & (C - 1);
+            }
+            uint64_t j = j0 + c, q = j & smask, jq = j - q;
+            Fr29 v = lds[(u << cb) + c].v;
+            uint64_t oidx = (jq << m) + q + ((uint64_t)u << log_s);
+            if (has_tw && !(debug_skip & 2)) {
+                // omega^(jq*u): jq is a multiple of s, so a direct table of omega^(s*t), t < N/s, serves later passes
+                Fr29 w = tdirect ? tdirect[(jq >> log_s) * u].v : tw_lookup(t1, t2, lo_bits, jq * u);
+                v = f29_mul(v, w);
+            }
+            if (out_mul) v = f29_mul(v, scale_s[3 + oidx % 3].v);
+            if (!has_tw && !out_mul) v = f29_mul(v, Fr29::one());   // weak bound (<= 21 r) -> < 1.2 r before packing
+            y[oidx] = f29_pack_canonical<FrP>(v);
         }
-        uint64_t j = j0 + c, q = j & smask, jq = j - q;
-        Fr29 v = lds[(u << cb) + c];
-        uint64_t oidx = (jq << m) + q + ((uint64_t)u << log_s);
-        if (has_tw) v = f29_mul(v, tw_lookup(t1, t2, lo_bits, jq * u));
-        if (out_mul) {
-            uint32_t r3 = (uint32_t)(oidx % 3);
-            v = f29_mul(v, r3 == 0 ? out3[0] : r3 == 1 ? out3[1] : out3[2]);
-        }
-        if (!has_tw && !out_mul) v = f29_mul(v, Fr29::one());   // weak bound (<= 21 r) -> < 1.2 r before packing
-        y[oidx] = f29_pack_canonical<FrP>(v);
+        __syncthreads();   // LDS is overwritten by the next tile
     }
+}
+
+// direct inter-pass twiddle table for a pass with stride 2^log_s: out[t] = omega^(t << log_s), t < count
+__global__ void ntt_direct_twiddle_kernel(Fr29L *out, Fr omega, uint32_t log_s, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i].v = fr29_from_sat(fe_pow_u64(omega, (uint64_t)i << log_s));
 }
 
 static int get_twiddles(h2hip_ctx *ctx, uint32_t log_n, const Fr &omega, TwiddleSet **out) {
@@ -141,22 +192,49 @@ static int get_twiddles(h2hip_ctx *ctx, uint32_t log_n, const Fr &omega, Twiddle
     t.omega = omega;
     t.lo_bits = (log_n + 1) / 2;
     uint32_t lo_count = 1u << t.lo_bits, hi_count = 1u << (log_n - t.lo_bits);
-    H2_HIPCHK(hipMalloc((void **)&t.t1, sizeof(Fr29) * lo_count));
-    H2_HIPCHK(hipMalloc((void **)&t.t2, sizeof(Fr29) * hi_count));
+    H2_HIPCHK(hipMalloc((void **)&t.t1, sizeof(Fr29L) * lo_count));
+    H2_HIPCHK(hipMalloc((void **)&t.t2, sizeof(Fr29L) * hi_count));
     uint32_t cnt = lo_count > hi_count ? lo_count : hi_count;
     prof_begin(ctx, "ntt_twiddle_kernel");
-    hipLaunchKernelGGL(ntt_twiddle_kernel, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, (Fr29 *)t.t1, (Fr29 *)t.t2, omega, t.lo_bits, hi_count);
+    hipLaunchKernelGGL(ntt_twiddle_kernel, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, (Fr29L *)t.t1, (Fr29L *)t.t2, omega, t.lo_bits, hi_count);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     if (ctx->twiddles.size() >= 16) {   // bounded cache: drop the oldest table
         H2_HIPCHK(hipStreamSynchronize(ctx->stream));
         hipFree(ctx->twiddles.front().t1);
         hipFree(ctx->twiddles.front().t2);
+        for (int k = 0; k < 4; ++k)
+            if (ctx->twiddles.front().direct[k]) hipFree(ctx->twiddles.front().direct[k]);
         ctx->twiddles.erase(ctx->twiddles.begin());
     }
     ctx->twiddles.push_back(t);
     *out = &ctx->twiddles.back();
     return H2HIP_OK;
+}
+
+// direct table omega^(t << log_s), t < 2^(log_n - log_s), for a non-first pass (only when it is small: <= 2^16 entries)
+static int get_direct_table(h2hip_ctx *ctx, TwiddleSet *tw, uint32_t log_s, const Fr29L **out) {
+    *out = nullptr;
+    const uint32_t bits = tw->log_n - log_s;
+    if (log_s == 0 || bits > 16) return H2HIP_OK;
+    for (int k = 0; k < 4; ++k)
+        if (tw->direct[k] && tw->direct_log_s[k] == log_s) {
+            *out = (const Fr29L *)tw->direct[k];
+            return H2HIP_OK;
+        }
+    for (int k = 0; k < 4; ++k)
+        if (!tw->direct[k]) {
+            const uint32_t count = 1u << bits;
+            H2_HIPCHK(hipMalloc(&tw->direct[k], sizeof(Fr29L) * count));
+            tw->direct_log_s[k] = log_s;
+            prof_begin(ctx, "ntt_twiddle_kernel");
+            hipLaunchKernelGGL(ntt_direct_twiddle_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, (Fr29L *)tw->direct[k], tw->omega, log_s, count);
+            prof_end(ctx);
+            H2_HIPCHK(hipGetLastError());
+            *out = (const Fr29L *)tw->direct[k];
+            return H2HIP_OK;
+        }
+    return H2HIP_OK;   // all slots taken: fall back to the composed lookup
 }
 
 // a: N = 2^log_n device elements (result lands here).  in_override (optional): read the input from there
@@ -197,11 +275,14 @@ int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in
         if (cb > log_n - m) cb = log_n - m;
         if (i > 0 && cb > log_s) cb = log_s;
         const uint32_t tiles = 1u << (log_n - m - cb);
-        const size_t shmem = sizeof(Fr29) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)));
+        const uint32_t grid = tiles < (uint32_t)ctx->num_cus * 3 ? tiles : (uint32_t)ctx->num_cus * 3;
+        const Fr29L *tdirect = nullptr;
+        if (i > 0 && i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
+        const size_t shmem = sizeof(Fr29L) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)) + 8);
         const bool first = (i == 0), last = (i == P - 1);
         prof_begin(ctx, "ntt_pass_kernel");
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles), dim3(256), shmem, ctx->stream, cur, dst, log_n, m, log_s, cb, (const Fr29 *)tw->t1, (const Fr29 *)tw->t2,
-                           tw->lo_bits, first ? in_len : N, (first && in_scale3) ? 1 : 0, (last && out_scale3) ? 1 : 0, sc);
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid), dim3(256), shmem, ctx->stream, cur, dst, log_n, m, log_s, cb, (const Fr29L *)tw->t1, (const Fr29L *)tw->t2,
+                           tw->lo_bits, tdirect, first ? in_len : N, (first && in_scale3) ? 1 : 0, (last && out_scale3) ? 1 : 0, sc, ctx->ntt_debug_skip);
         prof_end(ctx);
         H2_HIPCHK(hipGetLastError());
         cur = dst;
