@@ -90,12 +90,9 @@ struct h2hip_ctx {
     hipEvent_t fork_ev = nullptr;
 };
 
-namespace h2 {
-struct G1Affine29;
-}
 struct h2hip_bases {
     h2::G1Affine *pts = nullptr;      // [n] affine, saturated Montgomery limbs (as uploaded; h2hip_bases_download)
-    h2::G1Affine29 *pts29 = nullptr;  // [tables][n] the same points in the unsaturated layout the MSM kernels read
+    h2::G1Affine *pts29 = nullptr;    // [tables][n] the same points packed in the unsaturated domain (x*2^261, y*2^261; 64 B)
     size_t n = 0;
     uint32_t window_bits = 0;      // precomputed mode: window the table was built for
     uint32_t tables = 1;           // 1 = plain; W = precomputed 2^(c*w) multiples

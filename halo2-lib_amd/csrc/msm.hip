@@ -204,7 +204,7 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offset
 }
 
 template <int MINW>
-__global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine29 *__restrict__ bases,
+__global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
                                                         const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
                                                         XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
                                                         XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__
             next = offsets[cur + 1];
         }
         uint32_t v = sval[e];
-        G1Affine29 p = bases[v & 0x7fffffffu];
-        if (!p.is_identity()) xyzz29_add_affine(acc, p.x, p.y, (v >> 31) != 0);
+        G1Affine p = bases[v & 0x7fffffffu];   // packed R'-domain point, one aligned 64-byte gather
+        if (!p.is_identity()) xyzz29_add_affine(acc, f29_split<Q29P>(p.x), f29_split<Q29P>(p.y), (v >> 31) != 0);
     }
     // the list handed to msm_merge is sorted and hole-free: a single-run chunk emits (key, sum), (key, identity)
     if (first) {
@@ -439,9 +439,20 @@ int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_
 }
 
 // saturated affine table -> unsaturated 29-bit layout used by msm_accum_kernel
-__global__ __launch_bounds__(256) void bases_to_29_kernel(const G1Affine *__restrict__ in, G1Affine29 *__restrict__ out, size_t n) {
+// The table is stored PACKED: 64 B per point = canonical 8x32-bit limbs of x*2^261 and y*2^261 (the unsaturated
+// domain's Montgomery form), 64-byte aligned so that one gather touches exactly one half cache line; lanes unpack to
+// 9x29-bit limbs with shifts only (f29_split).  Identity stays all-zero.
+__global__ __launch_bounds__(256) void bases_to_29_kernel(const G1Affine *__restrict__ in, G1Affine *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = g1affine29_from_sat(in[i]);
+    if (i >= n) return;
+    G1Affine p = in[i], r;
+    if (p.is_identity()) {
+        r = p;
+    } else {
+        r.x = f29_pack_canonical<FqP>(f29_from_sat(p.x));
+        r.y = f29_pack_canonical<FqP>(f29_from_sat(p.y));
+    }
+    out[i] = r;
 }
 
 static uint32_t pick_window(size_t n) {
@@ -469,8 +480,8 @@ int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *b, bool precompute) {
         W = (255 + c - 1) / c;
         H2_REQUIRE((uint64_t)b->n * W < (1ull << 31), "precomputed table too large for 31-bit indices");
     }
-    G1Affine29 *t29 = nullptr;
-    hipError_t e = hipMalloc((void **)&t29, sizeof(G1Affine29) * (size_t)(n ? n : 1) * W);
+    G1Affine *t29 = nullptr;
+    hipError_t e = hipMalloc((void **)&t29, sizeof(G1Affine) * (size_t)(n ? n : 1) * W);
     if (e != hipSuccess) {
         set_error("hipMalloc for %zu bases x %u windows failed: %s", b->n, W, hipGetErrorString(e));
         return H2HIP_ERR_NOMEM;
@@ -592,10 +603,10 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
 
     prof_begin(ctx, "msm_accum_kernel");
     if (ctx->msm_accum_variant == 4)
-        hipLaunchKernelGGL(msm_accum_kernel<4>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine29 *)bases->pts29,
+        hipLaunchKernelGGL(msm_accum_kernel<4>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
                            (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     else
-        hipLaunchKernelGGL(msm_accum_kernel<3>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine29 *)bases->pts29,
+        hipLaunchKernelGGL(msm_accum_kernel<3>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
                            (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
