@@ -219,3 +219,16 @@ def test_msm_batch_pipelined(ctx):
     for d in dptrs:
         ctx.free(d)
     b.free()
+
+
+def test_unsaturated_arithmetic_against_saturated(tmp_path):
+    """fq29.cuh / ec29.cuh vs field.cuh / ec.cuh on the host (tests/emu/fq29_selftest.cpp), with limb-bound asserts."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fq29_selftest")
+    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++17", "-O2", "-I", os.path.join(root, "tests", "emu"),
+                           "-Wno-unused-value", "-o", exe, os.path.join(root, "tests", "emu", "fq29_selftest.cpp"), "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fq29 selftest OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

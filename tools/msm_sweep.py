@@ -1,6 +1,6 @@
 """MSM parameter sweep on the GPU (writes gpurun_out/sweep.json)."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import halo2_lib_amd as H
 from bench import synthetic_bases, synthetic_scalars

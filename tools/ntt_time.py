@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,".")
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import halo2_lib_amd as H
 from tests.util import rand_fr, domain_consts
 ctx=H.Context(0)

@@ -1,6 +1,6 @@
 """First-contact GPU probe: box facts + multiplier roofline + MSM/NTT timings (writes gpurun_out/probe.json)."""
 import json, os, subprocess, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import halo2_lib_amd as H
 from oracle import bn254 as O, c_oracle as CO
