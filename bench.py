@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="override msm_lanes (streams used by the batch API)")
     ap.add_argument("--no-replay", action="store_true", help="skip the k=19 create_proof kernel-sequence replay (extra field)")
     ap.add_argument("--precompute", type=int, default=1, help="1: bases carry precomputed 2^(c*w) window tables (fixed-base SRS, H2HIP_BASES_PRECOMPUTE)")
     ap.add_argument("--batch", type=int, default=4, help="MSMs issued per h2hip_msm_g1_batch_dev call (a prover commits several columns per round); 1 = synchronous")
@@ -132,6 +133,8 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     ctx = H.Context(device=local_rank, stream=tstream.cuda_stream)
+    if args.lanes:
+        ctx.set_param("msm_lanes", args.lanes)
     # each rank owns its own slice of the (world * n)-point MSM
     bases_h = synthetic_bases(n, seed=1000 + rank)
     scal_h = synthetic_scalars(n, seed=2000 + rank)

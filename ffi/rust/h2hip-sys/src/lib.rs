@@ -1,0 +1,75 @@
+//! Raw bindings to `include/h2hip.h` (one declaration per exported symbol) + the safe layer in `safe.rs`.
+//! NOT COMPILED in this repository's environment (no Rust toolchain) — see ffi/rust/README.md.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub mod safe;
+
+#[repr(C)]
+pub struct h2hip_ctx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct h2hip_bases {
+    _private: [u8; 0],
+}
+
+pub const H2HIP_OK: c_int = 0;
+pub const H2HIP_ERR_INVALID: c_int = -1;
+pub const H2HIP_ERR_HIP: c_int = -2;
+pub const H2HIP_ERR_NOMEM: c_int = -3;
+pub const H2HIP_ERR_NO_DEVICE: c_int = -4;
+pub const H2HIP_POINT_JACOBIAN: c_int = 0;
+pub const H2HIP_POINT_AFFINE: c_int = 1;
+pub const H2HIP_BASES_PLAIN: u32 = 0;
+pub const H2HIP_BASES_PRECOMPUTE: u32 = 1;
+
+extern "C" {
+    pub fn h2hip_last_error() -> *const c_char;
+    pub fn h2hip_version() -> c_int;
+    pub fn h2hip_device_count(count: *mut c_int) -> c_int;
+    pub fn h2hip_init(device: c_int, hip_stream: *mut c_void, out: *mut *mut h2hip_ctx) -> c_int;
+    pub fn h2hip_destroy(ctx: *mut h2hip_ctx);
+    pub fn h2hip_sync(ctx: *mut h2hip_ctx) -> c_int;
+    pub fn h2hip_set_param(ctx: *mut h2hip_ctx, name: *const c_char, value: c_int) -> c_int;
+    pub fn h2hip_get_param(ctx: *mut h2hip_ctx, name: *const c_char, value: *mut c_int) -> c_int;
+    pub fn h2hip_malloc(ctx: *mut h2hip_ctx, bytes: usize, dptr: *mut *mut c_void) -> c_int;
+    pub fn h2hip_free(ctx: *mut h2hip_ctx, dptr: *mut c_void) -> c_int;
+    pub fn h2hip_upload(ctx: *mut h2hip_ctx, dst_dev: *mut c_void, src_host: *const c_void, bytes: usize) -> c_int;
+    pub fn h2hip_download(ctx: *mut h2hip_ctx, dst_host: *mut c_void, src_dev: *const c_void, bytes: usize) -> c_int;
+    // K1 — arithmetic::best_multiexp / ParamsKZG::{commit, commit_lagrange}
+    pub fn h2hip_bases_upload(ctx: *mut h2hip_ctx, g1_affine_host: *const c_void, n: usize, flags: u32, out: *mut *mut h2hip_bases) -> c_int;
+    pub fn h2hip_bases_from_device(ctx: *mut h2hip_ctx, g1_affine_dev: *const c_void, n: usize, flags: u32, out: *mut *mut h2hip_bases) -> c_int;
+    pub fn h2hip_bases_free(ctx: *mut h2hip_ctx, bases: *mut h2hip_bases);
+    pub fn h2hip_bases_len(bases: *const h2hip_bases) -> usize;
+    pub fn h2hip_bases_download(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, out_host: *mut c_void) -> c_int;
+    pub fn h2hip_msm_g1(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_host: *const c_void, n: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
+    pub fn h2hip_msm_g1_dev(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_dev: *const c_void, n: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
+    pub fn h2hip_msm_g1_batch_dev(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_dev: *const *const c_void, n: usize, count: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
+    pub fn h2hip_g1_sum_jacobian_dev(ctx: *mut h2hip_ctx, points_dev: *const c_void, n: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
+    // a2 — ParamsKZG::setup
+    pub fn h2hip_params_kzg_setup(ctx: *mut h2hip_ctx, k: u32, s_fr: *const c_void, flags: u32, g_out: *mut *mut h2hip_bases, g_lagrange_out: *mut *mut h2hip_bases) -> c_int;
+    pub fn h2hip_g1_fixed_base_mul_batch_dev(ctx: *mut h2hip_ctx, base_affine: *const c_void, scalars_dev: *const c_void, n: usize, out_affine_dev: *mut c_void) -> c_int;
+    // K2/K3 — arithmetic::best_fft, EvaluationDomain::*
+    pub fn h2hip_best_fft(ctx: *mut h2hip_ctx, a_host: *mut c_void, omega: *const c_void, log_n: u32) -> c_int;
+    pub fn h2hip_best_fft_dev(ctx: *mut h2hip_ctx, a_dev: *mut c_void, omega: *const c_void, log_n: u32) -> c_int;
+    pub fn h2hip_ifft(ctx: *mut h2hip_ctx, a_host: *mut c_void, omega_inv: *const c_void, log_n: u32, divisor: *const c_void) -> c_int;
+    pub fn h2hip_ifft_dev(ctx: *mut h2hip_ctx, a_dev: *mut c_void, omega_inv: *const c_void, log_n: u32, divisor: *const c_void) -> c_int;
+    pub fn h2hip_coeff_to_extended(ctx: *mut h2hip_ctx, coeffs_host: *const c_void, k: u32, out_host: *mut c_void, ext_k: u32, ext_omega: *const c_void, zeta: *const c_void) -> c_int;
+    pub fn h2hip_coeff_to_extended_dev(ctx: *mut h2hip_ctx, coeffs_dev: *const c_void, k: u32, out_dev: *mut c_void, ext_k: u32, ext_omega: *const c_void, zeta: *const c_void) -> c_int;
+    pub fn h2hip_extended_to_coeff(ctx: *mut h2hip_ctx, a_host: *mut c_void, ext_k: u32, ext_omega_inv: *const c_void, ext_divisor: *const c_void, zeta_inv: *const c_void) -> c_int;
+    pub fn h2hip_extended_to_coeff_dev(ctx: *mut h2hip_ctx, a_dev: *mut c_void, ext_k: u32, ext_omega_inv: *const c_void, ext_divisor: *const c_void, zeta_inv: *const c_void) -> c_int;
+    // K4-K8
+    pub fn h2hip_fr_batch_invert_dev(ctx: *mut h2hip_ctx, a_dev: *mut c_void, n: usize) -> c_int;
+    pub fn h2hip_fr_prefix_product_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, in_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_fr_grand_product_dev(ctx: *mut h2hip_ctx, z_dev: *mut c_void, num_dev: *const c_void, den_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_fr_eval_polynomial_dev(ctx: *mut h2hip_ctx, coeffs_dev: *const c_void, n: usize, x: *const c_void, out_host: *mut c_void) -> c_int;
+    pub fn h2hip_fr_kate_division_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, b: *const c_void) -> c_int;
+    pub fn h2hip_quotient_flex_gate_dev(ctx: *mut h2hip_ctx, acc_dev: *mut c_void, q_dev: *const c_void, a_dev: *const c_void, ext_k: u32, k: u32, y: *const c_void) -> c_int;
+    pub fn h2hip_fr_add_batch_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_fr_sub_batch_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_fr_mul_batch_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_fr_mul_add_batch_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, c_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_poseidon_set_spec(ctx: *mut h2hip_ctx, t: u32, r_f: u32, r_p: u32, round_constants: *const c_void, mds: *const c_void) -> c_int;
+    pub fn h2hip_poseidon_permute_batch_dev(ctx: *mut h2hip_ctx, states_dev: *mut c_void, inputs_dev: *const c_void, num_inputs: u32, n: usize) -> c_int;
+}

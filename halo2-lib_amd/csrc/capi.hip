@@ -189,7 +189,7 @@ void h2hip_destroy(h2hip_ctx *ctx) {
         hipEventDestroy(p.second.second);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < 4; ++l)
         if (ctx->lane[l]) {
             h2hip_destroy(ctx->lane[l]);
             hipEventDestroy(ctx->lane_ev[l]);
@@ -213,6 +213,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
     if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
+    if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
     return nullptr;
 }
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
@@ -223,6 +224,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_chunk) H2_REQUIRE(value == 0 || (value >= 2 && value <= 4096), "msm_chunk must be 0 (auto) or 2..4096");
     if (p == &ctx->msm_chunk2) H2_REQUIRE(value >= 4 && value <= 4096, "msm_chunk2 must be 4..4096");
     if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
+    if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 1 && value <= 4, "msm_lanes must be 1..4");
     if (p == &ctx->msm_accum_variant) H2_REQUIRE(value == 3 || value == 4, "msm_accum_variant must be 3 or 4");
     if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
     *p = value;
@@ -382,7 +384,8 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
     if (!count) return H2HIP_OK;
     const bool affine = point_format == H2HIP_POINT_AFFINE;
     const size_t psz = affine ? sizeof(G1Affine) : sizeof(G1Jac);
-    for (int l = 0; l < 2; ++l) {
+    const int NL = ctx->msm_lanes < 1 ? 1 : ctx->msm_lanes > 4 ? 4 : ctx->msm_lanes;
+    for (int l = 0; l < NL; ++l) {
         if (!ctx->lane[l]) {
             h2hip_ctx *c = nullptr;
             H2_CHK(h2hip_init(ctx->device, nullptr, &c));
@@ -401,9 +404,9 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
     char *results = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH, psz * count, (void **)&results));
     H2_HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));   // inputs produced on the caller's stream are ready after this
-    for (int l = 0; l < 2; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->fork_ev, 0));
+    for (int l = 0; l < NL; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->fork_ev, 0));
     for (size_t j = 0; j < count; ++j) {
-        h2hip_ctx *c = ctx->lane[j & 1];
+        h2hip_ctx *c = ctx->lane[j % NL];
         H2_REQUIRE(n == 0 || scalars_dev[j], "NULL scalar column");
         char *outbuf = nullptr;
         H2_CHK(ws_reserve(c, h2hip_ctx::WS_OUT, 1024, (void **)&outbuf));
@@ -414,14 +417,14 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
         prof_end(c);
         H2_HIPCHK(hipGetLastError());
     }
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NL; ++l) {
         H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));
         H2_HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
     }
     H2_HIPCHK(hipMemcpyAsync(out_host, results, psz * count, hipMemcpyDeviceToHost, ctx->stream));
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->profiling)   // fold the lanes' kernel timers into the parent's table
-        for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < NL; ++l) {
             prof_collect(ctx->lane[l]);
             for (auto &kv : ctx->lane[l]->stats) {
                 ctx->stats[kv.first].total_ms += kv.second.total_ms;

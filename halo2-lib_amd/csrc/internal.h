@@ -85,8 +85,9 @@ struct h2hip_ctx {
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
     std::vector<hipEvent_t> event_pool;
     // batch lanes (h2hip_msm_g1_batch_dev): child contexts with their own stream + scratch
-    h2hip_ctx *lane[2] = {nullptr, nullptr};
-    hipEvent_t lane_ev[2] = {nullptr, nullptr};
+    h2hip_ctx *lane[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int msm_lanes = 3;   // lanes used by h2hip_msm_g1_batch_dev (1..4)
     hipEvent_t fork_ev = nullptr;
 };
 
