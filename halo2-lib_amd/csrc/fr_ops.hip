@@ -323,6 +323,75 @@ __global__ __launch_bounds__(256) void quotient_flex_gate_kernel(Fr *__restrict_
     }
 }
 
+// ------------------------------------------------------------------ K6: lookup and permutation identities of h(X)
+// Pointwise over the extended domain (ne = 2^ext_k points, one circuit row = `step` = 2^(ext_k-k) points), every
+// identity folded into the numerator as acc = acc*y + term in upstream's order [UPSTREAM evaluation.rs, SURVEY.md A.4/A.5;
+// halo2-base creates these arguments at halo2-base/src/gates/range/mod.rs:131-150 (lookup) and
+// halo2-base/src/gates/flex_gate/mod.rs:69,124-128 (equality-enabled columns)].
+struct LookupArgs {
+    const Fr *z, *a, *s, *ap, *sp, *l0, *l_last, *l_blind;
+    Fr beta, gamma, y;
+};
+// terms: l0*(1-z) ; l_last*(z^2-z) ; active*(z(wX)(a'+beta)(s'+gamma) - z(X)(a+beta)(s+gamma)) ; l0*(a'-s') ;
+//        active*(a'-s')*(a'-a'(w^-1 X)),   active = 1 - (l_last + l_blind)
+__global__ __launch_bounds__(256) void quotient_lookup_kernel(Fr *__restrict__ acc, LookupArgs g, size_t ne, uint32_t step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = ne - 1;
+    const Fr one = Fr::one();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += stride) {
+        const size_t inext = (i + step) & mask, iprev = (i + ne - step) & mask;
+        Fr z = g.z[i], a = g.a[i], sv = g.s[i], ap = g.ap[i], sp = g.sp[i], l0 = g.l0[i], ll = g.l_last[i];
+        Fr active = fe_sub(one, fe_add(ll, g.l_blind[i]));
+        Fr v = acc[i];
+        v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(one, z)));
+        v = fe_add(fe_mul(v, g.y), fe_mul(ll, fe_sub(fe_sqr(z), z)));
+        Fr left = fe_mul(fe_mul(g.z[inext], fe_add(ap, g.beta)), fe_add(sp, g.gamma));
+        Fr right = fe_mul(fe_mul(z, fe_add(a, g.beta)), fe_add(sv, g.gamma));
+        v = fe_add(fe_mul(v, g.y), fe_mul(active, fe_sub(left, right)));
+        Fr d = fe_sub(ap, sp);
+        v = fe_add(fe_mul(v, g.y), fe_mul(l0, d));
+        v = fe_add(fe_mul(v, g.y), fe_mul(active, fe_mul(d, fe_sub(ap, g.ap[iprev]))));
+        acc[i] = v;
+    }
+}
+
+constexpr int PERM_MAX_COLS = 8;
+struct PermArgs {
+    const Fr *z, *z_prev, *l0, *l_last, *l_blind;
+    const Fr *cols[PERM_MAX_COLS], *sigmas[PERM_MAX_COLS];
+    uint32_t ncols, is_first, is_last, last_rot_points;   // last_rot_points = last_rotation * step (already reduced mod ne)
+    Fr beta, gamma, delta, y;
+    Fr x0_delta;   // beta * zeta * delta^(first column index of this set): the X-term coefficient at extended point 0
+    Fr ext_omega;
+};
+// terms for one permutation set i: [first set] l0*(1-z) ; [last set] l_last*(z^2-z) ; [i>0] l0*(z_i - z_{i-1}(w^last X)) ;
+//        active*( z(wX) prod_j(p_j + beta*s_j + gamma) - z(X) prod_j(p_j + delta^j*beta*X + gamma) ),  X = zeta*w_ext^i
+__global__ __launch_bounds__(256) void quotient_permutation_kernel(Fr *__restrict__ acc, PermArgs g, size_t ne, uint32_t step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = ne - 1;
+    const Fr one = Fr::one();
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr xbase = fe_mul(g.x0_delta, fe_pow_u64(g.ext_omega, (uint64_t)i0));   // beta * delta^j0 * zeta * w_ext^i
+    const Fr xstep = fe_pow_u64(g.ext_omega, (uint64_t)stride);
+    for (size_t i = i0; i < ne; i += stride, xbase = fe_mul(xbase, xstep)) {
+        const size_t inext = (i + step) & mask;
+        Fr z = g.z[i], l0 = g.l0[i], ll = g.l_last[i];
+        Fr active = fe_sub(one, fe_add(ll, g.l_blind[i]));
+        Fr v = acc[i];
+        if (g.is_first) v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(one, z)));
+        if (g.is_last) v = fe_add(fe_mul(v, g.y), fe_mul(ll, fe_sub(fe_sqr(z), z)));
+        if (g.z_prev) v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(z, g.z_prev[(i + g.last_rot_points) & mask])));
+        Fr left = g.z[inext], right = z;
+        Fr xterm = xbase;
+        for (uint32_t j = 0; j < g.ncols; ++j) {
+            Fr p = g.cols[j][i];
+            left = fe_mul(left, fe_add(fe_add(p, fe_mul(g.beta, g.sigmas[j][i])), g.gamma));
+            right = fe_mul(right, fe_add(fe_add(p, xterm), g.gamma));
+            xterm = fe_mul(xterm, g.delta);
+        }
+        v = fe_add(fe_mul(v, g.y), fe_mul(active, fe_sub(left, right)));
+        acc[i] = v;
+    }
+}
+
 static uint32_t grid_for(h2hip_ctx *ctx, size_t n) {
     size_t blocks = (n + 255) / 256, cap = (size_t)ctx->num_cus * 8;
     if (blocks > cap) blocks = cap;
@@ -508,6 +577,57 @@ int h2hip_quotient_flex_gate_dev(h2hip_ctx *ctx, void *acc, const void *q, const
     prof_begin(ctx, "quotient_flex_gate_kernel");
     hipLaunchKernelGGL(quotient_flex_gate_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)acc, (const Fr *)q, (const Fr *)a, n_ext,
                        1u << (ext_k - k), yv);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+static Fr ld_fr(const void *p) {
+    Fr r;
+    memcpy(&r, p, sizeof(Fr));
+    return r;
+}
+int h2hip_quotient_lookup_dev(h2hip_ctx *ctx, void *acc, const void *z, const void *a, const void *s, const void *a_perm, const void *s_perm,
+                              const void *l0, const void *l_last, const void *l_blind, uint32_t ext_k, uint32_t k, const void *beta,
+                              const void *gamma, const void *y) {
+    H2_REQUIRE(ctx && acc && z && a && s && a_perm && s_perm && l0 && l_last && l_blind && beta && gamma && y, "NULL argument");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    LookupArgs g;
+    g.z = (const Fr *)z; g.a = (const Fr *)a; g.s = (const Fr *)s; g.ap = (const Fr *)a_perm; g.sp = (const Fr *)s_perm;
+    g.l0 = (const Fr *)l0; g.l_last = (const Fr *)l_last; g.l_blind = (const Fr *)l_blind;
+    g.beta = ld_fr(beta); g.gamma = ld_fr(gamma); g.y = ld_fr(y);
+    size_t ne = (size_t)1 << ext_k;
+    prof_begin(ctx, "quotient_lookup_kernel");
+    hipLaunchKernelGGL(quotient_lookup_kernel, dim3(grid_for(ctx, ne)), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, 1u << (ext_k - k));
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z, const void *z_prev, const void *const *cols,
+                                       const void *const *sigmas, uint32_t ncols, uint32_t first_col_index, const void *l0, const void *l_last,
+                                       const void *l_blind, uint32_t ext_k, uint32_t k, int is_first, int is_last, int32_t last_rotation,
+                                       const void *beta, const void *gamma, const void *delta, const void *zeta, const void *ext_omega, const void *y) {
+    H2_REQUIRE(ctx && acc && z && cols && sigmas && l0 && l_last && l_blind && beta && gamma && delta && zeta && ext_omega && y, "NULL argument");
+    H2_REQUIRE(ncols >= 1 && ncols <= PERM_MAX_COLS, "1..8 columns per permutation set");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    PermArgs g;
+    memset(&g, 0, sizeof(g));
+    g.z = (const Fr *)z; g.z_prev = (const Fr *)z_prev; g.l0 = (const Fr *)l0; g.l_last = (const Fr *)l_last; g.l_blind = (const Fr *)l_blind;
+    for (uint32_t j = 0; j < ncols; ++j) {
+        H2_REQUIRE(cols[j] && sigmas[j], "NULL column");
+        g.cols[j] = (const Fr *)cols[j];
+        g.sigmas[j] = (const Fr *)sigmas[j];
+    }
+    g.ncols = ncols; g.is_first = is_first ? 1 : 0; g.is_last = is_last ? 1 : 0;
+    const size_t ne = (size_t)1 << ext_k;
+    const uint32_t step = 1u << (ext_k - k);
+    const int64_t n = (int64_t)1 << k;
+    int64_t rot = ((int64_t)last_rotation % n + n) % n;
+    g.last_rot_points = (uint32_t)(((uint64_t)rot * step) & (ne - 1));
+    g.beta = ld_fr(beta); g.gamma = ld_fr(gamma); g.delta = ld_fr(delta); g.y = ld_fr(y); g.ext_omega = ld_fr(ext_omega);
+    g.x0_delta = fe_mul(fe_mul(g.beta, ld_fr(zeta)), fe_pow_u64(g.delta, first_col_index));
+    prof_begin(ctx, "quotient_permutation_kernel");
+    hipLaunchKernelGGL(quotient_permutation_kernel, dim3(grid_for(ctx, ne)), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;

@@ -62,6 +62,9 @@ _PROTOS = {
     "h2hip_fr_eval_polynomial_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "h2hip_fr_kate_division_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_quotient_flex_gate_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),
+    "h2hip_quotient_permutation_set_dev": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp, _vp, _u32, _u32, _int, _int,
+                                                  C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
     "h2hip_poseidon_permute_batch_dev": (_int, [_vp, _vp, _vp, _u32, _sz]),
     "h2hip_bench_modmul": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -421,3 +424,33 @@ class Context:
             self.free(ds)
             if di:
                 self.free(di)
+
+    # -- K6 lookup / permutation identities (host-array conveniences for tests)
+    def quotient_lookup(self, acc, z, a, s, a_perm, s_perm, l0, l_last, l_blind, ext_k, k, beta, gamma, y) -> np.ndarray:
+        arrs = [_fe(v) for v in (acc, z, a, s, a_perm, s_perm, l0, l_last, l_blind)]
+        d = [self.to_device(v) for v in arrs]
+        try:
+            self._chk(self.lib.h2hip_quotient_lookup_dev(self.handle, *[_vp(p) for p in d], ext_k, k, _ptr(_fe(beta)), _ptr(_fe(gamma)), _ptr(_fe(y))))
+            return self.download(d[0], arrs[0].shape)
+        finally:
+            for p in d:
+                self.free(p)
+
+    def quotient_permutation_set(self, acc, z, z_prev, cols, sigmas, first_col_index, l0, l_last, l_blind, ext_k, k, is_first, is_last,
+                                 last_rotation, beta, gamma, delta, zeta, ext_omega, y) -> np.ndarray:
+        d_acc, d_z = self.to_device(_fe(acc)), self.to_device(_fe(z))
+        d_zp = self.to_device(_fe(z_prev)) if z_prev is not None else None
+        d_cols = [self.to_device(_fe(c)) for c in cols]
+        d_sig = [self.to_device(_fe(c)) for c in sigmas]
+        d_l = [self.to_device(_fe(v)) for v in (l0, l_last, l_blind)]
+        n = len(cols)
+        pc, ps = (_vp * n)(*[_vp(p) for p in d_cols]), (_vp * n)(*[_vp(p) for p in d_sig])
+        try:
+            self._chk(self.lib.h2hip_quotient_permutation_set_dev(
+                self.handle, _vp(d_acc), _vp(d_z), _vp(d_zp) if d_zp else None, pc, ps, n, first_col_index, _vp(d_l[0]), _vp(d_l[1]), _vp(d_l[2]),
+                ext_k, k, int(is_first), int(is_last), int(last_rotation), _ptr(_fe(beta)), _ptr(_fe(gamma)), _ptr(_fe(delta)), _ptr(_fe(zeta)),
+                _ptr(_fe(ext_omega)), _ptr(_fe(y))))
+            return self.download(d_acc, _fe(acc).shape)
+        finally:
+            for p in [d_acc, d_z] + ([d_zp] if d_zp else []) + d_cols + d_sig + d_l:
+                self.free(p)

@@ -155,6 +155,21 @@ int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_d
 int h2hip_quotient_flex_gate_dev(h2hip_ctx *ctx, void *acc_dev, const void *q_dev, const void *a_dev, uint32_t ext_k, uint32_t k,
                                  const void *y);
 
+/* Lookup argument's five identities, folded in upstream's order: l0*(1-z); l_last*(z^2-z);
+ * active*(z(wX)(a'+beta)(s'+gamma) - z(a+beta)(s+gamma)); l0*(a'-s'); active*(a'-s')(a'-a'(w^-1 X)); active = 1-(l_last+l_blind).
+ * All arrays: 2^ext_k extended-domain evaluations (halo2-base's lookups: halo2-base/src/gates/range/mod.rs:131-150). */
+int h2hip_quotient_lookup_dev(h2hip_ctx *ctx, void *acc_dev, const void *z_dev, const void *a_dev, const void *s_dev, const void *a_perm_dev,
+                              const void *s_perm_dev, const void *l0_dev, const void *l_last_dev, const void *l_blind_dev, uint32_t ext_k,
+                              uint32_t k, const void *beta, const void *gamma, const void *y);
+/* One permutation set: [first] l0*(1-z); [last] l_last*(z^2-z); [z_prev != NULL] l0*(z - z_prev(w^last_rotation X));
+ * active*(z(wX)*prod_j(p_j + beta*sigma_j + gamma) - z*prod_j(p_j + delta^(first_col_index+j)*beta*X + gamma)), X = zeta*ext_omega^i.
+ * cols / sigmas: host arrays of ncols (<= 8) device pointers. */
+int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc_dev, const void *z_dev, const void *z_prev_dev, const void *const *cols_dev,
+                                       const void *const *sigmas_dev, uint32_t ncols, uint32_t first_col_index, const void *l0_dev,
+                                       const void *l_last_dev, const void *l_blind_dev, uint32_t ext_k, uint32_t k, int is_first, int is_last,
+                                       int32_t last_rotation, const void *beta, const void *gamma, const void *delta, const void *zeta,
+                                       const void *ext_omega, const void *y);
+
 /* ---- K8: Poseidon permutation batches (halo2-base PoseidonState::permutation, reference
  *      halo2-base/src/poseidon/hasher/state.rs:35-83,124-160).  The caller supplies the spec its
  *      OptimizedPoseidonSpec was derived from (hasher/spec.rs:88-175): (r_f+r_p)*t round constants and

@@ -417,3 +417,44 @@ def circuit_like_scalars(n: int, seed: int):
         else:
             out.append((g.next() | (g.next() << 64)) & ((1 << 88) - 1))
     return out
+
+
+# ------------------------------------------------------------------ quotient identities, pointwise
+def quotient_lookup_terms(acc, z, a, s, ap, sp, l0, l_last, l_blind, step, beta, gamma, y):
+    """acc[i] folded with the lookup argument's five identities in upstream's order; all lists are extended-domain
+    evaluations as canonical integers."""
+    ne, out = len(acc), []
+    for i in range(ne):
+        active = (1 - (l_last[i] + l_blind[i])) % R_MOD
+        v = acc[i]
+        v = (v * y + l0[i] * (1 - z[i])) % R_MOD
+        v = (v * y + l_last[i] * (z[i] * z[i] - z[i])) % R_MOD
+        left = z[(i + step) % ne] * (ap[i] + beta) % R_MOD * (sp[i] + gamma) % R_MOD
+        right = z[i] * (a[i] + beta) % R_MOD * (s[i] + gamma) % R_MOD
+        v = (v * y + active * (left - right)) % R_MOD
+        v = (v * y + l0[i] * (ap[i] - sp[i])) % R_MOD
+        v = (v * y + active * (ap[i] - sp[i]) % R_MOD * (ap[i] - ap[(i - step) % ne])) % R_MOD
+        out.append(v)
+    return out
+
+
+def quotient_permutation_set_terms(acc, z, z_prev, cols, sigmas, first_col_index, l0, l_last, l_blind, step, is_first, is_last,
+                                   last_rotation, beta, gamma, delta, zeta, ext_omega, y):
+    ne, out = len(acc), []
+    for i in range(ne):
+        active = (1 - (l_last[i] + l_blind[i])) % R_MOD
+        v = acc[i]
+        if is_first:
+            v = (v * y + l0[i] * (1 - z[i])) % R_MOD
+        if is_last:
+            v = (v * y + l_last[i] * (z[i] * z[i] - z[i])) % R_MOD
+        if z_prev is not None:
+            v = (v * y + l0[i] * (z[i] - z_prev[(i + last_rotation * step) % ne])) % R_MOD
+        x = zeta * pow(ext_omega, i, R_MOD) % R_MOD
+        left, right = z[(i + step) % ne], z[i]
+        for j, (p, sg) in enumerate(zip(cols, sigmas)):
+            left = left * ((p[i] + beta * sg[i] + gamma) % R_MOD) % R_MOD
+            right = right * ((p[i] + pow(delta, first_col_index + j, R_MOD) * beta % R_MOD * x + gamma) % R_MOD) % R_MOD
+        v = (v * y + active * (left - right)) % R_MOD
+        out.append(v)
+    return out

@@ -232,3 +232,26 @@ def test_unsaturated_arithmetic_against_saturated(tmp_path):
                            "-Wno-unused-value", "-o", exe, os.path.join(root, "tests", "emu", "fq29_selftest.cpp"), "-lpthread"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "fq29 selftest OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def _quotient_identity_checks(ctx, k, ek):
+    ne, step = 1 << ek, 1 << (ek - k)
+    rs = lambda seed: O.random_scalars(ne, seed)
+    acc, z, a, s, ap, sp, l0, ll, lb = [rs(i) for i in range(1, 10)]
+    beta, gamma, y = O.random_scalars(3, 77)
+    got = ctx.quotient_lookup(fr(acc), fr(z), fr(a), fr(s), fr(ap), fr(sp), fr(l0), fr(ll), fr(lb), ek, k, fr([beta]), fr([gamma]), fr([y]))
+    assert O.limbs_to_ints(got, R) == O.quotient_lookup_terms(acc, z, a, s, ap, sp, l0, ll, lb, step, beta, gamma, y)
+    cols, sigmas = [rs(20 + j) for j in range(3)], [rs(30 + j) for j in range(3)]
+    zp = rs(40)
+    we = O.omega_for(ek)
+    for (first, last, prev, j0, rot) in ((1, 0, None, 0, 0), (0, 1, zp, 3, -7), (1, 1, None, 0, 0)):
+        got = ctx.quotient_permutation_set(fr(acc), fr(z), None if prev is None else fr(prev), [fr(c) for c in cols], [fr(c) for c in sigmas], j0,
+                                           fr(l0), fr(ll), fr(lb), ek, k, first, last, rot, fr([beta]), fr([gamma]), fr([O.DELTA]), fr([O.ZETA]),
+                                           fr([we]), fr([y]))
+        want = O.quotient_permutation_set_terms(acc, z, prev, cols, sigmas, j0, l0, ll, lb, step, first, last, rot % (1 << k), beta, gamma,
+                                                O.DELTA, O.ZETA, we, y)
+        assert O.limbs_to_ints(got, R) == want
+
+
+def test_quotient_lookup_and_permutation_identities(ctx):
+    _quotient_identity_checks(ctx, 4, 6)

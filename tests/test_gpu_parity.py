@@ -214,3 +214,9 @@ def test_msm_batch_pipelined(ctx):
         for d in dptrs:
             ctx.free(d)
         b.free()
+
+
+def test_quotient_lookup_and_permutation_identities(ctx):
+    from tests.test_emu_kernels import _quotient_identity_checks
+
+    _quotient_identity_checks(ctx, 7, 9)
