@@ -92,3 +92,44 @@ def test_params_kzg_setup_k16_matches_oracle():
         assert O.limbs_to_points(gl[i:i + 1]) == [O.g1_mul(O.G1_GEN, li)]
     params.free()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_commit_identity_at_k21():
+    """BASELINE config #5 size (k = 21): SRS generation, precomputed tables, iNTT and two 2^21-point MSMs tied together by
+    the size-independent identity commit_lagrange(values) == commit(lagrange_to_coeff(values)); the Lagrange commitment
+    is additionally checked against the closed form sum_i v_i L_i(s) * G."""
+    ctx = H.Context(0)
+    k, s = 21, 0xABCDEF0123456789ABCDEF
+    n = 1 << k
+    params = HP.ParamsKZG.setup(ctx, k, s, precompute=True)
+    dom = HP.EvaluationDomain(ctx, 4, k)
+    vals = rand_fr(n, 3)
+    vals[5:100000] = 0   # a sparse stretch, like a padded advice column
+    c1 = params.commit_lagrange(vals, H.POINT_AFFINE)
+    coeffs = dom.lagrange_to_coeff(vals)
+    c2 = params.commit(coeffs, H.POINT_AFFINE)
+    assert np.array_equal(c1, c2) and c1.any()
+    # closed form p(s)*G with p(s) = sum_i v_i * L_i(s), evaluated on the host from the (non-zero) values
+    w, sn = O.omega_for(k), pow(s, n, R)
+    mult = (sn - 1) * pow(n, -1, R) % R
+    vi = O.limbs_to_ints(vals, R)
+    wi, acc = 1, 0
+    dens, nums = [], []
+    for i in range(n):
+        if vi[i]:
+            nums.append(vi[i] * wi % R)
+            dens.append((s - wi) % R)
+        wi = wi * w % R
+    # batch inversion on the host (python ints)
+    pref, run = [], 1
+    for d in dens:
+        pref.append(run)
+        run = run * d % R
+    inv = pow(run, -1, R)
+    for j in range(len(dens) - 1, -1, -1):
+        acc = (acc + nums[j] * (inv * pref[j] % R)) % R
+        inv = inv * dens[j] % R
+    assert O.limbs_to_points(c1) == [O.g1_mul(O.G1_GEN, mult * acc % R)]
+    params.free()
+    ctx.close()
