@@ -77,6 +77,7 @@ struct h2hip_ctx {
     int msm_seg = 8;           // buckets per running-sum segment
     int ntt_tile_bits = 10;
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
+    int msm_scatter_split = 0;   // bucket sub-ranges per window in the scatter (0 = auto, power of two)
     int msm_accum_variant = 3;   // min waves/SIMD the accumulate kernel is compiled for (3 or 4)
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]
     // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled

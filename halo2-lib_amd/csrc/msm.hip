@@ -168,17 +168,23 @@ static int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out,
 }
 
 // ------------------------------------------------------------------ 4. scatter with LDS cursors
+// Each workgroup scatters the entries of chunk g of window w whose bucket lies in sub-range h of S: all workgroups of
+// one (window, sub-range) segment run together on one XCD (1 workgroup per CU because of the LDS cursors), and the
+// segment's slice of the sorted array (n*4/S bytes) fits that XCD's 4 MiB L2, so the 4-byte writes combine there
+// instead of each costing a 64-byte HBM write.
 __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
-                                                           uint32_t G, uint32_t chunk, uint32_t table_stride,
+                                                           uint32_t G, uint32_t chunk, uint32_t S, uint32_t table_stride,
                                                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ bhist,
                                                            uint32_t *__restrict__ sval) {
     __shared__ uint32_t cursor[MAX_LDS_BUCKETS];
-    uint32_t w, g;
-    block_to_window_chunk(blockIdx.x, G, w, g);
-    if (w >= W) return;
-    const uint32_t *off_w = offsets + (size_t)w * B;
-    const uint32_t *bh = bhist + ((size_t)w * G + g) * B;
-    for (uint32_t b = threadIdx.x; b < B; b += 1024) cursor[b] = off_w[b] + bh[b];
+    uint32_t seg, g;
+    block_to_window_chunk(blockIdx.x, G, seg, g);
+    if (seg >= W * S) return;
+    const uint32_t w = seg / S, h = seg - w * S;
+    const uint32_t Bs = B / S, b0 = h * Bs;   // this workgroup's bucket range [b0, b0 + Bs)
+    const uint32_t *off_w = offsets + (size_t)w * B + b0;
+    const uint32_t *bh = bhist + ((size_t)w * G + g) * B + b0;
+    for (uint32_t b = threadIdx.x; b < Bs; b += 1024) cursor[b] = off_w[b] + bh[b];
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t *dw = digits + (size_t)w * n;
@@ -186,7 +192,9 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
         uint32_t dv = dw[i], d = dv & 0x7fffffffu;
         if (!d) continue;
-        uint32_t pos = atomicAdd(&cursor[d - 1], 1u);
+        uint32_t b = d - 1 - b0;
+        if (b >= Bs) continue;   // another sub-range's entry
+        uint32_t pos = atomicAdd(&cursor[b], 1u);
         sval[pos] = (idx_base + i) | (dv & 0x80000000u);
     }
 }
@@ -596,7 +604,14 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     H2_HIPCHK(hipGetLastError());
     H2_CHK(exclusive_scan_u32(ctx, counts, offsets, nkeys + 1));
     prof_begin(ctx, "msm_scatter_kernel");
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(sort_grid), dim3(1024), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk,
+    uint32_t S = (uint32_t)ctx->msm_scatter_split;   // sub-ranges per window: keep a segment's output slice (n*4/S bytes) within ~2 MiB
+    if (S == 0) {
+        S = 1;
+        while (S < 4 && S * 2 <= B && ((uint64_t)n * 4) / S > (2u << 20)) S *= 2;
+    }
+    if (S > B) S = B;
+    const uint32_t scatter_grid = 8 * G * ((W * S + 7) / 8);
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(1024), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S,
                        precomp ? (uint32_t)bases->n : 0u, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());

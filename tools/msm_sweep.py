@@ -11,9 +11,9 @@ ds = ctx.to_device(s)
 res = {}
 for pre in (1,):
     b = ctx.bases_upload(bases_h, pre)
-    for k1, seg, var in ((32, 8, 3), (32, 8, 4), (64, 8, 3), (64, 8, 4), (64, 16, 3), (96, 8, 3), (128, 8, 3)):
+    for k1, seg, var in ((64, 8, 1), (64, 8, 2), (64, 8, 4), (64, 8, 8), (64, 8, 16)):
         if True:
-            ctx.set_param("msm_chunk", k1); ctx.set_param("msm_seg", seg); ctx.set_param("msm_accum_variant", var)
+            ctx.set_param("msm_chunk", k1); ctx.set_param("msm_seg", seg); ctx.set_param("msm_scatter_split", var)
             ctx.msm_dev(b, ds, n)
             ctx.profile_enable(True); ctx.profile_reset()
             ctx.timer_start()
