@@ -213,6 +213,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
     if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
+    if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
     return nullptr;

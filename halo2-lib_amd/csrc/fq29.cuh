@@ -154,6 +154,25 @@ H2_HD F29<P> f29_sqr(const F29<P> &a) {
     return f29_reduce_columns<P>(c);
 }
 
+// Weak reduction without a multiplication: N value v < 32 p  ->  N value < 2 p representing the same residue.
+// q_est = floor(v8 * floor(2^43 / (p8 + 1)) / 2^43) never exceeds floor(v / p) and is at most one below it.
+template <class P>
+H2_HD F29<P> f29_weak_reduce(const F29<P> &a) {
+    constexpr uint64_t D = (uint64_t)P::p(8) + 1;
+    constexpr uint64_t M = ((uint64_t)1 << 43) / D;
+    H2_ASSERT29(a.l[8] < (1u << 27));
+    const uint32_t q = (uint32_t)(((uint64_t)a.l[8] * M) >> 43);
+    F29<P> r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int64_t v = (int64_t)a.l[i] - (int64_t)((uint64_t)q * P::p(i)) + carry;
+        r.l[i] = i < 8 ? (uint32_t)(v & MASK29) : (uint32_t)v;
+        carry = v >> 29;   // arithmetic shift: borrows propagate as negative carries
+    }
+    return r;
+}
+
 // a == k*q for some 0 <= k <= KMAX ?   (a must be N; use when a < (KMAX+1)*q)
 #define H2_MULK_LIMB(k, i) ((k) == 0 ? 0u : (k) == 1 ? P::mul1p(i) : (k) == 2 ? P::mul2p(i) : (k) == 3 ? P::mul3p(i) : (k) == 4 ? P::mul4p(i) : (k) == 5 ? P::mul5p(i) : (k) == 6 ? P::mul6p(i) : (k) == 7 ? P::mul7p(i) : P::mul8p(i))
 template <int KMAX, class P>

@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const Fr *__restrict__ x,
             uint64_t oidx = (jq << m) + q + ((uint64_t)u << log_s);
             if (has_tw && !(debug_skip & 2)) {
                 // omega^(jq*u): jq is a multiple of s, so a direct table of omega^(s*t), t < N/s, serves later passes
-                Fr29 w = tdirect ? tdirect[(jq >> log_s) * u].v : tw_lookup(t1, t2, lo_bits, jq * u);
+                Fr29 w = tdirect ? tdirect[(jq >> log_s) * u].v : tw_lookup(t1, t2, lo_bits, jq * u);   // log_s = 0: jq = j
                 v = f29_mul(v, w);
             }
             if (out_mul) v = f29_mul(v, scale_s[3 + oidx % 3].v);
-            if (!has_tw && !out_mul) v = f29_mul(v, Fr29::one());   // weak bound (<= 21 r) -> < 1.2 r before packing
+            if (!has_tw && !out_mul) v = f29_weak_reduce(v);   // weak bound (<= 21 r) -> < 2 r before packing, no multiply
             y[oidx] = f29_pack_canonical<FrP>(v);
         }
         __syncthreads();   // LDS is overwritten by the next tile
@@ -216,7 +216,10 @@ static int get_twiddles(h2hip_ctx *ctx, uint32_t log_n, const Fr &omega, Twiddle
 static int get_direct_table(h2hip_ctx *ctx, TwiddleSet *tw, uint32_t log_s, const Fr29L **out) {
     *out = nullptr;
     const uint32_t bits = tw->log_n - log_s;
-    if (log_s == 0 || bits > 16) return H2HIP_OK;
+    // later passes: small tables (<= 2^16 entries); first pass (log_s = 0): the full omega^e table, e < N, replaces the
+    // composed two-level lookup (one multiply per element) at 48 B of extra HBM read per element — the NTT is
+    // multiplier-bound, not bandwidth-bound.  Capped at 2^23 entries (384 MiB).
+    if ((log_s != 0 && bits > 16) || (log_s == 0 && (bits > 23 || !ctx->ntt_full_table))) return H2HIP_OK;
     for (int k = 0; k < 4; ++k)
         if (tw->direct[k] && tw->direct_log_s[k] == log_s) {
             *out = (const Fr29L *)tw->direct[k];
@@ -277,7 +280,7 @@ int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in
         const uint32_t tiles = 1u << (log_n - m - cb);
         const uint32_t grid = tiles < (uint32_t)ctx->num_cus * 3 ? tiles : (uint32_t)ctx->num_cus * 3;
         const Fr29L *tdirect = nullptr;
-        if (i > 0 && i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
+        if (i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
         const size_t shmem = sizeof(Fr29L) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)) + 8);
         const bool first = (i == 0), last = (i == P - 1);
         prof_begin(ctx, "ntt_pass_kernel");

@@ -61,6 +61,17 @@ static void field_checks(const char *name) {
         CHECK(to32(f29_sub<8>(f29_sub<6>(A, B), f29_sub<4>(B, A))) == fe_sub(fe_sub(a, b), fe_sub(b, a)));
         CHECK(to32(f29_mul(f29_add(A, A), f29_add(B, B))) == fe_mul(fe_dbl(a), fe_dbl(b)));   // lazy-add inputs
         CHECK(to32(f29_sqr(f29_add(A, A))) == fe_sqr(fe_dbl(a)));
+        {   // weak reduction of a value grown by repeated additions (up to ~20 p)
+            F29<P29> g = A;
+            Fe<PS> gs = a;
+            for (int r = 0; r < (int)(it % 19); ++r) {
+                g = f29_norm(f29_add(g, B));
+                gs = fe_add(gs, b);
+            }
+            F29<P29> w = f29_weak_reduce(g);
+            CHECK(to32(w) == gs);
+            CHECK(f29_pack_canonical<PS>(w) == f29_pack_canonical<PS>(f29_mul(g, F29<P29>::one())));
+        }
         // zero tests over the documented ranges
         F29<P29> d = f29_sub<6>(A, B);
         CHECK(f29_is_zero_mod_q<7>(d) == (a == b));
