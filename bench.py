@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (exchange staged through the host; testing)")
+    ap.add_argument("--share-device", action="store_true", help="testing on a 1-GPU box: every rank uses GPU 0 (requires --dist-backend gloo)")
     ap.add_argument("--lanes", type=int, default=0, help="override msm_lanes (streams used by the batch API)")
     ap.add_argument("--no-replay", action="store_true", help="skip the k=19 create_proof kernel-sequence replay (extra field)")
     ap.add_argument("--precompute", type=int, default=1, help="1: bases carry precomputed 2^(c*w) window tables (fixed-base SRS, H2HIP_BASES_PRECOMPUTE)")
@@ -122,11 +124,18 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.share_device:
+            assert args.dist_backend == "gloo", "--share-device needs --dist-backend gloo (RCCL refuses two ranks on one GPU)"
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if args.dist_backend == "nccl" else None   # where the all-gather tensors live
 
     n = 1 << args.log_n
     # a non-default torch stream: the legacy null stream adds implicit synchronisation to every launch
@@ -152,9 +161,9 @@ def main():
         while done < k:
             b = min(args.batch, k - done)
             if b == 1:
-                res = sharded_msm(ctx, bases, scal_d.data_ptr(), n, device=dev if world > 1 else None)
+                res = sharded_msm(ctx, bases, scal_d.data_ptr(), n, device=xdev if world > 1 else None)
             else:
-                res = sharded_msm_batch(ctx, bases, [scal_d.data_ptr()] * b, n, device=dev if world > 1 else None)
+                res = sharded_msm_batch(ctx, bases, [scal_d.data_ptr()] * b, n, device=xdev if world > 1 else None)
             done += b
         return res
 
@@ -172,7 +181,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 

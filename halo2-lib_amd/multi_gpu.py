@@ -34,9 +34,9 @@ def sharded_msm(ctx: Context, bases: Bases, scalars_dptr: int, n_local: int, gro
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         if point_format == POINT_JACOBIAN:
             return part
-        t = torch.from_numpy(part.view(np.int64).copy())
+        t = torch.from_numpy(part.view(np.int64).copy()).reshape(1, 1, 12)
         t = t.to(device) if device is not None else t
-        return ctx.g1_sum_jacobian_dev(t.data_ptr(), 1, point_format)
+        return _sum_gathered(ctx, t, 1, 1, point_format, device)
     world = dist.get_world_size(group)
     t = torch.from_numpy(part.view(np.int64).copy()).reshape(1, 12)
     if device is not None:
@@ -44,9 +44,32 @@ def sharded_msm(ctx: Context, bases: Bases, scalars_dptr: int, n_local: int, gro
     gathered = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(gathered, t, group=group)
     allp = torch.cat(gathered, dim=0).contiguous()
-    if device is not None:
+    return _sum_gathered(ctx, allp, world, 1, point_format, device)[0:1]
+
+
+def _sum_gathered(ctx: Context, allp, world: int, count: int, point_format: int, device) -> np.ndarray:
+    """allp: (count, world, 12) int64 tensor of Jacobian partials -> (count, 8|12) sums computed on the GPU.
+    A tensor gathered on the CPU (gloo) is staged into device memory first: the library only takes device pointers."""
+    import torch
+
+    width = 12 if point_format == POINT_JACOBIAN else 8
+    out = np.zeros((count, width), dtype=np.uint64)
+    staged = None
+    if allp.device.type == "cpu":
+        host = allp.numpy().view(np.uint64).reshape(-1)
+        staged = ctx.to_device(host)
+        base = staged
+    else:
         torch.cuda.current_stream(device).synchronize()
-    return ctx.g1_sum_jacobian_dev(allp.data_ptr(), world, point_format)
+        base = allp.data_ptr()
+    try:
+        stride = world * 12 * 8
+        for j in range(count):
+            out[j] = ctx.g1_sum_jacobian_dev(base + j * stride, world, point_format)[0]
+    finally:
+        if staged is not None:
+            ctx.free(staged)
+    return out
 
 
 def sharded_msm_batch(ctx: Context, bases: Bases, scalar_dptrs, n_local: int, group=None, device=None) -> np.ndarray:
@@ -67,10 +90,4 @@ def sharded_msm_batch(ctx: Context, bases: Bases, scalar_dptrs, n_local: int, gr
     gathered = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(gathered, t, group=group)
     allp = torch.cat(gathered, dim=0).permute(1, 0, 2).contiguous()   # (count, world, 12)
-    if device is not None:
-        torch.cuda.current_stream(device).synchronize()
-    out = np.zeros((count, 12), dtype=np.uint64)
-    stride = world * 12 * 8
-    for j in range(count):
-        out[j] = ctx.g1_sum_jacobian_dev(allp.data_ptr() + j * stride, world, POINT_JACOBIAN)[0]
-    return out
+    return _sum_gathered(ctx, allp, world, count, POINT_JACOBIAN, device)
