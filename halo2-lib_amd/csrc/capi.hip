@@ -215,6 +215,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
+    if (!strcmp(name, "msm_quad_tails")) return &ctx->msm_quad_tails;
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
     return nullptr;
 }
@@ -401,6 +402,7 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
         c->msm_seg = ctx->msm_seg;
         c->msm_accum_variant = ctx->msm_accum_variant;
         c->msm_scatter_split = ctx->msm_scatter_split;
+        c->msm_quad_tails = ctx->msm_quad_tails;
         c->msm_window_bits = ctx->msm_window_bits;
         c->profiling = ctx->profiling;
     }

@@ -24,6 +24,7 @@
 // serial 2^(c*w) fold disappears.  Signs are applied by negating y on load.
 #include "internal.h"
 #include "ec29.cuh"
+#include "quad29.cuh"
 
 namespace h2 {
 
@@ -391,6 +392,101 @@ __global__ __launch_bounds__(64) void msm_fold_kernel(const XYZZ29 *__restrict__
     if (tid == 0) out[0] = xyzz29_to_sat(sh[0]);   // back to saturated canonical limbs for the C ABI
 }
 
+
+// ---- quad-lane versions of the latency-bound tail (quad29.cuh): one point per 4 lanes ---------------------------
+// one quad per segment of L buckets: sum_{b in seg} (b+1) * bucket[b]; with `tree` the 64 quads of a workgroup (all in
+// the same window) are summed before leaving, so the window sum only has per/64 values left to add
+__global__ __launch_bounds__(256) void msm_seg_quad_kernel(const XYZZ29 *__restrict__ buckets, XYZZ29 *__restrict__ seg_out, uint32_t B, uint32_t L,
+                                                           uint32_t nseg_total, uint32_t lo_bits, uint32_t tree) {
+    __shared__ XYZZ29 sh[64];
+    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, qi = threadIdx.x >> 2;
+    uint32_t g = blockIdx.x * 64 + qi;
+    const bool live = g < nseg_total;
+    if (!live) g = nseg_total - 1;   // keep the quad in lock step on valid data; its result is discarded
+    uint32_t per = B / L, w = g / per, lo = (g - w * per) * L;
+    const XYZZ29 *bw = buckets + (size_t)w * B;
+    Fq29 run = Fq29::zero(), acc = Fq29::zero();
+    for (int b = (int)(lo + L) - 1; b >= (int)lo; --b) {
+        run = quad_xyzz_add(run, quad_load(bw + b, q), lane);
+        acc = quad_xyzz_add(acc, run, lane);
+    }
+    acc = quad_xyzz_add(acc, quad_xyzz_small_mul(run, lo, lo_bits, lane), lane);
+    if (!tree) {
+        if (live) quad_store(seg_out + g, q, acc);
+        return;
+    }
+    if (!live) acc = Fq29::zero();
+    quad_store(&sh[qi], q, acc);
+    __syncthreads();
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        Fq29 other = quad_load(&sh[(qi + d) & 63u], q);
+        Fq29 sum = quad_xyzz_add(acc, other, lane);
+        __syncthreads();
+        if (qi < d) {
+            acc = sum;
+            quad_store(&sh[qi], q, acc);
+        }
+        __syncthreads();
+    }
+    if (qi == 0) quad_store(seg_out + blockIdx.x, q, acc);
+}
+// one workgroup (1024 lanes = 256 quads) per window: tree sum of its `per` partial results
+__global__ __launch_bounds__(1024) void msm_winsum_quad_kernel(const XYZZ29 *__restrict__ seg, XYZZ29 *__restrict__ win_out, uint32_t per) {
+    __shared__ XYZZ29 sh[256];
+    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, qi = threadIdx.x >> 2, w = blockIdx.x;
+    Fq29 acc = Fq29::zero();
+    const uint32_t rounds = (per + 255) / 256;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        uint32_t i = qi + 256 * r;
+        Fq29 v = i < per ? quad_load(seg + (size_t)w * per + i, q) : Fq29::zero();
+        acc = rounds == 1 ? v : quad_xyzz_add(acc, v, lane);
+    }
+    quad_store(&sh[qi], q, acc);
+    __syncthreads();
+    uint32_t d0 = 128;
+    while (d0 > 1 && d0 >= per) d0 >>= 1;   // skip levels whose partners are all identity
+    if (per <= 1) d0 = 0;
+    for (uint32_t d = d0; d >= 1; d >>= 1) {
+        Fq29 other = qi + d < 256 ? quad_load(&sh[qi + d], q) : Fq29::zero();
+        Fq29 sum = quad_xyzz_add(acc, other, lane);
+        __syncthreads();
+        if (qi < d) {
+            acc = sum;
+            quad_store(&sh[qi], q, acc);
+        }
+        __syncthreads();
+    }
+    if (qi == 0) quad_store(win_out + w, q, acc);
+}
+// out = sum_w 2^(c*w) * win[w]   (Wr <= 64 windows, one quad each, then a tree); result in saturated limbs
+__global__ __launch_bounds__(256) void msm_fold_quad_kernel(const XYZZ29 *__restrict__ win, uint32_t Wr, uint32_t c, XYZZ *__restrict__ out) {
+    __shared__ XYZZ29 sh[64];
+    const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, qi = threadIdx.x >> 2;
+    Fq29 p = qi < Wr ? quad_load(win + qi, q) : Fq29::zero();
+    const uint32_t max_dbl = c * (Wr - 1);
+    for (uint32_t i = 0; i < max_dbl; ++i) {
+        Fq29 d = quad_xyzz_double(p, lane);
+        p = f29_select(i < c * qi && qi < Wr, d, p);
+    }
+    quad_store(&sh[qi], q, p);
+    __syncthreads();
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        Fq29 other = quad_load(&sh[(qi + d) & 63u], q);
+        Fq29 sum = quad_xyzz_add(p, other, lane);
+        __syncthreads();
+        if (qi < d) {
+            p = sum;
+            quad_store(&sh[qi], q, p);
+        }
+        __syncthreads();
+    }
+    if (qi == 0) {   // back to saturated canonical limbs for the C ABI, coordinate by coordinate
+        const bool id = quad_is_identity(p, lane);
+        Fq v = id ? Fq::zero() : f29_to_sat(p);
+        reinterpret_cast<Fq *>(out)[q] = v;
+    }
+}
+
 // ------------------------------------------------------------------ precomputed tables (H2HIP_BASES_PRECOMPUTE)
 // level w holds 2^(c*w) * P_i.  Step 1: Jacobian doublings of the previous level; step 2: batch normalisation
 // (Montgomery's trick over runs of NORM_RUN points, one Fermat inversion per run).
@@ -648,14 +744,33 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
         prof_end(ctx);
         red_in = presum;
     }
-    prof_begin(ctx, "msm_seg_kernel");
-    hipLaunchKernelGGL(msm_seg_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, red_in, seg, B, L, nseg);
-    prof_end(ctx);
-    prof_begin(ctx, "msm_winsum_kernel");
-    hipLaunchKernelGGL(msm_winsum_kernel, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, B / L);
-    prof_end(ctx);
+    // quad-lane arithmetic pays when the stage is latency-bound (few segments: precomputed bases); with 16 windows'
+    // worth of segments the stage is throughput-bound and the one-lane kernels win — the 2^(c*w) fold is always a chain
+    const bool quad_reduce = ctx->msm_quad_tails && nseg <= 16384;
+    if (quad_reduce) {
+        uint32_t lo_bits = 0;   // bits needed for a segment's first bucket index (< B)
+        while ((1u << lo_bits) < B) ++lo_bits;
+        const uint32_t per = B / L;
+        const uint32_t tree = (per % 64 == 0) ? 1u : 0u;   // a workgroup's 64 quads then belong to one window
+        prof_begin(ctx, "msm_seg_kernel");
+        hipLaunchKernelGGL(msm_seg_quad_kernel, dim3((nseg + 63) / 64), dim3(256), 0, st, red_in, seg, B, L, nseg, lo_bits, tree);
+        prof_end(ctx);
+        prof_begin(ctx, "msm_winsum_kernel");
+        hipLaunchKernelGGL(msm_winsum_quad_kernel, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, tree ? per / 64 : per);
+        prof_end(ctx);
+    } else {
+        prof_begin(ctx, "msm_seg_kernel");
+        hipLaunchKernelGGL(msm_seg_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, red_in, seg, B, L, nseg);
+        prof_end(ctx);
+        prof_begin(ctx, "msm_winsum_kernel");
+        hipLaunchKernelGGL(msm_winsum_kernel, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, B / L);
+        prof_end(ctx);
+    }
     prof_begin(ctx, "msm_fold_kernel");
-    hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ29 *)win, Wr, c, out);
+    if (ctx->msm_quad_tails)
+        hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(1), dim3(256), 0, st, (const XYZZ29 *)win, Wr, c, out);
+    else
+        hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ29 *)win, Wr, c, out);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;

@@ -38,23 +38,33 @@ struct uint2 { unsigned x, y; };
 
 namespace hipemu {
 inline thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+enum { FIBER_READY = 0, FIBER_AT_BARRIER = 1, FIBER_DONE = 2 };
 struct Worker {
     std::vector<ucontext_t> ctx;
     std::vector<char *> stacks;
-    std::vector<char> done;
+    std::vector<char> state;
     ucontext_t main_ctx;
     int cur = 0;
+    unsigned nthreads = 0;
+    dim3 bdim;
     std::function<void()> body;
     std::vector<char> dyn_smem;
     std::vector<int> or_calls;
     int or_val[3] = {0, 0, 0};
+    // cross-lane support (__shfl / __any): double-buffered slots + per-fiber call counters, wave-wide rendezvous
+    std::vector<uint32_t> xl_slot[2];   // 16 words per lane
+    std::vector<uint32_t> xl_calls;
     ~Worker() { for (char *p : stacks) free(p); }
 };
 inline thread_local Worker *t_worker = nullptr;
+inline void set_thread_idx(Worker *w, unsigned i) {
+    w->cur = (int)i;
+    t_threadIdx = dim3(i % w->bdim.x, (i / w->bdim.x) % w->bdim.y, i / (w->bdim.x * w->bdim.y));
+}
 inline void fiber_entry() {
     Worker *w = t_worker;
     w->body();
-    w->done[w->cur] = 1;
+    w->state[w->cur] = FIBER_DONE;
     swapcontext(&w->ctx[w->cur], &w->main_ctx);
 }
 constexpr size_t kStack = 256 * 1024;
@@ -63,35 +73,72 @@ inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
         size_t old = w.ctx.size();
         w.ctx.resize(nthreads);
         w.stacks.resize(nthreads, nullptr);
-        w.done.resize(nthreads);
         for (size_t i = old; i < nthreads; ++i) w.stacks[i] = (char *)malloc(kStack);
     }
+    w.nthreads = nthreads;
+    w.bdim = bdim;
+    w.state.assign(nthreads, FIBER_READY);
     for (unsigned i = 0; i < nthreads; ++i) {
         getcontext(&w.ctx[i]);
         w.ctx[i].uc_stack.ss_sp = w.stacks[i];
         w.ctx[i].uc_stack.ss_size = kStack;
         w.ctx[i].uc_link = &w.main_ctx;
         makecontext(&w.ctx[i], (void (*)())fiber_entry, 0);
-        w.done[i] = 0;
     }
     w.or_calls.assign(nthreads, 0);
     w.or_val[0] = w.or_val[1] = w.or_val[2] = 0;
-    unsigned remaining = nthreads;
-    while (remaining) {
+    w.xl_slot[0].assign((size_t)nthreads * 16, 0);
+    w.xl_slot[1].assign((size_t)nthreads * 16, 0);
+    w.xl_calls.assign(nthreads, 0);
+    for (;;) {
+        bool ran = false, alive = false;
         for (unsigned i = 0; i < nthreads; ++i) {
-            if (w.done[i]) continue;
-            w.cur = (int)i;
-            t_threadIdx = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
+            if (w.state[i] != FIBER_READY) continue;
+            ran = true;
+            set_thread_idx(&w, i);
             swapcontext(&w.main_ctx, &w.ctx[i]);
-            if (w.done[i]) --remaining;
         }
+        for (unsigned i = 0; i < nthreads; ++i) alive |= (w.state[i] != FIBER_DONE);
+        if (!alive) break;
+        if (!ran)   // everybody still alive is waiting at the barrier: release it
+            for (unsigned i = 0; i < nthreads; ++i)
+                if (w.state[i] == FIBER_AT_BARRIER) w.state[i] = FIBER_READY;
     }
 }
 inline void *dyn_smem_ptr() { return t_worker->dyn_smem.data(); }
 inline void syncthreads() {
     Worker *w = t_worker;
+    w->state[w->cur] = FIBER_AT_BARRIER;
     swapcontext(&w->ctx[w->cur], &w->main_ctx);
-    // resumed: restore threadIdx (set by scheduler before swap)
+}
+// run fiber j (a lane this fiber is waiting for) right now; returns when somebody resumes this fiber again
+inline void switch_to(unsigned j) {
+    Worker *w = t_worker;
+    int me = w->cur;
+    if (w->state[j] != FIBER_READY) abort();   // a lane reached a barrier / exited before the cross-lane op: non-uniform control flow
+    set_thread_idx(w, j);
+    swapcontext(&w->ctx[me], &w->ctx[j]);
+}
+// wave-wide rendezvous: post `v`, wait until every live lane of this wave has posted its call #k, return the slot array
+inline const uint32_t *crosslane_exchange(const uint32_t *v, unsigned nwords, unsigned &wave_lo, unsigned &wave_hi) {
+    Worker *w = t_worker;
+    const unsigned me = (unsigned)w->cur;
+    const uint32_t k = w->xl_calls[me];
+    for (unsigned i = 0; i < nwords; ++i) w->xl_slot[k & 1][(size_t)me * 16 + i] = v[i];
+    w->xl_calls[me] = k + 1;
+    wave_lo = me & ~63u;
+    wave_hi = wave_lo + 64 < w->nthreads ? wave_lo + 64 : w->nthreads;
+    for (;;) {
+        bool all = true;
+        for (unsigned j = wave_lo; j < wave_hi; ++j) {
+            if (w->state[j] == FIBER_DONE || w->xl_calls[j] > k) continue;
+            all = false;
+            switch_to(j);
+            break;
+        }
+        if (all) break;
+    }
+    return w->xl_slot[k & 1].data();
 }
 }  // namespace hipemu
 
@@ -101,6 +148,32 @@ inline void syncthreads() {
 #define blockDim (hipemu::t_blockDim)
 #define gridDim (hipemu::t_gridDim)
 inline void __syncthreads() { hipemu::syncthreads(); }
+inline unsigned __shfl(unsigned v, int src_lane, int /*width*/ = 64) {
+    unsigned lo, hi;
+    const uint32_t *slots = hipemu::crosslane_exchange(&v, 1, lo, hi);
+    unsigned src = lo + ((unsigned)src_lane & 63u);
+    return src < hi ? slots[(size_t)src * 16] : v;
+}
+// emulation-speed helper: shuffle up to 16 words with ONE rendezvous (the HIP build issues one __shfl per word)
+template <int N>
+inline void hipemu_shfl_words(uint32_t (&out)[N], const uint32_t (&in)[N], unsigned src_lane) {
+    static_assert(N <= 16, "at most 16 words");
+    unsigned lo, hi;
+    const uint32_t *slots = hipemu::crosslane_exchange(in, N, lo, hi);
+    unsigned src = lo + (src_lane & 63u);
+    for (int i = 0; i < N; ++i) out[i] = src < hi ? slots[(size_t)src * 16 + i] : in[i];
+}
+inline int __shfl(int v, int src_lane, int width = 64) { return (int)__shfl((unsigned)v, src_lane, width); }
+inline int __any(int pred) {
+    unsigned lo, hi;
+    uint32_t pv = pred ? 1u : 0u;
+    const uint32_t *slots = hipemu::crosslane_exchange(&pv, 1, lo, hi);
+    hipemu::Worker *w = hipemu::t_worker;
+    int r = 0;
+    for (unsigned j = lo; j < hi; ++j)
+        if (w->state[j] != hipemu::FIBER_DONE) r |= (int)slots[(size_t)j * 16];
+    return r;
+}
 inline int __syncthreads_or(int pred) {
     hipemu::Worker *w = hipemu::t_worker;
     int k = w->or_calls[w->cur]++;

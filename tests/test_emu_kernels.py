@@ -255,3 +255,23 @@ def _quotient_identity_checks(ctx, k, ek):
 
 def test_quotient_lookup_and_permutation_identities(ctx):
     _quotient_identity_checks(ctx, 4, 6)
+
+
+def test_msm_quad_and_serial_tails_agree(ctx):
+    """bucket reduction / fold on quad-lane arithmetic (quad29.cuh) vs the one-lane kernels, incl. duplicate-heavy input
+    (equal bucket sums -> the doubling branch) and the identity result"""
+    n = 900
+    P = O.g1_mul(O.G1_GEN, 31337)
+    bases = np.concatenate([CO.known_dlog_bases(n - 300, fr([17]), fr([2])), np.repeat(O.points_to_limbs([P]), 300, axis=0)])
+    cols = [rand_fr(n, 1), circuit_like_fr(n, 2), np.repeat(fr([0x1234567]), n, axis=0), np.zeros((n, 4), dtype=np.uint64)]
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    for flags in (0, BASES_PRECOMPUTE):
+        b = ctx.bases_upload(bases, flags)
+        for s in cols:
+            want = CO.best_multiexp(s, bases, threads=4)
+            for quad in (1, 0):
+                ctx.set_param("msm_quad_tails", quad)
+                assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), want)
+        ctx.set_param("msm_quad_tails", 1)
+        b.free()
