@@ -458,6 +458,7 @@ __global__ __launch_bounds__(1024) void msm_winsum_quad_kernel(const XYZZ29 *__r
     }
     if (qi == 0) quad_store(win_out + w, q, acc);
 }
+
 // out = sum_w 2^(c*w) * win[w]   (Wr <= 64 windows, one quad each, then a tree); result in saturated limbs
 __global__ __launch_bounds__(256) void msm_fold_quad_kernel(const XYZZ29 *__restrict__ win, uint32_t Wr, uint32_t c, XYZZ *__restrict__ out) {
     __shared__ XYZZ29 sh[64];
