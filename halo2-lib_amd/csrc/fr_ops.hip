@@ -3,6 +3,7 @@
 // sub / mul / mul_add on column values) plus the diagnostic multiplier micro-benchmark that defines the
 // integer roofline quoted by bench.py.
 #include "internal.h"
+#include "fq29.cuh"
 
 namespace h2 {
 
@@ -46,6 +47,28 @@ __global__ __launch_bounds__(256) void modmul_bench_kernel(Fr *__restrict__ io, 
     io[i] = acc;
 }
 
+
+// the same probe on the unsaturated 9 x 29-bit representation (fq29.cuh) the MSM and NTT kernels multiply in
+template <int CHAINS>
+__global__ __launch_bounds__(256) void modmul29_bench_kernel(Fr *__restrict__ io, uint32_t iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr y0 = io[i];
+    y0.l[7] &= 0x0fffffffu;
+    Fr29 y = f29_split<R29P>(y0), x[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; ++k) {
+        x[k] = y;
+        x[k].l[0] ^= (uint32_t)k;
+    }
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < CHAINS; ++k) x[k] = f29_mul(x[k], y);
+    }
+    Fr29 acc = x[0];
+#pragma unroll
+    for (int k = 1; k < CHAINS; ++k) acc = f29_norm(f29_add(acc, x[k]));
+    io[i] = f29_pack_canonical<FrP>(f29_mul(acc, Fr29::one()));
+}
 
 // ------------------------------------------------------------------ K4: BatchInvert (0 -> 0)
 // Montgomery's trick over strided runs: lane t owns a[t], a[t+T], a[t+2T], ... (coalesced), one Fermat
@@ -630,6 +653,24 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z,
     hipLaunchKernelGGL(quotient_permutation_kernel, dim3(grid_for(ctx, ne)), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+int h2hip_bench_modmul29(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls) {
+    H2_REQUIRE(ctx && elapsed_ms && modmuls && blocks && iters, "bad argument");
+    H2_REQUIRE(chains == 1 || chains == 2, "chains must be 1 or 2");
+    Fr *buf = nullptr;
+    size_t lanes = (size_t)blocks * 256;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(Fr) * lanes, (void **)&buf));
+    H2_HIPCHK(hipMemsetAsync(buf, 0x5a, sizeof(Fr) * lanes, ctx->stream));
+    for (int rep = 0; rep < 2; ++rep) {   // rep 0 = warm-up
+        H2_CHK(h2hip_timer_start(ctx));
+        if (chains == 1) hipLaunchKernelGGL(modmul29_bench_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, buf, iters);
+        if (chains == 2) hipLaunchKernelGGL(modmul29_bench_kernel<2>, dim3(blocks), dim3(256), 0, ctx->stream, buf, iters);
+        H2_HIPCHK(hipGetLastError());
+        H2_CHK(h2hip_timer_stop(ctx, elapsed_ms));
+    }
+    *modmuls = (double)lanes * iters * chains;
     return H2HIP_OK;
 }
 

@@ -67,6 +67,7 @@ _PROTOS = {
                                                   C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
     "h2hip_poseidon_permute_batch_dev": (_int, [_vp, _vp, _vp, _u32, _sz]),
+    "h2hip_bench_modmul29": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "h2hip_bench_modmul": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 # symbols added by later translation units register themselves here (see fr_ops section below)
@@ -336,10 +337,11 @@ class Context:
             for d in (da, db, dc):
                 self.free(d)
 
-    def bench_modmul(self, blocks: int = 4096, iters: int = 512, chains: int = 1):
-        """returns (elapsed_ms, modmuls) of the multiplier probe kernel"""
+    def bench_modmul(self, blocks: int = 4096, iters: int = 512, chains: int = 1, unsaturated: bool = False):
+        """returns (elapsed_ms, modmuls) of the multiplier probe kernel (saturated 8x32 or unsaturated 9x29 limbs)"""
         ms, mm = C.c_double(), C.c_double()
-        self._chk(self.lib.h2hip_bench_modmul(self.handle, blocks, iters, chains, C.byref(ms), C.byref(mm)))
+        fn = self.lib.h2hip_bench_modmul29 if unsaturated else self.lib.h2hip_bench_modmul
+        self._chk(fn(self.handle, blocks, iters, chains, C.byref(ms), C.byref(mm)))
         return ms.value, mm.value
 
     # -- K4/K5/K7 (host-array conveniences over the _dev entry points)

@@ -181,6 +181,8 @@ int h2hip_poseidon_permute_batch_dev(h2hip_ctx *ctx, void *states_dev, const voi
 
 /* ---- diagnostics: 254-bit Montgomery multiplier throughput (the integer roofline bench.py quotes) ------ */
 int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);
+/* the same probe on the unsaturated 9 x 29-bit representation the MSM / NTT kernels multiply in (chains: 1 or 2) */
+int h2hip_bench_modmul29(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);
 
 #ifdef __cplusplus
 }
