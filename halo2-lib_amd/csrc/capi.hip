@@ -214,6 +214,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
+    if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
     if (!strcmp(name, "msm_quad_tails")) return &ctx->msm_quad_tails;
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
@@ -230,6 +231,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
     if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 1 && value <= 4, "msm_lanes must be 1..4");
     if (p == &ctx->msm_accum_variant) H2_REQUIRE(value == 3 || value == 4, "msm_accum_variant must be 3 or 4");
+    if (p == &ctx->ntt_min_col_bits) H2_REQUIRE(value >= 0 && value <= 5, "ntt_min_col_bits must be 0..5");
     if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
     *p = value;
     return H2HIP_OK;

@@ -76,6 +76,7 @@ struct h2hip_ctx {
     int msm_chunk2 = 8;        // level>=2 entries per lane
     int msm_seg = 8;           // buckets per running-sum segment
     int ntt_tile_bits = 10;
+    int ntt_min_col_bits = 2;    // log2 of the minimum number of adjacent columns per tile (coalescing vs number of passes)
     int ntt_full_table = 1;      // first pass reads a full omega^e table instead of composing two table entries
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)

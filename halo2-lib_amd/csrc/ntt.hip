@@ -260,7 +260,7 @@ int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in
         P = 1;
         mlist[0] = log_n;
     } else {
-        uint32_t maxm = LT - 3;
+        uint32_t maxm = LT - (uint32_t)ctx->ntt_min_col_bits;   // at least 2^min_col_bits adjacent columns per tile (row segments of 32 B each)
         P = (log_n + maxm - 1) / maxm;
         for (uint32_t i = 0; i < P; ++i) mlist[i] = log_n / P + (i < log_n % P ? 1 : 0);
     }
