@@ -208,7 +208,6 @@ int h2hip_sync(h2hip_ctx *ctx) {
 static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_window_bits")) return &ctx->msm_window_bits;
     if (!strcmp(name, "msm_chunk")) return &ctx->msm_chunk;
-    if (!strcmp(name, "msm_chunk2")) return &ctx->msm_chunk2;
     if (!strcmp(name, "msm_seg")) return &ctx->msm_seg;
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
     if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
@@ -226,7 +225,6 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     H2_REQUIRE(p, "unknown parameter name");
     if (p == &ctx->msm_window_bits) H2_REQUIRE(value == 0 || (value >= 2 && value <= 23), "msm_window_bits must be 0 or 2..23");
     if (p == &ctx->msm_chunk) H2_REQUIRE(value == 0 || (value >= 2 && value <= 4096), "msm_chunk must be 0 (auto) or 2..4096");
-    if (p == &ctx->msm_chunk2) H2_REQUIRE(value >= 4 && value <= 4096, "msm_chunk2 must be 4..4096");
     if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
     if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 1 && value <= 4, "msm_lanes must be 1..4");

@@ -73,7 +73,6 @@ struct h2hip_ctx {
     // tuning knobs (h2hip_set_param)
     int msm_window_bits = 0;   // 0 = auto
     int msm_chunk = 0;         // level-1 entries per lane (0 = auto: 8..64, keeping >= 4 waves per SIMD)
-    int msm_chunk2 = 8;        // level>=2 entries per lane
     int msm_seg = 8;           // buckets per running-sum segment
     int ntt_tile_bits = 10;
     int ntt_min_col_bits = 2;    // log2 of the minimum number of adjacent columns per tile (coalescing vs number of passes)

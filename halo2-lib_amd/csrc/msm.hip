@@ -13,15 +13,19 @@
 //                     (base index | sign) into bucket order
 //   5. msm_accum      *distribution-oblivious* bucket accumulation: every lane owns K consecutive sorted
 //                     entries (perfect balance for uniform and for 0/1-heavy circuit columns alike), walks the
-//                     offsets table for bucket boundaries, adds in XYZZ, writes complete interior runs to
-//                     their bucket and emits its first/last (possibly shared) runs as (key, XYZZ) partials
+//                     offsets table for bucket boundaries, adds in XYZZ on unsaturated 9x29-bit limbs (ec29.cuh),
+//                     writes complete interior runs to their bucket and emits its first/last (possibly shared) runs
+//                     as (key, XYZZ) partials.  Bases are gathered as aligned, packed 64-byte entries.
 //   6. msm_merge      block-level segmented scan over the sorted partial list (early exit once no lane merges);
 //                     runs closed inside a block go to buckets, block-crossing runs to the next, 128x shorter level
 //   7. msm_presum/seg/winsum/fold   bucket reduction: per-window sum_j j*B_j over short segments (+ small
-//                     scalar multiple), tree sum per window, 2^(c*w) fold (skipped for precomputed bases)
+//                     scalar multiple), tree sums, 2^(c*w) fold (skipped for precomputed bases).  These stages are
+//                     chains of dependent point additions; when few segments exist (precomputed bases) and for the
+//                     fold they run on quad-lane point arithmetic (quad29.cuh: one point per 4 lanes, 4 concurrent
+//                     field products per level, operands exchanged by DPP quad permutes).
 // Bases stay resident in HBM (h2hip_bases); with H2HIP_BASES_PRECOMPUTE the table also holds 2^(c*w)*P_i for
 // every window (16x the memory — sized for 288 GB HBM), so all windows share one bucket set per index and the
-// serial 2^(c*w) fold disappears.  Signs are applied by negating y on load.
+// serial 2^(c*w) fold disappears.  Signs are applied inside the mixed addition (no negated copy of y).
 #include "internal.h"
 #include "ec29.cuh"
 #include "quad29.cuh"

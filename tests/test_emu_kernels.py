@@ -62,18 +62,18 @@ def test_msm_matches_oracle(ctx, n, kind):
     b.free()
 
 
-@pytest.mark.parametrize("c,k1,k2,seg", [(4, 2, 4, 1), (5, 4, 4, 2), (9, 16, 8, 8), (13, 32, 8, 16)])
-def test_msm_parameter_sweep(ctx, c, k1, k2, seg):
+@pytest.mark.parametrize("c,k1,seg", [(4, 2, 1), (5, 4, 2), (9, 16, 8), (13, 32, 16)])
+def test_msm_parameter_sweep(ctx, c, k1, seg):
     n = 1500
     bases = CO.known_dlog_bases(n, fr([5]), fr([3]))
     b = ctx.bases_upload(bases)
-    for name, v in (("msm_window_bits", c), ("msm_chunk", k1), ("msm_chunk2", k2), ("msm_seg", seg)):
+    for name, v in (("msm_window_bits", c), ("msm_chunk", k1), ("msm_seg", seg)):
         ctx.set_param(name, v)
     try:
         for s in (rand_fr(n, c), circuit_like_fr(n, c)):
             assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=4))
     finally:
-        for name, v in (("msm_window_bits", 0), ("msm_chunk", 0), ("msm_chunk2", 8), ("msm_seg", 8)):
+        for name, v in (("msm_window_bits", 0), ("msm_chunk", 0), ("msm_seg", 8)):
             ctx.set_param(name, v)
         b.free()
 
