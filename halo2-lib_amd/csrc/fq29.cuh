@@ -134,6 +134,24 @@ H2_HD F29<P> f29_mul(const F29<P> &a, const F29<P> &b) {
     }
     return f29_reduce_columns<P>(c);
 }
+// (a*b + c*d) * 2^-261 with ONE Montgomery reduction: all four inputs must be normalised (limbs < 2^29), so a column
+// holds at most 18 products < 2^58 (2^62.2) plus the reduction's 9 * 2^58; X_a*X_b + X_c*X_d <= 169.
+template <class P>
+H2_HD F29<P> f29_mul2(const F29<P> &a, const F29<P> &b, const F29<P> &c2, const F29<P> &d) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        H2_ASSERT29(a.l[i] < (1u << 29) + (i == 8 ? (1u << 29) : 0) && b.l[i] <= (1u << 29) && c2.l[i] <= (1u << 29) && d.l[i] <= (1u << 29));
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            c[i + j] += (uint64_t)a.l[i] * b.l[j];
+            c[i + j] += (uint64_t)c2.l[i] * d.l[j];
+        }
+    }
+    return f29_reduce_columns<P>(c);
+}
 template <class P>
 H2_HD F29<P> f29_sqr(const F29<P> &a) {
     uint64_t c[18];

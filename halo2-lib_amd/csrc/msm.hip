@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ ou
     for (int k = 0; k < 4; ++k)
         if (base + k < n) out[base + k] += add;
 }
-static int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n) {
+int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n) {
     uint32_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     uint32_t *sums = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SCAN, sizeof(uint32_t) * (ntiles + 1), (void **)&sums));

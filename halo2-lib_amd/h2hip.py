@@ -65,6 +65,7 @@ _PROTOS = {
     "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),
     "h2hip_quotient_permutation_set_dev": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp, _vp, _u32, _u32, _int, _int,
                                                   C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "h2hip_lookup_permute_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
     "h2hip_poseidon_permute_batch_dev": (_int, [_vp, _vp, _vp, _u32, _sz]),
     "h2hip_bench_modmul29": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -456,3 +457,15 @@ class Context:
         finally:
             for p in [d_acc, d_z] + ([d_zp] if d_zp else []) + d_cols + d_sig + d_l:
                 self.free(p)
+
+    def lookup_permute(self, a: np.ndarray, s: np.ndarray, usable_rows: int):
+        """(a_perm, s_perm) over rows [0, usable_rows)"""
+        a, s = _fe(a), _fe(s)
+        da, ds = self.to_device(a), self.to_device(s)
+        dap, dsp = self.malloc(max(a.nbytes, 32)), self.malloc(max(a.nbytes, 32))
+        try:
+            self._chk(self.lib.h2hip_lookup_permute_dev(self.handle, _vp(da), _vp(ds), usable_rows, _vp(dap), _vp(dsp)))
+            return self.download(dap, a.shape)[:usable_rows], self.download(dsp, a.shape)[:usable_rows]
+        finally:
+            for d in (da, ds, dap, dsp):
+                self.free(d)

@@ -68,6 +68,12 @@ def kate_division(ctx: Context, a: np.ndarray, b: np.ndarray) -> np.ndarray:
     return ctx.fr_kate_division(a, b)
 
 
+def permute_expression_pair(ctx: Context, input_expression: np.ndarray, table_expression: np.ndarray, usable_rows: int):
+    """plonk::lookup::prover::permute_expression_pair over the usable rows (the caller appends the blinding rows):
+    returns (permuted_input, permuted_table); raises like upstream's ConstraintSystemFailure if an input is not in the table."""
+    return ctx.lookup_permute(input_expression, table_expression, usable_rows)
+
+
 # ------------------------------------------------------------------ poly::EvaluationDomain
 class EvaluationDomain:
     """EvaluationDomain::new(j, k): j = constraint-system degree, n = 2^k rows, extended domain 2^extended_k with

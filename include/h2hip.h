@@ -172,6 +172,11 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc_dev, const void
                                        int32_t last_rotation, const void *beta, const void *gamma, const void *delta, const void *zeta,
                                        const void *ext_omega, const void *y);
 
+/* permute_expression_pair of the lookup argument: a_perm = sort(a[..usable]); s_perm[i] = a_perm[i] on
+ * run starts, the other rows take the unconsumed table elements (ascending) from the last repeated row backwards.
+ * Rows >= usable_rows are left untouched (blinding).  H2HIP_ERR_INVALID if an input value is missing from the table. */
+int h2hip_lookup_permute_dev(h2hip_ctx *ctx, const void *a_dev, const void *s_dev, size_t usable_rows, void *a_perm_dev, void *s_perm_dev);
+
 /* ---- K8: Poseidon permutation batches (halo2-base PoseidonState::permutation, reference
  *      halo2-base/src/poseidon/hasher/state.rs:35-83,124-160).  The caller supplies the spec its
  *      OptimizedPoseidonSpec was derived from (hasher/spec.rs:88-175): (r_f+r_p)*t round constants and

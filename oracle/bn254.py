@@ -458,3 +458,29 @@ def quotient_permutation_set_terms(acc, z, z_prev, cols, sigmas, first_col_index
         v = (v * y + active * (left - right)) % R_MOD
         out.append(v)
     return out
+
+
+def permute_expression_pair(a, s):
+    """Restatement of halo2's lookup `permute_expression_pair` over the usable rows [UPSTREAM plonk/lookup/prover.rs,
+    SURVEY.md A.5]: sorted input; table element placed wherever a new input value starts; leftover table elements
+    (BTreeMap order = ascending) assigned to the repeated rows popped from the END of the list.  Raises if an input
+    value is not in the table."""
+    from collections import Counter
+
+    ap = sorted(v % R_MOD for v in a)
+    left = Counter(v % R_MOD for v in s)
+    sp = [0] * len(ap)
+    repeated = []
+    for row, v in enumerate(ap):
+        if row == 0 or v != ap[row - 1]:
+            sp[row] = v
+            if left[v] == 0:
+                raise ValueError("input value missing from the table")
+            left[v] -= 1
+        else:
+            repeated.append(row)
+    for v in sorted(left):
+        for _ in range(left[v]):
+            sp[repeated.pop()] = v
+    assert not repeated
+    return ap, sp

@@ -275,3 +275,31 @@ def test_msm_quad_and_serial_tails_agree(ctx):
                 assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), want)
         ctx.set_param("msm_quad_tails", 1)
         b.free()
+
+
+def _lookup_permute_checks(ctx, sizes):
+    rng = np.random.default_rng(5)
+    for u, tbits in sizes:
+        table = list(range(1 << tbits)) + [0] * max(0, u - (1 << tbits))   # range table padded with zeros, like halo2-base's
+        table = table[:u] if len(table) >= u else table
+        if len(table) < u:
+            table += [0] * (u - len(table))
+        vals = [int(x) for x in rng.integers(0, 1 << tbits, size=u)]
+        vals[: u // 4] = [0] * (u // 4)            # many repeats of one value
+        if u >= 8:
+            big = O.random_scalars(3, 9)
+            vals[-3:], table[-3:] = big, big[::-1]  # a few full-size field elements
+        tset = set(table)
+        vals = [v if v in tset else 0 for v in vals]   # every input must occur in the (truncated / overwritten) table
+        want_a, want_s = O.permute_expression_pair(vals, table)
+        a = np.concatenate([fr(vals), rand_fr(7, 1)])   # rows beyond `usable` must be ignored
+        s = np.concatenate([fr(table), rand_fr(7, 2)])
+        got_a, got_s = ctx.lookup_permute(a, s, u)
+        assert O.limbs_to_ints(got_a, R) == want_a
+        assert O.limbs_to_ints(got_s, R) == want_s
+    with pytest.raises(H.H2HipError):
+        ctx.lookup_permute(fr([1, 2, 3, 99]), fr([1, 2, 3, 4]), 4)
+
+
+def test_lookup_permute_expression_pair(ctx):
+    _lookup_permute_checks(ctx, [(1, 1), (5, 2), (300, 5), (1024, 8), (3001, 9)])

@@ -220,3 +220,9 @@ def test_quotient_lookup_and_permutation_identities(ctx):
     from tests.test_emu_kernels import _quotient_identity_checks
 
     _quotient_identity_checks(ctx, 7, 9)
+
+
+def test_lookup_permute_expression_pair(ctx):
+    from tests.test_emu_kernels import _lookup_permute_checks
+
+    _lookup_permute_checks(ctx, [(5, 2), (3001, 9), ((1 << 17) - 20, 15)])
