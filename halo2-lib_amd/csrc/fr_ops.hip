@@ -605,6 +605,37 @@ int h2hip_quotient_flex_gate_dev(h2hip_ctx *ctx, void *acc, const void *q, const
     return H2HIP_OK;
 }
 
+// EvaluationDomain::divide_by_vanishing_poly [UPSTREAM poly/domain.rs, SURVEY.md A.2]: t(X) = X^n - 1 takes only
+// L = 2^(ext_k-k) distinct values on the coset {zeta * ext_omega^i}: t_i = zeta^n * (ext_omega^n)^i - 1, period L.
+__global__ __launch_bounds__(64) void vanishing_inverses_kernel(Fr *__restrict__ tinv, uint32_t L, Fr zeta_n, Fr step) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    Fr t = fe_sub(fe_mul(zeta_n, fe_pow_u64(step, i)), Fr::one());
+    tinv[i] = fe_inv(t);   // t != 0: the coset avoids the n-th roots of unity
+}
+__global__ __launch_bounds__(256) void divide_by_vanishing_kernel(Fr *__restrict__ a, const Fr *__restrict__ tinv, size_t n_ext, uint32_t mask) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ext; i += stride) a[i] = fe_mul(a[i], tinv[i & mask]);
+}
+int h2hip_divide_by_vanishing_poly_dev(h2hip_ctx *ctx, void *a, uint32_t ext_k, uint32_t k, const void *ext_omega, const void *zeta) {
+    H2_REQUIRE(ctx && a && ext_omega && zeta, "NULL argument");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28 && ext_k - k <= 16, "need k <= ext_k <= 28 and ext_k - k <= 16");
+    Fr w, z;
+    memcpy(&w, ext_omega, sizeof(Fr));
+    memcpy(&z, zeta, sizeof(Fr));
+    const uint64_t n = 1ull << k;
+    const uint32_t L = 1u << (ext_k - k);
+    Fr *tinv;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_VANISH, sizeof(Fr) * L, (void **)&tinv));
+    prof_begin(ctx, "divide_by_vanishing_kernels");
+    hipLaunchKernelGGL(vanishing_inverses_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, tinv, L, fe_pow_u64(z, n), fe_pow_u64(w, n));
+    size_t n_ext = (size_t)1 << ext_k;
+    hipLaunchKernelGGL(divide_by_vanishing_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)a, (const Fr *)tinv, n_ext, L - 1);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
 static Fr ld_fr(const void *p) {
     Fr r;
     memcpy(&r, p, sizeof(Fr));

@@ -67,7 +67,7 @@ struct h2hip_ctx {
     int num_cus = 256;
     // scratch
     enum { WS_NTT = 0, WS_DIGITS, WS_COUNTS, WS_OFFSETS, WS_CURSOR, WS_SKEY, WS_SVAL, WS_BUCKETS, WS_PKEY0, WS_PVAL0, WS_PKEY1,
-           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_POSEIDON, WS_FBTABLE, WS_BATCH, WS_LK0, WS_LK1, WS_LK2, WS_LK3, WS_LK4, WS_COUNT };
+           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_POSEIDON, WS_FBTABLE, WS_BATCH, WS_LK0, WS_LK1, WS_LK2, WS_LK3, WS_LK4, WS_VANISH, WS_COUNT };
     h2::DevBuf ws[WS_COUNT];
     std::vector<h2::TwiddleSet> twiddles;
     // tuning knobs (h2hip_set_param)

@@ -65,6 +65,7 @@ _PROTOS = {
     "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),
     "h2hip_quotient_permutation_set_dev": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp, _vp, _u32, _u32, _int, _int,
                                                   C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "h2hip_divide_by_vanishing_poly_dev": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "h2hip_lookup_permute_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
     "h2hip_poseidon_permute_batch_dev": (_int, [_vp, _vp, _vp, _u32, _sz]),
@@ -404,6 +405,15 @@ class Context:
         finally:
             for d in (da, dq, dv):
                 self.free(d)
+
+    def divide_by_vanishing_poly(self, a: np.ndarray, ext_k: int, k: int, ext_omega: np.ndarray, zeta: np.ndarray) -> np.ndarray:
+        a = _fe(a)
+        da = self.to_device(a)
+        try:
+            self._chk(self.lib.h2hip_divide_by_vanishing_poly_dev(self.handle, _vp(da), ext_k, k, _ptr(_fe(ext_omega)), _ptr(_fe(zeta))))
+            return self.download(da, a.shape)
+        finally:
+            self.free(da)
 
     # -- K8 Poseidon
     def poseidon_set_spec(self, t: int, r_f: int, r_p: int, round_constants: np.ndarray, mds: np.ndarray):

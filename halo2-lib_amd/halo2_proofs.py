@@ -122,6 +122,12 @@ class EvaluationDomain:
         out = self.ctx.extended_to_coeff(a, self.extended_k, self.extended_omega_inv, self.extended_ifft_divisor, self.g_coset_inv)
         return out[: self.n * self.quotient_poly_degree]
 
+    def divide_by_vanishing_poly(self, a: np.ndarray) -> np.ndarray:
+        """a[i] /= t(zeta * extended_omega^i), t(X) = X^n - 1, on the extended (coset) domain"""
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        assert len(a) == self.extended_len()
+        return self.ctx.divide_by_vanishing_poly(a, self.extended_k, self.k, self.extended_omega, self.g_coset)
+
     def rotate_omega(self, value: np.ndarray, rotation: int) -> np.ndarray:
         w = pow(fr_int(self.omega), rotation % self.n, R_MOD)
         return fr_limbs(fr_int(value) * w % R_MOD)

@@ -157,6 +157,10 @@ int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_d
 int h2hip_quotient_flex_gate_dev(h2hip_ctx *ctx, void *acc_dev, const void *q_dev, const void *a_dev, uint32_t ext_k, uint32_t k,
                                  const void *y);
 
+/* EvaluationDomain::divide_by_vanishing_poly: a[i] *= 1 / ((zeta * ext_omega^i)^n - 1) over the 2^ext_k extended-domain
+ * evaluations (n = 2^k); the 2^(ext_k-k) distinct inverses are computed on the device. */
+int h2hip_divide_by_vanishing_poly_dev(h2hip_ctx *ctx, void *a_dev, uint32_t ext_k, uint32_t k, const void *ext_omega, const void *zeta);
+
 /* Lookup argument's five identities, folded in upstream's order: l0*(1-z); l_last*(z^2-z);
  * active*(z(wX)(a'+beta)(s'+gamma) - z(a+beta)(s+gamma)); l0*(a'-s'); active*(a'-s')(a'-a'(w^-1 X)); active = 1-(l_last+l_blind).
  * All arrays: 2^ext_k extended-domain evaluations (halo2-base's lookups: halo2-base/src/gates/range/mod.rs:131-150). */
