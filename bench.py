@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (exchange staged through the host; testing)")
     ap.add_argument("--share-device", action="store_true", help="testing on a 1-GPU box: every rank uses GPU 0 (requires --dist-backend gloo)")
+    ap.add_argument("--param", action="append", default=[], help="name=value tuning knob passed to h2hip_set_param (repeatable)")
     ap.add_argument("--lanes", type=int, default=0, help="override msm_lanes (streams used by the batch API)")
     ap.add_argument("--no-replay", action="store_true", help="skip the k=19 create_proof kernel-sequence replay (extra field)")
     ap.add_argument("--precompute", type=int, default=1, help="1: bases carry precomputed 2^(c*w) window tables (fixed-base SRS, H2HIP_BASES_PRECOMPUTE)")
@@ -144,6 +145,9 @@ def main():
     ctx = H.Context(device=local_rank, stream=tstream.cuda_stream)
     if args.lanes:
         ctx.set_param("msm_lanes", args.lanes)
+    for kv in args.param:
+        name, val = kv.split("=")
+        ctx.set_param(name, int(val))
     # each rank owns its own slice of the (world * n)-point MSM
     bases_h = synthetic_bases(n, seed=1000 + rank)
     scal_h = synthetic_scalars(n, seed=2000 + rank)

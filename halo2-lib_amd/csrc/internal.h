@@ -79,6 +79,7 @@ struct h2hip_ctx {
     int ntt_full_table = 1;      // first pass reads a full omega^e table instead of composing two table entries
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
+    int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
     int msm_scatter_split = 0;   // bucket sub-ranges per window in the scatter (0 = auto, power of two)
     int msm_accum_variant = 3;   // min waves/SIMD the accumulate kernel is compiled for (3 or 4)
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]

@@ -32,6 +32,15 @@
 
 namespace h2 {
 
+// The latency-bound tail kernels (a few waves of dependent point additions) run next to another MSM's multiplier-bound
+// accumulation when MSMs are pipelined over lanes: raise their wave priority so the SIMD arbiter issues them first.
+#ifdef H2_HIPEMU
+#define H2_TAIL_PRIORITY() ((void)0)
+#else
+#define H2_TAIL_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#endif
+
+
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t MAX_LDS_BUCKETS = 1u << 15;   // 128 KiB of u32 counters
 
@@ -75,17 +84,17 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t *__restri
     uint32_t w, g;
     block_to_window_chunk(blockIdx.x, G, w, g);
     if (w >= W) return;
-    for (uint32_t b = threadIdx.x; b < B; b += 1024) hist[b] = 0;
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t *dw = digits + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         uint32_t d = dw[i] & 0x7fffffffu;
         if (d) atomicAdd(&hist[d - 1], 1u);
     }
     __syncthreads();
     uint32_t *out = bhist + ((size_t)w * G + g) * B;
-    for (uint32_t b = threadIdx.x; b < B; b += 1024) out[b] = hist[b];
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) out[b] = hist[b];
 }
 
 // ------------------------------------------------------------------ 3. prefix over chunks per (window, bucket)
@@ -189,12 +198,12 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     const uint32_t Bs = B / S, b0 = h * Bs;   // this workgroup's bucket range [b0, b0 + Bs)
     const uint32_t *off_w = offsets + (size_t)w * B + b0;
     const uint32_t *bh = bhist + ((size_t)w * G + g) * B + b0;
-    for (uint32_t b = threadIdx.x; b < Bs; b += 1024) cursor[b] = off_w[b] + bh[b];
+    for (uint32_t b = threadIdx.x; b < Bs; b += blockDim.x) cursor[b] = off_w[b] + bh[b];
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t *dw = digits + (size_t)w * n;
     const uint32_t idx_base = w * table_stride;   // precomputed bases: window w reads table level w
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         uint32_t dv = dw[i], d = dv & 0x7fffffffu;
         if (!d) continue;
         uint32_t b = d - 1 - b0;
@@ -273,6 +282,7 @@ __global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__
 __global__ __launch_bounds__(256) void msm_merge_kernel(const uint32_t *__restrict__ kin, const XYZZ29 *__restrict__ vin, uint32_t len,
                                                         XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ kout,
                                                         XYZZ29 *__restrict__ vout, uint32_t final_level) {
+    H2_TAIL_PRIORITY();
     __shared__ XYZZ29 sv[256];
     __shared__ uint32_t sk[256];
     const uint32_t tid = threadIdx.x, blk = blockIdx.x;
@@ -332,6 +342,7 @@ __device__ __forceinline__ XYZZ29 xyzz_small_mul(const XYZZ29 &p, uint32_t k) {
 // (rows = number of windows of `in`, summed in groups of `group`; launched twice: W -> ceil(W/4) -> 1 rows)
 __global__ __launch_bounds__(64) void msm_presum_kernel(const XYZZ29 *__restrict__ in, XYZZ29 *__restrict__ out, uint32_t B, uint32_t rows,
                                                         uint32_t group) {
+    H2_TAIL_PRIORITY();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t groups = (rows + group - 1) / group;
     if (t >= B * groups) return;
@@ -344,6 +355,7 @@ __global__ __launch_bounds__(64) void msm_presum_kernel(const XYZZ29 *__restrict
 // one lane per segment of L buckets: sum_{b in seg} (b+1) * bucket[b]
 __global__ __launch_bounds__(64) void msm_seg_kernel(const XYZZ29 *__restrict__ buckets, XYZZ29 *__restrict__ seg_out, uint32_t B, uint32_t L,
                                                      uint32_t nseg_total) {
+    H2_TAIL_PRIORITY();
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nseg_total) return;
     uint32_t per = B / L, w = g / per, lo = (g - w * per) * L;
@@ -358,6 +370,7 @@ __global__ __launch_bounds__(64) void msm_seg_kernel(const XYZZ29 *__restrict__ 
 }
 // one workgroup per window: tree sum of its segment results
 __global__ __launch_bounds__(1024) void msm_winsum_kernel(const XYZZ29 *__restrict__ seg, XYZZ29 *__restrict__ win_out, uint32_t per) {
+    H2_TAIL_PRIORITY();
     __shared__ XYZZ29 sh[1024];
     uint32_t tid = threadIdx.x, w = blockIdx.x;
     XYZZ29 acc = XYZZ29::identity();
@@ -376,6 +389,7 @@ __global__ __launch_bounds__(1024) void msm_winsum_kernel(const XYZZ29 *__restri
 }
 // out = sum_w 2^(c*w) * win[w]   (Wr <= 64 windows, one lane each, then a tree)
 __global__ __launch_bounds__(64) void msm_fold_kernel(const XYZZ29 *__restrict__ win, uint32_t Wr, uint32_t c, XYZZ *__restrict__ out) {
+    H2_TAIL_PRIORITY();
     __shared__ XYZZ29 sh[64];
     uint32_t tid = threadIdx.x;
     XYZZ29 p = XYZZ29::identity();
@@ -402,6 +416,7 @@ __global__ __launch_bounds__(64) void msm_fold_kernel(const XYZZ29 *__restrict__
 // the same window) are summed before leaving, so the window sum only has per/64 values left to add
 __global__ __launch_bounds__(256) void msm_seg_quad_kernel(const XYZZ29 *__restrict__ buckets, XYZZ29 *__restrict__ seg_out, uint32_t B, uint32_t L,
                                                            uint32_t nseg_total, uint32_t lo_bits, uint32_t tree) {
+    H2_TAIL_PRIORITY();
     __shared__ XYZZ29 sh[64];
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, qi = threadIdx.x >> 2;
     uint32_t g = blockIdx.x * 64 + qi;
@@ -436,6 +451,7 @@ __global__ __launch_bounds__(256) void msm_seg_quad_kernel(const XYZZ29 *__restr
 }
 // one workgroup (1024 lanes = 256 quads) per window: tree sum of its `per` partial results
 __global__ __launch_bounds__(1024) void msm_winsum_quad_kernel(const XYZZ29 *__restrict__ seg, XYZZ29 *__restrict__ win_out, uint32_t per) {
+    H2_TAIL_PRIORITY();
     __shared__ XYZZ29 sh[256];
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, qi = threadIdx.x >> 2, w = blockIdx.x;
     Fq29 acc = Fq29::zero();
@@ -465,6 +481,7 @@ __global__ __launch_bounds__(1024) void msm_winsum_quad_kernel(const XYZZ29 *__r
 
 // out = sum_w 2^(c*w) * win[w]   (Wr <= 64 windows, one quad each, then a tree); result in saturated limbs
 __global__ __launch_bounds__(256) void msm_fold_quad_kernel(const XYZZ29 *__restrict__ win, uint32_t Wr, uint32_t c, XYZZ *__restrict__ out) {
+    H2_TAIL_PRIORITY();
     __shared__ XYZZ29 sh[64];
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, qi = threadIdx.x >> 2;
     Fq29 p = qi < Wr ? quad_load(win + qi, q) : Fq29::zero();
@@ -696,8 +713,9 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     prof_begin(ctx, "msm_digits_kernel");
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, scalars, (uint32_t)n, c, W, digits);
     prof_end(ctx);
+    const uint32_t sort_threads = (uint32_t)ctx->msm_sort_threads;
     prof_begin(ctx, "msm_hist_kernel");
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(1024), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(sort_threads), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
     prof_end(ctx);
     prof_begin(ctx, "msm_hist_scan_kernel");
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, bhist, W, B, G, counts);
@@ -712,7 +730,7 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     }
     if (S > B) S = B;
     const uint32_t scatter_grid = 8 * G * ((W * S + 7) / 8);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(1024), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S,
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(sort_threads), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S,
                        precomp ? (uint32_t)bases->n : 0u, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());

@@ -15,6 +15,9 @@ BASES_PLAIN = 0
 BASES_PRECOMPUTE = 1
 
 _vp, _sz, _u32, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+# names accepted by h2hip_profile_get for the stages of one MSM
+MSM_PROFILE_NAMES = ("msm_digits_kernel", "msm_hist_kernel", "msm_hist_scan_kernel", "scan_kernels", "msm_scatter_kernel", "msm_accum_kernel",
+                     "msm_merge_kernel", "msm_presum_kernel", "msm_seg_kernel", "msm_winsum_kernel", "msm_fold_kernel")
 _PROTOS = {
     "h2hip_last_error": (C.c_char_p, []),
     "h2hip_version": (_int, []),
