@@ -34,10 +34,17 @@ namespace h2 {
 
 // The latency-bound tail kernels (a few waves of dependent point additions) run next to another MSM's multiplier-bound
 // accumulation when MSMs are pipelined over lanes: raise their wave priority so the SIMD arbiter issues them first.
+// The LDS-histogram sort kernels take their 128 KiB as DYNAMIC shared memory: with a static array that leaves room for
+// one workgroup per CU the compiler pads the kernel's register allocation to 96 VGPRs per lane ("occupancy is LDS-bound
+// anyway"), and a 1024-lane workgroup (4 waves per SIMD) then never fits next to three resident accumulation waves
+// (3 x 144 of 512 registers) — the sort of MSM i+1 waited for the accumulation of MSM i to drain (rocprofv3 timeline,
+// profiles/r01_pipeline_timeline_*.md).  With dynamic LDS the kernels allocate the 8-16 registers they use.
 #ifdef H2_HIPEMU
 #define H2_TAIL_PRIORITY() ((void)0)
+#define H2_SORT_PRIORITY() ((void)0)
 #else
 #define H2_TAIL_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#define H2_SORT_PRIORITY() __builtin_amdgcn_s_setprio(2)   // digits / LDS-histogram sort of the next MSM: issue-light, latency-bound on LDS atomics
 #endif
 
 
@@ -47,6 +54,7 @@ constexpr uint32_t MAX_LDS_BUCKETS = 1u << 15;   // 128 KiB of u32 counters
 // ------------------------------------------------------------------ 1. digits
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr *__restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
                                                          uint32_t *__restrict__ digits) {
+    H2_SORT_PRIORITY();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s = fe_from_mont(scalars[i]);
@@ -80,7 +88,8 @@ __device__ __forceinline__ void block_to_window_chunk(uint32_t L, uint32_t G, ui
 // ------------------------------------------------------------------ 2. per-(window, chunk) LDS histogram
 __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
                                                         uint32_t G, uint32_t chunk, uint32_t *__restrict__ bhist) {
-    __shared__ uint32_t hist[MAX_LDS_BUCKETS];
+    H2_SORT_PRIORITY();
+    HIP_DYNAMIC_SHARED(uint32_t, hist)   // B counters
     uint32_t w, g;
     block_to_window_chunk(blockIdx.x, G, w, g);
     if (w >= W) return;
@@ -100,6 +109,7 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t *__restri
 // ------------------------------------------------------------------ 3. prefix over chunks per (window, bucket)
 __global__ __launch_bounds__(256) void msm_hist_scan_kernel(uint32_t *__restrict__ bhist, uint32_t W, uint32_t B, uint32_t G,
                                                             uint32_t *__restrict__ counts) {
+    H2_SORT_PRIORITY();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * B) return;
     uint32_t w = t / B, b = t - w * B;
@@ -117,6 +127,7 @@ __global__ __launch_bounds__(256) void msm_hist_scan_kernel(uint32_t *__restrict
 constexpr uint32_t SCAN_TILE = 1024;   // 256 lanes x 4
 __global__ __launch_bounds__(256) void scan_tile_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                         uint32_t *__restrict__ tile_sums, uint32_t n) {
+    H2_SORT_PRIORITY();
     __shared__ uint32_t sh[256];
     uint32_t tid = threadIdx.x, base = blockIdx.x * SCAN_TILE + tid * 4;
     uint32_t v[4], sum = 0;
@@ -142,6 +153,7 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const uint32_t *__restri
     if (tid == 255) tile_sums[blockIdx.x] = sh[255];
 }
 __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ tile_sums, uint32_t ntiles) {
+    H2_SORT_PRIORITY();
     __shared__ uint32_t sh[1024];
     uint32_t tid = threadIdx.x;
     uint32_t per = (ntiles + 1023) / 1024, lo = tid * per, hi = lo + per < ntiles ? lo + per : ntiles;
@@ -163,6 +175,7 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ 
     }
 }
 __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ out, const uint32_t *__restrict__ tile_sums, uint32_t n) {
+    H2_SORT_PRIORITY();
     uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 4, add = tile_sums[blockIdx.x];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -190,7 +203,8 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
                                                            uint32_t G, uint32_t chunk, uint32_t S, uint32_t table_stride,
                                                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ bhist,
                                                            uint32_t *__restrict__ sval) {
-    __shared__ uint32_t cursor[MAX_LDS_BUCKETS];
+    H2_SORT_PRIORITY();
+    HIP_DYNAMIC_SHARED(uint32_t, cursor)   // B / S cursors
     uint32_t seg, g;
     block_to_window_chunk(blockIdx.x, G, seg, g);
     if (seg >= W * S) return;
@@ -225,11 +239,9 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offset
     return lo;
 }
 
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
-                                                        const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
-                                                        XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
-                                                        XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
+__device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
+                                               const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K, XYZZ29 *__restrict__ buckets,
+                                               uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nthreads) return;
     const uint32_t total = offsets[nkeys];
@@ -272,6 +284,26 @@ __global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__
         out_keys[2 * (size_t)t] = hk;
     }
     out_keys[2 * (size_t)t + 1] = cur;
+}
+
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
+                                                        const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
+                                                        XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
+                                                        XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
+    msm_accum_body(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
+}
+// Same body with the register allocation padded to 176 per lane: two waves per SIMD instead of three, which leaves a
+// third of every SIMD's register file free at all times for the tail / sort kernels of the neighbouring pipelined MSMs
+// (msm_accum_variant = 2).
+__global__ __launch_bounds__(256) void msm_accum_w2_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
+                                                           const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
+                                                           XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
+                                                           XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
+#ifndef H2_HIPEMU
+    asm volatile("" ::: "v119");
+#endif
+    msm_accum_body(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
 }
 
 // ------------------------------------------------------------------ 6. segmented merge of the partial list
@@ -714,8 +746,14 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, scalars, (uint32_t)n, c, W, digits);
     prof_end(ctx);
     const uint32_t sort_threads = (uint32_t)ctx->msm_sort_threads;
+    static bool lds_attr_set = false;   // dynamic LDS above 64 KiB has to be enabled per kernel once
+    if (!lds_attr_set) {
+        H2_HIPCHK(hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
+        H2_HIPCHK(hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
+        lds_attr_set = true;
+    }
     prof_begin(ctx, "msm_hist_kernel");
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(sort_threads), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * B, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
     prof_end(ctx);
     prof_begin(ctx, "msm_hist_scan_kernel");
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, bhist, W, B, G, counts);
@@ -730,13 +768,17 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     }
     if (S > B) S = B;
     const uint32_t scatter_grid = 8 * G * ((W * S + 7) / 8);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(sort_threads), 0, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S,
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(sort_threads), sizeof(uint32_t) * MAX_LDS_BUCKETS, st,   // full 128 KiB: one workgroup per CU keeps a segment's writes on one XCD
+                       (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S,
                        precomp ? (uint32_t)bases->n : 0u, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
 
     prof_begin(ctx, "msm_accum_kernel");
-    if (ctx->msm_accum_variant == 4)
+    if (ctx->msm_accum_variant == 2)
+        hipLaunchKernelGGL(msm_accum_w2_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+                           (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+    else if (ctx->msm_accum_variant == 4)
         hipLaunchKernelGGL(msm_accum_kernel<4>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
                            (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     else
