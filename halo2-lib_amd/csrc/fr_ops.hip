@@ -25,6 +25,18 @@ __global__ __launch_bounds__(256) void fr_mul_add_kernel(Fr *__restrict__ out, c
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = fe_add(fe_mul(a[i], b[i]), c[i]);
 }
 
+// y[i] = y[i]*s + a*x[i]: the polynomial linear combinations of the multiopen argument (Polynomial * F, += of scaled
+// polynomials in SHPLONK's rotation-set quotients); x may be null (pure scaling)
+__global__ __launch_bounds__(256) void fr_axpby_kernel(Fr *__restrict__ y, Fr s, bool scale_y, const Fr *__restrict__ x, Fr a, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Fr v = y[i];
+        if (scale_y) v = fe_mul(v, s);
+        if (x) v = fe_add(v, fe_mul(a, x[i]));
+        y[i] = v;
+    }
+}
+
 // Multiplier roofline probe: every lane runs CHAINS independent dependent-multiply chains of `iters` steps.
 template <int CHAINS>
 __global__ __launch_bounds__(256) void modmul_bench_kernel(Fr *__restrict__ io, uint32_t iters) {
@@ -452,7 +464,28 @@ int h2hip_fr_mul_add_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const v
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
 }
-
+int h2hip_fr_axpy_dev(h2hip_ctx *ctx, void *y, const void *a, const void *x, size_t n) {
+    H2_REQUIRE(ctx && a && (n == 0 || (y && x)), "NULL argument");
+    if (!n) return H2HIP_OK;
+    Fr av;
+    memcpy(&av, a, sizeof(Fr));
+    prof_begin(ctx, "fr_axpby_kernel");
+    hipLaunchKernelGGL(fr_axpby_kernel, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (Fr *)y, Fr::one(), false, (const Fr *)x, av, n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+int h2hip_fr_scale_dev(h2hip_ctx *ctx, void *y, const void *s, size_t n) {
+    H2_REQUIRE(ctx && s && (n == 0 || y), "NULL argument");
+    if (!n) return H2HIP_OK;
+    Fr sv;
+    memcpy(&sv, s, sizeof(Fr));
+    prof_begin(ctx, "fr_axpby_kernel");
+    hipLaunchKernelGGL(fr_axpby_kernel, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (Fr *)y, sv, true, (const Fr *)nullptr, Fr::one(), n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
 
 // ------------------------------------------------------------------ K4 / K5
 int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a, size_t n) {

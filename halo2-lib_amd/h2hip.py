@@ -68,6 +68,8 @@ _PROTOS = {
     "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),
     "h2hip_quotient_permutation_set_dev": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp, _vp, _u32, _u32, _int, _int,
                                                   C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "h2hip_fr_axpy_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "h2hip_fr_scale_dev": (_int, [_vp, _vp, _vp, _sz]),
     "h2hip_divide_by_vanishing_poly_dev": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "h2hip_lookup_permute_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
@@ -350,6 +352,27 @@ class Context:
         return ms.value, mm.value
 
     # -- K4/K5/K7 (host-array conveniences over the _dev entry points)
+    def fr_axpy(self, y: np.ndarray, a: np.ndarray, x: np.ndarray) -> np.ndarray:
+        """y + a*x (a: one field element)"""
+        y, x = _fe(y), _fe(x)
+        assert y.shape == x.shape
+        dy, dx = self.to_device(y), self.to_device(x)
+        try:
+            self._chk(self.lib.h2hip_fr_axpy_dev(self.handle, _vp(dy), _ptr(_fe(a)), _vp(dx), len(y)))
+            return self.download(dy, y.shape)
+        finally:
+            self.free(dy)
+            self.free(dx)
+
+    def fr_scale(self, y: np.ndarray, s: np.ndarray) -> np.ndarray:
+        y = _fe(y)
+        dy = self.to_device(y)
+        try:
+            self._chk(self.lib.h2hip_fr_scale_dev(self.handle, _vp(dy), _ptr(_fe(s)), len(y)))
+            return self.download(dy, y.shape)
+        finally:
+            self.free(dy)
+
     def fr_batch_invert(self, a: np.ndarray) -> np.ndarray:
         a = _fe(a)
         d = self.to_device(a)

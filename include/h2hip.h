@@ -136,6 +136,10 @@ int h2hip_fr_add_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, con
 int h2hip_fr_sub_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, const void *b_dev, size_t n);
 int h2hip_fr_mul_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, const void *b_dev, size_t n);
 int h2hip_fr_mul_add_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev, const void *b_dev, const void *c_dev, size_t n);
+/* polynomial linear combinations (Polynomial * F and += of scaled polynomials in the multiopen argument):
+ * y[i] += a * x[i]   and   y[i] *= s ; a, s: host pointers to one Montgomery Fr */
+int h2hip_fr_axpy_dev(h2hip_ctx *ctx, void *y_dev, const void *a, const void *x_dev, size_t n);
+int h2hip_fr_scale_dev(h2hip_ctx *ctx, void *y_dev, const void *s, size_t n);
 
 /* ---- K4: BatchInvert, in place, 0 -> 0 (ff::BatchInvert / batch_invert_assigned [UPSTREAM]; the deferred
  *      denominators come from reference halo2-base/src/gates/flex_gate/mod.rs:677-681,791-795) ---------- */

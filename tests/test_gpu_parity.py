@@ -125,6 +125,10 @@ def test_fr_batches(ctx):
     assert np.array_equal(ctx.fr_add(a, b), CO.fr_add(a, b))
     assert np.array_equal(ctx.fr_sub(a, b), CO.fr_sub(a, b))
     assert np.array_equal(ctx.fr_mul_add(a, b, c), CO.fr_add(CO.fr_mul(a, b), c))
+    sc = rand_fr(1, 9)
+    rep = np.repeat(sc, len(a), 0)
+    assert np.array_equal(ctx.fr_axpy(a, sc, b), CO.fr_add(a, CO.fr_mul(rep, b)))
+    assert np.array_equal(ctx.fr_scale(a, sc), CO.fr_mul(a, rep))
 
 
 @pytest.mark.parametrize("n", [700, 1 << 16])

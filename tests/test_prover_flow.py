@@ -141,6 +141,20 @@ def _prove_and_verify(ctx, k, seed=1):
         for j, v in enumerate(hi[i * n:(i + 1) * n]):
             comb[j] = (comb[j] + w * v) % R
     check_opening(C_hx, fr(comb), x, h_x)
+    # batched opening at x (the multiopen argument's linear combination by powers of v, built with fr_axpy on the GPU):
+    # P(X) = sum_j v^j p_j(X) opens to sum_j v^j p_j(x) under the commitment sum_j v^j C_j
+    v = rnd(1)[0]
+    batch = [("adv", C_adv, ev["a0"]), ("lk", C_lk, ev["lk"]), ("ap", C_ap, ev["ap"]), ("sp", C_sp, ev["sp"]), ("z", C_z, ev["z"])]
+    P = np.zeros((n, 4), dtype=np.uint64)
+    C_P, val_P, vj = None, 0, 1
+    for name, C, val in batch:
+        P = ctx.fr_axpy(P, fr([vj]), coeff[name])
+        C_P = O.g1_add(C_P, O.g1_mul(C, vj))
+        val_P = (val_P + vj * val) % R
+        vj = vj * v % R
+    assert HP.fr_int(HP.eval_polynomial(ctx, P, fr([x]))) == val_P
+    check_opening(C_P, P, x, val_P)
+
     # soundness smoke: openings of a tampered advice column (one cell flipped) no longer satisfy the identity
     bad = list(adv)
     bad[3] = (bad[3] + 1) % R
