@@ -481,25 +481,29 @@ __global__ __launch_bounds__(256) void msm_seg_quad_kernel(const XYZZ29 *__restr
     }
     if (qi == 0) quad_store(seg_out + blockIdx.x, q, acc);
 }
-// one workgroup (1024 lanes = 256 quads) per window: tree sum of its `per` partial results
-__global__ __launch_bounds__(1024) void msm_winsum_quad_kernel(const XYZZ29 *__restrict__ seg, XYZZ29 *__restrict__ win_out, uint32_t per) {
+// one workgroup (THREADS lanes = THREADS/4 quads) per window: tree sum of its `per` partial results.  The 256-lane
+// build (one wave per SIMD) is the one used next to a pipelined accumulation: a 1024-lane workgroup needs four waves
+// of 120 registers on every SIMD of a CU, i.e. an almost empty CU, and was measured waiting ~1 ms for one.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void msm_winsum_quad_kernel(const XYZZ29 *__restrict__ seg, XYZZ29 *__restrict__ win_out, uint32_t per) {
     H2_TAIL_PRIORITY();
-    __shared__ XYZZ29 sh[256];
+    constexpr uint32_t NQ = THREADS / 4;
+    __shared__ XYZZ29 sh[NQ];
     const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, qi = threadIdx.x >> 2, w = blockIdx.x;
     Fq29 acc = Fq29::zero();
-    const uint32_t rounds = (per + 255) / 256;
+    const uint32_t rounds = (per + NQ - 1) / NQ;
     for (uint32_t r = 0; r < rounds; ++r) {
-        uint32_t i = qi + 256 * r;
+        uint32_t i = qi + NQ * r;
         Fq29 v = i < per ? quad_load(seg + (size_t)w * per + i, q) : Fq29::zero();
         acc = rounds == 1 ? v : quad_xyzz_add(acc, v, lane);
     }
     quad_store(&sh[qi], q, acc);
     __syncthreads();
-    uint32_t d0 = 128;
+    uint32_t d0 = NQ / 2;
     while (d0 > 1 && d0 >= per) d0 >>= 1;   // skip levels whose partners are all identity
     if (per <= 1) d0 = 0;
     for (uint32_t d = d0; d >= 1; d >>= 1) {
-        Fq29 other = qi + d < 256 ? quad_load(&sh[qi + d], q) : Fq29::zero();
+        Fq29 other = qi + d < NQ ? quad_load(&sh[qi + d], q) : Fq29::zero();
         Fq29 sum = quad_xyzz_add(acc, other, lane);
         __syncthreads();
         if (qi < d) {
@@ -821,7 +825,11 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
         hipLaunchKernelGGL(msm_seg_quad_kernel, dim3((nseg + 63) / 64), dim3(256), 0, st, red_in, seg, B, L, nseg, lo_bits, tree);
         prof_end(ctx);
         prof_begin(ctx, "msm_winsum_kernel");
-        hipLaunchKernelGGL(msm_winsum_quad_kernel, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, tree ? per / 64 : per);
+        const uint32_t wper = tree ? per / 64 : per;
+        if (wper <= 128)
+            hipLaunchKernelGGL(msm_winsum_quad_kernel<256>, dim3(Wr), dim3(256), 0, st, (const XYZZ29 *)seg, win, wper);
+        else
+            hipLaunchKernelGGL(msm_winsum_quad_kernel<1024>, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, wper);
         prof_end(ctx);
     } else {
         prof_begin(ctx, "msm_seg_kernel");
