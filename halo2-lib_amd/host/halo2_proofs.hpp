@@ -92,6 +92,41 @@ inline Fr mul(const Fr &a, const Fr &b) {
     }
     return r;
 }
+inline Fr add(const Fr &a, const Fr &b) {
+    Fr r;
+    u128 c = 0;
+    for (int i = 0; i < 4; ++i) {
+        c += (u128)a.l[i] + b.l[i];
+        r.l[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    bool ge = true;   // a, b < r < 2^254: no carry out
+    for (int i = 3; i >= 0; --i)
+        if (r.l[i] != MOD[i]) {
+            ge = r.l[i] > MOD[i];
+            break;
+        }
+    if (ge) {
+        u128 br = 0;
+        for (int i = 0; i < 4; ++i) {
+            u128 d = (u128)r.l[i] - MOD[i] - br;
+            r.l[i] = (uint64_t)d;
+            br = (d >> 64) & 1;
+        }
+    }
+    return r;
+}
+inline Fr neg(const Fr &a) {
+    if ((a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0) return a;
+    Fr r;
+    u128 br = 0;
+    for (int i = 0; i < 4; ++i) {
+        u128 d = (u128)MOD[i] - a.l[i] - br;
+        r.l[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+    return r;
+}
 inline Fr from_u64(uint64_t v) { return mul(Fr{{v, 0, 0, 0}}, R2); }
 inline Fr from_canonical(const uint64_t v[4]) { return mul(Fr{{v[0], v[1], v[2], v[3]}}, R2); }
 inline Fr pow(const Fr &a, const uint64_t e[4]) {
@@ -147,7 +182,46 @@ class Bases {   // resident G1Affine bases (an SRS column)
     h2hip_bases *h_ = nullptr;
 };
 
+// a polynomial / column resident in HBM (what the `_dev` entry points take)
+class DeviceVec {
+  public:
+    DeviceVec(Backend &b, size_t n) : be_(&b), n_(n) { check(h2hip_malloc(b.raw(), sizeof(Fr) * (n ? n : 1), &p_)); }
+    DeviceVec(Backend &b, const std::vector<Fr> &v) : DeviceVec(b, v.size()) {
+        if (n_) check(h2hip_upload(b.raw(), p_, v.data(), sizeof(Fr) * n_));
+    }
+    DeviceVec(const DeviceVec &) = delete;
+    ~DeviceVec() { h2hip_free(be_->raw(), p_); }
+    void *ptr() const { return p_; }
+    size_t len() const { return n_; }
+    std::vector<Fr> to_host() const {
+        std::vector<Fr> out(n_);
+        if (n_) check(h2hip_download(be_->raw(), out.data(), p_, sizeof(Fr) * n_));
+        return out;
+    }
+
+  private:
+    Backend *be_;
+    void *p_ = nullptr;
+    size_t n_;
+};
+
 namespace arithmetic {
+// eval_polynomial(poly, point)
+inline Fr eval_polynomial(Backend &b, const std::vector<Fr> &poly, const Fr &point) {
+    DeviceVec d(b, poly);
+    Fr out;
+    check(h2hip_fr_eval_polynomial_dev(b.raw(), d.ptr(), poly.size(), &point, &out));
+    return out;
+}
+// kate_division(a, b): (a(X) - a(b)) / (X - b), len a.len() - 1
+inline std::vector<Fr> kate_division(Backend &b, const std::vector<Fr> &a, const Fr &point) {
+    if (a.empty()) throw Error(H2HIP_ERR_INVALID, "kate_division of an empty polynomial");
+    DeviceVec da(b, a), dq(b, a.size());
+    check(h2hip_fr_kate_division_dev(b.raw(), dq.ptr(), da.ptr(), a.size(), &point));
+    std::vector<Fr> q = dq.to_host();
+    q.resize(a.size() - 1);
+    return q;
+}
 // best_multiexp(coeffs, bases) -> C::Curve; panics (throws) like upstream's assert_eq!(coeffs.len(), bases.len())
 inline G1 best_multiexp(Backend &b, const std::vector<Fr> &coeffs, const Bases &bases) {
     if (coeffs.size() != bases.len()) throw Error(H2HIP_ERR_INVALID, "assertion failed: coeffs.len() == bases.len()");
@@ -197,6 +271,13 @@ class EvaluationDomain {
         check(h2hip_coeff_to_extended(be_->raw(), a.data(), k_, out.data(), extended_k_, &extended_omega_, &g_coset_));
         return out;
     }
+    // a[i] /= t(zeta * extended_omega^i), t(X) = X^n - 1 (the numerator of h(X) on the coset)
+    void divide_by_vanishing_poly(std::vector<Fr> &a) const {
+        expect(a.size() == extended_len());
+        DeviceVec d(*be_, a);
+        check(h2hip_divide_by_vanishing_poly_dev(be_->raw(), d.ptr(), extended_k_, k_, &extended_omega_, &g_coset_));
+        a = d.to_host();
+    }
     // in place, then truncated to n*(j-1) coefficients like upstream
     void extended_to_coeff(std::vector<Fr> &a) const {
         expect(a.size() == extended_len());
@@ -245,4 +326,21 @@ class ParamsKZG {
 };
 }  // namespace kzg
 }  // namespace poly
+
+namespace plonk {
+namespace lookup {
+// permute_expression_pair over the usable rows: (permuted_input, permuted_table); throws where upstream returns
+// Err(ConstraintSystemFailure) (an input value that the table does not contain)
+inline std::pair<std::vector<Fr>, std::vector<Fr>> permute_expression_pair(Backend &b, const std::vector<Fr> &input, const std::vector<Fr> &table,
+                                                                             size_t usable_rows) {
+    if (input.size() != table.size() || usable_rows > input.size()) throw Error(H2HIP_ERR_INVALID, "permute_expression_pair: length mismatch");
+    DeviceVec da(b, input), ds(b, table), dap(b, input.size()), dsp(b, input.size());
+    check(h2hip_lookup_permute_dev(b.raw(), da.ptr(), ds.ptr(), usable_rows, dap.ptr(), dsp.ptr()));
+    std::vector<Fr> ap = dap.to_host(), sp = dsp.to_host();
+    ap.resize(usable_rows);
+    sp.resize(usable_rows);
+    return {ap, sp};
+}
+}  // namespace lookup
+}  // namespace plonk
 }  // namespace halo2_proofs

@@ -57,6 +57,53 @@ int main(int argc, char **argv) {
         poly::kzg::ParamsKZG params = poly::kzg::ParamsKZG::setup(be, k, s, true);
         G1 c1 = params.commit_lagrange(vals), c2 = params.commit(coeffs);
         if (!jac_equal(be, c1, c2)) throw Error(-1, "commit_lagrange(values) != commit(coeffs)");
+        // eval_polynomial vs host Horner; kate_division: q(y)*(y - b) + f(b) == f(y)
+        Fr x = host_fr::from_u64(0xfeedfacecafeULL), y = host_fr::from_u64(0x1234567ULL);
+        Fr hx = Fr{{0, 0, 0, 0}}, hy = hx;
+        for (size_t i = coeffs.size(); i-- > 0;) {
+            hx = host_fr::add(host_fr::mul(hx, x), coeffs[i]);
+            hy = host_fr::add(host_fr::mul(hy, y), coeffs[i]);
+        }
+        if (!(arithmetic::eval_polynomial(be, coeffs, x) == hx)) throw Error(-1, "eval_polynomial");
+        std::vector<Fr> q = arithmetic::kate_division(be, coeffs, x);
+        Fr qy = arithmetic::eval_polynomial(be, q, y);
+        if (!(host_fr::add(host_fr::mul(qy, host_fr::add(y, host_fr::neg(x))), hx) == hy)) throw Error(-1, "kate_division");
+        // divide_by_vanishing_poly: (f * t) / t == f on the extended coset, t(x_i) = zeta^n * (w_ext^n)^i - 1 from the host
+        {
+            std::vector<Fr> e = dom.coeff_to_extended(coeffs), num(e.size());
+            uint64_t nexp[4] = {(uint64_t)1 << k, 0, 0, 0};
+            Fr zn = host_fr::pow(host_fr::from_canonical(host_fr::ZETA), nexp), step = host_fr::pow(dom.get_extended_omega(), nexp);
+            Fr xn = zn, minus_one = host_fr::neg(host_fr::R1);
+            for (size_t i = 0; i < e.size(); ++i) {
+                num[i] = host_fr::mul(e[i], host_fr::add(xn, minus_one));
+                xn = host_fr::mul(xn, step);
+            }
+            dom.divide_by_vanishing_poly(num);
+            if (!(num == e)) throw Error(-1, "divide_by_vanishing_poly");
+        }
+        // lookup permutation: inputs drawn from a small table
+        {
+            size_t rows = (size_t)1 << k, usable = rows - 6;
+            std::vector<Fr> table(rows), input(rows);
+            for (size_t i = 0; i < rows; ++i) table[i] = host_fr::from_u64(i < 64 ? i : 0);
+            for (size_t i = 0; i < rows; ++i) input[i] = host_fr::from_u64(sm(seed) % 64);
+            for (size_t i = usable; i < rows; ++i) table[i] = input[i] = host_fr::from_u64(sm(seed));   // blinding rows: ignored
+            auto perm = plonk::lookup::permute_expression_pair(be, input, table, usable);
+            if (perm.first.size() != usable || perm.second.size() != usable) throw Error(-1, "permute size");
+            if (!(perm.first[0] == perm.second[0])) throw Error(-1, "permute: first row");
+            for (size_t i = 1; i < usable; ++i) {
+                bool same_as_prev = perm.first[i] == perm.first[i - 1];
+                if (!same_as_prev && !(perm.first[i] == perm.second[i])) throw Error(-1, "permute: A'[i] != S'[i] at a run start");
+            }
+            bool threw2 = false;
+            try {
+                input[0] = host_fr::from_u64(1000);   // not in the table
+                plonk::lookup::permute_expression_pair(be, input, table, usable);
+            } catch (const Error &) {
+                threw2 = true;
+            }
+            if (!threw2) throw Error(-1, "permute: missing table value not reported");
+        }
         bool threw = false;
         try {
             std::vector<Fr> shorter(coeffs.begin(), coeffs.end() - 1);
