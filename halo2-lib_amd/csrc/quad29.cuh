@@ -13,6 +13,15 @@
 
 namespace h2 {
 
+// The quad-lane point operations are real functions (one shared copy per code object) on the GPU: the tail kernels
+// that use them are latency-bound, and keeping their instruction footprint small matters when they share a CU's
+// instruction cache with another MSM's accumulation kernel.
+#ifdef H2_HIPEMU
+#define H2_QUAD_FN __device__ __forceinline__
+#else
+#define H2_QUAD_FN __device__ __attribute__((noinline))
+#endif
+
 // Quad permutes are DPP moves (v_mov_b32_dpp quad_perm:[..], full-rate VALU, no LDS round trip).  PERM encodes the
 // source lane (within the quad) of lanes 0..3: p0 | p1<<2 | p2<<4 | p3<<6.
 constexpr int QP_BCAST0 = 0x00, QP_BCAST1 = 0x55, QP_BCAST2 = 0xAA, QP_BCAST3 = 0xFF;
@@ -55,7 +64,7 @@ __device__ __forceinline__ uint32_t f29_or_limbs(const Fq29 &v) {
 __device__ __forceinline__ bool quad_is_identity(const Fq29 &c, uint32_t lane) { return quad_perm_u32<QP_BCAST2>(f29_or_limbs(c), lane) == 0; }
 
 // 2*P for the quad's point (3 product levels)
-__device__ __forceinline__ Fq29 quad_xyzz_double(const Fq29 &a, uint32_t lane) {
+H2_QUAD_FN Fq29 quad_xyzz_double(Fq29 a, uint32_t lane) {
     const uint32_t q = lane & 3u;
     const bool a_id = quad_is_identity(a, lane);
     const Fq29 U = f29_add(a, a);   // lane 1: 2Y (lazy); other lanes: unused but within the limb bounds
@@ -76,7 +85,7 @@ __device__ __forceinline__ Fq29 quad_xyzz_double(const Fq29 &a, uint32_t lane) {
 }
 
 // P + Q for two quad-distributed points (4 product levels)
-__device__ __forceinline__ Fq29 quad_xyzz_add(const Fq29 &a, const Fq29 &b, uint32_t lane) {
+H2_QUAD_FN Fq29 quad_xyzz_add(Fq29 a, Fq29 b, uint32_t lane) {
     const uint32_t q = lane & 3u;
     const bool a_id = quad_is_identity(a, lane), b_id = quad_is_identity(b, lane);
     // L1: q0: U1 = X1*ZZ2 ; q1: U2 = X2*ZZ1 ; q2: S1 = Y1*ZZZ2 ; q3: S2 = Y2*ZZZ1
