@@ -22,6 +22,15 @@ def main():
         if len(name) > 90:
             name = name[:87] + "..."
         print(f"| {name} | {r[1]} | {r[2]/1e6:.3f} | {r[3]/1e3:.1f} | {r[4]/1e3:.1f} | {r[5]/1e3:.1f} | {100*r[2]/total:.1f} | {r[6]} | {r[7]} | {r[8]} | {r[9]} | {r[10]} |")
+    # the accumulation kernel runs at several problem sizes in one bench command (2^20 bench steps, 2^19 replay): split by grid
+    sub = cur.execute("select grid_x, count(*), avg(duration), min(duration), max(duration) from kernels where name like '%msm_accum%' "
+                      "group by grid_x order by grid_x desc").fetchall()
+    if sub:
+        print("\n# msm_accum_kernel by launch size (grid_x = lanes = sorted entries / K; 262144 lanes = the 2^20-point bench workload)")
+        print("| grid_x | calls | avg_us | min_us | max_us |")
+        print("|---|---|---|---|---|")
+        for r in sub:
+            print(f"| {r[0]} | {r[1]} | {r[2]/1e3:.1f} | {r[3]/1e3:.1f} | {r[4]/1e3:.1f} |")
     if "--pmc" in sys.argv:
         try:
             cols = [c[1] for c in cur.execute("pragma table_info('counters_collection')")]
