@@ -267,6 +267,10 @@ def main():
             except Exception as e:
                 out["ntt_2_22"] = {"error": repr(e)}
             try:
+                out["k8_witness_batches"] = k8_batches(ctx, torch, dev, modmul_peak_sat)
+            except Exception as e:
+                out["k8_witness_batches"] = {"error": repr(e)}
+            try:
                 out["create_proof_k19_replay"] = replay_ecdsa_k19(ctx, torch, dev)
             except Exception as e:   # the replay is an extra; never let it break the contract line
                 out["create_proof_k19_replay"] = {"error": repr(e)}
@@ -394,6 +398,38 @@ def ntt_config3(ctx, torch, dev, modmul_peak):
                          "unit": "GB/s", "frac": alg_bytes / (fwd_ms * 1e-3) / 8e12, "algorithmic_bytes_per_transform": alg_bytes},
             "roofline_int": {"achieved": alg_mul / (fwd_ms * 1e-3), "peak": modmul_peak, "unit": "modmul/s", "frac": alg_mul / (fwd_ms * 1e-3) / modmul_peak,
                              "note": "algorithmic products = (n/2)*log2(n)"}}
+
+
+def k8_batches(ctx, torch, dev, modmul_peak_sat):
+    """north_star's K8: witness-column Montgomery multiplications and Poseidon permutation batches through the same
+    kernel layer (halo2-base GateInstructions::mul, PoseidonState::permutation).  Synthetic operands and synthetic round
+    constants (the timing does not depend on their values; parity against the reference's KATs is in the tests)."""
+    n = 1 << 22
+    a = torch.from_numpy(synthetic_scalars(n, 31).view(np.int64)).to(dev)
+    b = torch.from_numpy(synthetic_scalars(n, 32).view(np.int64)).to(dev)
+    o = torch.empty_like(a)
+    mul = lambda: ctx._chk(ctx.lib.h2hip_fr_mul_batch_dev(ctx.handle, o.data_ptr(), a.data_ptr(), b.data_ptr(), n))
+    mul()
+    ctx.timer_start()
+    for _ in range(10):
+        mul()
+    mul_ms = ctx.timer_stop() / 10
+    t, r_f, r_p, m = 3, 8, 57, 1 << 18          # the reference's t = 3, rate 2 spec shape (hasher/tests/state.rs)
+    ctx.poseidon_set_spec(t, r_f, r_p, synthetic_scalars((r_f + r_p) * t, 33), synthetic_scalars(t * t, 34))
+    st = torch.from_numpy(synthetic_scalars(m * t, 35).view(np.int64)).to(dev)
+    inp = torch.from_numpy(synthetic_scalars(m * 2, 36).view(np.int64)).to(dev)
+    perm = lambda: ctx._chk(ctx.lib.h2hip_poseidon_permute_batch_dev(ctx.handle, st.data_ptr(), inp.data_ptr(), 2, m))
+    perm()
+    ctx.timer_start()
+    for _ in range(5):
+        perm()
+    pos_ms = ctx.timer_stop() / 5
+    # multiplications of one permutation: full rounds t S-boxes (3 mul each) + t*t MDS; partial rounds 1 S-box + t*t MDS (dense form)
+    muls = r_f * (3 * t + t * t) + r_p * (3 + t * t)
+    return {"fr_mul_batch": {"elements": n, "ms": mul_ms, "GB_per_s": 96.0 * n / (mul_ms * 1e-3) / 1e9, "hbm_frac": 96.0 * n / (mul_ms * 1e-3) / 8e12,
+                             "modmul_per_s": n / (mul_ms * 1e-3)},
+            "poseidon_t3_batch": {"permutations": m, "ms": pos_ms, "permutations_per_s": m / (pos_ms * 1e-3),
+                                  "modmul_per_s": muls * m / (pos_ms * 1e-3), "frac_of_saturated_multiplier_peak": muls * m / (pos_ms * 1e-3) / modmul_peak_sat}}
 
 
 def cpu_baseline(bases_h, scal_h, adds_per_msm):
