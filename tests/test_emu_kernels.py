@@ -308,3 +308,9 @@ def _lookup_permute_checks(ctx, sizes):
 
 def test_lookup_permute_expression_pair(ctx):
     _lookup_permute_checks(ctx, [(1, 1), (5, 2), (300, 5), (1024, 8), (3001, 9)])
+
+
+def test_emulated_kernels_match_committed_golden_fixtures(ctx):
+    from tests.golden_checks import check_backend_against_golden
+
+    check_backend_against_golden(ctx)

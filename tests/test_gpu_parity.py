@@ -230,3 +230,9 @@ def test_lookup_permute_expression_pair(ctx):
     from tests.test_emu_kernels import _lookup_permute_checks
 
     _lookup_permute_checks(ctx, [(5, 2), (3001, 9), ((1 << 17) - 20, 15)])
+
+
+def test_gpu_matches_committed_golden_fixtures(ctx):
+    from tests.golden_checks import check_backend_against_golden
+
+    check_backend_against_golden(ctx)

@@ -161,3 +161,19 @@ def test_poseidon_pinned_by_reference_golden_vectors():
         6644334865470350789317807668685953492649391266180911382577082600917830417726,
         3372108894677221197912083238087960099443657816445944159266857514496320565191,
     ]
+
+
+def test_c_oracle_and_python_oracle_match_committed_golden_fixtures():
+    from tests.golden_checks import check_c_oracle_against_golden, load
+
+    check_c_oracle_against_golden()
+    # the fixtures are reproducible from the pure-Python oracle (tests/golden/make_golden.py)
+    g = load("hotpath_small_cases.json")
+    k, a = g["ntt"]["k"], [int(v, 16) for v in g["ntt"]["input"]]
+    assert [hex(v) for v in O.best_fft(list(a), int(g["ntt"]["omega"], 16), k)] == g["ntt"]["best_fft"]
+    kats = load("poseidon_reference_kats.json")
+    from oracle.poseidon import Spec
+
+    for key in ("t3", "t5"):
+        kat = kats[key]
+        assert Spec(kat["t"], kat["r_f"], kat["r_p"]).absorb_and_permute(kat["state_in"], kat["inputs"]) == [int(v) for v in kat["state_out"]]
