@@ -393,7 +393,7 @@ constexpr int PERM_MAX_COLS = 8;
 struct PermArgs {
     const Fr *z, *z_prev, *l0, *l_last, *l_blind;
     const Fr *cols[PERM_MAX_COLS], *sigmas[PERM_MAX_COLS];
-    uint32_t ncols, is_first, is_last, last_rot_points;   // last_rot_points = last_rotation * step (already reduced mod ne)
+    uint32_t ncols, terms, last_rot_points;   // terms: H2HIP_PERM_* mask; last_rot_points = last_rotation * step (already reduced mod ne)
     Fr beta, gamma, delta, y;
     Fr x0_delta;   // beta * zeta * delta^(first column index of this set): the X-term coefficient at extended point 0
     Fr ext_omega;
@@ -411,18 +411,20 @@ __global__ __launch_bounds__(256) void quotient_permutation_kernel(Fr *__restric
         Fr z = g.z[i], l0 = g.l0[i], ll = g.l_last[i];
         Fr active = fe_sub(one, fe_add(ll, g.l_blind[i]));
         Fr v = acc[i];
-        if (g.is_first) v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(one, z)));
-        if (g.is_last) v = fe_add(fe_mul(v, g.y), fe_mul(ll, fe_sub(fe_sqr(z), z)));
-        if (g.z_prev) v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(z, g.z_prev[(i + g.last_rot_points) & mask])));
-        Fr left = g.z[inext], right = z;
-        Fr xterm = xbase;
-        for (uint32_t j = 0; j < g.ncols; ++j) {
-            Fr p = g.cols[j][i];
-            left = fe_mul(left, fe_add(fe_add(p, fe_mul(g.beta, g.sigmas[j][i])), g.gamma));
-            right = fe_mul(right, fe_add(fe_add(p, xterm), g.gamma));
-            xterm = fe_mul(xterm, g.delta);
+        if (g.terms & H2HIP_PERM_FIRST) v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(one, z)));
+        if (g.terms & H2HIP_PERM_LAST) v = fe_add(fe_mul(v, g.y), fe_mul(ll, fe_sub(fe_sqr(z), z)));
+        if (g.terms & H2HIP_PERM_CHAIN) v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(z, g.z_prev[(i + g.last_rot_points) & mask])));
+        if (g.terms & H2HIP_PERM_PRODUCT) {
+            Fr left = g.z[inext], right = z;
+            Fr xterm = xbase;
+            for (uint32_t j = 0; j < g.ncols; ++j) {
+                Fr p = g.cols[j][i];
+                left = fe_mul(left, fe_add(fe_add(p, fe_mul(g.beta, g.sigmas[j][i])), g.gamma));
+                right = fe_mul(right, fe_add(fe_add(p, xterm), g.gamma));
+                xterm = fe_mul(xterm, g.delta);
+            }
+            v = fe_add(fe_mul(v, g.y), fe_mul(active, fe_sub(left, right)));
         }
-        v = fe_add(fe_mul(v, g.y), fe_mul(active, fe_sub(left, right)));
         acc[i] = v;
     }
 }
@@ -692,10 +694,13 @@ int h2hip_quotient_lookup_dev(h2hip_ctx *ctx, void *acc, const void *z, const vo
 }
 int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z, const void *z_prev, const void *const *cols,
                                        const void *const *sigmas, uint32_t ncols, uint32_t first_col_index, const void *l0, const void *l_last,
-                                       const void *l_blind, uint32_t ext_k, uint32_t k, int is_first, int is_last, int32_t last_rotation,
+                                       const void *l_blind, uint32_t ext_k, uint32_t k, uint32_t terms, int32_t last_rotation,
                                        const void *beta, const void *gamma, const void *delta, const void *zeta, const void *ext_omega, const void *y) {
-    H2_REQUIRE(ctx && acc && z && cols && sigmas && l0 && l_last && l_blind && beta && gamma && delta && zeta && ext_omega && y, "NULL argument");
-    H2_REQUIRE(ncols >= 1 && ncols <= PERM_MAX_COLS, "1..8 columns per permutation set");
+    H2_REQUIRE(ctx && acc && z && l0 && l_last && l_blind && beta && gamma && delta && zeta && ext_omega && y, "NULL argument");
+    H2_REQUIRE(terms != 0 && (terms & ~15u) == 0, "terms must be a non-empty mask of H2HIP_PERM_*");
+    H2_REQUIRE(!(terms & H2HIP_PERM_CHAIN) || z_prev, "H2HIP_PERM_CHAIN needs z_prev_dev");
+    if (!(terms & H2HIP_PERM_PRODUCT)) ncols = 0;
+    H2_REQUIRE(!(terms & H2HIP_PERM_PRODUCT) || (cols && sigmas && ncols >= 1 && ncols <= PERM_MAX_COLS), "1..8 columns per permutation set");
     H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
     PermArgs g;
     memset(&g, 0, sizeof(g));
@@ -705,7 +710,7 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z,
         g.cols[j] = (const Fr *)cols[j];
         g.sigmas[j] = (const Fr *)sigmas[j];
     }
-    g.ncols = ncols; g.is_first = is_first ? 1 : 0; g.is_last = is_last ? 1 : 0;
+    g.ncols = ncols; g.terms = terms;
     const size_t ne = (size_t)1 << ext_k;
     const uint32_t step = 1u << (ext_k - k);
     const int64_t n = (int64_t)1 << k;

@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 POINT_JACOBIAN = 0
 POINT_AFFINE = 1
+PERM_FIRST, PERM_LAST, PERM_CHAIN, PERM_PRODUCT = 1, 2, 4, 8   # H2HIP_PERM_* term mask of quotient_permutation_set
 BASES_PLAIN = 0
 BASES_PRECOMPUTE = 1
 
@@ -66,7 +67,7 @@ _PROTOS = {
     "h2hip_fr_kate_division_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_quotient_flex_gate_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),
-    "h2hip_quotient_permutation_set_dev": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp, _vp, _u32, _u32, _int, _int,
+    "h2hip_quotient_permutation_set_dev": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp, _vp, _u32, _u32, _u32,
                                                   C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2hip_fr_axpy_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "h2hip_fr_scale_dev": (_int, [_vp, _vp, _vp, _sz]),
@@ -475,7 +476,7 @@ class Context:
             for p in d:
                 self.free(p)
 
-    def quotient_permutation_set(self, acc, z, z_prev, cols, sigmas, first_col_index, l0, l_last, l_blind, ext_k, k, is_first, is_last,
+    def quotient_permutation_set(self, acc, z, z_prev, cols, sigmas, first_col_index, l0, l_last, l_blind, ext_k, k, terms,
                                  last_rotation, beta, gamma, delta, zeta, ext_omega, y) -> np.ndarray:
         d_acc, d_z = self.to_device(_fe(acc)), self.to_device(_fe(z))
         d_zp = self.to_device(_fe(z_prev)) if z_prev is not None else None
@@ -487,7 +488,7 @@ class Context:
         try:
             self._chk(self.lib.h2hip_quotient_permutation_set_dev(
                 self.handle, _vp(d_acc), _vp(d_z), _vp(d_zp) if d_zp else None, pc, ps, n, first_col_index, _vp(d_l[0]), _vp(d_l[1]), _vp(d_l[2]),
-                ext_k, k, int(is_first), int(is_last), int(last_rotation), _ptr(_fe(beta)), _ptr(_fe(gamma)), _ptr(_fe(delta)), _ptr(_fe(zeta)),
+                ext_k, k, int(terms), int(last_rotation), _ptr(_fe(beta)), _ptr(_fe(gamma)), _ptr(_fe(delta)), _ptr(_fe(zeta)),
                 _ptr(_fe(ext_omega)), _ptr(_fe(y))))
             return self.download(d_acc, _fe(acc).shape)
         finally:

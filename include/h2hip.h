@@ -171,12 +171,22 @@ int h2hip_divide_by_vanishing_poly_dev(h2hip_ctx *ctx, void *a_dev, uint32_t ext
 int h2hip_quotient_lookup_dev(h2hip_ctx *ctx, void *acc_dev, const void *z_dev, const void *a_dev, const void *s_dev, const void *a_perm_dev,
                               const void *s_perm_dev, const void *l0_dev, const void *l_last_dev, const void *l_blind_dev, uint32_t ext_k,
                               uint32_t k, const void *beta, const void *gamma, const void *y);
-/* One permutation set: [first] l0*(1-z); [last] l_last*(z^2-z); [z_prev != NULL] l0*(z - z_prev(w^last_rotation X));
- * active*(z(wX)*prod_j(p_j + beta*sigma_j + gamma) - z*prod_j(p_j + delta^(first_col_index+j)*beta*X + gamma)), X = zeta*ext_omega^i.
- * cols / sigmas: host arrays of ncols (<= 8) device pointers. */
+/* Terms of ONE permutation set, selected by `terms` and folded into acc by y in this order:
+ *   H2HIP_PERM_FIRST    l0*(1 - z)                                   (upstream: first set only)
+ *   H2HIP_PERM_LAST     l_last*(z^2 - z)                             (last set only)
+ *   H2HIP_PERM_CHAIN    l0*(z - z_prev(w^last_rotation X))           (every set but the first; needs z_prev_dev)
+ *   H2HIP_PERM_PRODUCT  active*(z(wX)*prod_j(p_j + beta*sigma_j + gamma) - z*prod_j(p_j + delta^(first_col_index+j)*beta*X + gamma))
+ * with X = zeta*ext_omega^i, active = 1 - (l_last + l_blind).  Upstream's evaluate_h folds FIRST (set 0), LAST (last set),
+ * CHAIN (sets 1..) and then PRODUCT (all sets) as four separate loops over the sets: issue one call per (loop, set) to
+ * reproduce that order with several sets; a single-set argument is one call with FIRST|LAST|PRODUCT.
+ * cols / sigmas: host arrays of ncols (<= 8) device pointers (only read for PRODUCT). */
+#define H2HIP_PERM_FIRST 1u
+#define H2HIP_PERM_LAST 2u
+#define H2HIP_PERM_CHAIN 4u
+#define H2HIP_PERM_PRODUCT 8u
 int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc_dev, const void *z_dev, const void *z_prev_dev, const void *const *cols_dev,
                                        const void *const *sigmas_dev, uint32_t ncols, uint32_t first_col_index, const void *l0_dev,
-                                       const void *l_last_dev, const void *l_blind_dev, uint32_t ext_k, uint32_t k, int is_first, int is_last,
+                                       const void *l_last_dev, const void *l_blind_dev, uint32_t ext_k, uint32_t k, uint32_t terms,
                                        int32_t last_rotation, const void *beta, const void *gamma, const void *delta, const void *zeta,
                                        const void *ext_omega, const void *y);
 

@@ -438,24 +438,26 @@ def quotient_lookup_terms(acc, z, a, s, ap, sp, l0, l_last, l_blind, step, beta,
     return out
 
 
-def quotient_permutation_set_terms(acc, z, z_prev, cols, sigmas, first_col_index, l0, l_last, l_blind, step, is_first, is_last,
+def quotient_permutation_set_terms(acc, z, z_prev, cols, sigmas, first_col_index, l0, l_last, l_blind, step, terms,
                                    last_rotation, beta, gamma, delta, zeta, ext_omega, y):
+    """terms: mask 1 = first-set term, 2 = last-set term, 4 = chaining term, 8 = product term (include/h2hip.h H2HIP_PERM_*)"""
     ne, out = len(acc), []
     for i in range(ne):
         active = (1 - (l_last[i] + l_blind[i])) % R_MOD
         v = acc[i]
-        if is_first:
+        if terms & 1:
             v = (v * y + l0[i] * (1 - z[i])) % R_MOD
-        if is_last:
+        if terms & 2:
             v = (v * y + l_last[i] * (z[i] * z[i] - z[i])) % R_MOD
-        if z_prev is not None:
+        if terms & 4:
             v = (v * y + l0[i] * (z[i] - z_prev[(i + last_rotation * step) % ne])) % R_MOD
-        x = zeta * pow(ext_omega, i, R_MOD) % R_MOD
-        left, right = z[(i + step) % ne], z[i]
-        for j, (p, sg) in enumerate(zip(cols, sigmas)):
-            left = left * ((p[i] + beta * sg[i] + gamma) % R_MOD) % R_MOD
-            right = right * ((p[i] + pow(delta, first_col_index + j, R_MOD) * beta % R_MOD * x + gamma) % R_MOD) % R_MOD
-        v = (v * y + active * (left - right)) % R_MOD
+        if terms & 8:
+            x = zeta * pow(ext_omega, i, R_MOD) % R_MOD
+            left, right = z[(i + step) % ne], z[i]
+            for j, (p, sg) in enumerate(zip(cols, sigmas)):
+                left = left * ((p[i] + beta * sg[i] + gamma) % R_MOD) % R_MOD
+                right = right * ((p[i] + pow(delta, first_col_index + j, R_MOD) * beta % R_MOD * x + gamma) % R_MOD) % R_MOD
+            v = (v * y + active * (left - right)) % R_MOD
         out.append(v)
     return out
 

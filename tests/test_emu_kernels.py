@@ -249,11 +249,12 @@ def _quotient_identity_checks(ctx, k, ek):
     cols, sigmas = [rs(20 + j) for j in range(3)], [rs(30 + j) for j in range(3)]
     zp = rs(40)
     we = O.omega_for(ek)
-    for (first, last, prev, j0, rot) in ((1, 0, None, 0, 0), (0, 1, zp, 3, -7), (1, 1, None, 0, 0)):
+    # single-set call, a last set with the chaining term, and the separate loops upstream uses with several sets
+    for (terms, prev, j0, rot) in ((1 | 8, None, 0, 0), (2 | 4 | 8, zp, 3, -7), (1 | 2 | 8, None, 0, 0), (1, None, 0, 0), (2, None, 0, 0), (4, zp, 0, -7), (8, None, 3, 0)):
         got = ctx.quotient_permutation_set(fr(acc), fr(z), None if prev is None else fr(prev), [fr(c) for c in cols], [fr(c) for c in sigmas], j0,
-                                           fr(l0), fr(ll), fr(lb), ek, k, first, last, rot, fr([beta]), fr([gamma]), fr([O.DELTA]), fr([O.ZETA]),
+                                           fr(l0), fr(ll), fr(lb), ek, k, terms, rot, fr([beta]), fr([gamma]), fr([O.DELTA]), fr([O.ZETA]),
                                            fr([we]), fr([y]))
-        want = O.quotient_permutation_set_terms(acc, z, prev, cols, sigmas, j0, l0, ll, lb, step, first, last, rot % (1 << k), beta, gamma,
+        want = O.quotient_permutation_set_terms(acc, z, prev, cols, sigmas, j0, l0, ll, lb, step, terms, rot % (1 << k), beta, gamma,
                                                 O.DELTA, O.ZETA, we, y)
         assert O.limbs_to_ints(got, R) == want
 

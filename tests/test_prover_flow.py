@@ -1,10 +1,12 @@
 """End-to-end composition of the hot-path kernels: a small PLONK/KZG prover for halo2-base's circuit shape — one advice
-column with the single gate q*(a + b*c - d) (halo2-base/src/gates/flex_gate/mod.rs:80-91) plus one RangeChip-style
-lookup column (halo2-base/src/gates/range/mod.rs:131-150) — following create_proof's steps with every
+column with the single gate q*(a + b*c - d) (halo2-base/src/gates/flex_gate/mod.rs:80-91), one RangeChip-style lookup
+column (halo2-base/src/gates/range/mod.rs:131-150) and a permutation argument over four columns in two sets (advice,
+lookup advice, constants, instance: the equality-enabled columns of halo2-base's BaseConfig) — following create_proof's steps with every
 data-parallel step going through the C ABI, and a verifier written with the oracle's big-int arithmetic only:
 
   * quotient identity   N(x) == h(x) * (x^n - 1)   at a random x, N rebuilt from the openings exactly as a halo2
-    verifier does (gate term + the lookup argument's five identities folded by y);
+    verifier does (gate term, the permutation argument's terms in evaluate_h's loop order, the lookup argument's five
+    identities, folded by y);
   * KZG openings        C - v*G == (s - x) * W     in G1 (the toxic waste s is known to the test, so no pairing).
 
 Config #0 of BASELINE.json (`cargo bench --bench mul`, k = 9) is the GPU case; the emulated build runs k = 5."""
@@ -42,6 +44,9 @@ def _prove_and_verify(ctx, k, seed=1):
         a, b, c = vals[3 * j: 3 * j + 3]
         adv[4 * j: 4 * j + 4] = [a, b, c, (a + b * c) % R]
         q[4 * j] = 1
+    for j in (1, 2):                              # the first three gates share their `a` input (a 3-cycle of copies)
+        adv[4 * j] = adv[0]
+        adv[4 * j + 3] = (adv[4 * j] + adv[4 * j + 1] * adv[4 * j + 2]) % R
     adv[u:] = rnd(n - u)
     # ---- lookup column: values of a range table 0..2^t padded with zeros (halo2-base's table layout)
     t = k - 1
@@ -54,7 +59,31 @@ def _prove_and_verify(ctx, k, seed=1):
     l_last[u] = 1
     l_blind = [0] * u + [0] + [1] * (n - u - 1)
 
+    # ---- copy constraints over the columns (adv, lk, cst, inst): gate outputs exposed in a constants column, lookup cells
+    #      tied to an instance column, and the 3-cycle above.  sigma maps (column, row) -> (column, row).
+    ncopy = min(8, u // 4)
+    cst = [adv[4 * j + 3] if j < ncopy else 0 for j in range(n)]
+    inst = [lk[r] if r < ncopy else 0 for r in range(n)]
+    perm_cols = [adv, lk, cst, inst]
+    sigma = {(c, r): (c, r) for c in range(4) for r in range(n)}
+
+    def tie(cells):   # one cycle through the listed cells
+        for a_, b_ in zip(cells, cells[1:] + cells[:1]):
+            sigma[a_] = b_
+
+    for j in range(ncopy):
+        tie([(0, 4 * j + 3), (2, j)])
+        tie([(1, j), (3, j)])
+    tie([(0, 0), (0, 4), (0, 8)])
+    for (c, r), (c2, r2) in sigma.items():
+        assert perm_cols[c][r] == perm_cols[c2][r2] and (r < u) == (r2 < u)
+    delta = O.DELTA
+    sig_vals = [[pow(delta, sigma[(c, r)][0], R) * pow(omega, sigma[(c, r)][1], R) % R for r in range(n)] for c in range(4)]
+    id_vals = [[pow(delta, c, R) * pow(omega, r, R) % R for r in range(n)] for c in range(4)]
+    perm_sets = [[0, 1, 2], [3]]                  # chunk length = degree - 2 = 3 columns per grand product
+
     A, Q_, LK, S = fr(adv), fr(q), fr(lk), fr(table)
+    PC, SG = [fr(c) for c in perm_cols], [fr(c) for c in sig_vals]
     # ---- step 1: advice commitments
     commit = lambda vals_: jac_to_affine_ints(params.commit_lagrange(vals_, H.POINT_JACOBIAN))
     C_adv, C_lk = commit(A), commit(LK)
@@ -74,14 +103,47 @@ def _prove_and_verify(ctx, k, seed=1):
     assert _ints(z[:1]) == [1] and _ints(z[u:u + 1]) == [1], "lookup product must close"
     Z = np.concatenate([z, fr(rnd(n - u - 1))])
     C_z = commit(Z)
+    # ---- permutation grand products, one per column set, chained through the last usable row
+    Bu = np.repeat(fr([beta]), u, 0)
+    ZP, C_zp, carry = [], [], fr([1])
+    for cset in perm_sets:
+        num = den = None
+        for c in cset:
+            t_id = ctx.fr_add(ctx.fr_add(PC[c][:u], ctx.fr_mul(Bu, fr(id_vals[c][:u]))), Gv)
+            t_sg = ctx.fr_add(ctx.fr_add(PC[c][:u], ctx.fr_mul(Bu, SG[c][:u])), Gv)
+            num = t_id if num is None else ctx.fr_mul(num, t_id)
+            den = t_sg if den is None else ctx.fr_mul(den, t_sg)
+        zp = ctx.fr_scale(ctx.fr_grand_product(num, den), carry)     # starts where the previous set ended
+        carry = zp[u:u + 1]
+        ZP.append(np.concatenate([zp, fr(rnd(n - u - 1))]))
+        C_zp.append(commit(ZP[-1]))
+    assert _ints(carry) == [1], "permutation product must close"
     # ---- step 5: quotient
     y = rnd(1)[0]
     Y = fr([y])
-    cols = {"adv": A, "q": Q_, "lk": LK, "s": S, "ap": AP, "sp": SP, "z": Z, "l0": fr(l0), "l_last": fr(l_last), "l_blind": fr(l_blind)}
+    cols = {"adv": A, "q": Q_, "lk": LK, "s": S, "ap": AP, "sp": SP, "z": Z, "l0": fr(l0), "l_last": fr(l_last), "l_blind": fr(l_blind),
+            "cst": PC[2], "inst": PC[3], "zp0": ZP[0], "zp1": ZP[1], "sg0": SG[0], "sg1": SG[1], "sg2": SG[2], "sg3": SG[3]}
     coeff = {name: dom.lagrange_to_coeff(v) for name, v in cols.items()}
     ext = {name: dom.coeff_to_extended(c) for name, c in coeff.items()}
     acc = np.zeros((1 << ek, 4), dtype=np.uint64)
     acc = ctx.quotient_flex_gate(acc, ext["q"], ext["adv"], ek, k, Y)
+    # permutation argument in evaluate_h's order: first-set term, last-set term, chaining terms, then every set's product
+    pcol = ["adv", "lk", "cst", "inst"]
+    last_rot = -(BLINDING_FACTORS + 1)
+    ext_w = fr([HP.fr_int(dom.extended_omega)])
+
+    def perm_terms(acc_, j, terms):
+        cset = perm_sets[j]
+        return ctx.quotient_permutation_set(acc_, ext["zp%d" % j], ext["zp%d" % (j - 1)] if j else None, [ext[pcol[c]] for c in cset],
+                                            [ext["sg%d" % c] for c in cset], cset[0], ext["l0"], ext["l_last"], ext["l_blind"], ek, k, terms,
+                                            last_rot, fr([beta]), fr([gamma]), fr([delta]), fr([O.ZETA]), ext_w, Y)
+
+    acc = perm_terms(acc, 0, H.h2hip.PERM_FIRST)
+    acc = perm_terms(acc, len(perm_sets) - 1, H.h2hip.PERM_LAST)
+    for j in range(1, len(perm_sets)):
+        acc = perm_terms(acc, j, H.h2hip.PERM_CHAIN)
+    for j in range(len(perm_sets)):
+        acc = perm_terms(acc, j, H.h2hip.PERM_PRODUCT)
     acc = ctx.quotient_lookup(acc, ext["z"], ext["lk"], ext["s"], ext["ap"], ext["sp"], ext["l0"], ext["l_last"], ext["l_blind"], ek, k,
                               fr([beta]), fr([gamma]), Y)
     acc = dom.divide_by_vanishing_poly(acc)
@@ -98,6 +160,8 @@ def _prove_and_verify(ctx, k, seed=1):
         "a0": at("adv"), "a1": at("adv", 1), "a2": at("adv", 2), "a3": at("adv", 3), "q": at("q"),
         "lk": at("lk"), "s": at("s"), "ap": at("ap"), "ap_prev": at("ap", -1), "sp": at("sp"),
         "z": at("z"), "z_next": at("z", 1), "l0": at("l0"), "l_last": at("l_last"), "l_blind": at("l_blind"),
+        "cst": at("cst"), "inst": at("inst"), "zp0": at("zp0"), "zp0_next": at("zp0", 1), "zp0_last": at("zp0", last_rot),
+        "zp1": at("zp1"), "zp1_next": at("zp1", 1), "sg": [at("sg%d" % c) for c in range(4)],
     }
     h_x = 0
     for i, p in enumerate(pieces):
@@ -105,8 +169,22 @@ def _prove_and_verify(ctx, k, seed=1):
 
     # ================= verifier (oracle big-int arithmetic only) =================
     active = (1 - ev["l_last"] - ev["l_blind"]) % R
+    pv = [ev["a0"], ev["lk"], ev["cst"], ev["inst"]]
+
+    def perm_product(j):
+        left, right = ev["zp%d_next" % j], ev["zp%d" % j]
+        for c in perm_sets[j]:
+            left = left * (pv[c] + beta * ev["sg"][c] + gamma) % R
+            right = right * (pv[c] + pow(delta, c, R) * beta % R * x + gamma) % R
+        return active * (left - right)
+
     terms = [
         ev["q"] * (ev["a0"] + ev["a1"] * ev["a2"] - ev["a3"]),
+        ev["l0"] * (1 - ev["zp0"]),
+        ev["l_last"] * (ev["zp1"] * ev["zp1"] - ev["zp1"]),
+        ev["l0"] * (ev["zp1"] - ev["zp0_last"]),
+        perm_product(0),
+        perm_product(1),
         ev["l0"] * (1 - ev["z"]),
         ev["l_last"] * (ev["z"] * ev["z"] - ev["z"]),
         active * (ev["z_next"] * (ev["ap"] + beta) * (ev["sp"] + gamma) - ev["z"] * (ev["lk"] + beta) * (ev["s"] + gamma)),
@@ -131,6 +209,8 @@ def _prove_and_verify(ctx, k, seed=1):
     check_opening(C_ap, "ap", x * pow(omega, n - 1, R) % R, ev["ap_prev"])
     check_opening(C_sp, "sp", x, ev["sp"])
     check_opening(C_z, "z", x * omega % R, ev["z_next"])
+    check_opening(C_zp[0], "zp0", x * pow(omega, last_rot % n, R) % R, ev["zp0_last"])
+    check_opening(C_zp[1], "zp1", x * omega % R, ev["zp1_next"])
     # h(X) = sum_i X^(n i) h_i(X): its commitment is the same combination of the piece commitments
     C_hx = None
     for i, C in enumerate(C_h):
