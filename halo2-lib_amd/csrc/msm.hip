@@ -617,12 +617,17 @@ __global__ __launch_bounds__(256) void bases_to_29_kernel(const G1Affine *__rest
     out[i] = r;
 }
 
-static uint32_t pick_window(size_t n) {
+// Window size by a cost model in field multiplications.  Plain bases: every window has its own bucket set, reduced at
+// ~28 multiplications per bucket.  Precomputed tables: ONE bucket set, but its reduction is a chain of dependent
+// additions whose latency is worth ~150 multiplications of the (parallel) accumulation per bucket — fitted to the
+// measured optimum c = 13/14 at 2^16, 15/16 at 2^18, 16 at 2^19 and above (tools/c_sweep.sh).
+static uint32_t pick_window(size_t n, bool precomp = false) {
     uint32_t best = 4;
     double best_cost = 1e300;
     for (uint32_t c = 4; c <= 16; ++c) {
         double W = (double)((255 + c - 1) / c);
-        double cost = W * (10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + 400.0 * c);
+        double cost = precomp ? W * 10.0 * (double)n + 150.0 * (double)(1u << (c - 1))
+                              : W * (10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + 400.0 * c);
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
@@ -637,7 +642,7 @@ int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *b, bool precompute) {
     const uint32_t n = (uint32_t)b->n;
     uint32_t c = 0, W = 1;
     if (precompute && n) {
-        c = ctx->msm_window_bits ? (uint32_t)ctx->msm_window_bits : pick_window(b->n);
+        c = ctx->msm_window_bits ? (uint32_t)ctx->msm_window_bits : pick_window(b->n, true);
         H2_REQUIRE(c >= 2 && c <= 16, "window bits out of range for precomputed bases");
         W = (255 + c - 1) / c;
         H2_REQUIRE((uint64_t)b->n * W < (1ull << 31), "precomputed table too large for 31-bit indices");
