@@ -218,6 +218,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_quad_tails")) return &ctx->msm_quad_tails;
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
     if (!strcmp(name, "msm_sort_threads")) return &ctx->msm_sort_threads;
+    if (!strcmp(name, "msm_fuse_cols")) return &ctx->msm_fuse_cols;
     return nullptr;
 }
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
@@ -227,6 +228,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_window_bits) H2_REQUIRE(value == 0 || (value >= 2 && value <= 23), "msm_window_bits must be 0 or 2..23");
     if (p == &ctx->msm_chunk) H2_REQUIRE(value == 0 || (value >= 2 && value <= 4096), "msm_chunk must be 0 (auto) or 2..4096");
     if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
+    if (p == &ctx->msm_fuse_cols) H2_REQUIRE(value >= 0 && value <= (int)MSM_MAX_COLS, "msm_fuse_cols must be 0 (auto) or 1..8");
     if (p == &ctx->msm_sort_threads) H2_REQUIRE(value == 256 || value == 512 || value == 1024, "msm_sort_threads must be 256, 512 or 1024");
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
     if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 1 && value <= 4, "msm_lanes must be 1..4");
@@ -414,17 +416,29 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH, psz * count, (void **)&results));
     H2_HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));   // inputs produced on the caller's stream are ready after this
     for (int l = 0; l < NL; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->fork_ev, 0));
-    for (size_t j = 0; j < count; ++j) {
-        h2hip_ctx *c = ctx->lane[j % NL];
-        H2_REQUIRE(n == 0 || scalars_dev[j], "NULL scalar column");
+    // Precomputed bases: columns are fused into groups that go through the pipeline as ONE multi-column MSM (the
+    // latency-bound bucket reduction then runs once per group); the groups are dealt to the lanes.
+    // Measured (tools/fuse_sweep*.sh): fusing pays up to 2^17 points (-15 % per MSM: the reduction dominates small MSMs),
+    // beyond that the 4x larger offset / histogram arrays fall out of the XCD's L2 and the lane pipeline is faster.
+    size_t fuse = bases->tables > 1 ? (size_t)ctx->msm_fuse_cols : 1;
+    if (bases->tables > 1 && ctx->msm_fuse_cols == 0) fuse = n <= ((size_t)1 << 17) ? 4 : 1;
+    if (fuse < 1) fuse = 1;
+    if (fuse > MSM_MAX_COLS) fuse = MSM_MAX_COLS;
+    const size_t ngroups = (count + fuse - 1) / fuse;
+    for (size_t g = 0, j0 = 0; g < ngroups; ++g) {
+        const size_t gsize = (count - j0 + (ngroups - g) - 1) / (ngroups - g);   // balanced group sizes
+        h2hip_ctx *c = ctx->lane[g % NL];
+        for (size_t j = j0; j < j0 + gsize; ++j) H2_REQUIRE(n == 0 || scalars_dev[j], "NULL scalar column");
         char *outbuf = nullptr;
-        H2_CHK(ws_reserve(c, h2hip_ctx::WS_OUT, 1024, (void **)&outbuf));
-        H2_CHK(msm_run(c, bases, (const Fr *)scalars_dev[j], n, (XYZZ *)outbuf));
+        H2_CHK(ws_reserve(c, h2hip_ctx::WS_OUT, 2048, (void **)&outbuf));
+        H2_CHK(msm_run_cols(c, bases, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf));
         prof_begin(c, "point_finish_kernel");
-        hipLaunchKernelGGL(point_finish_slot_kernel, dim3(1), dim3(64), 0, c->stream, (const XYZZ *)outbuf, affine ? (G1Jac *)nullptr : (G1Jac *)results,
-                           affine ? (G1Affine *)results : (G1Affine *)nullptr, (uint32_t)j);
+        for (size_t j = j0; j < j0 + gsize; ++j)
+            hipLaunchKernelGGL(point_finish_slot_kernel, dim3(1), dim3(64), 0, c->stream, (const XYZZ *)outbuf + (j - j0),
+                               affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr, (uint32_t)j);
         prof_end(c);
         H2_HIPCHK(hipGetLastError());
+        j0 += gsize;
     }
     for (int l = 0; l < NL; ++l) {
         H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));

@@ -92,6 +92,7 @@ struct h2hip_ctx {
     h2hip_ctx *lane[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int msm_lanes = 3;   // lanes used by h2hip_msm_g1_batch_dev (1..4)
+    int msm_fuse_cols = 0;   // columns fused into one multi-column MSM by h2hip_msm_g1_batch_dev (precomputed bases): 0 = auto (4 up to 2^17 points, else 1)
     hipEvent_t fork_ev = nullptr;
 };
 
@@ -117,4 +118,6 @@ int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32
 int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_t n);
 int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *bases, bool precompute);
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
+constexpr uint32_t MSM_MAX_COLS = 8;   // columns one fused multi-column MSM handles
+int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev);
 }  // namespace h2

@@ -200,7 +200,7 @@ int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32
 // segment's slice of the sorted array (n*4/S bytes) fits that XCD's 4 MiB L2, so the 4-byte writes combine there
 // instead of each costing a 64-byte HBM write.
 __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
-                                                           uint32_t G, uint32_t chunk, uint32_t S, uint32_t table_stride,
+                                                           uint32_t G, uint32_t chunk, uint32_t S, uint32_t table_stride, uint32_t Wcol,
                                                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ bhist,
                                                            uint32_t *__restrict__ sval) {
     H2_SORT_PRIORITY();
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t *dw = digits + (size_t)w * n;
-    const uint32_t idx_base = w * table_stride;   // precomputed bases: window w reads table level w
+    const uint32_t idx_base = (w % Wcol) * table_stride;   // precomputed bases: window w of a column reads table level w
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         uint32_t dv = dw[i], d = dv & 0x7fffffffu;
         if (!d) continue;
@@ -378,6 +378,8 @@ __global__ __launch_bounds__(64) void msm_presum_kernel(const XYZZ29 *__restrict
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t groups = (rows + group - 1) / group;
     if (t >= B * groups) return;
+    in += (size_t)blockIdx.y * rows * B;     // blockIdx.y = column of a fused multi-column MSM
+    out += (size_t)blockIdx.y * groups * B;
     uint32_t gi = t / B, b = t - gi * B;
     uint32_t w0 = gi * group, w1 = w0 + group < rows ? w0 + group : rows;
     XYZZ29 acc = in[(size_t)w0 * B + b];
@@ -693,21 +695,28 @@ int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *b, bool precompute) {
 }
 
 // ------------------------------------------------------------------ host driver
-int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
+// One MSM per scalar column over the same bases, all columns in ONE pass through the pipeline: the sort, accumulation and
+// merge kernels see ncols * W windows (column-major), and the latency-bound bucket reduction runs once for all columns
+// (its chains are as long as for one column, just ncols times wider).  ncols > 1 needs precomputed window tables
+// (every column then owns ONE bucket set after the per-index presum).  out: ncols results.
+int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out) {
+    H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..8 columns per fused MSM");
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
     H2_REQUIRE(n < (1u << 27), "n too large for 32-bit entry indices");
     hipStream_t st = ctx->stream;
     if (n == 0) {
-        H2_HIPCHK(hipMemsetAsync(out, 0, sizeof(XYZZ), st));
+        H2_HIPCHK(hipMemsetAsync(out, 0, sizeof(XYZZ) * ncols, st));
         return H2HIP_OK;
     }
     const bool precomp = bases->tables > 1;
+    H2_REQUIRE(ncols == 1 || precomp, "a fused multi-column MSM needs precomputed bases");
     const uint32_t c = precomp ? bases->window_bits : (ctx->msm_window_bits ? (uint32_t)ctx->msm_window_bits : pick_window(n));
     H2_REQUIRE(c >= 2 && c <= 16, "window bits must be 2..16 (a window's bucket histogram lives in LDS)");
-    const uint32_t W = (255 + c - 1) / c;
-    H2_REQUIRE(W <= 64, "too many windows");
-    H2_REQUIRE(!precomp || bases->tables >= W, "precomputed table has too few windows");
+    const uint32_t Wcol = (255 + c - 1) / c;   // windows of one column
+    H2_REQUIRE(Wcol <= 64, "too many windows");
+    const uint32_t W = Wcol * ncols;           // windows the sort / accumulation see
+    H2_REQUIRE(!precomp || bases->tables >= Wcol, "precomputed table has too few windows");
     const uint32_t B = 1u << (c - 1);
     const uint32_t nkeys = W * B;
     const uint64_t emax = (uint64_t)n * W;
@@ -740,19 +749,23 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL0, sizeof(XYZZ29) * (size_t)len1, (void **)&pval[0]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY1, sizeof(uint32_t) * 2 * (size_t)blocks1, (void **)&pkey[1]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ29) * 2 * (size_t)blocks1, (void **)&pval[1]));
-    const uint32_t Wr = precomp ? 1 : W;   // windows left after the optional per-index presum
+    const uint32_t Wr = precomp ? ncols : W;   // bucket sets left after the optional per-index presum (one per column)
     const uint32_t nseg = Wr * (B / L);
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(XYZZ29) * nseg, (void **)&seg));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(XYZZ29) * 64, (void **)&win));
-    const uint32_t pre_rows = (W + 3) / 4;
-    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ29) * B * (pre_rows + 1), (void **)&presum));
+    const uint32_t pre_rows = (Wcol + 3) / 4;
+    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ29) * B * (size_t)ncols * (pre_rows + 1), (void **)&presum));
 
     H2_HIPCHK(hipMemsetAsync(counts + nkeys, 0, sizeof(uint32_t), st));
     H2_HIPCHK(hipMemsetAsync(offsets + nkeys + 1, 0xff, sizeof(uint32_t), st));   // sentinel read by the boundary walk
     H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
 
     prof_begin(ctx, "msm_digits_kernel");
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, scalars, (uint32_t)n, c, W, digits);
+    for (uint32_t col = 0; col < ncols; ++col) {
+        H2_REQUIRE(scalars[col], "NULL scalar column");
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, scalars[col], (uint32_t)n, c, Wcol,
+                           digits + (size_t)col * Wcol * n);
+    }
     prof_end(ctx);
     const uint32_t sort_threads = (uint32_t)ctx->msm_sort_threads;
     static bool lds_attr_set = false;   // dynamic LDS above 64 KiB has to be enabled per kernel once
@@ -779,7 +792,7 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     const uint32_t scatter_grid = 8 * G * ((W * S + 7) / 8);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(sort_threads), sizeof(uint32_t) * MAX_LDS_BUCKETS, st,   // full 128 KiB: one workgroup per CU keeps a segment's writes on one XCD
                        (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S,
-                       precomp ? (uint32_t)bases->n : 0u, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
+                       precomp ? (uint32_t)bases->n : 0u, Wcol, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
 
@@ -813,8 +826,9 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
     const XYZZ29 *red_in = buckets;
     if (precomp) {
         prof_begin(ctx, "msm_presum_kernel");
-        hipLaunchKernelGGL(msm_presum_kernel, dim3((B * pre_rows + 63) / 64), dim3(64), 0, st, (const XYZZ29 *)buckets, presum + B, B, W, 4u);
-        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const XYZZ29 *)(presum + B), presum, B, pre_rows, pre_rows);
+        XYZZ29 *stage1 = presum + (size_t)ncols * B;   // [ncols][pre_rows][B]; the final [ncols][B] sits in front of it
+        hipLaunchKernelGGL(msm_presum_kernel, dim3((B * pre_rows + 63) / 64, ncols), dim3(64), 0, st, (const XYZZ29 *)buckets, stage1, B, Wcol, 4u);
+        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64, ncols), dim3(64), 0, st, (const XYZZ29 *)stage1, presum, B, pre_rows, pre_rows);
         prof_end(ctx);
         red_in = presum;
     }
@@ -845,13 +859,25 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t 
         prof_end(ctx);
     }
     prof_begin(ctx, "msm_fold_kernel");
-    if (ctx->msm_quad_tails)
+    if (precomp) {   // every column's bucket set carries weight 1: the "fold" only converts the column's sum
+        for (uint32_t col = 0; col < ncols; ++col) {
+            if (ctx->msm_quad_tails)
+                hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(1), dim3(256), 0, st, (const XYZZ29 *)(win + col), 1u, c, out + col);
+            else
+                hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ29 *)(win + col), 1u, c, out + col);
+        }
+    } else if (ctx->msm_quad_tails) {
         hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(1), dim3(256), 0, st, (const XYZZ29 *)win, Wr, c, out);
-    else
+    } else {
         hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ29 *)win, Wr, c, out);
+    }
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
+}
+
+int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
+    return msm_run_cols(ctx, bases, &scalars, 1, n, out);
 }
 
 }  // namespace h2

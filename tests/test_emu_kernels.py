@@ -221,6 +221,21 @@ def test_msm_batch_pipelined(ctx):
         assert np.array_equal(got[j:j + 1], CO.best_multiexp(c, bases, threads=2))
     gotj = ctx.msm_batch_dev(b, dptrs[:2], n, H.POINT_JACOBIAN)
     assert [jac_to_affine_ints(gotj[0])] == O.limbs_to_points(got[0:1])
+    # precomputed tables: the columns are fused into multi-column MSMs (msm_fuse_cols per group, groups over the lanes)
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    bp = ctx.bases_upload(bases, BASES_PRECOMPUTE)
+    many = dptrs + dptrs[:4]                       # 9 columns: groups of 5 + 4 at the default, 3 x 3 at fuse = 3
+    for fuse in (8, 3, 1):
+        ctx.set_param("msm_fuse_cols", fuse)
+        gotf = ctx.msm_batch_dev(bp, many, n, H.POINT_AFFINE)
+        for j in range(len(many)):
+            assert np.array_equal(gotf[j:j + 1], got[j % 5:j % 5 + 1]), (fuse, j)
+    ctx.set_param("msm_fuse_cols", 0)              # auto: groups of 4 at this size
+    assert np.array_equal(ctx.msm_batch_dev(bp, dptrs[:1], n, H.POINT_AFFINE), got[0:1])
+    gota = ctx.msm_batch_dev(bp, many, n, H.POINT_AFFINE)
+    assert all(np.array_equal(gota[j:j + 1], got[j % 5:j % 5 + 1]) for j in range(len(many)))
+    bp.free()
     for d in dptrs:
         ctx.free(d)
     b.free()
