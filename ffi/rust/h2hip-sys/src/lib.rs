@@ -23,6 +23,10 @@ pub const H2HIP_POINT_JACOBIAN: c_int = 0;
 pub const H2HIP_POINT_AFFINE: c_int = 1;
 pub const H2HIP_BASES_PLAIN: u32 = 0;
 pub const H2HIP_BASES_PRECOMPUTE: u32 = 1;
+pub const H2HIP_PERM_FIRST: u32 = 1;
+pub const H2HIP_PERM_LAST: u32 = 2;
+pub const H2HIP_PERM_CHAIN: u32 = 4;
+pub const H2HIP_PERM_PRODUCT: u32 = 8;
 
 extern "C" {
     pub fn h2hip_last_error() -> *const c_char;
@@ -72,4 +76,27 @@ extern "C" {
     pub fn h2hip_fr_mul_add_batch_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, c_dev: *const c_void, n: usize) -> c_int;
     pub fn h2hip_poseidon_set_spec(ctx: *mut h2hip_ctx, t: u32, r_f: u32, r_p: u32, round_constants: *const c_void, mds: *const c_void) -> c_int;
     pub fn h2hip_poseidon_permute_batch_dev(ctx: *mut h2hip_ctx, states_dev: *mut c_void, inputs_dev: *const c_void, num_inputs: u32, n: usize) -> c_int;
+    // polynomial linear combinations (multiopen), h(X) = numerator / (X^n - 1)
+    pub fn h2hip_fr_axpy_dev(ctx: *mut h2hip_ctx, y_dev: *mut c_void, a: *const c_void, x_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_fr_scale_dev(ctx: *mut h2hip_ctx, y_dev: *mut c_void, s: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_divide_by_vanishing_poly_dev(ctx: *mut h2hip_ctx, a_dev: *mut c_void, ext_k: u32, k: u32, ext_omega: *const c_void, zeta: *const c_void) -> c_int;
+    // lookup / permutation arguments
+    pub fn h2hip_quotient_lookup_dev(ctx: *mut h2hip_ctx, acc_dev: *mut c_void, z_dev: *const c_void, a_dev: *const c_void, s_dev: *const c_void,
+                                     a_perm_dev: *const c_void, s_perm_dev: *const c_void, l0_dev: *const c_void, l_last_dev: *const c_void,
+                                     l_blind_dev: *const c_void, ext_k: u32, k: u32, beta: *const c_void, gamma: *const c_void, y: *const c_void) -> c_int;
+    pub fn h2hip_quotient_permutation_set_dev(ctx: *mut h2hip_ctx, acc_dev: *mut c_void, z_dev: *const c_void, z_prev_dev: *const c_void,
+                                              cols_dev: *const *const c_void, sigmas_dev: *const *const c_void, ncols: u32, first_col_index: u32,
+                                              l0_dev: *const c_void, l_last_dev: *const c_void, l_blind_dev: *const c_void, ext_k: u32, k: u32,
+                                              terms: u32, last_rotation: i32, beta: *const c_void, gamma: *const c_void, delta: *const c_void,
+                                              zeta: *const c_void, ext_omega: *const c_void, y: *const c_void) -> c_int;
+    pub fn h2hip_lookup_permute_dev(ctx: *mut h2hip_ctx, a_dev: *const c_void, s_dev: *const c_void, usable_rows: usize, a_perm_dev: *mut c_void,
+                                    s_perm_dev: *mut c_void) -> c_int;
+    // timing / diagnostics
+    pub fn h2hip_profile_enable(ctx: *mut h2hip_ctx, on: c_int) -> c_int;
+    pub fn h2hip_profile_reset(ctx: *mut h2hip_ctx) -> c_int;
+    pub fn h2hip_profile_get(ctx: *mut h2hip_ctx, prefix: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
+    pub fn h2hip_timer_start(ctx: *mut h2hip_ctx) -> c_int;
+    pub fn h2hip_timer_stop(ctx: *mut h2hip_ctx, elapsed_ms: *mut f64) -> c_int;
+    pub fn h2hip_bench_modmul(ctx: *mut h2hip_ctx, blocks: u32, iters: u32, chains: u32, elapsed_ms: *mut f64, modmuls: *mut f64) -> c_int;
+    pub fn h2hip_bench_modmul29(ctx: *mut h2hip_ctx, blocks: u32, iters: u32, chains: u32, elapsed_ms: *mut f64, modmuls: *mut f64) -> c_int;
 }

@@ -55,3 +55,15 @@ def test_missing_library_fails_loudly(tmp_path):
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         H.load_library(str(tmp_path / "libh2hip.so"))
+
+
+def test_rust_sys_crate_declares_every_header_symbol():
+    """ffi/rust/h2hip-sys/src/lib.rs (uncompiled here: no Rust toolchain) must at least name every exported function"""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "h2hip.h")).read()
+    rs = open(os.path.join(root, "ffi", "rust", "h2hip-sys", "src", "lib.rs")).read()
+    in_header = set(re.findall(r"\b(h2hip_[a-z0-9_]+)\s*\(", hdr))
+    in_rust = set(re.findall(r"pub fn (h2hip_[a-z0-9_]+)", rs))
+    assert in_header == in_rust, (sorted(in_header - in_rust), sorted(in_rust - in_header))
