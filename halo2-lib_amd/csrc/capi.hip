@@ -76,6 +76,14 @@ static void prof_collect(h2hip_ctx *ctx) {
     ctx->pending.clear();
 }
 
+// one workgroup per result slot
+__global__ void point_finish_batch_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff) {
+    if (threadIdx.x == 0) {
+        XYZZ p = in[blockIdx.x];
+        if (jac) jac[blockIdx.x] = xyzz_to_jacobian(p);
+        if (aff) aff[blockIdx.x] = xyzz_to_affine(p);
+    }
+}
 __global__ void point_finish_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         XYZZ p = in[0];
@@ -219,6 +227,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
     if (!strcmp(name, "msm_sort_threads")) return &ctx->msm_sort_threads;
     if (!strcmp(name, "msm_fuse_cols")) return &ctx->msm_fuse_cols;
+    if (!strcmp(name, "msm_defer_reduce")) return &ctx->msm_defer_reduce;
     return nullptr;
 }
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
@@ -416,14 +425,23 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH, psz * count, (void **)&results));
     H2_HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));   // inputs produced on the caller's stream are ready after this
     for (int l = 0; l < NL; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->fork_ev, 0));
-    // Precomputed bases: columns are fused into groups that go through the pipeline as ONE multi-column MSM (the
-    // latency-bound bucket reduction then runs once per group); the groups are dealt to the lanes.
-    // Measured (tools/fuse_sweep*.sh): fusing pays up to 2^17 points (-15 % per MSM: the reduction dominates small MSMs),
-    // beyond that the 4x larger offset / histogram arrays fall out of the XCD's L2 and the lane pipeline is faster.
-    size_t fuse = bases->tables > 1 ? (size_t)ctx->msm_fuse_cols : 1;
-    if (bases->tables > 1 && ctx->msm_fuse_cols == 0) fuse = n <= ((size_t)1 << 17) ? 4 : 1;
+    // Precomputed bases, two shapes (measured, tools/fuse_sweep*.sh):
+    //  * up to 2^17 points: columns are FUSED into groups that go through the whole pipeline as one multi-column MSM;
+    //  * larger: every column runs its own sort / accumulation / merge on a lane (pipelined), and the latency-bound
+    //    bucket reduction is DEFERRED: it runs once, for all columns together, after the lanes have joined.
+    const bool precomp = bases->tables > 1;
+    size_t fuse = precomp ? (size_t)ctx->msm_fuse_cols : 1;
+    if (precomp && ctx->msm_fuse_cols == 0) fuse = n <= ((size_t)1 << 17) ? 4 : 1;
     if (fuse < 1) fuse = 1;
     if (fuse > MSM_MAX_COLS) fuse = MSM_MAX_COLS;
+    const bool deferred = precomp && fuse == 1 && ctx->msm_defer_reduce && count >= 2 && count <= 64 && n > 0;
+    XYZZ29 *all_buckets = nullptr;
+    size_t keys_per_col = 0;
+    if (deferred) {
+        const uint32_t cw = bases->window_bits;
+        keys_per_col = (size_t)((255 + cw - 1) / cw) << (cw - 1);
+        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH_BUCKETS, sizeof(XYZZ29) * keys_per_col * count, (void **)&all_buckets));
+    }
     const size_t ngroups = (count + fuse - 1) / fuse;
     for (size_t g = 0, j0 = 0; g < ngroups; ++g) {
         const size_t gsize = (count - j0 + (ngroups - g) - 1) / (ngroups - g);   // balanced group sizes
@@ -431,18 +449,31 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
         for (size_t j = j0; j < j0 + gsize; ++j) H2_REQUIRE(n == 0 || scalars_dev[j], "NULL scalar column");
         char *outbuf = nullptr;
         H2_CHK(ws_reserve(c, h2hip_ctx::WS_OUT, 2048, (void **)&outbuf));
-        H2_CHK(msm_run_cols(c, bases, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf));
-        prof_begin(c, "point_finish_kernel");
-        for (size_t j = j0; j < j0 + gsize; ++j)
-            hipLaunchKernelGGL(point_finish_slot_kernel, dim3(1), dim3(64), 0, c->stream, (const XYZZ *)outbuf + (j - j0),
-                               affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr, (uint32_t)j);
-        prof_end(c);
+        H2_CHK(msm_run_cols(c, bases, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
+                            deferred ? all_buckets + keys_per_col * j0 : nullptr));
+        if (!deferred) {
+            prof_begin(c, "point_finish_kernel");
+            for (size_t j = j0; j < j0 + gsize; ++j)
+                hipLaunchKernelGGL(point_finish_slot_kernel, dim3(1), dim3(64), 0, c->stream, (const XYZZ *)outbuf + (j - j0),
+                                   affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr, (uint32_t)j);
+            prof_end(c);
+        }
         H2_HIPCHK(hipGetLastError());
         j0 += gsize;
     }
     for (int l = 0; l < NL; ++l) {
         H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));
         H2_HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
+    }
+    if (deferred) {   // one bucket reduction for all columns, on the caller's stream
+        XYZZ *sums = nullptr;
+        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, sizeof(XYZZ) * 64, (void **)&sums));
+        H2_CHK(msm_reduce_cols(ctx, bases, bases->window_bits, all_buckets, (uint32_t)count, sums));
+        prof_begin(ctx, "point_finish_kernel");
+        hipLaunchKernelGGL(point_finish_batch_kernel, dim3((uint32_t)count), dim3(64), 0, ctx->stream, (const XYZZ *)sums,
+                           affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr);
+        prof_end(ctx);
+        H2_HIPCHK(hipGetLastError());
     }
     H2_HIPCHK(hipMemcpyAsync(out_host, results, psz * count, hipMemcpyDeviceToHost, ctx->stream));
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));

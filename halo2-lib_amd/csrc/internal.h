@@ -10,6 +10,7 @@
 
 #include "../../include/h2hip.h"
 #include "ec.cuh"
+#include "ec29.cuh"
 
 namespace h2 {
 
@@ -67,7 +68,7 @@ struct h2hip_ctx {
     int num_cus = 256;
     // scratch
     enum { WS_NTT = 0, WS_DIGITS, WS_COUNTS, WS_OFFSETS, WS_CURSOR, WS_SKEY, WS_SVAL, WS_BUCKETS, WS_PKEY0, WS_PVAL0, WS_PKEY1,
-           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_POSEIDON, WS_FBTABLE, WS_BATCH, WS_LK0, WS_LK1, WS_LK2, WS_LK3, WS_LK4, WS_VANISH, WS_COUNT };
+           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_POSEIDON, WS_FBTABLE, WS_BATCH, WS_LK0, WS_LK1, WS_LK2, WS_LK3, WS_LK4, WS_VANISH, WS_BATCH_BUCKETS, WS_COUNT };
     h2::DevBuf ws[WS_COUNT];
     std::vector<h2::TwiddleSet> twiddles;
     // tuning knobs (h2hip_set_param)
@@ -92,6 +93,7 @@ struct h2hip_ctx {
     h2hip_ctx *lane[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int msm_lanes = 3;   // lanes used by h2hip_msm_g1_batch_dev (1..4)
+    int msm_defer_reduce = 1;   // batch API, precomputed bases, > 2^17 points: one bucket reduction for all columns after the lanes join
     int msm_fuse_cols = 0;   // columns fused into one multi-column MSM by h2hip_msm_g1_batch_dev (precomputed bases): 0 = auto (4 up to 2^17 points, else 1)
     hipEvent_t fork_ev = nullptr;
 };
@@ -119,5 +121,8 @@ int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_
 int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *bases, bool precompute);
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
 constexpr uint32_t MSM_MAX_COLS = 8;   // columns one fused multi-column MSM handles
-int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev);
+// ext_buckets != nullptr: stop after the merge and leave the column's buckets ([W][B], zeroed here) there for msm_reduce_cols
+int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev,
+                 XYZZ29 *ext_buckets);
+int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t window_bits, const XYZZ29 *buckets, uint32_t ncols, XYZZ *out_dev);
 }  // namespace h2

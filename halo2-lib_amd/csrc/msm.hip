@@ -699,13 +699,86 @@ int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *b, bool precompute) {
 // merge kernels see ncols * W windows (column-major), and the latency-bound bucket reduction runs once for all columns
 // (its chains are as long as for one column, just ncols times wider).  ncols > 1 needs precomputed window tables
 // (every column then owns ONE bucket set after the per-index presum).  out: ncols results.
-int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out) {
+// precomputed tables: every column's bucket set carries weight 1, the "fold" is only the conversion of its sum
+__global__ __launch_bounds__(64) void msm_cols_out_kernel(const XYZZ29 *__restrict__ win, uint32_t ncols, XYZZ *__restrict__ out) {
+    H2_TAIL_PRIORITY();
+    uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col < ncols) out[col] = xyzz29_to_sat(win[col]);
+}
+
+// Bucket reduction for ncols bucket sets laid out [col][Wcol][B] (plain bases: one column, Wcol weighted windows):
+// per-index presum over a column's windows (precomputed tables), sum_b (b+1)*bucket[b] per set, conversion / fold.
+// All columns go through the same launches: the dependent chains are as long as for one column.
+int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t c, const XYZZ29 *buckets, uint32_t ncols, XYZZ *out) {
+    hipStream_t st = ctx->stream;
+    const bool precomp = bases->tables > 1;
+    H2_REQUIRE(ncols >= 1 && ncols <= 64 && (ncols == 1 || precomp), "1..64 bucket sets (several need precomputed bases)");
+    const uint32_t Wcol = (255 + c - 1) / c, B = 1u << (c - 1);
+    uint32_t L = (uint32_t)ctx->msm_seg;
+    if (L > B) L = B;
+    const uint32_t Wr = precomp ? ncols : Wcol;   // bucket sets left after the optional per-index presum (one per column)
+    const uint32_t nseg = Wr * (B / L);
+    const uint32_t pre_rows = (Wcol + 3) / 4;
+    XYZZ29 *seg, *win, *presum = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(XYZZ29) * nseg, (void **)&seg));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(XYZZ29) * 64, (void **)&win));
+    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ29) * B * (size_t)ncols * (pre_rows + 1), (void **)&presum));
+    const XYZZ29 *red_in = buckets;
+    if (precomp) {
+        prof_begin(ctx, "msm_presum_kernel");
+        XYZZ29 *stage1 = presum + (size_t)ncols * B;   // [ncols][pre_rows][B]; the final [ncols][B] sits in front of it
+        hipLaunchKernelGGL(msm_presum_kernel, dim3((B * pre_rows + 63) / 64, ncols), dim3(64), 0, st, buckets, stage1, B, Wcol, 4u);
+        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64, ncols), dim3(64), 0, st, (const XYZZ29 *)stage1, presum, B, pre_rows, pre_rows);
+        prof_end(ctx);
+        red_in = presum;
+    }
+    // quad-lane arithmetic pays when the stage is latency-bound (few segments: precomputed bases); with 16 windows'
+    // worth of segments the stage is throughput-bound and the one-lane kernels win — the 2^(c*w) fold is always a chain
+    const bool quad_reduce = ctx->msm_quad_tails && nseg <= 16384;
+    if (quad_reduce) {
+        uint32_t lo_bits = 0;   // bits needed for a segment's first bucket index (< B)
+        while ((1u << lo_bits) < B) ++lo_bits;
+        const uint32_t per = B / L;
+        const uint32_t tree = (per % 64 == 0) ? 1u : 0u;   // a workgroup's 64 quads then belong to one window
+        prof_begin(ctx, "msm_seg_kernel");
+        hipLaunchKernelGGL(msm_seg_quad_kernel, dim3((nseg + 63) / 64), dim3(256), 0, st, red_in, seg, B, L, nseg, lo_bits, tree);
+        prof_end(ctx);
+        prof_begin(ctx, "msm_winsum_kernel");
+        const uint32_t wper = tree ? per / 64 : per;
+        if (wper <= 128)
+            hipLaunchKernelGGL(msm_winsum_quad_kernel<256>, dim3(Wr), dim3(256), 0, st, (const XYZZ29 *)seg, win, wper);
+        else
+            hipLaunchKernelGGL(msm_winsum_quad_kernel<1024>, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, wper);
+        prof_end(ctx);
+    } else {
+        prof_begin(ctx, "msm_seg_kernel");
+        hipLaunchKernelGGL(msm_seg_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, red_in, seg, B, L, nseg);
+        prof_end(ctx);
+        prof_begin(ctx, "msm_winsum_kernel");
+        hipLaunchKernelGGL(msm_winsum_kernel, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, B / L);
+        prof_end(ctx);
+    }
+    prof_begin(ctx, "msm_fold_kernel");
+    if (precomp) {
+        hipLaunchKernelGGL(msm_cols_out_kernel, dim3(1), dim3(64), 0, st, (const XYZZ29 *)win, ncols, out);
+    } else if (ctx->msm_quad_tails) {
+        hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(1), dim3(256), 0, st, (const XYZZ29 *)win, Wr, c, out);
+    } else {
+        hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ29 *)win, Wr, c, out);
+    }
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out, XYZZ29 *ext_buckets) {
     H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..8 columns per fused MSM");
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
     H2_REQUIRE(n < (1u << 27), "n too large for 32-bit entry indices");
     hipStream_t st = ctx->stream;
     if (n == 0) {
+        H2_REQUIRE(!ext_buckets, "empty MSM in a deferred-reduction batch");
         H2_HIPCHK(hipMemsetAsync(out, 0, sizeof(XYZZ) * ncols, st));
         return H2HIP_OK;
     }
@@ -726,8 +799,6 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         uint64_t k = emax / 262144;
         K1 = k < 8 ? 8u : k > 64 ? 64u : (uint32_t)k;
     }
-    uint32_t L = (uint32_t)ctx->msm_seg;
-    if (L > B) L = B;
     // chunking of the counting sort: about 32 chunks per window, 4Ki..64Ki scalars each
     uint32_t chunk = (uint32_t)((n + 31) / 32);
     if (chunk < 4096) chunk = 4096;
@@ -736,25 +807,20 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     const uint32_t sort_grid = 8 * G * ((W + 7) / 8);
 
     uint32_t *digits, *bhist, *counts, *offsets, *sval, *pkey[2];
-    XYZZ29 *buckets, *pval[2], *seg, *win, *presum = nullptr;
+    XYZZ29 *buckets, *pval[2];
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_DIGITS, sizeof(uint32_t) * emax, (void **)&digits));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * (nkeys + 1), (void **)&counts));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * (nkeys + 2), (void **)&offsets));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SVAL, sizeof(uint32_t) * emax, (void **)&sval));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(XYZZ29) * nkeys, (void **)&buckets));
+    if (ext_buckets) buckets = ext_buckets;
+    else H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(XYZZ29) * nkeys, (void **)&buckets));
     const uint32_t T1 = (uint32_t)((emax + K1 - 1) / K1);
     const uint32_t len1 = 2 * T1, blocks1 = (len1 + 255) / 256;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY0, sizeof(uint32_t) * (size_t)len1, (void **)&pkey[0]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL0, sizeof(XYZZ29) * (size_t)len1, (void **)&pval[0]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY1, sizeof(uint32_t) * 2 * (size_t)blocks1, (void **)&pkey[1]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ29) * 2 * (size_t)blocks1, (void **)&pval[1]));
-    const uint32_t Wr = precomp ? ncols : W;   // bucket sets left after the optional per-index presum (one per column)
-    const uint32_t nseg = Wr * (B / L);
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(XYZZ29) * nseg, (void **)&seg));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(XYZZ29) * 64, (void **)&win));
-    const uint32_t pre_rows = (Wcol + 3) / 4;
-    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ29) * B * (size_t)ncols * (pre_rows + 1), (void **)&presum));
 
     H2_HIPCHK(hipMemsetAsync(counts + nkeys, 0, sizeof(uint32_t), st));
     H2_HIPCHK(hipMemsetAsync(offsets + nkeys + 1, 0xff, sizeof(uint32_t), st));   // sentinel read by the boundary walk
@@ -823,61 +889,12 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         src ^= 1;
     }
 
-    const XYZZ29 *red_in = buckets;
-    if (precomp) {
-        prof_begin(ctx, "msm_presum_kernel");
-        XYZZ29 *stage1 = presum + (size_t)ncols * B;   // [ncols][pre_rows][B]; the final [ncols][B] sits in front of it
-        hipLaunchKernelGGL(msm_presum_kernel, dim3((B * pre_rows + 63) / 64, ncols), dim3(64), 0, st, (const XYZZ29 *)buckets, stage1, B, Wcol, 4u);
-        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64, ncols), dim3(64), 0, st, (const XYZZ29 *)stage1, presum, B, pre_rows, pre_rows);
-        prof_end(ctx);
-        red_in = presum;
-    }
-    // quad-lane arithmetic pays when the stage is latency-bound (few segments: precomputed bases); with 16 windows'
-    // worth of segments the stage is throughput-bound and the one-lane kernels win — the 2^(c*w) fold is always a chain
-    const bool quad_reduce = ctx->msm_quad_tails && nseg <= 16384;
-    if (quad_reduce) {
-        uint32_t lo_bits = 0;   // bits needed for a segment's first bucket index (< B)
-        while ((1u << lo_bits) < B) ++lo_bits;
-        const uint32_t per = B / L;
-        const uint32_t tree = (per % 64 == 0) ? 1u : 0u;   // a workgroup's 64 quads then belong to one window
-        prof_begin(ctx, "msm_seg_kernel");
-        hipLaunchKernelGGL(msm_seg_quad_kernel, dim3((nseg + 63) / 64), dim3(256), 0, st, red_in, seg, B, L, nseg, lo_bits, tree);
-        prof_end(ctx);
-        prof_begin(ctx, "msm_winsum_kernel");
-        const uint32_t wper = tree ? per / 64 : per;
-        if (wper <= 128)
-            hipLaunchKernelGGL(msm_winsum_quad_kernel<256>, dim3(Wr), dim3(256), 0, st, (const XYZZ29 *)seg, win, wper);
-        else
-            hipLaunchKernelGGL(msm_winsum_quad_kernel<1024>, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, wper);
-        prof_end(ctx);
-    } else {
-        prof_begin(ctx, "msm_seg_kernel");
-        hipLaunchKernelGGL(msm_seg_kernel, dim3((nseg + 63) / 64), dim3(64), 0, st, red_in, seg, B, L, nseg);
-        prof_end(ctx);
-        prof_begin(ctx, "msm_winsum_kernel");
-        hipLaunchKernelGGL(msm_winsum_kernel, dim3(Wr), dim3(1024), 0, st, (const XYZZ29 *)seg, win, B / L);
-        prof_end(ctx);
-    }
-    prof_begin(ctx, "msm_fold_kernel");
-    if (precomp) {   // every column's bucket set carries weight 1: the "fold" only converts the column's sum
-        for (uint32_t col = 0; col < ncols; ++col) {
-            if (ctx->msm_quad_tails)
-                hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(1), dim3(256), 0, st, (const XYZZ29 *)(win + col), 1u, c, out + col);
-            else
-                hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ29 *)(win + col), 1u, c, out + col);
-        }
-    } else if (ctx->msm_quad_tails) {
-        hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(1), dim3(256), 0, st, (const XYZZ29 *)win, Wr, c, out);
-    } else {
-        hipLaunchKernelGGL(msm_fold_kernel, dim3(1), dim3(64), 0, st, (const XYZZ29 *)win, Wr, c, out);
-    }
-    prof_end(ctx);
-    H2_HIPCHK(hipGetLastError());
-    return H2HIP_OK;
+    if (ext_buckets) return H2HIP_OK;   // accumulation only: the caller reduces several MSMs' buckets together
+    return msm_reduce_cols(ctx, bases, c, buckets, ncols, out);
 }
 
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
-    return msm_run_cols(ctx, bases, &scalars, 1, n, out);
+    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr);
 }
 
 }  // namespace h2
