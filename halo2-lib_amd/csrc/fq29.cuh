@@ -93,6 +93,19 @@ H2_HD F29<P> f29_sub(const F29<P> &a, const F29<P> &b) {
     }
     return f29_norm(r);
 }
+// a - b + K*q WITHOUT carry propagation: limbs < 2^29 + 2^30 when a is N (only valid as the wide operand of f29_mul_wide
+// or as an operand of a normalising add / sub)
+template <int K, class P>
+H2_HD F29<P> f29_sub_lazy(const F29<P> &a, const F29<P> &b) {
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        H2_ASSERT29(i == 8 || b.l[i] <= MASK29);
+        H2_ASSERT29(H2_SUBK_LIMB(K, i) >= b.l[i]);
+        r.l[i] = a.l[i] + (H2_SUBK_LIMB(K, i) - b.l[i]);
+    }
+    return r;
+}
 template <int K, class P>
 H2_HD F29<P> f29_neg(const F29<P> &b) {   // K*p - b
     return f29_sub<K>(F29<P>::zero(), b);
@@ -129,6 +142,21 @@ H2_HD F29<P> f29_mul(const F29<P> &a, const F29<P> &b) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         H2_ASSERT29(a.l[i] <= (1u << 30) && b.l[i] <= (1u << 30));
+#pragma unroll
+        for (int j = 0; j < 9; ++j) c[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+    return f29_reduce_columns<P>(c);
+}
+// a*b with a "wide" first operand: limbs of a < 2^31 (a lazy sum or lazy difference of normalised values), b normalised
+// (limbs < 2^29): a column holds at most 9 * 2^60 plus the reduction's 9 * 2^58 < 2^64.
+template <class P>
+H2_HD F29<P> f29_mul_wide(const F29<P> &a, const F29<P> &b) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        H2_ASSERT29(a.l[i] < (1u << 31) && b.l[i] <= (1u << 29));
 #pragma unroll
         for (int j = 0; j < 9; ++j) c[i + j] += (uint64_t)a.l[i] * b.l[j];
     }

@@ -137,11 +137,12 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const Fr *__restrict__ x,
                     x1 = f29_mul(x1, w1);
                     x3 = f29_mul(x3, w1);
                 }
-                Fr29 y0 = f29_norm(f29_add(x0, x1)), y1 = f29_sub<2>(x0, x1);
-                Fr29 y2 = f29_norm(f29_add(x2, x3)), y3 = f29_sub<2>(x2, x3);
+                // the stage-st outputs stay lazy (no carry propagation): y0, y1 only feed normalising adds / subs and
+                // y2, y3 are the wide operands of the twiddle products — four of the round's eight normalisations go away
+                Fr29 y0 = f29_add(x0, x1), y1 = f29_sub_lazy<2>(x0, x1);
                 // stage st+1 (half = 2h): omega_{4h}^i and omega_{4h}^(i+h)
-                y2 = f29_mul(y2, tw_s[i << (m - 2 - st)].v);
-                y3 = f29_mul(y3, tw_s[(i + h) << (m - 2 - st)].v);
+                Fr29 y2 = f29_mul_wide(f29_add(x2, x3), tw_s[i << (m - 2 - st)].v);
+                Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), tw_s[(i + h) << (m - 2 - st)].v);
                 lds[e0].v = f29_norm(f29_add(y0, y2));
                 lds[e0 + 2 * stride].v = f29_sub<2>(y0, y2);
                 lds[e0 + stride].v = f29_norm(f29_add(y1, y3));
