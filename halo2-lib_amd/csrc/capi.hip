@@ -2,6 +2,8 @@
 // pointer entry points that route to the kernels in ntt.hip, msm.hip and fr_ops.hip.
 #include <stdarg.h>
 
+#include <algorithm>
+
 #include "internal.h"
 
 namespace h2 {
@@ -69,6 +71,8 @@ static void prof_collect(h2hip_ctx *ctx) {
             KernelStat &s = ctx->stats[p.first];
             s.total_ms += ms;
             s.launches += 1;
+            float t0 = 0;
+            if (ctx->prof_ref && hipEventElapsedTime(&t0, ctx->prof_ref, p.second.first) == hipSuccess) s.spans.push_back({t0, t0 + ms});
         }
         ctx->event_pool.push_back(p.second.first);
         ctx->event_pool.push_back(p.second.second);
@@ -197,6 +201,7 @@ void h2hip_destroy(h2hip_ctx *ctx) {
         hipEventDestroy(p.second.second);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->prof_ref && ctx->own_prof_ref) hipEventDestroy(ctx->prof_ref);
     for (int l = 0; l < 4; ++l)
         if (ctx->lane[l]) {
             h2hip_destroy(ctx->lane[l]);
@@ -297,6 +302,39 @@ int h2hip_profile_reset(h2hip_ctx *ctx) {
     H2_REQUIRE(ctx, "ctx is NULL");
     prof_collect(ctx);
     ctx->stats.clear();
+    if (!ctx->prof_ref) {
+        H2_HIPCHK(hipEventCreate(&ctx->prof_ref));
+        ctx->own_prof_ref = true;
+    }
+    if (ctx->own_prof_ref) {
+        H2_HIPCHK(hipEventRecord(ctx->prof_ref, ctx->stream));
+        H2_HIPCHK(hipEventSynchronize(ctx->prof_ref));
+    }
+    return H2HIP_OK;
+}
+// time during which at least one launch of the matching kernels was executing (union of the launch spans): with
+// pipelined MSMs several launches of one kernel overlap, and busy / launches is what one launch effectively costs
+int h2hip_profile_get_busy(h2hip_ctx *ctx, const char *prefix, double *busy_ms) {
+    H2_REQUIRE(ctx && prefix && busy_ms, "NULL argument");
+    prof_collect(ctx);
+    std::vector<std::pair<float, float>> all;
+    size_t len = strlen(prefix);
+    for (auto &kv : ctx->stats)
+        if (kv.first.compare(0, len, prefix) == 0) all.insert(all.end(), kv.second.spans.begin(), kv.second.spans.end());
+    std::sort(all.begin(), all.end());
+    double busy = 0;
+    float cur0 = 0, cur1 = -1;
+    for (auto &sp : all) {
+        if (cur1 < cur0 || sp.first > cur1) {
+            if (cur1 >= cur0) busy += cur1 - cur0;
+            cur0 = sp.first;
+            cur1 = sp.second;
+        } else if (sp.second > cur1) {
+            cur1 = sp.second;
+        }
+    }
+    if (cur1 >= cur0) busy += cur1 - cur0;
+    *busy_ms = busy;
     return H2HIP_OK;
 }
 int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches) {
@@ -419,6 +457,7 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
         c->msm_quad_tails = ctx->msm_quad_tails;
         c->msm_window_bits = ctx->msm_window_bits;
         c->profiling = ctx->profiling;
+        c->prof_ref = ctx->prof_ref;   // launch spans of all lanes share the parent's time origin
     }
     if (!ctx->fork_ev) H2_HIPCHK(hipEventCreate(&ctx->fork_ev));
     char *results = nullptr;
@@ -483,6 +522,7 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
             for (auto &kv : ctx->lane[l]->stats) {
                 ctx->stats[kv.first].total_ms += kv.second.total_ms;
                 ctx->stats[kv.first].launches += kv.second.launches;
+                ctx->stats[kv.first].spans.insert(ctx->stats[kv.first].spans.end(), kv.second.spans.begin(), kv.second.spans.end());
             }
             ctx->lane[l]->stats.clear();
         }

@@ -57,6 +57,7 @@ struct TwiddleSet {   // omega^i tables for one (log_n, omega)
 struct KernelStat {
     double total_ms = 0;
     uint64_t launches = 0;
+    std::vector<std::pair<float, float>> spans;   // (start, end) of every launch in ms since the profile's reference event
 };
 
 }  // namespace h2
@@ -89,6 +90,8 @@ struct h2hip_ctx {
     std::map<std::string, h2::KernelStat> stats;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
     std::vector<hipEvent_t> event_pool;
+    hipEvent_t prof_ref = nullptr;       // reference event (recorded at h2hip_profile_reset) the launch spans are measured from
+    bool own_prof_ref = false;           // lanes borrow the parent's reference
     // batch lanes (h2hip_msm_g1_batch_dev): child contexts with their own stream + scratch
     h2hip_ctx *lane[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};

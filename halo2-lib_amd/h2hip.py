@@ -34,6 +34,7 @@ _PROTOS = {
     "h2hip_download": (_int, [_vp, _vp, _vp, _sz]),
     "h2hip_profile_enable": (_int, [_vp, _int]),
     "h2hip_profile_reset": (_int, [_vp]),
+    "h2hip_profile_get_busy": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "h2hip_profile_get": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "h2hip_timer_start": (_int, [_vp]),
     "h2hip_timer_stop": (_int, [_vp, C.POINTER(C.c_double)]),
@@ -206,6 +207,12 @@ class Context:
 
     def profile_reset(self):
         self._chk(self.lib.h2hip_profile_reset(self.handle))
+
+    def profile_get_busy(self, prefix: str) -> float:
+        """ms during which at least one launch of the kernels matching `prefix` was running (union of the launch spans)"""
+        ms = C.c_double(0)
+        self._chk(self.lib.h2hip_profile_get_busy(self.handle, prefix.encode(), C.byref(ms)))
+        return ms.value
 
     def profile_get(self, prefix: str):
         ms, cnt = C.c_double(), C.c_uint64()

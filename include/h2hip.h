@@ -72,6 +72,9 @@ int h2hip_profile_enable(h2hip_ctx *ctx, int on);
 int h2hip_profile_reset(h2hip_ctx *ctx);
 /* total milliseconds and launch count accumulated for kernels whose name starts with `prefix` */
 int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);
+/* milliseconds (since the last h2hip_profile_reset) during which at least one launch of the matching kernels was executing:
+ * the union of the launch spans — with pipelined MSMs several launches of one kernel overlap */
+int h2hip_profile_get_busy(h2hip_ctx *ctx, const char *prefix, double *busy_ms);
 /* bracket an arbitrary region with events on the context's stream (bench.py's timed region) */
 int h2hip_timer_start(h2hip_ctx *ctx);
 int h2hip_timer_stop(h2hip_ctx *ctx, double *elapsed_ms);
