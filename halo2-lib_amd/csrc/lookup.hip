@@ -5,7 +5,7 @@
 //   of A') receive the table elements not consumed that way, in ascending order, assigned from the LAST repeated
 //   row backwards (upstream: BTreeMap iteration ascending, repeated_input_rows.pop()).
 // The order of field elements is the numeric order of their canonical values (Fr: Ord compares to_repr() from the
-// most significant byte).  Sorting is a bitonic network on 32-byte keys: stages with partner distance < 1024 run in
+// most significant byte).  Sorting is a bitonic network on 32-byte keys: stages with partner distance < 4096 run in
 // LDS, the others as global passes; everything else is flags + prefix sums + binary searches.
 #include "internal.h"
 
@@ -44,18 +44,19 @@ __global__ __launch_bounds__(256) void lk_keys_kernel(const Fr *__restrict__ in,
     keys[i] = k;
 }
 
-constexpr uint32_t LK_TILE = 1024;   // keys per workgroup in the LDS stages (32 KiB)
+constexpr uint32_t LK_MIN_TILE = 1024;   // keys per workgroup in the LDS stages: 1024 (32 KiB, 256 lanes) or, from 2^19 keys, 4096 (128 KiB, 1024 lanes)
 // all stages (k, j) with j < LK_TILE for k in [k_lo, k_hi] (k_lo = 2: full presort of each tile; k_lo = k_hi = k: the
 // tail j = LK_TILE/2 .. 1 of a larger merge step)
-__global__ __launch_bounds__(256) void lk_bitonic_local_kernel(Key256 *__restrict__ keys, uint32_t k_lo, uint32_t k_hi) {
-    __shared__ Key256 sh[LK_TILE];
+template <uint32_t LK_TILE, uint32_t LK_THREADS>
+__global__ __launch_bounds__(LK_THREADS) void lk_bitonic_local_kernel(Key256 *__restrict__ keys, uint32_t k_lo, uint32_t k_hi) {
+    HIP_DYNAMIC_SHARED(Key256, sh)   // LK_TILE keys
     const uint32_t base = blockIdx.x * LK_TILE, tid = threadIdx.x;
-    for (uint32_t e = tid; e < LK_TILE; e += 256) sh[e] = keys[base + e];
+    for (uint32_t e = tid; e < LK_TILE; e += LK_THREADS) sh[e] = keys[base + e];
     __syncthreads();
     for (uint32_t k = k_lo; k <= k_hi; k <<= 1) {
         uint32_t j0 = (k >> 1) < LK_TILE ? (k >> 1) : (LK_TILE >> 1);
         for (uint32_t j = j0; j >= 1; j >>= 1) {
-            for (uint32_t p = tid; p < LK_TILE / 2; p += 256) {
+            for (uint32_t p = tid; p < LK_TILE / 2; p += LK_THREADS) {
                 uint32_t lo = ((p & ~(j - 1)) << 1) | (p & (j - 1)), hi = lo | j;
                 bool up = ((base + lo) & k) == 0;
                 Key256 a = sh[lo], b = sh[hi];
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void lk_bitonic_local_kernel(Key256 *__restric
         }
         if (k == 0x80000000u) break;
     }
-    for (uint32_t e = tid; e < LK_TILE; e += 256) keys[base + e] = sh[e];
+    for (uint32_t e = tid; e < LK_TILE; e += LK_THREADS) keys[base + e] = sh[e];
 }
 // one global stage (k, j) with j >= LK_TILE
 __global__ __launch_bounds__(256) void lk_bitonic_global_kernel(Key256 *__restrict__ keys, uint32_t N, uint32_t j, uint32_t k) {
@@ -142,18 +143,30 @@ __global__ __launch_bounds__(256) void lk_assign_kernel(const uint32_t *__restri
     s_perm[rep_rows[m - 1 - j]] = fe_to_mont(c);
 }
 
-static int bitonic_sort(h2hip_ctx *ctx, Key256 *keys, uint32_t N) {
+template <uint32_t LK_TILE, uint32_t LK_THREADS>
+static int bitonic_sort_tiled(h2hip_ctx *ctx, Key256 *keys, uint32_t N) {
     hipStream_t st = ctx->stream;
-    if (N < LK_TILE) return H2HIP_ERR_INVALID;   // callers pad to at least one tile
     const uint32_t tiles = N / LK_TILE;
-    hipLaunchKernelGGL(lk_bitonic_local_kernel, dim3(tiles), dim3(256), 0, st, keys, 2u, LK_TILE);
+    const size_t lds = sizeof(Key256) * LK_TILE;
+    static bool lds_attr_set = false;   // dynamic LDS above 64 KiB has to be enabled once per kernel
+    if (!lds_attr_set && lds > (64u << 10)) {
+        H2_HIPCHK(hipFuncSetAttribute((const void *)lk_bitonic_local_kernel<LK_TILE, LK_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL((lk_bitonic_local_kernel<LK_TILE, LK_THREADS>), dim3(tiles), dim3(LK_THREADS), lds, st, keys, 2u, LK_TILE);
     for (uint32_t k = LK_TILE << 1; k <= N && k != 0; k <<= 1) {
         for (uint32_t j = k >> 1; j >= LK_TILE; j >>= 1)
             hipLaunchKernelGGL(lk_bitonic_global_kernel, dim3((N / 2 + 255) / 256), dim3(256), 0, st, keys, N, j, k);
-        hipLaunchKernelGGL(lk_bitonic_local_kernel, dim3(tiles), dim3(256), 0, st, keys, k, k);
+        hipLaunchKernelGGL((lk_bitonic_local_kernel<LK_TILE, LK_THREADS>), dim3(tiles), dim3(LK_THREADS), lds, st, keys, k, k);
     }
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
+}
+static int bitonic_sort(h2hip_ctx *ctx, Key256 *keys, uint32_t N) {
+    if (N < LK_MIN_TILE) return H2HIP_ERR_INVALID;   // callers pad to at least one tile
+    // measured: the 4096-key tile (fewer global passes) wins from 2^19 keys, the 1024-key tile (more workgroups) below
+    if (N >= (1u << ctx->lookup_big_tile_bits)) return bitonic_sort_tiled<4096, 1024>(ctx, keys, N);
+    return bitonic_sort_tiled<1024, 256>(ctx, keys, N);
 }
 
 }  // namespace h2
@@ -170,7 +183,7 @@ int h2hip_lookup_permute_dev(h2hip_ctx *ctx, const void *a_dev, const void *s_de
     H2_REQUIRE(usable_rows < (1u << 28), "too many rows");
     if (!usable_rows) return H2HIP_OK;
     const uint32_t u = (uint32_t)usable_rows;
-    uint32_t N = LK_TILE;
+    uint32_t N = LK_MIN_TILE;
     while (N < u) N <<= 1;
     hipStream_t st = ctx->stream;
     Key256 *ka, *ks, *leftover;

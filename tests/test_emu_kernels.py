@@ -324,6 +324,11 @@ def _lookup_permute_checks(ctx, sizes):
 
 def test_lookup_permute_expression_pair(ctx):
     _lookup_permute_checks(ctx, [(1, 1), (5, 2), (300, 5), (1024, 8), (3001, 9)])
+    ctx.set_param("lookup_big_tile_bits", 12)      # the 4096-key LDS tile (default: from 2^19 keys) on 4096 / 8192 padded keys
+    try:
+        _lookup_permute_checks(ctx, [(4000, 9), (5000, 10)])
+    finally:
+        ctx.set_param("lookup_big_tile_bits", 19)
 
 
 def test_emulated_kernels_match_committed_golden_fixtures(ctx):

@@ -229,7 +229,7 @@ def test_quotient_lookup_and_permutation_identities(ctx):
 def test_lookup_permute_expression_pair(ctx):
     from tests.test_emu_kernels import _lookup_permute_checks
 
-    _lookup_permute_checks(ctx, [(5, 2), (3001, 9), ((1 << 17) - 20, 15)])
+    _lookup_permute_checks(ctx, [(5, 2), (3001, 9), ((1 << 17) - 20, 15), ((1 << 19) - 6, 18)])   # the last one sorts with 4096-key tiles
 
 
 def test_gpu_matches_committed_golden_fixtures(ctx):
