@@ -79,8 +79,9 @@ H2_HD void xyzz29_add_affine(XYZZ29 &acc, const Fq29 &x2, const Fq29 &y2, bool n
     Fq29 U2 = f29_mul(x2, acc.zz);                            // < 1.01
     Fq29 S2 = f29_mul(y2, acc.zzz);                           // < 1.01
     Fq29 Pd = f29_sub<6>(U2, acc.x);                          // in (0.75, 7.01) q
-    Fq29 Rd = neg ? f29_neg<6>(f29_norm(f29_add(S2, acc.y)))  // 6q - (S2 + Y), in (1.69, 6] q
-                  : f29_sub<4>(S2, acc.y);                    // in (0.7, 5.01) q
+    // Rd = +-S2 - Y1 + K*q with the sign folded in limb-wise (one instruction stream for both signs of the digit):
+    //   neg: (2q - S2) + (4q - Y1) in (1.69, 6] q ;  otherwise: S2 + (4q - Y1) in (0.7, 5.01) q
+    Fq29 Rd = f29_signed_sub4(S2, neg, acc.y);
     if (f29_is_zero_mod_q<7>(Pd)) {
         if (f29_is_zero_mod_q<7>(Rd)) acc = xyzz29_double_affine(x2, neg ? f29_neg<2>(y2) : y2);
         else acc = XYZZ29::identity();

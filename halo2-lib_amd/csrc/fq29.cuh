@@ -106,6 +106,19 @@ H2_HD F29<P> f29_sub_lazy(const F29<P> &a, const F29<P> &b) {
     }
     return r;
 }
+// (neg ? 2q - a : a) - b + 4q, normalised; a, b N with a < 2q and b < 4q.  Limbs stay below 2^31 before the carry pass.
+template <class P>
+H2_HD F29<P> f29_signed_sub4(const F29<P> &a, bool neg, const F29<P> &b) {
+    F29<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        H2_ASSERT29(i == 8 || (a.l[i] <= MASK29 && b.l[i] <= MASK29));
+        H2_ASSERT29(P::sub2p(i) >= a.l[i] && P::sub4p(i) >= b.l[i]);
+        const uint32_t u = neg ? P::sub2p(i) - a.l[i] : a.l[i];
+        r.l[i] = u + (P::sub4p(i) - b.l[i]);
+    }
+    return f29_norm(r);
+}
 template <int K, class P>
 H2_HD F29<P> f29_neg(const F29<P> &b) {   // K*p - b
     return f29_sub<K>(F29<P>::zero(), b);
