@@ -234,13 +234,20 @@ H2_HD F29<P> f29_weak_reduce(const F29<P> &a) {
 
 // a == k*q for some 0 <= k <= KMAX ?   (a must be N; use when a < (KMAX+1)*q)
 #define H2_MULK_LIMB(k, i) ((k) == 0 ? 0u : (k) == 1 ? P::mul1p(i) : (k) == 2 ? P::mul2p(i) : (k) == 3 ? P::mul3p(i) : (k) == 4 ? P::mul4p(i) : (k) == 5 ? P::mul5p(i) : (k) == 6 ? P::mul6p(i) : (k) == 7 ? P::mul7p(i) : P::mul8p(i))
+// The candidate multiple comes from the lowest limb alone (a = k*q  =>  k = a_0 * q_0^-1 mod 2^29: three instructions);
+// the exact limb-by-limb comparison sits behind a WAVE-UNIFORM branch, so the common case really skips it (a per-lane
+// `if` of this size is if-converted by the compiler and was ~150 always-executed instructions per point addition).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(H2_HIPEMU)
+#define H2_ANY_LANE(c) (__any((c) ? 1 : 0) != 0)
+#else
+#define H2_ANY_LANE(c) (c)
+#endif
 template <int KMAX, class P>
 H2_HD bool f29_is_zero_mod_q(const F29<P> &a) {
     static_assert(KMAX <= 8, "range too large");
-    bool cand = false;
-#pragma unroll
-    for (int k = 0; k <= KMAX; ++k) cand |= (a.l[0] == H2_MULK_LIMB(k, 0));
-    if (!cand) return false;
+    const uint32_t kc = (0u - a.l[0] * P::INV) & MASK29;   // P::INV = -q^-1 mod 2^29
+    const bool cand = kc <= (uint32_t)KMAX;
+    if (!H2_ANY_LANE(cand)) return false;
     bool hit = false;
 #pragma unroll
     for (int k = 0; k <= KMAX; ++k) {
@@ -249,7 +256,7 @@ H2_HD bool f29_is_zero_mod_q(const F29<P> &a) {
         for (int i = 0; i < 9; ++i) d |= a.l[i] ^ H2_MULK_LIMB(k, i);
         hit |= (d == 0);
     }
-    return hit;
+    return cand && hit;
 }
 
 // saturated Montgomery (R = 2^256, canonical < q)  ->  unsaturated (R' = 2^261), N, value < 1.01 q
