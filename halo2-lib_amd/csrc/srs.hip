@@ -101,6 +101,59 @@ static int fixed_base_mul(h2hip_ctx *ctx, const G1Affine *table, const Fr *scala
     return batch_normalize_jac(ctx, jtmp, out, n);
 }
 
+// ------------------------------------------------------------------ g_to_lagrange: the group-element inverse FFT
+// ParamsKZG without Lagrange bases (a ceremony file, ParamsKZG::from_parts(.., None, ..), downsize) derives them as
+//   g_lagrange[i] = n^-1 * sum_j omega^(-i j) * g[j]
+// [UPSTREAM poly/kzg/commitment.rs g_to_lagrange: best_fft over G1 with omega^-1, then * n^-1, then batch_normalize].
+// Radix-2 decimation in time on XYZZ points: bit-reversed load, log n stages of butterflies whose twiddle product is a
+// 254-bit double-and-add scalar multiplication (one lane per butterfly; throughput-bound, ~0.2 s at k = 19 — a one-off
+// per SRS next to upstream's minutes on the CPU).
+__device__ __forceinline__ XYZZ29 xyzz29_scalar_mul(const XYZZ29 &p, const Fr &canonical) {
+    XYZZ29 r = XYZZ29::identity();
+    for (int bit = 253; bit >= 0; --bit) {
+        r = xyzz29_double(r);
+        if ((canonical.l[bit >> 5] >> (bit & 31)) & 1u) xyzz29_add(r, p);
+    }
+    return r;
+}
+__global__ __launch_bounds__(256) void gl_load_kernel(const G1Affine *__restrict__ g, XYZZ29 *__restrict__ a, uint32_t k) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << k)) return;
+    G1Affine p = g[i];
+    XYZZ29 v = XYZZ29::identity();
+    if (!p.is_identity()) {
+        G1Affine29 q = g1affine29_from_sat(p);
+        v.x = q.x;
+        v.y = q.y;
+        v.zz = Fq29::one();
+        v.zzz = Fq29::one();
+    }
+    a[k ? (__brev(i) >> (32 - k)) : 0] = v;
+}
+// tw[j] = canonical limbs of omega_inv^j, j < n/2
+__global__ __launch_bounds__(256) void gl_twiddle_kernel(Fr *__restrict__ tw, Fr omega_inv, uint32_t count) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) tw[j] = fe_from_mont(fe_pow_u64(omega_inv, j));
+}
+__global__ __launch_bounds__(256) void gl_stage_kernel(XYZZ29 *__restrict__ a, const Fr *__restrict__ tw, uint32_t k, uint32_t s) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (1u << (k - 1))) return;
+    const uint32_t half = 1u << s, j = b & (half - 1);
+    const uint32_t i = ((b >> s) << (s + 1)) + j, e = j << (k - 1 - s);
+    XYZZ29 t = a[i + half];
+    if (e) t = xyzz29_scalar_mul(t, tw[e]);
+    XYZZ29 u = a[i], v = u;
+    xyzz29_add(u, t);
+    if (!t.is_identity()) t.y = f29_neg<4>(t.y);
+    xyzz29_add(v, t);
+    a[i] = u;
+    a[i + half] = v;
+}
+__global__ __launch_bounds__(256) void gl_scale_kernel(const XYZZ29 *__restrict__ a, Fr n_inv_canonical, uint32_t n, G1Jac *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = xyzz_to_jacobian(xyzz29_to_sat(xyzz29_scalar_mul(a[i], n_inv_canonical)));
+}
+
 }  // namespace h2
 
 using namespace h2;
@@ -116,6 +169,37 @@ int h2hip_g1_fixed_base_mul_batch_dev(h2hip_ctx *ctx, const void *base_affine, c
     G1Affine *table = nullptr;
     H2_CHK(fixed_base_table(ctx, base, &table));
     return fixed_base_mul(ctx, table, (const Fr *)scalars_dev, (uint32_t)n, (G1Affine *)out_affine_dev);
+}
+
+int h2hip_g1_to_lagrange(h2hip_ctx *ctx, const h2hip_bases *g, uint32_t k, uint32_t flags, h2hip_bases **g_lagrange_out) {
+    H2_REQUIRE(ctx && g && g_lagrange_out, "NULL argument");
+    H2_REQUIRE(k <= 26 && g->n >= ((size_t)1 << k), "need at least 2^k monomial bases, k <= 26");
+    const uint32_t n = 1u << k;
+    Fr rou_canon = {{0x60c37c9cu, 0xd34f1ed9u, 0xd39329c8u, 0x3215cf6du, 0x3dd31f74u, 0x98865ea9u, 0x166d18b7u, 0x03ddb9f5u}};
+    Fr omega = fe_to_mont(rou_canon);
+    for (uint32_t i = k; i < 28; ++i) omega = fe_sqr(omega);
+    const Fr omega_inv = fe_inv(omega);
+    Fr n_fr = Fr::zero();
+    n_fr.l[0] = n;
+    const Fr n_inv = fe_from_mont(fe_inv(fe_to_mont(n_fr)));
+    XYZZ29 *a = nullptr;
+    Fr *tw = nullptr;
+    G1Jac *jac = nullptr;
+    G1Affine *aff = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ29) * (size_t)n, (void **)&a));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP1, sizeof(G1Jac) * (size_t)n + sizeof(Fr) * (size_t)(n / 2 + 1), (void **)&jac));
+    tw = (Fr *)(jac + n);
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_FBTABLE, sizeof(G1Affine) * (size_t)n, (void **)&aff));
+    const dim3 blk(256), grid_n((n + 255) / 256), grid_h((n / 2 + 255) / 256);
+    prof_begin(ctx, "g_to_lagrange_kernels");
+    hipLaunchKernelGGL(gl_load_kernel, grid_n, blk, 0, ctx->stream, (const G1Affine *)g->pts, a, k);
+    if (n > 1) hipLaunchKernelGGL(gl_twiddle_kernel, grid_h, blk, 0, ctx->stream, tw, omega_inv, n / 2);
+    for (uint32_t s = 0; s < k; ++s) hipLaunchKernelGGL(gl_stage_kernel, grid_h, blk, 0, ctx->stream, a, (const Fr *)tw, k, s);
+    hipLaunchKernelGGL(gl_scale_kernel, grid_n, blk, 0, ctx->stream, (const XYZZ29 *)a, n_inv, n, jac);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_CHK(batch_normalize_jac(ctx, jac, aff, n));
+    return h2hip_bases_from_device(ctx, aff, n, flags, g_lagrange_out);
 }
 
 int h2hip_params_kzg_setup(h2hip_ctx *ctx, uint32_t k, const void *s_fr, uint32_t flags, h2hip_bases **g_out, h2hip_bases **g_lagrange_out) {

@@ -45,6 +45,7 @@ _PROTOS = {
     "h2hip_msm_g1": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "h2hip_msm_g1_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "h2hip_msm_g1_batch_dev": (_int, [_vp, _vp, C.POINTER(_vp), _sz, _sz, _int, _vp]),
+    "h2hip_g1_to_lagrange": (_int, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),
     "h2hip_params_kzg_setup": (_int, [_vp, _u32, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp)]),
     "h2hip_g1_fixed_base_mul_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_bases_download": (_int, [_vp, _vp, _vp]),
@@ -249,6 +250,12 @@ class Context:
         out = np.zeros((1, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
         self._chk(self.lib.h2hip_msm_g1_dev(self.handle, bases.handle, _vp(scalars_dptr), n, point_format, _ptr(out)))
         return out
+
+    def g1_to_lagrange(self, g: "Bases", k: int, flags: int = 0) -> "Bases":
+        """g_to_lagrange: Lagrange bases from the first 2^k monomial bases (group inverse FFT on the device)"""
+        out = _vp()
+        self._chk(self.lib.h2hip_g1_to_lagrange(self.handle, g.handle, k, flags, C.byref(out)))
+        return Bases(self, out, 1 << k)
 
     def params_kzg_setup(self, k: int, s: np.ndarray, flags: int = BASES_PLAIN):
         """(g, g_lagrange) resident base sets of ParamsKZG::setup(k) for the toxic-waste scalar s"""

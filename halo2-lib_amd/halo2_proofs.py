@@ -149,6 +149,14 @@ class ParamsKZG:
         g, gl = ctx.params_kzg_setup(k, fr_limbs(s), BASES_PRECOMPUTE if precompute else BASES_PLAIN)
         return cls(ctx, k, g, gl)
 
+    @classmethod
+    def from_parts(cls, ctx: Context, k: int, g: Bases, g_lagrange: Bases = None, g2_raw: bytes = b"", precompute: bool = True) -> "ParamsKZG":
+        """ParamsKZG::from_parts(k, g, g_lagrange: Option<..>, g2, s_g2): a missing Lagrange basis is derived on the GPU
+        (upstream's g_to_lagrange: group inverse FFT of g)."""
+        if g_lagrange is None:
+            g_lagrange = ctx.g1_to_lagrange(g, k, BASES_PRECOMPUTE if precompute else BASES_PLAIN)
+        return cls(ctx, k, g, g_lagrange, g2_raw)
+
     def commit(self, coeffs: np.ndarray, point_format: int = POINT_JACOBIAN) -> np.ndarray:
         """Params::commit(poly): best_multiexp(coeffs, g[..len]) (KZG ignores the blind, SURVEY.md A.6)"""
         coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)

@@ -305,6 +305,12 @@ class ParamsKZG {
         check(h2hip_params_kzg_setup(b.raw(), k, &s, precompute ? H2HIP_BASES_PRECOMPUTE : H2HIP_BASES_PLAIN, &g, &gl));
         return ParamsKZG(b, k, Bases(b, g), Bases(b, gl));
     }
+    // ParamsKZG::from_parts(k, g, None, ..): the Lagrange basis is derived on the GPU (upstream's g_to_lagrange)
+    static ParamsKZG from_parts(Backend &b, uint32_t k, Bases g, bool precompute = true) {
+        h2hip_bases *gl = nullptr;
+        check(h2hip_g1_to_lagrange(b.raw(), g.raw(), k, precompute ? H2HIP_BASES_PRECOMPUTE : H2HIP_BASES_PLAIN, &gl));
+        return ParamsKZG(b, k, std::move(g), Bases(b, gl));
+    }
     uint32_t k() const { return k_; }
     uint64_t n() const { return (uint64_t)1 << k_; }
     G1 commit(const std::vector<Fr> &coeffs) const { return msm(g_, coeffs); }

@@ -104,6 +104,10 @@ int main(int argc, char **argv) {
             }
             if (!threw2) throw Error(-1, "permute: missing table value not reported");
         }
+        if (k <= 12) {   // g_to_lagrange(g) reproduces the setup's Lagrange basis
+            poly::kzg::ParamsKZG derived = poly::kzg::ParamsKZG::from_parts(be, k, Bases(be, params.get_g().download(), false), false);
+            if (!(derived.get_g_lagrange().download() == params.get_g_lagrange().download())) throw Error(-1, "g_to_lagrange");
+        }
         bool threw = false;
         try {
             std::vector<Fr> shorter(coeffs.begin(), coeffs.end() - 1);

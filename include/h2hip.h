@@ -103,6 +103,10 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
  *      the GPU (fixed-base window tables) and stay resident as two base sets; `flags` as in h2hip_bases_upload.
  *      The G2 half (g2, s*g2) is verifier-side and stays with the host library. --------------------------- */
 int h2hip_params_kzg_setup(h2hip_ctx *ctx, uint32_t k, const void *s_fr, uint32_t flags, h2hip_bases **g_out, h2hip_bases **g_lagrange_out);
+/* g_to_lagrange [UPSTREAM poly/kzg/commitment.rs]: Lagrange-basis SRS from the monomial one, g_lagrange[i] = n^-1 * sum_j
+ * omega^(-ij) * g[j] with n = 2^k (group-element inverse FFT on the device) — for SRS sources that carry only g
+ * (ceremony files, ParamsKZG::from_parts(.., None, ..), downsize).  Uses the first 2^k bases of g. */
+int h2hip_g1_to_lagrange(h2hip_ctx *ctx, const h2hip_bases *g, uint32_t k, uint32_t flags, h2hip_bases **g_lagrange_out);
 /* out[i] = scalars[i] * base for a fixed G1Affine base (host pointer); scalars and out are device arrays */
 int h2hip_g1_fixed_base_mul_batch_dev(h2hip_ctx *ctx, const void *base_affine, const void *scalars_dev, size_t n, void *out_affine_dev);
 /* copy the resident affine points back to the host (n x 64 B) — ParamsKZG::write / tests */

@@ -133,3 +133,36 @@ def test_commit_identity_at_k21():
     assert O.limbs_to_points(c1) == [O.g1_mul(O.G1_GEN, mult * acc % R)]
     params.free()
     ctx.close()
+
+
+def _g_to_lagrange_check(ctx, k):
+    """g_to_lagrange(g) must reproduce, bit for bit, the Lagrange basis the setup derives from the known toxic waste
+    (L_i(s)*G by fixed-base multiplications): two independent routes to the same affine points."""
+    params = HP.ParamsKZG.setup(ctx, k, 0x5EED5EED5EED0001 + k, precompute=False)
+    derived = HP.ParamsKZG.from_parts(ctx, k, params.g, None, precompute=False)
+    assert np.array_equal(ctx.bases_download(derived.g_lagrange), ctx.bases_download(params.g_lagrange))
+    vals = rand_fr(1 << k, 3)
+    assert np.array_equal(derived.commit_lagrange(vals, H.POINT_AFFINE), params.commit_lagrange(vals, H.POINT_AFFINE))
+    derived.g_lagrange.free()
+    params.free()
+
+
+def test_g_to_lagrange_emulated():
+    from tests.emu_util import emu_context
+
+    ctx = emu_context()
+    try:
+        _g_to_lagrange_check(ctx, 3)
+        _g_to_lagrange_check(ctx, 5)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 6, 12])
+def test_g_to_lagrange_gpu(k):
+    ctx = H.Context()
+    try:
+        _g_to_lagrange_check(ctx, k)
+    finally:
+        ctx.close()
