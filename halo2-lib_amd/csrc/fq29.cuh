@@ -193,6 +193,25 @@ H2_HD F29<P> f29_mul2(const F29<P> &a, const F29<P> &b, const F29<P> &c2, const 
     }
     return f29_reduce_columns<P>(c);
 }
+// sum_b a[b]*b_[b] * 2^-261 with ONE Montgomery reduction (T <= 5): every input normalised (limbs < 2^29), so a column holds
+// at most 9*T products < 2^58 plus the reduction's 9 * 2^58 (54 * 2^58 < 2^64); sum_b X_a*X_b <= 169.
+template <int T, class P>
+H2_HD F29<P> f29_dot(const F29<P> (&a)[T], const F29<P> (&b)[T]) {
+    static_assert(T >= 1 && T <= 5, "column accumulators would overflow");
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) c[k] = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            H2_ASSERT29(a[t].l[i] <= (1u << 29) && b[t].l[i] <= (1u << 29));
+#pragma unroll
+            for (int j = 0; j < 9; ++j) c[i + j] += (uint64_t)a[t].l[i] * b[t].l[j];
+        }
+    }
+    return f29_reduce_columns<P>(c);
+}
 template <class P>
 H2_HD F29<P> f29_sqr(const F29<P> &a) {
     uint64_t c[18];
@@ -311,6 +330,20 @@ H2_HD Fq f29_to_sat(const Fq29 &v) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) k.l[i] = Q29P::conv_out(i);
     return f29_pack_canonical<FqP>(f29_mul(v, k));   // the product is N and < 1.04 q: at most one subtraction of q
+}
+
+// the same conversions for the scalar field (Poseidon batches, NTT tables)
+H2_HD Fr29 fr29_from_sat(const Fr &s) {   // saturated Montgomery (x*2^256) -> R' = 2^261 form, N, < 1.01 r
+    Fr29 k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k.l[i] = R29P::conv_in(i);
+    return f29_mul(f29_split<R29P>(s), k);
+}
+H2_HD Fr fr29_to_sat(const Fr29 &v) {
+    Fr29 k;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k.l[i] = R29P::conv_out(i);
+    return f29_pack_canonical<FrP>(f29_mul(v, k));
 }
 
 }  // namespace h2

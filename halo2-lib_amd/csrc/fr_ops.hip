@@ -303,45 +303,51 @@ __global__ __launch_bounds__(256) void fr_kate_apply_kernel(const Fr *__restrict
 // One lane per instance, textbook rounds (ARK, x^5, MDS) with the caller's spec — algebraically equal to
 // halo2-base's optimised PoseidonState::permutation (reference halo2-base/src/poseidon/hasher/state.rs:35-83,
 // absorb rule :124-160: inputs added to s[1..], a padding 1 after the last input when fewer than RATE).
+// One lane per permutation, state in the unsaturated R' = 2^261 domain for the whole permutation (converted on entry and
+// exit: 2T of the ~400 products): the S-box is two squarings and a product on lazy sums, and an MDS row is ONE dual...
+// T-fold product with a single Montgomery reduction (f29_dot) instead of T products and T reductions.  rc / mds arrive
+// pre-converted (R' form, packed 8 x 32 bit) from h2hip_poseidon_set_spec.
 template <int T>
 __global__ __launch_bounds__(256) void poseidon_permute_kernel(Fr *__restrict__ states, const Fr *__restrict__ inputs, uint32_t num_inputs,
                                                                size_t n, const Fr *__restrict__ rc, const Fr *__restrict__ mds, uint32_t r_f,
                                                                uint32_t r_p) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr s[T];
+    Fr29 s[T];
 #pragma unroll
-    for (int k = 0; k < T; ++k) s[k] = states[i * T + k];
+    for (int k = 0; k < T; ++k) s[k] = fr29_from_sat(states[i * T + k]);
 #pragma unroll
     for (int k = 0; k < T - 1; ++k) {
-        if ((uint32_t)k < num_inputs) s[k + 1] = fe_add(s[k + 1], inputs[i * num_inputs + k]);
-        else if ((uint32_t)k == num_inputs) s[k + 1] = fe_add(s[k + 1], Fr::one());
+        if ((uint32_t)k < num_inputs) s[k + 1] = f29_norm(f29_add(s[k + 1], fr29_from_sat(inputs[i * num_inputs + k])));
+        else if ((uint32_t)k == num_inputs) s[k + 1] = f29_norm(f29_add(s[k + 1], Fr29::one()));
     }
     const uint32_t half = r_f / 2;
     for (uint32_t r = 0; r < r_f + r_p; ++r) {
         const bool full = r < half || r >= half + r_p;
 #pragma unroll
         for (int k = 0; k < T; ++k) {
-            Fr v = fe_add(s[k], rc[r * T + k]);
+            Fr29 v = f29_add(s[k], f29_split<R29P>(rc[r * T + k]));   // lazy: value < 3.1 r, limbs <= 2^30
             if (full || k == 0) {
-                Fr v2 = fe_sqr(v);
-                v = fe_mul(v, fe_sqr(v2));
+                Fr29 v2 = f29_sqr(v);
+                v = f29_mul(f29_sqr(v2), v);                            // x^5, N, < 1.03 r
+            } else {
+                v = f29_norm(v);
             }
             s[k] = v;
         }
-        Fr o[T];
+        Fr29 o[T];
 #pragma unroll
         for (int a = 0; a < T; ++a) {
-            Fr acc = fe_mul(mds[a * T], s[0]);
+            Fr29 row[T];
 #pragma unroll
-            for (int b = 1; b < T; ++b) acc = fe_add(acc, fe_mul(mds[a * T + b], s[b]));
-            o[a] = acc;
+            for (int b = 0; b < T; ++b) row[b] = f29_split<R29P>(mds[a * T + b]);
+            o[a] = f29_dot<T>(row, s);                                  // sum_b X_a*X_b <= 5 * 1.01 * 3.1 -> < 1.1 r
         }
 #pragma unroll
         for (int k = 0; k < T; ++k) s[k] = o[k];
     }
 #pragma unroll
-    for (int k = 0; k < T; ++k) states[i * T + k] = s[k];
+    for (int k = 0; k < T; ++k) states[i * T + k] = fr29_to_sat(s[k]);
 }
 
 // ------------------------------------------------------------------ K6: halo2-base gate term of the quotient
@@ -595,8 +601,14 @@ int h2hip_poseidon_set_spec(h2hip_ctx *ctx, uint32_t t, uint32_t r_f, uint32_t r
     size_t nrc = (size_t)(r_f + r_p) * t, nm = (size_t)t * t;
     Fr *buf = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_POSEIDON, sizeof(Fr) * (nrc + nm), (void **)&buf));
-    H2_HIPCHK(hipMemcpyAsync(buf, round_constants, sizeof(Fr) * nrc, hipMemcpyHostToDevice, ctx->stream));
-    H2_HIPCHK(hipMemcpyAsync(buf + nrc, mds, sizeof(Fr) * nm, hipMemcpyHostToDevice, ctx->stream));
+    // the kernel multiplies in the unsaturated R' = 2^261 domain: store c * 2^261 (packed 8 x 32 bit) once here
+    std::vector<Fr> conv(nrc + nm);
+    for (size_t j = 0; j < nrc + nm; ++j) {
+        Fr c;
+        memcpy(&c, (const char *)(j < nrc ? round_constants : mds) + sizeof(Fr) * (j < nrc ? j : j - nrc), sizeof(Fr));
+        conv[j] = f29_pack_canonical<FrP>(fr29_from_sat(c));
+    }
+    H2_HIPCHK(hipMemcpyAsync(buf, conv.data(), sizeof(Fr) * (nrc + nm), hipMemcpyHostToDevice, ctx->stream));
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->pos_t = t;
     ctx->pos_rf = r_f;

@@ -30,13 +30,6 @@ struct NttScale {
     Fr out3[3];
 };
 
-// saturated Montgomery (x*2^256) -> unsaturated R' = 2^261 form, normalised, < 1.01 r
-__device__ __forceinline__ Fr29 fr29_from_sat(const Fr &s) {
-    Fr29 k;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) k.l[i] = R29P::conv_in(i);
-    return f29_mul(f29_split<R29P>(s), k);
-}
 
 __global__ void ntt_twiddle_kernel(Fr29L *t1, Fr29L *t2, Fr omega, uint32_t lo_bits, uint32_t hi_count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
