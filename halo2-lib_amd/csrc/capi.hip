@@ -234,6 +234,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_fuse_cols")) return &ctx->msm_fuse_cols;
     if (!strcmp(name, "msm_defer_reduce")) return &ctx->msm_defer_reduce;
     if (!strcmp(name, "lookup_big_tile_bits")) return &ctx->lookup_big_tile_bits;
+    if (!strcmp(name, "fr_invert_run")) return &ctx->fr_invert_run;
     return nullptr;
 }
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
@@ -244,6 +245,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_chunk) H2_REQUIRE(value == 0 || (value >= 2 && value <= 4096), "msm_chunk must be 0 (auto) or 2..4096");
     if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
     if (p == &ctx->msm_fuse_cols) H2_REQUIRE(value >= 0 && value <= (int)MSM_MAX_COLS, "msm_fuse_cols must be 0 (auto) or 1..8");
+    if (p == &ctx->fr_invert_run) H2_REQUIRE(value >= 0 && value <= 1024, "fr_invert_run must be 0 (auto) or 1..1024");
     if (p == &ctx->lookup_big_tile_bits) H2_REQUIRE(value >= 12 && value <= 28, "lookup_big_tile_bits must be 12..28");
     if (p == &ctx->msm_sort_threads) H2_REQUIRE(value == 256 || value == 512 || value == 1024, "msm_sort_threads must be 256, 512 or 1024");
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");

@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void modmul29_bench_kernel(Fr *__restrict__ io
 }
 
 // ------------------------------------------------------------------ K4: BatchInvert (0 -> 0)
-// Montgomery's trick over strided runs: lane t owns a[t], a[t+T], a[t+2T], ... (coalesced), one Fermat
-// inversion per lane.  [UPSTREAM ff::BatchInvert / halo2 batch_invert_assigned; denominators come from
+// Montgomery's trick over strided runs: lane t owns a[t], a[t+T], a[t+2T], ... (coalesced), one inversion
+// (division steps, modinv.cuh) per lane.  [UPSTREAM ff::BatchInvert / halo2 batch_invert_assigned; denominators come from
 // reference halo2-base/src/gates/flex_gate/mod.rs:677-681,791-795]
 __global__ __launch_bounds__(256) void fr_batch_invert_kernel(Fr *__restrict__ a, Fr *__restrict__ scratch, size_t n) {
     const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -501,7 +501,14 @@ int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a, size_t n) {
     if (!n) return H2HIP_OK;
     Fr *scratch = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP1, sizeof(Fr) * n, (void **)&scratch));
-    size_t lanes = (n + 31) / 32;   // ~32 elements per lane
+    // elements per lane: the inversion (division steps, ~50 products' worth of instructions) is cheap enough to spend one
+    // per 8 elements — the dependent chain per lane (3 products per element + the inversion) is what the kernel waits for
+    size_t per_lane = (size_t)ctx->fr_invert_run;
+    if (per_lane < 1) {   // auto: about 2^16 lanes (measured optimum: 4 at 2^16, 8 at 2^19, 16-32 at 2^21; tools/invert_sweep.py)
+        per_lane = n >> 16;
+        per_lane = per_lane < 4 ? 4 : per_lane > 32 ? 32 : per_lane;
+    }
+    size_t lanes = (n + per_lane - 1) / per_lane;
     uint32_t blocks = (uint32_t)((lanes + 255) / 256);
     prof_begin(ctx, "fr_batch_invert_kernel");
     hipLaunchKernelGGL(fr_batch_invert_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (Fr *)a, scratch, n);

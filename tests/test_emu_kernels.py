@@ -254,6 +254,19 @@ def test_unsaturated_arithmetic_against_saturated(tmp_path):
     assert out.returncode == 0 and "fq29 selftest OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_division_step_inversion_matches_fermat(tmp_path):
+    """modinv.cuh (Bernstein-Yang division steps, the product's fe_inv) vs Fermat's a^(p-2) on the host, both fields"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "modinv_selftest")
+    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-x", "c++", "-std=c++17", "-O2", "-I", os.path.join(root, "tests", "emu"),
+                           "-Wno-unused-value", "-o", exe, os.path.join(root, "tests", "emu", "modinv_selftest.cpp"), "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "modinv selftest OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def _quotient_identity_checks(ctx, k, ek):
     ne, step = 1 << ek, 1 << (ek - k)
     rs = lambda seed: O.random_scalars(ne, seed)
