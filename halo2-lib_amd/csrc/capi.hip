@@ -233,6 +233,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_sort_threads")) return &ctx->msm_sort_threads;
     if (!strcmp(name, "msm_fuse_cols")) return &ctx->msm_fuse_cols;
     if (!strcmp(name, "msm_defer_reduce")) return &ctx->msm_defer_reduce;
+    if (!strcmp(name, "msm_quad_seg_max")) return &ctx->msm_quad_seg_max;
     if (!strcmp(name, "lookup_big_tile_bits")) return &ctx->lookup_big_tile_bits;
     if (!strcmp(name, "fr_invert_run")) return &ctx->fr_invert_run;
     return nullptr;

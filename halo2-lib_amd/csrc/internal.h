@@ -98,6 +98,7 @@ struct h2hip_ctx {
     int msm_lanes = 3;   // lanes used by h2hip_msm_g1_batch_dev (1..4)
     int fr_invert_run = 0;           // elements per lane (= per inversion) in h2hip_fr_batch_invert_dev; 0 = auto (n / 2^16 in 4..32)
     int lookup_big_tile_bits = 19;   // lookup sort: 4096-key LDS tiles from 2^bits padded keys (12..28), 1024-key tiles below
+    int msm_quad_seg_max = 32768;   // bucket reduction: quad-lane kernels up to this many segments (latency-bound), one-lane kernels above
     int msm_defer_reduce = 1;   // batch API, precomputed bases, > 2^17 points: one bucket reduction for all columns after the lanes join
     int msm_fuse_cols = 0;   // columns fused into one multi-column MSM by h2hip_msm_g1_batch_dev (precomputed bases): 0 = auto (4 up to 2^17 points, else 1)
     hipEvent_t fork_ev = nullptr;

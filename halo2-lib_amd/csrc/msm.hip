@@ -734,7 +734,7 @@ int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t c, const 
     }
     // quad-lane arithmetic pays when the stage is latency-bound (few segments: precomputed bases); with 16 windows'
     // worth of segments the stage is throughput-bound and the one-lane kernels win — the 2^(c*w) fold is always a chain
-    const bool quad_reduce = ctx->msm_quad_tails && nseg <= 16384;
+    const bool quad_reduce = ctx->msm_quad_tails && nseg <= (uint32_t)ctx->msm_quad_seg_max;
     if (quad_reduce) {
         uint32_t lo_bits = 0;   // bits needed for a segment's first bucket index (< B)
         while ((1u << lo_bits) < B) ++lo_bits;
