@@ -94,7 +94,7 @@ H2_HD void xyzz29_add_affine(XYZZ29 &acc, const Fq29 &x2, const Fq29 &y2, bool n
     Fq29 t = f29_norm(f29_add(f29_add(PPP, Q), Q));           // < 3.14
     Fq29 X3 = f29_sub<4>(R2, t);                              // < 5.22
     // Y3 = Rd*(Q - X3) - Y1*PPP as ONE reduction: Rd*(Q - X3 + 6q) + (4q - Y1)*PPP   (42.2 + 4.3 -> < 1.28 q)
-    Fq29 Y3 = f29_mul2(Rd, f29_sub<6>(Q, X3), f29_neg<4>(acc.y), PPP);
+    Fq29 Y3 = f29_mul2(Rd, f29_sub_lazy<6>(Q, X3), f29_sub_lazy<4>(Fq29::zero(), acc.y), PPP);   // lazy operands: no carry passes
     acc.x = X3;
     acc.y = Y3;
     acc.zz = f29_mul(acc.zz, PP);

@@ -175,8 +175,9 @@ H2_HD F29<P> f29_mul_wide(const F29<P> &a, const F29<P> &b) {
     }
     return f29_reduce_columns<P>(c);
 }
-// (a*b + c*d) * 2^-261 with ONE Montgomery reduction: all four inputs must be normalised (limbs < 2^29), so a column
-// holds at most 18 products < 2^58 (2^62.2) plus the reduction's 9 * 2^58; X_a*X_b + X_c*X_d <= 169.
+// (a*b + c*d) * 2^-261 with ONE Montgomery reduction.  a and d must be normalised (limbs < 2^29); b and c may be LAZY
+// differences of normalised values (f29_sub_lazy: limbs < 2^29 + 2^30): a column then holds at most
+// 9 * 2^29 * 1.5 * 2^30 + 9 * 2^30 * 2^29 = 11.25 * 2^60 plus the reduction's 9 * 2^58 < 2^64.  X_a*X_b + X_c*X_d <= 169.
 template <class P>
 H2_HD F29<P> f29_mul2(const F29<P> &a, const F29<P> &b, const F29<P> &c2, const F29<P> &d) {
     uint64_t c[18];
@@ -184,7 +185,7 @@ H2_HD F29<P> f29_mul2(const F29<P> &a, const F29<P> &b, const F29<P> &c2, const 
     for (int k = 0; k < 18; ++k) c[k] = 0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        H2_ASSERT29(a.l[i] < (1u << 29) + (i == 8 ? (1u << 29) : 0) && b.l[i] <= (1u << 29) && c2.l[i] <= (1u << 29) && d.l[i] <= (1u << 29));
+        H2_ASSERT29(a.l[i] < (1u << 29) + (i == 8 ? (1u << 29) : 0) && b.l[i] < (3u << 29) && c2.l[i] <= (1u << 30) && d.l[i] <= (1u << 29));
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             c[i + j] += (uint64_t)a.l[i] * b.l[j];
