@@ -236,3 +236,39 @@ def test_gpu_matches_committed_golden_fixtures(ctx):
     from tests.golden_checks import check_backend_against_golden
 
     check_backend_against_golden(ctx)
+
+
+def test_msm_randomized_shapes(ctx):
+    """differential test over random sizes / base kinds / scalar distributions / batch shapes (fused, deferred, per-lane)"""
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    rng = np.random.default_rng(20260925)
+    nmax = 40000
+    bases_all = CO.known_dlog_bases(nmax, fr([4242]), fr([17]))
+    for case in range(10):
+        n = int(rng.integers(1, nmax))
+        flags = BASES_PRECOMPUTE if rng.integers(0, 2) else 0
+        cols = []
+        for j in range(int(rng.integers(1, 7))):
+            kind = int(rng.integers(0, 4))
+            s = rand_fr(n, 100 * case + j) if kind == 0 else circuit_like_fr(n, 100 * case + j)
+            if kind == 2:
+                s[: n // 2] = s[0]                       # one scalar repeated: long runs in one bucket
+            if kind == 3:
+                s[rng.integers(0, n, size=max(1, n // 3))] = 0
+            cols.append(s)
+        b = ctx.bases_upload(bases_all[:n], flags)
+        want = [CO.best_multiexp(s, bases_all[:n], threads=8) for s in cols]
+        assert np.array_equal(ctx.msm(b, cols[0], H.POINT_AFFINE), want[0]), (case, n, flags)
+        dptrs = [ctx.to_device(s) for s in cols]
+        for fuse, defer in ((0, 1), (1, 1), (1, 0), (3, 1)):
+            ctx.set_param("msm_fuse_cols", fuse)
+            ctx.set_param("msm_defer_reduce", defer)
+            got = ctx.msm_batch_dev(b, dptrs, n, H.POINT_AFFINE)
+            for j in range(len(cols)):
+                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, j)
+        ctx.set_param("msm_fuse_cols", 0)
+        ctx.set_param("msm_defer_reduce", 1)
+        for d in dptrs:
+            ctx.free(d)
+        b.free()
