@@ -348,3 +348,31 @@ def test_emulated_kernels_match_committed_golden_fixtures(ctx):
     from tests.golden_checks import check_backend_against_golden
 
     check_backend_against_golden(ctx)
+
+
+def test_msm_randomized_shapes_emulated(ctx):
+    """small-size twin of the GPU suite's randomized differential test (sizes, base kinds, distributions, batch shapes)"""
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    rng = np.random.default_rng(77)
+    nmax = 1500
+    bases_all = CO.known_dlog_bases(nmax, fr([99]), fr([5]))
+    for case in range(4):
+        n = int(rng.integers(1, nmax))
+        flags = BASES_PRECOMPUTE if case % 2 else 0
+        cols = [rand_fr(n, 10 * case), circuit_like_fr(n, 10 * case + 1), rand_fr(n, 10 * case + 2)]
+        cols[2][: n // 2] = cols[2][0]
+        b = ctx.bases_upload(bases_all[:n], flags)
+        want = [CO.best_multiexp(s, bases_all[:n], threads=4) for s in cols]
+        dptrs = [ctx.to_device(s) for s in cols]
+        for fuse, defer in ((0, 1), (1, 1), (1, 0)):
+            ctx.set_param("msm_fuse_cols", fuse)
+            ctx.set_param("msm_defer_reduce", defer)
+            got = ctx.msm_batch_dev(b, dptrs, n, H.POINT_AFFINE)
+            for j in range(len(cols)):
+                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, j)
+        ctx.set_param("msm_fuse_cols", 0)
+        ctx.set_param("msm_defer_reduce", 1)
+        for d in dptrs:
+            ctx.free(d)
+        b.free()
