@@ -49,6 +49,7 @@ extern "C" {
     pub fn h2hip_bases_download(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, out_host: *mut c_void) -> c_int;
     pub fn h2hip_msm_g1(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_host: *const c_void, n: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     pub fn h2hip_msm_g1_dev(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_dev: *const c_void, n: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
+    pub fn h2hip_msm_g1_batch(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_host: *const *const c_void, n: usize, count: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     pub fn h2hip_msm_g1_batch_dev(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_dev: *const *const c_void, n: usize, count: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     pub fn h2hip_g1_sum_jacobian_dev(ctx: *mut h2hip_ctx, points_dev: *const c_void, n: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     // a2 — ParamsKZG::setup

@@ -437,9 +437,9 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
 // Several independent MSMs over the same bases (e.g. the h(X) pieces, or all advice columns of a phase): MSM j runs
 // on lane j mod 2 — a child context with its own stream and scratch — so the latency-bound tail of one MSM (merge,
 // bucket reduction) overlaps the multiplier-bound accumulation of the next.
-int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count, int point_format,
-                           void *out_host) {
-    H2_REQUIRE(ctx && bases && (count == 0 || (scalars_dev && out_host)), "NULL argument");
+static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_in, bool scalars_on_host, size_t n, size_t count,
+                          int point_format, void *out_host) {
+    H2_REQUIRE(ctx && bases && (count == 0 || (scalars_in && out_host)), "NULL argument");
     H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
     if (!count) return H2HIP_OK;
     const bool affine = point_format == H2HIP_POINT_AFFINE;
@@ -486,11 +486,24 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
         keys_per_col = (size_t)((255 + cw - 1) / cw) << (cw - 1);
         H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH_BUCKETS, sizeof(XYZZ29) * keys_per_col * count, (void **)&all_buckets));
     }
+    // host columns: one staging area for all of them; column j is copied on its lane's stream right before its kernels are
+    // queued, so the (host-blocking, pageable) copy of column j+1 overlaps the GPU work of column j
+    std::vector<const void *> staged(count, nullptr);
+    const void *const *scalars_dev = scalars_in;
+    if (scalars_on_host && n) {
+        char *stage = nullptr;
+        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_STAGE, sizeof(Fr) * n * count, (void **)&stage));
+        for (size_t j = 0; j < count; ++j) staged[j] = stage + sizeof(Fr) * n * j;
+        scalars_dev = staged.data();
+    }
     const size_t ngroups = (count + fuse - 1) / fuse;
     for (size_t g = 0, j0 = 0; g < ngroups; ++g) {
         const size_t gsize = (count - j0 + (ngroups - g) - 1) / (ngroups - g);   // balanced group sizes
         h2hip_ctx *c = ctx->lane[g % NL];
-        for (size_t j = j0; j < j0 + gsize; ++j) H2_REQUIRE(n == 0 || scalars_dev[j], "NULL scalar column");
+        for (size_t j = j0; j < j0 + gsize; ++j) {
+            H2_REQUIRE(n == 0 || scalars_in[j], "NULL scalar column");
+            if (scalars_on_host && n) H2_HIPCHK(hipMemcpyAsync((void *)staged[j], scalars_in[j], sizeof(Fr) * n, hipMemcpyHostToDevice, c->stream));
+        }
         char *outbuf = nullptr;
         H2_CHK(ws_reserve(c, h2hip_ctx::WS_OUT, 2048, (void **)&outbuf));
         H2_CHK(msm_run_cols(c, bases, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
@@ -532,6 +545,15 @@ int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void 
             ctx->lane[l]->stats.clear();
         }
     return H2HIP_OK;
+}
+
+int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count, int point_format,
+                           void *out_host) {
+    return msm_batch_impl(ctx, bases, scalars_dev, false, n, count, point_format, out_host);
+}
+int h2hip_msm_g1_batch(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_host, size_t n, size_t count, int point_format,
+                       void *out_host) {
+    return msm_batch_impl(ctx, bases, scalars_host, true, n, count, point_format, out_host);
 }
 
 int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host) {

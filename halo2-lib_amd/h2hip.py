@@ -44,6 +44,7 @@ _PROTOS = {
     "h2hip_bases_len": (_sz, [_vp]),
     "h2hip_msm_g1": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "h2hip_msm_g1_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
+    "h2hip_msm_g1_batch": (_int, [_vp, _vp, C.POINTER(_vp), _sz, _sz, _int, _vp]),
     "h2hip_msm_g1_batch_dev": (_int, [_vp, _vp, C.POINTER(_vp), _sz, _sz, _int, _vp]),
     "h2hip_g1_to_lagrange": (_int, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),
     "h2hip_params_kzg_setup": (_int, [_vp, _u32, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp)]),
@@ -290,6 +291,16 @@ class Context:
         arr = (_vp * count)(*[_vp(int(p)) for p in scalar_dptrs])
         out = np.zeros((count, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
         self._chk(self.lib.h2hip_msm_g1_batch_dev(self.handle, bases.handle, arr, n, count, point_format, _ptr(out)))
+        return out
+
+    def msm_batch(self, bases: Bases, scalar_columns, point_format: int = POINT_JACOBIAN) -> np.ndarray:
+        """the same with the scalar columns in host memory (equal lengths): column j+1 is uploaded while column j computes"""
+        cols = [_fe(c) for c in scalar_columns]
+        count, n = len(cols), (len(cols[0]) if cols else 0)
+        assert all(len(c) == n for c in cols)
+        arr = (_vp * count)(*[_vp(c.ctypes.data) for c in cols])
+        out = np.zeros((count, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
+        self._chk(self.lib.h2hip_msm_g1_batch(self.handle, bases.handle, arr, n, count, point_format, _ptr(out)))
         return out
 
     # -- NTT family (arithmetic::best_fft, EvaluationDomain::*)

@@ -97,6 +97,10 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
  * pipelined over two internal streams so that one MSM's latency-bound tail overlaps the next one's accumulation. */
 int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count,
                            int point_format, void *out_host);
+/* the same for scalar columns in HOST memory (an unmodified prover's Vec<Fr>): each column is uploaded on its lane's stream
+ * right before its kernels are queued, so the upload of column j+1 overlaps the GPU work of column j */
+int h2hip_msm_g1_batch(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_host, size_t n, size_t count, int point_format,
+                       void *out_host);
 
 /* ---- a2: KZG SRS (ParamsKZG::<Bn256>::setup [UPSTREAM]; reference gen_srs halo2-base/src/utils/mod.rs:439-443,
  *      halo2-base/benches/mul.rs:39).  g[i] = s^i*G1 and g_lagrange[i] = L_i(s)*G1 for i < 2^k are generated on

@@ -221,6 +221,7 @@ def test_msm_batch_pipelined(ctx):
         assert np.array_equal(got[j:j + 1], CO.best_multiexp(c, bases, threads=2))
     gotj = ctx.msm_batch_dev(b, dptrs[:2], n, H.POINT_JACOBIAN)
     assert [jac_to_affine_ints(gotj[0])] == O.limbs_to_points(got[0:1])
+    assert np.array_equal(ctx.msm_batch(b, cols, H.POINT_AFFINE), got)   # host columns: staged per lane
     # precomputed tables: the columns are fused into multi-column MSMs (msm_fuse_cols per group, groups over the lanes)
     from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
 

@@ -260,6 +260,7 @@ def test_msm_randomized_shapes(ctx):
         b = ctx.bases_upload(bases_all[:n], flags)
         want = [CO.best_multiexp(s, bases_all[:n], threads=8) for s in cols]
         assert np.array_equal(ctx.msm(b, cols[0], H.POINT_AFFINE), want[0]), (case, n, flags)
+        assert np.array_equal(ctx.msm_batch(b, cols, H.POINT_AFFINE), np.concatenate(want)), (case, n, flags, "host columns")
         dptrs = [ctx.to_device(s) for s in cols]
         for fuse, defer in ((0, 1), (1, 1), (1, 0), (3, 1)):
             ctx.set_param("msm_fuse_cols", fuse)
