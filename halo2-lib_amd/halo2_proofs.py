@@ -170,6 +170,14 @@ class ParamsKZG:
             raise AssertionError("assertion failed: bases.len() >= size")
         return self.ctx.msm(self.g_lagrange, values, point_format)
 
+    def commit_many(self, polys, lagrange: bool = False, point_format: int = POINT_JACOBIAN) -> np.ndarray:
+        """the commitments of one prover round (equal-length host polynomials) as ONE batch call: uploads overlapped with
+        compute, sort / accumulation pipelined over lanes, one joint bucket reduction"""
+        cols = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in polys]
+        if any(len(c) > self.n for c in cols):
+            raise AssertionError("assertion failed: bases.len() >= size")
+        return self.ctx.msm_batch(self.g_lagrange if lagrange else self.g, cols, point_format)
+
     # SerdeFormat::RawBytes layout [UPSTREAM-RECALL, unverified for 0.5.3 — SURVEY.md A.8]:
     # u32 k (LE) | g[0..n) 64 B each | g_lagrange[0..n) 64 B each | g2 128 B | s_g2 128 B
     def write(self, path: str):

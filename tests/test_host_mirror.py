@@ -33,6 +33,11 @@ def _run_all(ctx, k, tmp_path):
     assert np.array_equal(HP.kate_division(ctx, coeffs, x), CO.fr_kate_division(coeffs, x))
     with pytest.raises(AssertionError):
         HP.best_fft(ctx, coeffs[:-1], w, k)
+    pm = HP.ParamsKZG.setup(ctx, k, 0xC0FFEE, precompute=True)
+    many = pm.commit_many([vals, coeffs, vals], lagrange=True, point_format=H.POINT_AFFINE)
+    assert np.array_equal(many[0:1], pm.commit_lagrange(vals, H.POINT_AFFINE)) and np.array_equal(many[1:2], pm.commit_lagrange(coeffs, H.POINT_AFFINE))
+    assert np.array_equal(many[2], many[0])
+    pm.free()
     # ParamsKZG: commit_lagrange(values) == commit(coeffs) == p(s)*G  (closed form for SRS-shaped bases)
     s = 0x1234567890ABCDEF1234567890ABCDEF
     for pre in (False, True):
