@@ -301,9 +301,11 @@ def _fr_from_ints(vals):
 
 
 def replay_ecdsa_k19(ctx, torch, dev):
+    import ctypes as C
+
     """GPU part of create_proof for the k=19 secp256k1-ECDSA circuit shape (SURVEY.md §3.2: 1 advice column + lookup,
     degree 5 -> extended_k = 21): 12 MSMs of 2^19 (5 on g_lagrange incl. the 0/1-heavy advice column, 7 on g),
-    the lookup's permute_expression_pair over 2^19 rows, 5 iNTTs of 2^19, 5 coset-NTTs to 2^21, the gate term of h(X), 1 coset-iNTT of 2^21, batch inversion and the grand
+    the lookup's permute_expression_pair over 2^19 rows, 5 iNTTs of 2^19, 5 coset-NTTs to 2^21, the gate / permutation / lookup terms of h(X) and the division by the vanishing polynomial, 1 coset-iNTT of 2^21, batch inversion and the grand
     products, evaluations and one quotient division.  Host-side work of the real prover (witness generation,
     transcript) is NOT included: this is the kernel sequence only, on synthetic columns."""
     from halo2_lib_amd import halo2_proofs as HP
@@ -346,6 +348,16 @@ def replay_ecdsa_k19(ctx, torch, dev):
             ctx.coeff_to_extended_dev(c.data_ptr(), k, e.data_ptr(), ek, dom.extended_omega, dom.g_coset)
         ctx._chk(ctx.lib.h2hip_quotient_flex_gate_dev(ctx.handle, d_acc.data_ptr(), d_ext[1].data_ptr(), d_ext[0].data_ptr(), ek, k,
                                                       y.ctypes.data))
+        # one permutation set over three columns and the lookup argument's identities (synthetic operands of the right shape)
+        e = [t.data_ptr() for t in d_ext]
+        cols3, sig3 = (C.c_void_p * 3)(e[0], e[1], e[2]), (C.c_void_p * 3)(e[2], e[3], e[4])
+        ctx._chk(ctx.lib.h2hip_quotient_permutation_set_dev(ctx.handle, d_acc.data_ptr(), e[3], None, cols3, sig3, 3, 0, e[4], e[4], e[4], ek, k,
+                                                            1 | 2 | 8, -6, y.ctypes.data, x.ctypes.data, y.ctypes.data, dom.g_coset.ctypes.data,
+                                                            dom.extended_omega.ctypes.data, y.ctypes.data))
+        ctx._chk(ctx.lib.h2hip_quotient_lookup_dev(ctx.handle, d_acc.data_ptr(), e[0], e[1], e[2], e[3], e[4], e[4], e[4], e[4], ek, k,
+                                                   y.ctypes.data, x.ctypes.data, y.ctypes.data))
+        ctx._chk(ctx.lib.h2hip_divide_by_vanishing_poly_dev(ctx.handle, d_acc.data_ptr(), ek, k, dom.extended_omega.ctypes.data,
+                                                            dom.g_coset.ctypes.data))
         ctx.extended_to_coeff_dev(d_acc.data_ptr(), ek, dom.extended_omega_inv, dom.extended_ifft_divisor, dom.g_coset_inv)
         pieces = [d_acc.data_ptr() + i * n * 32 for i in range(4)]            # h(X) pieces
         ctx.msm_batch_dev(params.g, pieces + ptrs[:3], n)                      # 7 monomial-basis commitments
@@ -365,7 +377,7 @@ def replay_ecdsa_k19(ctx, torch, dev):
     cells = usable   # advice cells of the 1-column k=19 shape (unusable_rows = 20, halo2-ecc/src/secp256k1/tests/ecdsa.rs:121-128)
     params.free()
     return {"what": "GPU kernel sequence of create_proof for the k=19 ECDSA shape (12 MSM 2^19, 5 iNTT 2^19, 5 coset-NTT 2^21, 1 coset-iNTT 2^21, "
-                    "lookup permute_expression_pair, batch inversion, grand products, gate term, evaluations, quotient division); host work (witness gen, transcript) excluded",
+                    "lookup permute_expression_pair, batch inversion, grand products, gate / permutation / lookup terms of h(X), division by the vanishing polynomial, evaluations, quotient division); host work (witness gen, transcript) excluded",
             "seconds": sec, "constraints": cells, "constraints_per_sec_gpu_part": cells / sec,
             "reference_published_total_proof_time_s": 7.6, "reference_source": "/root/reference/README.md:242 (32 vCPU r6a / M2 Max, end-to-end incl. witness generation)"}
 
