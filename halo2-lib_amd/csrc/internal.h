@@ -102,6 +102,7 @@ struct h2hip_ctx {
     int msm_defer_reduce = 1;   // batch API, precomputed bases, > 2^17 points: one bucket reduction for all columns after the lanes join
     int msm_fuse_cols = 0;   // columns fused into one multi-column MSM by h2hip_msm_g1_batch_dev (precomputed bases): 0 = auto (4 up to 2^17 points, else 1)
     hipEvent_t fork_ev = nullptr;
+    bool msm_lds_attr_set = false, lookup_lds_attr_set = false;   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 };
 
 struct h2hip_bases {

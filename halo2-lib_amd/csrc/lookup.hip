@@ -148,10 +148,9 @@ static int bitonic_sort_tiled(h2hip_ctx *ctx, Key256 *keys, uint32_t N) {
     hipStream_t st = ctx->stream;
     const uint32_t tiles = N / LK_TILE;
     const size_t lds = sizeof(Key256) * LK_TILE;
-    static bool lds_attr_set = false;   // dynamic LDS above 64 KiB has to be enabled once per kernel
-    if (!lds_attr_set && lds > (64u << 10)) {
+    if (!ctx->lookup_lds_attr_set && lds > (64u << 10)) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
         H2_HIPCHK(hipFuncSetAttribute((const void *)lk_bitonic_local_kernel<LK_TILE, LK_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr_set = true;
+        ctx->lookup_lds_attr_set = true;
     }
     hipLaunchKernelGGL((lk_bitonic_local_kernel<LK_TILE, LK_THREADS>), dim3(tiles), dim3(LK_THREADS), lds, st, keys, 2u, LK_TILE);
     for (uint32_t k = LK_TILE << 1; k <= N && k != 0; k <<= 1) {

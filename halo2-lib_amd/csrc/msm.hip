@@ -834,11 +834,10 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     }
     prof_end(ctx);
     const uint32_t sort_threads = (uint32_t)ctx->msm_sort_threads;
-    static bool lds_attr_set = false;   // dynamic LDS above 64 KiB has to be enabled per kernel once
-    if (!lds_attr_set) {
+    if (!ctx->msm_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
         H2_HIPCHK(hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
         H2_HIPCHK(hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
-        lds_attr_set = true;
+        ctx->msm_lds_attr_set = true;
     }
     prof_begin(ctx, "msm_hist_kernel");
     hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * B, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
