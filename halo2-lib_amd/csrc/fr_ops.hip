@@ -403,6 +403,7 @@ struct PermArgs {
     Fr beta, gamma, delta, y;
     Fr x0_delta;   // beta * zeta * delta^(first column index of this set): the X-term coefficient at extended point 0
     Fr ext_omega;
+    Fr xstep;      // ext_omega^(grid stride), computed on the host
 };
 // terms for one permutation set i: [first set] l0*(1-z) ; [last set] l_last*(z^2-z) ; [i>0] l0*(z_i - z_{i-1}(w^last X)) ;
 //        active*( z(wX) prod_j(p_j + beta*s_j + gamma) - z(X) prod_j(p_j + delta^j*beta*X + gamma) ),  X = zeta*w_ext^i
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void quotient_permutation_kernel(Fr *__restric
     const Fr one = Fr::one();
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr xbase = fe_mul(g.x0_delta, fe_pow_u64(g.ext_omega, (uint64_t)i0));   // beta * delta^j0 * zeta * w_ext^i
-    const Fr xstep = fe_pow_u64(g.ext_omega, (uint64_t)stride);
+    const Fr xstep = g.xstep;
     for (size_t i = i0; i < ne; i += stride, xbase = fe_mul(xbase, xstep)) {
         const size_t inext = (i + step) & mask;
         Fr z = g.z[i], l0 = g.l0[i], ll = g.l_last[i];
@@ -671,6 +672,19 @@ __global__ __launch_bounds__(256) void divide_by_vanishing_kernel(Fr *__restrict
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ext; i += stride) a[i] = fe_mul(a[i], tinv[i & mask]);
 }
+struct VanishSmall {
+    Fr v[8];
+};
+__global__ __launch_bounds__(256) void divide_by_vanishing_small_kernel(Fr *__restrict__ a, VanishSmall t, size_t n_ext, uint32_t mask) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ext; i += stride) {
+        Fr f = t.v[0];
+#pragma unroll
+        for (uint32_t k = 1; k < 8; ++k)
+            if ((i & mask) == k) f = t.v[k];
+        a[i] = fe_mul(a[i], f);
+    }
+}
 int h2hip_divide_by_vanishing_poly_dev(h2hip_ctx *ctx, void *a, uint32_t ext_k, uint32_t k, const void *ext_omega, const void *zeta) {
     H2_REQUIRE(ctx && a && ext_omega && zeta, "NULL argument");
     H2_REQUIRE(k <= ext_k && ext_k <= 28 && ext_k - k <= 16, "need k <= ext_k <= 28 and ext_k - k <= 16");
@@ -682,9 +696,20 @@ int h2hip_divide_by_vanishing_poly_dev(h2hip_ctx *ctx, void *a, uint32_t ext_k, 
     Fr *tinv;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_VANISH, sizeof(Fr) * L, (void **)&tinv));
     prof_begin(ctx, "divide_by_vanishing_kernels");
-    hipLaunchKernelGGL(vanishing_inverses_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, tinv, L, fe_pow_u64(z, n), fe_pow_u64(w, n));
+    const Fr zn = fe_pow_u64(z, n), wn = fe_pow_u64(w, n);
     size_t n_ext = (size_t)1 << ext_k;
-    hipLaunchKernelGGL(divide_by_vanishing_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)a, (const Fr *)tinv, n_ext, L - 1);
+    if (L <= 8) {   // the usual case (ext_k - k <= 3): the few inverses are computed on the host and travel as kernel arguments
+        VanishSmall t;
+        Fr cur = zn;
+        for (uint32_t i = 0; i < 8; ++i) {
+            t.v[i] = i < L ? fe_inv(fe_sub(cur, Fr::one())) : Fr::zero();
+            cur = fe_mul(cur, wn);
+        }
+        hipLaunchKernelGGL(divide_by_vanishing_small_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)a, t, n_ext, L - 1);
+    } else {
+        hipLaunchKernelGGL(vanishing_inverses_kernel, dim3((L + 63) / 64), dim3(64), 0, ctx->stream, tinv, L, zn, wn);
+        hipLaunchKernelGGL(divide_by_vanishing_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)a, (const Fr *)tinv, n_ext, L - 1);
+    }
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
@@ -737,8 +762,13 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z,
     g.last_rot_points = (uint32_t)(((uint64_t)rot * step) & (ne - 1));
     g.beta = ld_fr(beta); g.gamma = ld_fr(gamma); g.delta = ld_fr(delta); g.y = ld_fr(y); g.ext_omega = ld_fr(ext_omega);
     g.x0_delta = fe_mul(fe_mul(g.beta, ld_fr(zeta)), fe_pow_u64(g.delta, first_col_index));
+    // 8 extended points per lane: the per-lane start-up (ext_omega^i0, ~28 products) is amortised, the stride power is one
+    // host-side exponentiation
+    uint32_t pgrid = (uint32_t)((ne / 8 + 255) / 256);
+    if (pgrid < 1) pgrid = 1;
+    g.xstep = fe_pow_u64(g.ext_omega, (uint64_t)pgrid * 256);
     prof_begin(ctx, "quotient_permutation_kernel");
-    hipLaunchKernelGGL(quotient_permutation_kernel, dim3(grid_for(ctx, ne)), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
+    hipLaunchKernelGGL(quotient_permutation_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;

@@ -377,3 +377,14 @@ def test_msm_randomized_shapes_emulated(ctx):
         for d in dptrs:
             ctx.free(d)
         b.free()
+
+
+@pytest.mark.parametrize("k,ek", [(3, 5), (2, 6), (0, 3)])
+def test_divide_by_vanishing_poly(ctx, k, ek):
+    """a[i] / ((zeta * w_ext^i)^n - 1): the few-inverses path (ext_k - k <= 3, kernel arguments) and the table path"""
+    ne, n = 1 << ek, 1 << k
+    a = O.random_scalars(ne, 3)
+    we = O.omega_for(ek)
+    got = ctx.divide_by_vanishing_poly(fr(a), ek, k, fr([we]), fr([O.ZETA]))
+    want = [v * O.inv_mod((pow(O.ZETA * pow(we, i, R) % R, n, R) - 1) % R, R) % R for i, v in enumerate(a)]
+    assert O.limbs_to_ints(got, R) == want
