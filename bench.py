@@ -4,8 +4,9 @@ bench.py — headline benchmark of the MI355X prover backend (contract: see the 
 
 Workload (BASELINE.json configs[1]): one step = one 2^20-point BN254 G1 Pippenger MSM
 (`h2hip_msm_g1_dev`: scalars and bases already resident in HBM, the Jacobian result is returned to the
-host like arithmetic::best_multiexp returns C::Curve).  Synthetic data: uniformly random scalars; bases
-are 4096 distinct curve points (built here in pure Python) tiled with random signs to 2^20.
+host like arithmetic::best_multiexp returns C::Curve).  Synthetic data: uniformly random scalars (a distinct
+column per MSM of a batch); bases are 2^20 DISTINCT points P_i = (k0 + i*d)*G built on the GPU, whose known discrete
+logs give the closed form (sum_i s_i*(k0+i*d))*G against which the last timed batch is verified in-run.
 
   value      = G1-adds/s over the whole job, with the add count defined by SURVEY.md §8d:
                adds(n) = n*W + 2*W*2^(c-1) for the window the kernel actually used (c, W reported).
@@ -56,24 +57,63 @@ def _limbs(vals, p):
     return out
 
 
-def synthetic_bases(n: int, seed: int) -> np.ndarray:
-    """n valid G1Affine points: 4096 distinct multiples of G=(1,2) tiled with random signs."""
-    m = min(n, 4096)
-    pts, P = [], (1, 2)
-    step = _g1_add(_g1_add((1, 2), (1, 2)), (1, 2))   # 3G
-    for _ in range(m):
-        pts.append(P)
-        P = _g1_add(P, step)
-    xs = _limbs([p[0] for p in pts], Q)
-    ys = _limbs([p[1] for p in pts], Q)
-    ysn = _limbs([(-p[1]) % Q for p in pts], Q)
-    g = np.random.default_rng(seed)
-    idx = g.integers(0, m, size=n)
-    sign = g.integers(0, 2, size=n).astype(bool)
-    out = np.empty((n, 8), dtype=np.uint64)
-    out[:, :4] = xs[idx]
-    out[:, 4:] = np.where(sign[:, None], ysn[idx], ys[idx])
-    return out
+def _g1_mul(k: int, P=(1, 2)):
+    """k*P by double-and-add in affine big-int arithmetic (None = identity); used only to verify the timed results"""
+    acc = None
+    for bit in bin(k % R)[2:] if k % R else "":
+        acc = None if acc is None else _g1_add(acc, acc)
+        if bit == "1":
+            acc = P if acc is None else _g1_add(acc, P)
+    return acc
+
+
+def known_dlog_bases_gpu(ctx, torch, dev, n: int, k0: int, d: int, first_index: int = 0):
+    """n DISTINCT bases P_i = (k0 + (first_index + i)*d) * G built on the GPU (h2hip_g1_fixed_base_mul_batch_dev); returns a device
+    tensor of n G1Affine points.  Because the discrete logs are known, an MSM over them has the closed form
+    (sum_i s_i*(k0 + i*d)) * G, which bench.py uses to verify the timed results without any CPU MSM."""
+    assert k0 + (first_index + n) * d < 1 << 63
+    e = np.zeros((n, 4), dtype=np.uint64)
+    e[:, 0] = np.uint64(k0) + (np.uint64(first_index) + np.arange(n, dtype=np.uint64)) * np.uint64(d)   # canonical integers
+    r2 = _limbs([1 << 256], R)                                                       # Montgomery form of R: x (*) R^2 = x*R
+    d_e = torch.from_numpy(e.view(np.int64)).to(dev)
+    d_r2 = torch.from_numpy(np.repeat(r2, n, axis=0).view(np.int64)).to(dev)
+    ctx._chk(ctx.lib.h2hip_fr_mul_batch_dev(ctx.handle, d_e.data_ptr(), d_e.data_ptr(), d_r2.data_ptr(), n))   # -> Montgomery limbs
+    pts = torch.empty(n * 8, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()   # the context may run on a stream torch does not know about
+    g = np.concatenate([_limbs([1], Q), _limbs([2], Q)], axis=1)
+    ctx._chk(ctx.lib.h2hip_g1_fixed_base_mul_batch_dev(ctx.handle, g.ctypes.data, d_e.data_ptr(), n, pts.data_ptr()))
+    ctx.sync()
+    return pts
+
+
+def closed_form_dlog(scal_limbs: np.ndarray, k0: int, d: int, first_index: int = 0) -> int:
+    """sum_i v_i * (k0 + (first_index+i)*d) mod r for scalars given as raw Montgomery limbs (v_i = limbs_i / 2^256), vectorised:
+    every 64-bit limb is split into 16-bit pieces so that the index-weighted sums stay below 2^64."""
+    a = np.ascontiguousarray(scal_limbs, dtype=np.uint64).reshape(-1, 4)
+    n = len(a)
+    idx = np.arange(n, dtype=np.uint64) + np.uint64(first_index)
+    s0 = s1 = 0
+    for limb in range(4):
+        for piece in range(4):
+            v = (a[:, limb] >> np.uint64(16 * piece)) & np.uint64(0xFFFF)
+            shift = 64 * limb + 16 * piece
+            s0 += int(v.sum(dtype=np.uint64)) << shift
+            s1 += int((v * idx).sum(dtype=np.uint64)) << shift
+    return (s0 * k0 + s1 * d) * pow(1 << 256, -1, R) % R
+
+
+def jac_to_affine(j):
+    """(12,) u64 Montgomery limbs of a Jacobian point -> affine integer pair or None"""
+    vals = []
+    rinv = pow(1 << 256, -1, Q)
+    for c in range(3):
+        row = [int(x) for x in np.asarray(j).reshape(12)[4 * c:4 * c + 4]]
+        vals.append((row[0] | row[1] << 64 | row[2] << 128 | row[3] << 192) * rinv % Q)
+    X, Y, Z = vals
+    if Z == 0:
+        return None
+    zi = pow(Z, -1, Q)
+    return (X * zi * zi % Q, Y * zi * zi * zi % Q)
 
 
 def synthetic_scalars(n: int, seed: int) -> np.ndarray:
@@ -100,8 +140,8 @@ def window_for(ctx, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=512, help="timed MSMs (default: a timed region of about one second)")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (exchange staged through the host; testing)")
@@ -148,17 +188,24 @@ def main():
     for kv in args.param:
         name, val = kv.split("=")
         ctx.set_param(name, int(val))
-    # each rank owns its own slice of the (world * n)-point MSM
-    bases_h = synthetic_bases(n, seed=1000 + rank)
-    scal_h = synthetic_scalars(n, seed=2000 + rank)
-    bases = ctx.bases_upload(bases_h, 1 if args.precompute else 0)
-    scal_d = torch.from_numpy(scal_h.view(np.int64)).to(dev)
+    # each rank owns its own slice of the (world * n)-point MSM: n DISTINCT known-dlog bases built on the GPU, and --batch
+    # distinct uniformly random scalar columns (a prover round commits different columns; identical columns would share
+    # cache lines between the concurrent lanes)
+    K0, D = 0x1234567, 3
+    pts_d = known_dlog_bases_gpu(ctx, torch, dev, n, K0, D, first_index=rank * n)
+    bases = ctx.bases_from_device(pts_d.data_ptr(), n, 1 if args.precompute else 0)
+    ncols = max(1, args.batch)
+    scal_cols_h = [synthetic_scalars(n, seed=2000 + 97 * rank + j) for j in range(ncols)]
+    scal_cols_d = [torch.from_numpy(c.view(np.int64)).to(dev) for c in scal_cols_h]
+    scal_h, scal_d = scal_cols_h[0], scal_cols_d[0]
     torch.cuda.synchronize()
 
     from halo2_lib_amd.multi_gpu import sharded_msm, sharded_msm_batch
 
+    last = {}
+
     def run_steps(k):
-        """k steps = k MSMs over this rank's slice, issued in batches of --batch (pipelined over two streams);
+        """k steps = k MSMs over this rank's slice, issued in batches of --batch (pipelined over the context's lanes);
         N>1: one RCCL all-gather of the 96 B partials per batch + on-GPU sums."""
         done = 0
         res = None
@@ -167,7 +214,8 @@ def main():
             if b == 1:
                 res = sharded_msm(ctx, bases, scal_d.data_ptr(), n, device=xdev if world > 1 else None)
             else:
-                res = sharded_msm_batch(ctx, bases, [scal_d.data_ptr()] * b, n, device=xdev if world > 1 else None)
+                res = sharded_msm_batch(ctx, bases, [t.data_ptr() for t in scal_cols_d[:b]], n, device=xdev if world > 1 else None)
+            last["cols"] = b
             done += b
         return res
 
@@ -190,9 +238,22 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    # ---- verify the LAST timed batch against the closed form (sum_i s_i * dlog_i) * G — no MSM implementation involved
+    mine = [closed_form_dlog(scal_cols_h[j], K0, D, first_index=rank * n) for j in range(last["cols"])]
+    if world > 1:
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+        mine = [sum(v[j] for v in allv) % R for j in range(last["cols"])]
+    verified = all(jac_to_affine(result[j]) == _g1_mul(mine[j]) for j in range(last["cols"]))
+    if not verified:
+        raise SystemExit("bench.py: the timed MSM results do not match the closed form — refusing to report a number")
+
     if rank == 0:
         c, W = window_for(ctx, n)
-        adds_per_msm = n * W + 2 * W * (1 << (c - 1))
+        # G1 additions actually performed (SURVEY.md §8d's definition, specialised to the kernel's structure): one mixed addition per
+        # (scalar, window) pair, plus the running-sum reduction of ONE bucket set with precomputed 2^(c*w) tables (all windows share
+        # it) or of W bucket sets with plain bases
+        adds_per_msm = n * W + 2 * (1 if args.precompute else W) * (1 << (c - 1))
         units = world * args.steps * adds_per_msm
         ms_per_step = elapsed / args.steps * 1e3
         # dominant kernel, timed with HIP events on the launch stream inside the timed region
@@ -220,12 +281,12 @@ def main():
         ctx.profile_enable(False)
         iso_avg_s = iso_ms / max(iso_cnt, 1) * 1e-3
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_msm20_pmc_hbm.json")
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_msm20_pmc_hbm.json", "r01_msm20_pmc_hbm.json")) if os.path.exists(q)), "")
         if os.path.exists(pmc_path) and args.log_n == 20 and args.precompute:
             pmc = json.load(open(pmc_path))
             for kname, v in pmc.items():
                 if kname.startswith("msm_accum_kernel"):
-                    traffic, traffic_src = v["traffic_bytes_per_launch"], "profiles/r01_msm20_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2)"
+                    traffic, traffic_src = v["traffic_bytes_per_launch"], os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2)"
         mm_ms, mm_n = ctx.bench_modmul(16384, 256, 2)
         modmul_peak_sat = mm_n / (mm_ms * 1e-3)
         mm_ms, mm_n = ctx.bench_modmul(16384, 256, 2, unsaturated=True)
@@ -244,22 +305,26 @@ def main():
             "vs_baseline": None,
             "dtype": "u32x8 (254-bit Montgomery integers)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 2^%d-point BN254 G1 MSM, uniform random scalars, bases resident in HBM" % args.log_n,
+            "config": {"workload": "BASELINE configs[1]: 2^%d-point BN254 G1 MSM, uniform random scalars (distinct column per MSM of a batch), 2^%d distinct random-looking bases (known-dlog multiples of G built on the GPU) resident in HBM" % (args.log_n, args.log_n),
                        "points_per_gpu": n, "bases": "precomputed 2^(c*w) tables" if args.precompute else "plain", "window_bits": c, "windows": W, "adds_per_msm": adds_per_msm,
                        "sharding": "point-range, one 2^%d slice per GPU, all-gather of 96 B partials" % args.log_n},
-            "pairs_per_sec": world * args.steps * n / elapsed, "batch": args.batch, "sync_ms_per_msm": sync_ms,
+            "pairs_per_sec": world * args.steps * n / elapsed, "batch": args.batch, "result_verified": "last timed batch == (sum_i s_i*dlog_i)*G for every column (closed form, known-dlog bases)", "sync_ms_per_msm": sync_ms,
             "kernel_ms_per_msm": breakdown,
-            "roofline": {"bound": "hbm", "kernel": "msm_accum_kernel", "achieved": achieved_gbs, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved_gbs / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "hbm", "kernel": "msm_accum_kernel", "achieved": (alg_bytes / k_busy_s / 1e9) if k_busy_s > 0 else achieved_gbs, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (alg_bytes / k_busy_s / 8e12) if k_busy_s > 0 else achieved_gbs / 8000.0, "duration_used": "busy_ms_per_launch",
+                         "frac_per_dispatch": achieved_gbs / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg_s * 1e3, "launches": int(k_cnt),
                          "avg_launch_ms_isolated": iso_avg_s * 1e3, "busy_ms_per_launch": k_busy_s * 1e3,
                          "frac_busy": (alg_bytes / k_busy_s / 8e12) if k_busy_s > 0 else 0.0,
-                         "note": "avg_launch_ms = mean per-dispatch duration inside the timed region (what rocprofv3 reports): launches of up to three "
+                         "note": "achieved/frac use busy_ms_per_launch (launches of concurrent lanes overlap, so the per-dispatch mean exceeds ms_per_step and is not a per-launch cost); avg_launch_ms = mean per-dispatch duration inside the timed region (what rocprofv3 reports): launches of up to three "
                                  "pipelined MSMs run concurrently there, each at a fraction of the chip; busy_ms_per_launch = (time during which at least "
                                  "one launch was executing) / launches = what one launch effectively costs; _isolated = the same kernel in a synchronous MSM"},
             "roofline_int": {"bound": "integer multiplier (v_mad_u64_u32, 4 cycles per wave64)", "kernel": "msm_accum_kernel",
-                             "achieved": alg_modmul / k_avg_s if k_avg_s > 0 else 0.0, "peak": modmul_peak, "unit": "modmul/s",
-                             "frac": (alg_modmul / k_avg_s / modmul_peak) if k_avg_s > 0 else 0.0,
+                             "achieved": alg_modmul / k_busy_s if k_busy_s > 0 else 0.0, "peak": modmul_peak, "unit": "modmul/s",
+                             "frac": (alg_modmul / k_busy_s / modmul_peak) if k_busy_s > 0 else 0.0,
+                             "frac_per_dispatch": (alg_modmul / k_avg_s / modmul_peak) if k_avg_s > 0 else 0.0,
+                             "frac_whole_msm": alg_modmul / (ms_per_step * 1e-3) / modmul_peak,
+                             "silicon_issue_peak": 256 * 4 * 16 * 2.4e9 / 171.0,
                              "frac_isolated": (alg_modmul / iso_avg_s / modmul_peak) if iso_avg_s > 0 else 0.0,
                              "frac_busy": (alg_modmul / k_busy_s / modmul_peak) if k_busy_s > 0 else 0.0,
                              "peak_saturated_8x32": modmul_peak_sat,
@@ -281,7 +346,7 @@ def main():
             except Exception as e:   # the replay is an extra; never let it break the contract line
                 out["create_proof_k19_replay"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(bases_h, scal_h, adds_per_msm)
+            out["cpu_baseline"] = cpu_baseline(ctx.bases_download(bases), scal_h, adds_per_msm)
         print(json.dumps(out), flush=True)
     bases.free()
     ctx.close()

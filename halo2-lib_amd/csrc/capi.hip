@@ -208,11 +208,14 @@ void h2hip_destroy(h2hip_ctx *ctx) {
             hipEventDestroy(ctx->lane_ev[l]);
         }
     if (ctx->fork_ev) hipEventDestroy(ctx->fork_ev);
+    for (auto e : ctx->timer_ev)
+        if (e) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 int h2hip_sync(h2hip_ctx *ctx) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx, "ctx is NULL");
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
     return H2HIP_OK;
@@ -239,10 +242,11 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     return nullptr;
 }
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && name, "NULL argument");
     int *p = param_slot(ctx, name);
     H2_REQUIRE(p, "unknown parameter name");
-    if (p == &ctx->msm_window_bits) H2_REQUIRE(value == 0 || (value >= 2 && value <= 23), "msm_window_bits must be 0 or 2..23");
+    if (p == &ctx->msm_window_bits) H2_REQUIRE(value == 0 || (value >= 4 && value <= 16), "msm_window_bits must be 0 (auto) or 4..16 (a window's histogram lives in LDS; at most 64 windows)");
     if (p == &ctx->msm_chunk) H2_REQUIRE(value == 0 || (value >= 2 && value <= 4096), "msm_chunk must be 0 (auto) or 2..4096");
     if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
     if (p == &ctx->msm_fuse_cols) H2_REQUIRE(value >= 0 && value <= (int)MSM_MAX_COLS, "msm_fuse_cols must be 0 (auto) or 1..8");
@@ -258,6 +262,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     return H2HIP_OK;
 }
 int h2hip_get_param(h2hip_ctx *ctx, const char *name, int *value) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && name && value, "NULL argument");
     int *p = param_slot(ctx, name);
     H2_REQUIRE(p, "unknown parameter name");
@@ -266,6 +271,7 @@ int h2hip_get_param(h2hip_ctx *ctx, const char *name, int *value) {
 }
 
 int h2hip_malloc(h2hip_ctx *ctx, size_t bytes, void **dptr) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && dptr, "NULL argument");
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 256);
     if (e != hipSuccess) {
@@ -275,6 +281,7 @@ int h2hip_malloc(h2hip_ctx *ctx, size_t bytes, void **dptr) {
     return H2HIP_OK;
 }
 int h2hip_free(h2hip_ctx *ctx, void *dptr) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx, "ctx is NULL");
     if (!dptr) return H2HIP_OK;
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -282,6 +289,7 @@ int h2hip_free(h2hip_ctx *ctx, void *dptr) {
     return H2HIP_OK;
 }
 int h2hip_upload(h2hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (bytes == 0 || (dst_dev && src_host)), "NULL argument");
     if (!bytes) return H2HIP_OK;
     H2_HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -289,6 +297,7 @@ int h2hip_upload(h2hip_ctx *ctx, void *dst_dev, const void *src_host, size_t byt
     return H2HIP_OK;
 }
 int h2hip_download(h2hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (bytes == 0 || (dst_host && src_dev)), "NULL argument");
     if (!bytes) return H2HIP_OK;
     H2_HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -298,12 +307,14 @@ int h2hip_download(h2hip_ctx *ctx, void *dst_host, const void *src_dev, size_t b
 
 // ------------------------------------------------------------------ profiling
 int h2hip_profile_enable(h2hip_ctx *ctx, int on) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx, "ctx is NULL");
     prof_collect(ctx);
     ctx->profiling = on != 0;
     return H2HIP_OK;
 }
 int h2hip_profile_reset(h2hip_ctx *ctx) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx, "ctx is NULL");
     prof_collect(ctx);
     ctx->stats.clear();
@@ -320,6 +331,7 @@ int h2hip_profile_reset(h2hip_ctx *ctx) {
 // time during which at least one launch of the matching kernels was executing (union of the launch spans): with
 // pipelined MSMs several launches of one kernel overlap, and busy / launches is what one launch effectively costs
 int h2hip_profile_get_busy(h2hip_ctx *ctx, const char *prefix, double *busy_ms) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && prefix && busy_ms, "NULL argument");
     prof_collect(ctx);
     std::vector<std::pair<float, float>> all;
@@ -343,6 +355,7 @@ int h2hip_profile_get_busy(h2hip_ctx *ctx, const char *prefix, double *busy_ms) 
     return H2HIP_OK;
 }
 int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && prefix, "NULL argument");
     prof_collect(ctx);
     double ms = 0;
@@ -357,22 +370,23 @@ int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint
     if (launches) *launches = cnt;
     return H2HIP_OK;
 }
-static thread_local hipEvent_t g_t0 = nullptr, g_t1 = nullptr;
 int h2hip_timer_start(h2hip_ctx *ctx) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx, "ctx is NULL");
-    if (!g_t0) {
-        H2_HIPCHK(hipEventCreate(&g_t0));
-        H2_HIPCHK(hipEventCreate(&g_t1));
+    if (!ctx->timer_ev[0]) {   // per context: an event belongs to the device it was created on
+        H2_HIPCHK(hipEventCreate(&ctx->timer_ev[0]));
+        H2_HIPCHK(hipEventCreate(&ctx->timer_ev[1]));
     }
-    H2_HIPCHK(hipEventRecord(g_t0, ctx->stream));
+    H2_HIPCHK(hipEventRecord(ctx->timer_ev[0], ctx->stream));
     return H2HIP_OK;
 }
 int h2hip_timer_stop(h2hip_ctx *ctx, double *elapsed_ms) {
-    H2_REQUIRE(ctx && elapsed_ms && g_t0, "timer not started");
-    H2_HIPCHK(hipEventRecord(g_t1, ctx->stream));
-    H2_HIPCHK(hipEventSynchronize(g_t1));
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && elapsed_ms && ctx->timer_ev[0], "timer not started");
+    H2_HIPCHK(hipEventRecord(ctx->timer_ev[1], ctx->stream));
+    H2_HIPCHK(hipEventSynchronize(ctx->timer_ev[1]));
     float ms = 0;
-    H2_HIPCHK(hipEventElapsedTime(&ms, g_t0, g_t1));
+    H2_HIPCHK(hipEventElapsedTime(&ms, ctx->timer_ev[0], ctx->timer_ev[1]));
     *elapsed_ms = ms;
     return H2HIP_OK;
 }
@@ -411,12 +425,15 @@ static int bases_create(h2hip_ctx *ctx, const void *src, bool src_on_device, siz
     return H2HIP_OK;
 }
 int h2hip_bases_upload(h2hip_ctx *ctx, const void *g1_affine_host, size_t n, uint32_t flags, h2hip_bases **out) {
+    H2_DEVICE_GUARD(ctx);
     return bases_create(ctx, g1_affine_host, false, n, flags, out);
 }
 int h2hip_bases_from_device(h2hip_ctx *ctx, const void *g1_affine_dev, size_t n, uint32_t flags, h2hip_bases **out) {
+    H2_DEVICE_GUARD(ctx);
     return bases_create(ctx, g1_affine_dev, true, n, flags, out);
 }
 void h2hip_bases_free(h2hip_ctx *ctx, h2hip_bases *bases) {
+    H2_DEVICE_GUARD(ctx);
     if (!bases) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
     if (bases->pts) hipFree(bases->pts);
@@ -427,6 +444,7 @@ size_t h2hip_bases_len(const h2hip_bases *bases) { return bases ? bases->n : 0; 
 
 static int finish_point(h2hip_ctx *ctx, char *outbuf, int point_format, void *out_host);
 int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_dev, size_t n, int point_format, void *out_host) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_dev), "NULL argument");
     H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
     char *outbuf = nullptr;
@@ -437,11 +455,35 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
 // Several independent MSMs over the same bases (e.g. the h(X) pieces, or all advice columns of a phase): MSM j runs
 // on lane j mod 2 — a child context with its own stream and scratch — so the latency-bound tail of one MSM (merge,
 // bucket reduction) overlaps the multiplier-bound accumulation of the next.
+// once groups are queued on the lanes, an error return must not leave them running on buffers the caller's next call reuses
+static void join_lanes(h2hip_ctx *ctx, int nl) {
+    for (int l = 0; l < nl; ++l)
+        if (ctx->lane[l]) hipStreamSynchronize(ctx->lane[l]->stream);
+}
+#define H2_LANES(expr)                                                                           \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            h2::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            join_lanes(ctx, NL);                                                                 \
+            return H2HIP_ERR_HIP;                                                                \
+        }                                                                                        \
+    } while (0)
+#define H2_LANES_RC(expr)         \
+    do {                          \
+        int r__ = (expr);         \
+        if (r__ != H2HIP_OK) {    \
+            join_lanes(ctx, NL);  \
+            return r__;           \
+        }                         \
+    } while (0)
 static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_in, bool scalars_on_host, size_t n, size_t count,
                           int point_format, void *out_host) {
     H2_REQUIRE(ctx && bases && (count == 0 || (scalars_in && out_host)), "NULL argument");
     H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
     if (!count) return H2HIP_OK;
+    H2_REQUIRE(n <= bases->n, "more scalars than bases");
+    for (size_t j = 0; j < count; ++j) H2_REQUIRE(n == 0 || scalars_in[j], "NULL scalar column");   // everything checked before the first launch
     const bool affine = point_format == H2HIP_POINT_AFFINE;
     const size_t psz = affine ? sizeof(G1Affine) : sizeof(G1Jac);
     const int NL = ctx->msm_lanes < 1 ? 1 : ctx->msm_lanes > 4 ? 4 : ctx->msm_lanes;
@@ -460,6 +502,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *
         c->msm_scatter_split = ctx->msm_scatter_split;
         c->msm_sort_threads = ctx->msm_sort_threads;
         c->msm_quad_tails = ctx->msm_quad_tails;
+        c->msm_quad_seg_max = ctx->msm_quad_seg_max;
         c->msm_window_bits = ctx->msm_window_bits;
         c->profiling = ctx->profiling;
         c->prof_ref = ctx->prof_ref;   // launch spans of all lanes share the parent's time origin
@@ -501,13 +544,12 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *
         const size_t gsize = (count - j0 + (ngroups - g) - 1) / (ngroups - g);   // balanced group sizes
         h2hip_ctx *c = ctx->lane[g % NL];
         for (size_t j = j0; j < j0 + gsize; ++j) {
-            H2_REQUIRE(n == 0 || scalars_in[j], "NULL scalar column");
-            if (scalars_on_host && n) H2_HIPCHK(hipMemcpyAsync((void *)staged[j], scalars_in[j], sizeof(Fr) * n, hipMemcpyHostToDevice, c->stream));
+            if (scalars_on_host && n) H2_LANES(hipMemcpyAsync((void *)staged[j], scalars_in[j], sizeof(Fr) * n, hipMemcpyHostToDevice, c->stream));
         }
         char *outbuf = nullptr;
-        H2_CHK(ws_reserve(c, h2hip_ctx::WS_OUT, 2048, (void **)&outbuf));
-        H2_CHK(msm_run_cols(c, bases, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
-                            deferred ? all_buckets + keys_per_col * j0 : nullptr));
+        H2_LANES_RC(ws_reserve(c, h2hip_ctx::WS_OUT, 2048, (void **)&outbuf));
+        H2_LANES_RC(msm_run_cols(c, bases, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
+                                 deferred ? all_buckets + keys_per_col * j0 : nullptr));
         if (!deferred) {
             prof_begin(c, "point_finish_kernel");
             for (size_t j = j0; j < j0 + gsize; ++j)
@@ -515,7 +557,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *
                                    affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr, (uint32_t)j);
             prof_end(c);
         }
-        H2_HIPCHK(hipGetLastError());
+        H2_LANES(hipGetLastError());
         j0 += gsize;
     }
     for (int l = 0; l < NL; ++l) {
@@ -549,14 +591,17 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *
 
 int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count, int point_format,
                            void *out_host) {
+    H2_DEVICE_GUARD(ctx);
     return msm_batch_impl(ctx, bases, scalars_dev, false, n, count, point_format, out_host);
 }
 int h2hip_msm_g1_batch(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_host, size_t n, size_t count, int point_format,
                        void *out_host) {
+    H2_DEVICE_GUARD(ctx);
     return msm_batch_impl(ctx, bases, scalars_host, true, n, count, point_format, out_host);
 }
 
 int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_host), "NULL argument");
     Fr *stage = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_STAGE, sizeof(Fr) * n, (void **)&stage));
@@ -581,6 +626,7 @@ static int finish_point(h2hip_ctx *ctx, char *outbuf, int point_format, void *ou
 }
 
 int h2hip_g1_sum_jacobian_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, int point_format, void *out_host) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && out_host && (n == 0 || points_dev), "NULL argument");
     H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
     H2_REQUIRE(n < (1u << 24), "too many points");
@@ -611,10 +657,12 @@ static int stage_out(h2hip_ctx *ctx, void *host, const Fr *dev, size_t elems) {
 }
 
 int h2hip_best_fft_dev(h2hip_ctx *ctx, void *a_dev, const void *omega, uint32_t log_n) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && a_dev && omega, "NULL argument");
     return ntt_run(ctx, (Fr *)a_dev, log_n, load_fr(omega), nullptr, 0, nullptr, nullptr);
 }
 int h2hip_best_fft(h2hip_ctx *ctx, void *a_host, const void *omega, uint32_t log_n) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && a_host && omega && log_n <= 28, "bad argument");
     Fr *d = nullptr;
     H2_CHK(stage_in(ctx, a_host, (size_t)1 << log_n, &d));
@@ -622,12 +670,14 @@ int h2hip_best_fft(h2hip_ctx *ctx, void *a_host, const void *omega, uint32_t log
     return stage_out(ctx, a_host, d, (size_t)1 << log_n);
 }
 int h2hip_ifft_dev(h2hip_ctx *ctx, void *a_dev, const void *omega_inv, uint32_t log_n, const void *divisor) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && a_dev && omega_inv && divisor, "NULL argument");
     Fr d = load_fr(divisor);
     Fr out3[3] = {d, d, d};
     return ntt_run(ctx, (Fr *)a_dev, log_n, load_fr(omega_inv), nullptr, 0, nullptr, out3);
 }
 int h2hip_ifft(h2hip_ctx *ctx, void *a_host, const void *omega_inv, uint32_t log_n, const void *divisor) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && a_host && omega_inv && divisor && log_n <= 28, "bad argument");
     Fr *d = nullptr;
     H2_CHK(stage_in(ctx, a_host, (size_t)1 << log_n, &d));
@@ -636,6 +686,7 @@ int h2hip_ifft(h2hip_ctx *ctx, void *a_host, const void *omega_inv, uint32_t log
 }
 int h2hip_coeff_to_extended_dev(h2hip_ctx *ctx, const void *coeffs_dev, uint32_t k, void *out_dev, uint32_t ext_k, const void *ext_omega,
                                 const void *zeta) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && coeffs_dev && out_dev && ext_omega && zeta, "NULL argument");
     H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
     H2_REQUIRE(coeffs_dev != out_dev || k == ext_k, "coeffs and out must not alias");
@@ -645,6 +696,7 @@ int h2hip_coeff_to_extended_dev(h2hip_ctx *ctx, const void *coeffs_dev, uint32_t
 }
 int h2hip_coeff_to_extended(h2hip_ctx *ctx, const void *coeffs_host, uint32_t k, void *out_host, uint32_t ext_k, const void *ext_omega,
                             const void *zeta) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && coeffs_host && out_host && ext_omega && zeta, "NULL argument");
     H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
     Fr *d = nullptr;
@@ -656,6 +708,7 @@ int h2hip_coeff_to_extended(h2hip_ctx *ctx, const void *coeffs_host, uint32_t k,
 }
 int h2hip_extended_to_coeff_dev(h2hip_ctx *ctx, void *a_dev, uint32_t ext_k, const void *ext_omega_inv, const void *ext_divisor,
                                 const void *zeta_inv) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && a_dev && ext_omega_inv && ext_divisor && zeta_inv, "NULL argument");
     Fr d = load_fr(ext_divisor), zi = load_fr(zeta_inv);
     Fr out3[3] = {d, fe_mul(d, zi), fe_mul(d, fe_mul(zi, zi))};
@@ -663,6 +716,7 @@ int h2hip_extended_to_coeff_dev(h2hip_ctx *ctx, void *a_dev, uint32_t ext_k, con
 }
 int h2hip_extended_to_coeff(h2hip_ctx *ctx, void *a_host, uint32_t ext_k, const void *ext_omega_inv, const void *ext_divisor,
                             const void *zeta_inv) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && a_host && ext_omega_inv && ext_divisor && zeta_inv && ext_k <= 28, "bad argument");
     Fr *d = nullptr;
     H2_CHK(stage_in(ctx, a_host, (size_t)1 << ext_k, &d));

@@ -460,10 +460,14 @@ static int binop(h2hip_ctx *ctx, int op, void *out, const void *a, const void *b
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
 }
-int h2hip_fr_add_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const void *b, size_t n) { return binop(ctx, OP_ADD, out, a, b, n); }
-int h2hip_fr_sub_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const void *b, size_t n) { return binop(ctx, OP_SUB, out, a, b, n); }
-int h2hip_fr_mul_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const void *b, size_t n) { return binop(ctx, OP_MUL, out, a, b, n); }
+int h2hip_fr_add_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const void *b, size_t n) {
+    H2_DEVICE_GUARD(ctx); return binop(ctx, OP_ADD, out, a, b, n); }
+int h2hip_fr_sub_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const void *b, size_t n) {
+    H2_DEVICE_GUARD(ctx); return binop(ctx, OP_SUB, out, a, b, n); }
+int h2hip_fr_mul_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const void *b, size_t n) {
+    H2_DEVICE_GUARD(ctx); return binop(ctx, OP_MUL, out, a, b, n); }
 int h2hip_fr_mul_add_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const void *b, const void *c, size_t n) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (n == 0 || (out && a && b && c)), "NULL argument");
     if (!n) return H2HIP_OK;
     prof_begin(ctx, "fr_mul_add_kernel");
@@ -474,6 +478,7 @@ int h2hip_fr_mul_add_batch_dev(h2hip_ctx *ctx, void *out, const void *a, const v
     return H2HIP_OK;
 }
 int h2hip_fr_axpy_dev(h2hip_ctx *ctx, void *y, const void *a, const void *x, size_t n) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && a && (n == 0 || (y && x)), "NULL argument");
     if (!n) return H2HIP_OK;
     Fr av;
@@ -485,6 +490,7 @@ int h2hip_fr_axpy_dev(h2hip_ctx *ctx, void *y, const void *a, const void *x, siz
     return H2HIP_OK;
 }
 int h2hip_fr_scale_dev(h2hip_ctx *ctx, void *y, const void *s, size_t n) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && s && (n == 0 || y), "NULL argument");
     if (!n) return H2HIP_OK;
     Fr sv;
@@ -498,6 +504,7 @@ int h2hip_fr_scale_dev(h2hip_ctx *ctx, void *y, const void *s, size_t n) {
 
 // ------------------------------------------------------------------ K4 / K5
 int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a, size_t n) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (n == 0 || a), "NULL argument");
     if (!n) return H2HIP_OK;
     Fr *scratch = nullptr;
@@ -532,12 +539,14 @@ static int prefix_product_inplace(h2hip_ctx *ctx, const Fr *in, Fr *out, size_t 
     return H2HIP_OK;
 }
 int h2hip_fr_prefix_product_dev(h2hip_ctx *ctx, void *out, const void *in, size_t n) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (n == 0 || (out && in)), "NULL argument");
     if (!n) return H2HIP_OK;
     return prefix_product_inplace(ctx, (const Fr *)in, (Fr *)out, n);
 }
 // z[0] = 1, z[i+1] = z[i] * num[i] / den[i], i < n  (z has n+1 elements; 0 denominators count as 0^-1 := 0)
 int h2hip_fr_grand_product_dev(h2hip_ctx *ctx, void *z, const void *num, const void *den, size_t n) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && z && (n == 0 || (num && den)), "NULL argument");
     Fr *zz = (Fr *)z;
     hipLaunchKernelGGL(fr_set_one_kernel, dim3(1), dim3(64), 0, ctx->stream, zz);
@@ -560,6 +569,7 @@ static void pow_table(const Fr &x, uint32_t j, PowTable &pw) {
     }
 }
 int h2hip_fr_eval_polynomial_dev(h2hip_ctx *ctx, const void *coeffs, size_t n, const void *x, void *out_host) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && out_host && x && (n == 0 || coeffs), "NULL argument");
     Fr xv;
     memcpy(&xv, x, sizeof(Fr));
@@ -581,6 +591,7 @@ int h2hip_fr_eval_polynomial_dev(h2hip_ctx *ctx, const void *coeffs, size_t n, c
 }
 // q[0..n-1) = (f(X) - f(b)) / (X - b)   [UPSTREAM arithmetic::kate_division]
 int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *b) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && b && n >= 1 && coeffs && (n == 1 || q), "bad argument");
     H2_REQUIRE(q != coeffs, "q must not alias coeffs");
     if (n == 1) return H2HIP_OK;
@@ -603,6 +614,7 @@ int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size
 
 // ------------------------------------------------------------------ K8 Poseidon
 int h2hip_poseidon_set_spec(h2hip_ctx *ctx, uint32_t t, uint32_t r_f, uint32_t r_p, const void *round_constants, const void *mds) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && round_constants && mds, "NULL argument");
     H2_REQUIRE(t == 3 || t == 5, "state width t must be 3 or 5");
     H2_REQUIRE(r_f >= 2 && (r_f % 2) == 0 && r_f <= 16 && r_p <= 256, "round numbers out of range");
@@ -624,6 +636,7 @@ int h2hip_poseidon_set_spec(h2hip_ctx *ctx, uint32_t t, uint32_t r_f, uint32_t r
     return H2HIP_OK;
 }
 int h2hip_poseidon_permute_batch_dev(h2hip_ctx *ctx, void *states, const void *inputs, uint32_t num_inputs, size_t n) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (n == 0 || states), "NULL argument");
     H2_REQUIRE(ctx->pos_t != 0, "call h2hip_poseidon_set_spec first");
     H2_REQUIRE(num_inputs < ctx->pos_t, "num_inputs must be <= RATE = t-1");
@@ -646,6 +659,7 @@ int h2hip_poseidon_permute_batch_dev(h2hip_ctx *ctx, void *states, const void *i
 
 // ------------------------------------------------------------------ K6 (halo2-base gate term)
 int h2hip_quotient_flex_gate_dev(h2hip_ctx *ctx, void *acc, const void *q, const void *a, uint32_t ext_k, uint32_t k, const void *y) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && acc && q && a && y, "NULL argument");
     H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
     H2_REQUIRE(acc != a && acc != q, "acc must not alias an input");
@@ -686,6 +700,7 @@ __global__ __launch_bounds__(256) void divide_by_vanishing_small_kernel(Fr *__re
     }
 }
 int h2hip_divide_by_vanishing_poly_dev(h2hip_ctx *ctx, void *a, uint32_t ext_k, uint32_t k, const void *ext_omega, const void *zeta) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && a && ext_omega && zeta, "NULL argument");
     H2_REQUIRE(k <= ext_k && ext_k <= 28 && ext_k - k <= 16, "need k <= ext_k <= 28 and ext_k - k <= 16");
     Fr w, z;
@@ -723,6 +738,7 @@ static Fr ld_fr(const void *p) {
 int h2hip_quotient_lookup_dev(h2hip_ctx *ctx, void *acc, const void *z, const void *a, const void *s, const void *a_perm, const void *s_perm,
                               const void *l0, const void *l_last, const void *l_blind, uint32_t ext_k, uint32_t k, const void *beta,
                               const void *gamma, const void *y) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && acc && z && a && s && a_perm && s_perm && l0 && l_last && l_blind && beta && gamma && y, "NULL argument");
     H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
     LookupArgs g;
@@ -740,6 +756,7 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z,
                                        const void *const *sigmas, uint32_t ncols, uint32_t first_col_index, const void *l0, const void *l_last,
                                        const void *l_blind, uint32_t ext_k, uint32_t k, uint32_t terms, int32_t last_rotation,
                                        const void *beta, const void *gamma, const void *delta, const void *zeta, const void *ext_omega, const void *y) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && acc && z && l0 && l_last && l_blind && beta && gamma && delta && zeta && ext_omega && y, "NULL argument");
     H2_REQUIRE(terms != 0 && (terms & ~15u) == 0, "terms must be a non-empty mask of H2HIP_PERM_*");
     H2_REQUIRE(!(terms & H2HIP_PERM_CHAIN) || z_prev, "H2HIP_PERM_CHAIN needs z_prev_dev");
@@ -775,6 +792,7 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z,
 }
 
 int h2hip_bench_modmul29(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && elapsed_ms && modmuls && blocks && iters, "bad argument");
     H2_REQUIRE(chains == 1 || chains == 2, "chains must be 1 or 2");
     Fr *buf = nullptr;
@@ -793,6 +811,7 @@ int h2hip_bench_modmul29(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32
 }
 
 int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && elapsed_ms && modmuls && blocks && iters, "bad argument");
     H2_REQUIRE(chains == 1 || chains == 2 || chains == 4, "chains must be 1, 2 or 4");
     Fr *buf = nullptr;

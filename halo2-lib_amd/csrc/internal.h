@@ -102,8 +102,28 @@ struct h2hip_ctx {
     int msm_defer_reduce = 1;   // batch API, precomputed bases, > 2^17 points: one bucket reduction for all columns after the lanes join
     int msm_fuse_cols = 0;   // columns fused into one multi-column MSM by h2hip_msm_g1_batch_dev (precomputed bases): 0 = auto (4 up to 2^17 points, else 1)
     hipEvent_t fork_ev = nullptr;
+    hipEvent_t timer_ev[2] = {nullptr, nullptr};   // h2hip_timer_start / _stop
     bool msm_lds_attr_set = false, lookup_lds_attr_set = false;   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 };
+
+namespace h2 {
+// HIP's current device is per-thread: every extern "C" entry that takes a context makes the context's device current for
+// its duration (allocations, events and attribute calls would otherwise target whatever device the calling thread used
+// last — another context's, or torch's) and restores the caller's device on exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const h2hip_ctx *c) {
+        if (c && hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+}  // namespace h2
+#define H2_DEVICE_GUARD(ctx) h2::DeviceGuard device_guard__(ctx)
 
 struct h2hip_bases {
     h2::G1Affine *pts = nullptr;      // [n] affine, saturated Montgomery limbs (as uploaded; h2hip_bases_download)

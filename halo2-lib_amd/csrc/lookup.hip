@@ -178,6 +178,7 @@ extern "C" {
 // a_perm_dev, s_perm_dev: outputs, rows [0, usable) are written (the caller appends the blinding rows).
 // Returns H2HIP_ERR_INVALID ("input value missing from the table") where upstream returns ConstraintSystemFailure.
 int h2hip_lookup_permute_dev(h2hip_ctx *ctx, const void *a_dev, const void *s_dev, size_t usable_rows, void *a_perm_dev, void *s_perm_dev) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (usable_rows == 0 || (a_dev && s_dev && a_perm_dev && s_perm_dev)), "NULL argument");
     H2_REQUIRE(usable_rows < (1u << 28), "too many rows");
     if (!usable_rows) return H2HIP_OK;

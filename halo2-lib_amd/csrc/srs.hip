@@ -162,6 +162,7 @@ extern "C" {
 
 // out[i] = scalars[i] * base   (device arrays; base is a host G1Affine)
 int h2hip_g1_fixed_base_mul_batch_dev(h2hip_ctx *ctx, const void *base_affine, const void *scalars_dev, size_t n, void *out_affine_dev) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && base_affine && (n == 0 || (scalars_dev && out_affine_dev)), "NULL argument");
     H2_REQUIRE(n < (1u << 31), "n too large");
     G1Affine base;
@@ -172,6 +173,7 @@ int h2hip_g1_fixed_base_mul_batch_dev(h2hip_ctx *ctx, const void *base_affine, c
 }
 
 int h2hip_g1_to_lagrange(h2hip_ctx *ctx, const h2hip_bases *g, uint32_t k, uint32_t flags, h2hip_bases **g_lagrange_out) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && g && g_lagrange_out, "NULL argument");
     H2_REQUIRE(k <= 26 && g->n >= ((size_t)1 << k), "need at least 2^k monomial bases, k <= 26");
     const uint32_t n = 1u << k;
@@ -203,6 +205,7 @@ int h2hip_g1_to_lagrange(h2hip_ctx *ctx, const h2hip_bases *g, uint32_t k, uint3
 }
 
 int h2hip_params_kzg_setup(h2hip_ctx *ctx, uint32_t k, const void *s_fr, uint32_t flags, h2hip_bases **g_out, h2hip_bases **g_lagrange_out) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && s_fr && g_out && g_lagrange_out, "NULL argument");
     H2_REQUIRE(k <= 26, "k too large");
     const uint32_t n = 1u << k;
@@ -257,6 +260,7 @@ int h2hip_params_kzg_setup(h2hip_ctx *ctx, uint32_t k, const void *s_fr, uint32_
 
 // copies the (level-0) affine points of a resident base set back to the host
 int h2hip_bases_download(h2hip_ctx *ctx, const h2hip_bases *bases, void *out_host) {
+    H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && bases && out_host, "NULL argument");
     if (!bases->n) return H2HIP_OK;
     H2_HIPCHK(hipMemcpyAsync(out_host, bases->pts, sizeof(G1Affine) * bases->n, hipMemcpyDeviceToHost, ctx->stream));

@@ -523,6 +523,8 @@ class Context:
     def lookup_permute(self, a: np.ndarray, s: np.ndarray, usable_rows: int):
         """(a_perm, s_perm) over rows [0, usable_rows)"""
         a, s = _fe(a), _fe(s)
+        if not (len(a) == len(s) and 0 <= usable_rows <= len(a)):
+            raise ValueError("lookup_permute: need len(a) == len(s) >= usable_rows")
         da, ds = self.to_device(a), self.to_device(s)
         dap, dsp = self.malloc(max(a.nbytes, 32)), self.malloc(max(a.nbytes, 32))
         try:

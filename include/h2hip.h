@@ -94,7 +94,8 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
 
 /* `count` independent MSMs over the same bases (all advice columns of a phase, the pieces of h(X), ...).
  * scalars_dev: host array of `count` device pointers, n scalars each; out_host: `count` points.  The MSMs are
- * pipelined over two internal streams so that one MSM's latency-bound tail overlaps the next one's accumulation. */
+ * pipelined over the context's lanes ("msm_lanes" internal streams, default 3) so that one MSM's sort and latency-bound tail
+ * overlap another one's accumulation. */
 int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count,
                            int point_format, void *out_host);
 /* the same for scalar columns in HOST memory (an unmodified prover's Vec<Fr>): each column is uploaded on its lane's stream

@@ -220,6 +220,35 @@ def test_msm_batch_pipelined(ctx):
         b.free()
 
 
+@pytest.mark.parametrize("log_n,batch", [(19, 4), (19, 8), (20, 4), (20, 8)])
+def test_msm_batch_bench_path_closed_form(ctx, log_n, batch):
+    """The code path bench.py times, at the sizes it times: h2hip_msm_g1_batch_dev over precomputed bases (lane pipeline, deferred
+    joint bucket reduction), `batch` DISTINCT scalar columns, bases built on the GPU exactly as bench.py builds them; every
+    result is checked against the known-dlog closed form (no MSM implementation involved) and column 0 against the C oracle."""
+    import torch
+
+    import bench as B
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    n, k0, d = 1 << log_n, 0x1234567, 3
+    dev = torch.device("cuda", 0)
+    pts = B.known_dlog_bases_gpu(ctx, torch, dev, n, k0, d)
+    host_pts = pts.cpu().numpy().view(np.uint64).reshape(n, 8)
+    idx = [0, 1, 2, 12345, n - 1]
+    assert np.array_equal(host_pts[idx], O.points_to_limbs([O.g1_mul(O.G1_GEN, k0 + i * d) for i in idx]))
+    b = ctx.bases_from_device(pts.data_ptr(), n, BASES_PRECOMPUTE)
+    cols = [rand_fr(n, 500 + j) if j % 3 else circuit_like_fr(n, 500 + j) for j in range(batch)]
+    cols[1] = B.synthetic_scalars(n, 2001)
+    dcols = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+    torch.cuda.synchronize()
+    assert ctx.get_param("msm_defer_reduce") == 1 and ctx.get_param("msm_fuse_cols") == 0
+    got = ctx.msm_batch_dev(b, [t.data_ptr() for t in dcols], n, H.POINT_JACOBIAN)
+    for j in range(batch):
+        assert B.jac_to_affine(got[j]) == O.g1_mul(O.G1_GEN, B.closed_form_dlog(cols[j], k0, d)), (log_n, batch, j)
+    assert [B.jac_to_affine(got[0])] == O.limbs_to_points(CO.best_multiexp(cols[0], host_pts, threads=NT))
+    b.free()
+
+
 def test_quotient_lookup_and_permutation_identities(ctx):
     from tests.test_emu_kernels import _quotient_identity_checks
 
