@@ -286,7 +286,7 @@ class Context:
         return out
 
     def msm_batch_dev(self, bases: Bases, scalar_dptrs, n: int, point_format: int = POINT_JACOBIAN) -> np.ndarray:
-        """several independent MSMs over the same bases, pipelined over two streams; returns (count, 8|12)"""
+        """several independent MSMs over the same bases, pipelined over the lanes of the context; returns (count, 8|12)"""
         count = len(scalar_dptrs)
         arr = (_vp * count)(*[_vp(int(p)) for p in scalar_dptrs])
         out = np.zeros((count, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
