@@ -481,3 +481,219 @@ void orc_best_multiexp(g1a *out, const fe *scalars_mont, const g1a *bases, size_
     g1j_to_affine(out, &total);
     free(canon);
 }
+
+/* ================================================================== create_proof vector steps
+ * CPU restatement of the data-parallel steps of halo2's PLONK/KZG prover around the MSMs and FFTs
+ * [UPSTREAM halo2-axiom 0.5.3: plonk/{prover,permutation/prover,lookup/prover,vanishing/prover,evaluation}.rs,
+ * poly/domain.rs — SURVEY.md §3.2, A.3-A.6], reached from the reference only through
+ * halo2-base/src/utils/testing.rs:40-47.  oracle/plonk.py orchestrates them (transcript, challenges, ordering);
+ * bench.py's create_proof cpu_baseline times exactly that composition.  `threads` mirrors upstream's rayon
+ * `parallelize` chunking; results do not depend on it. */
+typedef void (*range_fn)(size_t lo, size_t hi, void *arg);
+typedef struct { range_fn fn; void *arg; size_t lo, hi; } pf_job;
+static void *pf_worker(void *p) { pf_job *j = (pf_job *)p; j->fn(j->lo, j->hi, j->arg); return NULL; }
+static void parallel_for(size_t n, int threads, range_fn fn, void *arg) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if (n < 2048 || threads == 1) { fn(0, n, arg); return; }
+    pthread_t th[256];
+    pf_job jobs[256];
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = (pf_job){fn, arg, n * (size_t)t / threads, n * (size_t)(t + 1) / threads};
+        pthread_create(&th[t], NULL, pf_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+}
+static void fe_pow_u64(fe *r, const fe *a, uint64_t e) { uint64_t ee[4] = {e, 0, 0, 0}; fe_pow(r, a, ee, &FR); }
+
+/* out[i] = a[i]*sa (+ b[i]*sb) (+ c);  sa / sb / c may be NULL (= 1 / 1 / 0), b may be NULL */
+typedef struct { fe *out; const fe *a, *sa, *b, *sb, *c; } lin_arg;
+static void lin_range(size_t lo, size_t hi, void *p) {
+    lin_arg *g = (lin_arg *)p;
+    for (size_t i = lo; i < hi; ++i) {
+        fe v = g->a[i], t;
+        if (g->sa) fe_mul(&v, &v, g->sa, &FR);
+        if (g->b) { t = g->b[i]; if (g->sb) fe_mul(&t, &t, g->sb, &FR); fe_add(&v, &v, &t, &FR); }
+        if (g->c) fe_add(&v, &v, g->c, &FR);
+        g->out[i] = v;
+    }
+}
+void orc_fr_lincomb(fe *out, const fe *a, const fe *sa, const fe *b, const fe *sb, const fe *c, size_t n, int threads) {
+    lin_arg g = {out, a, sa, b, sb, c};
+    parallel_for(n, threads, lin_range, &g);
+}
+typedef struct { fe *out; const fe *a, *b; } mul_arg;
+static void mul_range(size_t lo, size_t hi, void *p) { mul_arg *g = (mul_arg *)p; for (size_t i = lo; i < hi; ++i) fe_mul(&g->out[i], &g->a[i], &g->b[i], &FR); }
+void orc_fr_mul_batch_mt(fe *out, const fe *a, const fe *b, size_t n, int threads) { mul_arg g = {out, a, b}; parallel_for(n, threads, mul_range, &g); }
+/* out[i] = start * ratio^i */
+typedef struct { fe *out; const fe *start, *ratio; } geom_arg;
+static void geom_range(size_t lo, size_t hi, void *p) {
+    geom_arg *g = (geom_arg *)p;
+    fe cur; fe_pow_u64(&cur, g->ratio, lo); fe_mul(&cur, &cur, g->start, &FR);
+    for (size_t i = lo; i < hi; ++i) { g->out[i] = cur; fe_mul(&cur, &cur, g->ratio, &FR); }
+}
+void orc_fr_geom(fe *out, const fe *start, const fe *ratio, size_t n, int threads) { geom_arg g = {out, start, ratio}; parallel_for(n, threads, geom_range, &g); }
+static void inv_range(size_t lo, size_t hi, void *p) { orc_fr_batch_invert((fe *)p + lo, hi - lo); }
+void orc_fr_batch_invert_mt(fe *a, size_t n, int threads) { parallel_for(n, threads, inv_range, a); }
+/* z[0] = first; z[i+1] = z[i]*vals[i] for i < n  (n+1 values) */
+void orc_fr_running_product(fe *z, const fe *first, const fe *vals, size_t n) {
+    z[0] = *first;
+    for (size_t i = 0; i < n; ++i) fe_mul(&z[i + 1], &z[i], &vals[i], &FR);
+}
+typedef struct { fe *y; const fe *a, *x; } axpy_arg;
+static void axpy_range(size_t lo, size_t hi, void *p) {
+    axpy_arg *g = (axpy_arg *)p;
+    for (size_t i = lo; i < hi; ++i) { fe t; fe_mul(&t, &g->x[i], g->a, &FR); fe_add(&g->y[i], &g->y[i], &t, &FR); }
+}
+void orc_fr_axpy(fe *y, const fe *a, const fe *x, size_t n, int threads) { axpy_arg g = {y, a, x}; parallel_for(n, threads, axpy_range, &g); }
+static void scale_range(size_t lo, size_t hi, void *p) { axpy_arg *g = (axpy_arg *)p; for (size_t i = lo; i < hi; ++i) fe_mul(&g->y[i], &g->y[i], g->a, &FR); }
+void orc_fr_scale(fe *y, const fe *s, size_t n, int threads) { axpy_arg g = {y, s, NULL}; parallel_for(n, threads, scale_range, &g); }
+
+/* lookup::prover::permute_expression_pair over the usable rows [UPSTREAM]: a' = sorted input (Ord on the canonical
+ * representation); s'[row] = a'[row] where a run of equal inputs starts (consuming one table element of that value); the
+ * leftover table elements, in ascending order, fill the repeated rows popped from the END.  Returns 0, or -1 when an
+ * input value is missing from the table (upstream: Error::ConstraintSystemFailure). */
+static int canon_cmp(const void *x, const void *y) {
+    const fe *a = (const fe *)x, *b = (const fe *)y;
+    for (int i = 3; i >= 0; --i) if (a->l[i] != b->l[i]) return a->l[i] < b->l[i] ? -1 : 1;
+    return 0;
+}
+int orc_permute_expression_pair(fe *ap, fe *sp, const fe *a, const fe *s, size_t usable) {
+    fe *ca = (fe *)malloc(sizeof(fe) * (usable ? usable : 1)), *cs = (fe *)malloc(sizeof(fe) * (usable ? usable : 1));
+    size_t *rep = (size_t *)malloc(sizeof(size_t) * (usable ? usable : 1));
+    unsigned char *used = (unsigned char *)calloc(usable ? usable : 1, 1);
+    for (size_t i = 0; i < usable; ++i) { fe_from_mont(&ca[i], &a[i], &FR); fe_from_mont(&cs[i], &s[i], &FR); }
+    qsort(ca, usable, sizeof(fe), canon_cmp);
+    qsort(cs, usable, sizeof(fe), canon_cmp);   /* sorted table = the BTreeMap's iteration order, with multiplicity */
+    size_t nrep = 0, t = 0;
+    int rc = 0;
+    for (size_t row = 0; row < usable && !rc; ++row) {
+        if (row == 0 || canon_cmp(&ca[row], &ca[row - 1]) != 0) {
+            while (t < usable && canon_cmp(&cs[t], &ca[row]) < 0) ++t;          /* first table element >= the input value */
+            if (t >= usable || canon_cmp(&cs[t], &ca[row]) != 0) { rc = -1; break; }
+            used[t++] = 1;
+            sp[row] = ca[row];
+        } else rep[nrep++] = row;
+    }
+    if (!rc) {
+        for (size_t j = 0; j < usable; ++j) if (!used[j]) sp[rep[--nrep]] = cs[j];
+        for (size_t i = 0; i < usable; ++i) { fe_to_mont(&ap[i], &ca[i], &FR); fe_to_mont(&sp[i], &sp[i], &FR); }
+    }
+    free(ca); free(cs); free(rep); free(used);
+    return rc;
+}
+
+/* evaluate_h, custom gate of halo2-base (reference halo2-base/src/gates/flex_gate/mod.rs:80-91):
+ * acc[i] = acc[i]*y + q[i]*(a[i] + a[i+s]*a[i+2s] - a[i+3s]) on the extended domain, s = rot_scale */
+typedef struct { fe *acc; const fe *q, *a, *y; size_t ne, step; } gate_arg;
+static void gate_range(size_t lo, size_t hi, void *p) {
+    gate_arg *g = (gate_arg *)p;
+    size_t m = g->ne - 1;
+    for (size_t i = lo; i < hi; ++i) {
+        fe t, v;
+        fe_mul(&t, &g->a[(i + g->step) & m], &g->a[(i + 2 * g->step) & m], &FR);
+        fe_add(&t, &t, &g->a[i], &FR);
+        fe_sub(&t, &t, &g->a[(i + 3 * g->step) & m], &FR);
+        fe_mul(&t, &t, &g->q[i], &FR);
+        fe_mul(&v, &g->acc[i], g->y, &FR);
+        fe_add(&g->acc[i], &v, &t, &FR);
+    }
+}
+void orc_quotient_gate(fe *acc, const fe *q, const fe *a, const fe *y, size_t ne, size_t step, int threads) {
+    gate_arg g = {acc, q, a, y, ne, step};
+    parallel_for(ne, threads, gate_range, &g);
+}
+/* evaluate_h, permutation argument [UPSTREAM plonk/evaluation.rs]: per extended-domain point, in this order:
+ * l0*(1-z_0); l_last*(z_last^2-z_last); for sets 1..: l0*(z_i - z_{i-1}(w^last X)); for every set:
+ * l_active*(z_i(wX)*prod(v + beta*sigma + gamma) - z_i*prod(v + delta^j*beta*X + gamma)), each folded with y. */
+typedef struct { fe *acc; const fe *const *z; uint32_t nsets; const fe *const *cols, *const *sig; uint32_t ncols, chunk; const fe *l0, *l_last, *l_active;
+                 size_t ne, step; int64_t last_rot; const fe *beta, *gamma, *y, *delta, *zeta, *ext_omega; } perm_arg;
+static void perm_range(size_t lo, size_t hi, void *p) {
+    perm_arg *g = (perm_arg *)p;
+    size_t m = g->ne - 1;
+    fe one = FR.r1, beta_term, delta_start;
+    fe_pow_u64(&beta_term, g->ext_omega, lo);
+    fe_mul(&delta_start, g->beta, g->zeta, &FR);
+    for (size_t i = lo; i < hi; ++i) {
+        size_t r_next = (i + g->step) & m, r_last = (size_t)((int64_t)i + g->last_rot * (int64_t)g->step) & m;
+        fe v = g->acc[i], t, u;
+        const fe *zf = g->z[0], *zl = g->z[g->nsets - 1];
+        fe_sub(&t, &one, &zf[i], &FR); fe_mul(&t, &t, &g->l0[i], &FR);
+        fe_mul(&v, &v, g->y, &FR); fe_add(&v, &v, &t, &FR);
+        fe_mul(&t, &zl[i], &zl[i], &FR); fe_sub(&t, &t, &zl[i], &FR); fe_mul(&t, &t, &g->l_last[i], &FR);
+        fe_mul(&v, &v, g->y, &FR); fe_add(&v, &v, &t, &FR);
+        for (uint32_t s = 1; s < g->nsets; ++s) {
+            fe_sub(&t, &g->z[s][i], &g->z[s - 1][r_last], &FR); fe_mul(&t, &t, &g->l0[i], &FR);
+            fe_mul(&v, &v, g->y, &FR); fe_add(&v, &v, &t, &FR);
+        }
+        fe cur_delta; fe_mul(&cur_delta, &delta_start, &beta_term, &FR);
+        for (uint32_t s = 0, c0 = 0; s < g->nsets; ++s, c0 += g->chunk) {
+            uint32_t c1 = c0 + g->chunk > g->ncols ? g->ncols : c0 + g->chunk;
+            fe left = g->z[s][r_next], right = g->z[s][i];
+            for (uint32_t c = c0; c < c1; ++c) {
+                fe_mul(&t, g->beta, &g->sig[c][i], &FR); fe_add(&t, &t, &g->cols[c][i], &FR); fe_add(&t, &t, g->gamma, &FR);
+                fe_mul(&left, &left, &t, &FR);
+            }
+            for (uint32_t c = c0; c < c1; ++c) {
+                fe_add(&u, &g->cols[c][i], &cur_delta, &FR); fe_add(&u, &u, g->gamma, &FR);
+                fe_mul(&right, &right, &u, &FR);
+                fe_mul(&cur_delta, &cur_delta, g->delta, &FR);
+            }
+            fe_sub(&t, &left, &right, &FR); fe_mul(&t, &t, &g->l_active[i], &FR);
+            fe_mul(&v, &v, g->y, &FR); fe_add(&v, &v, &t, &FR);
+        }
+        g->acc[i] = v;
+        fe_mul(&beta_term, &beta_term, g->ext_omega, &FR);
+    }
+}
+void orc_quotient_permutation(fe *acc, const fe *const *z_sets, uint32_t nsets, const fe *const *cols, const fe *const *sigmas, uint32_t ncols,
+                              uint32_t chunk_len, const fe *l0, const fe *l_last, const fe *l_active, size_t ne, size_t step, int32_t last_rotation,
+                              const fe *beta, const fe *gamma, const fe *y, const fe *delta, const fe *zeta, const fe *ext_omega, int threads) {
+    perm_arg g = {acc, z_sets, nsets, cols, sigmas, ncols, chunk_len, l0, l_last, l_active, ne, step, last_rotation, beta, gamma, y, delta, zeta, ext_omega};
+    parallel_for(ne, threads, perm_range, &g);
+}
+/* evaluate_h, one lookup argument [UPSTREAM plonk/evaluation.rs]; input / table: the theta-compressed expressions evaluated on
+ * the extended domain (for halo2-base: q_lookup*a or a, and the table column; halo2-base/src/gates/range/mod.rs:131-150) */
+typedef struct { fe *acc; const fe *z, *in, *tab, *ap, *sp, *l0, *l_last, *l_active; size_t ne, step; const fe *beta, *gamma, *y; } lk_arg;
+static void lk_range(size_t lo, size_t hi, void *p) {
+    lk_arg *g = (lk_arg *)p;
+    size_t m = g->ne - 1;
+    fe one = FR.r1;
+    for (size_t i = lo; i < hi; ++i) {
+        size_t r_next = (i + g->step) & m, r_prev = (i - g->step) & m;
+        fe v = g->acc[i], t, u, table_value, a_minus_s;
+        fe_add(&t, &g->in[i], g->beta, &FR); fe_add(&u, &g->tab[i], g->gamma, &FR); fe_mul(&table_value, &t, &u, &FR);
+        fe_sub(&a_minus_s, &g->ap[i], &g->sp[i], &FR);
+        fe_sub(&t, &one, &g->z[i], &FR); fe_mul(&t, &t, &g->l0[i], &FR);
+        fe_mul(&v, &v, g->y, &FR); fe_add(&v, &v, &t, &FR);
+        fe_mul(&t, &g->z[i], &g->z[i], &FR); fe_sub(&t, &t, &g->z[i], &FR); fe_mul(&t, &t, &g->l_last[i], &FR);
+        fe_mul(&v, &v, g->y, &FR); fe_add(&v, &v, &t, &FR);
+        fe_add(&t, &g->ap[i], g->beta, &FR); fe_add(&u, &g->sp[i], g->gamma, &FR); fe_mul(&t, &t, &u, &FR); fe_mul(&t, &t, &g->z[r_next], &FR);
+        fe_mul(&u, &g->z[i], &table_value, &FR); fe_sub(&t, &t, &u, &FR); fe_mul(&t, &t, &g->l_active[i], &FR);
+        fe_mul(&v, &v, g->y, &FR); fe_add(&v, &v, &t, &FR);
+        fe_mul(&t, &a_minus_s, &g->l0[i], &FR);
+        fe_mul(&v, &v, g->y, &FR); fe_add(&v, &v, &t, &FR);
+        fe_sub(&t, &g->ap[i], &g->ap[r_prev], &FR); fe_mul(&t, &t, &a_minus_s, &FR); fe_mul(&t, &t, &g->l_active[i], &FR);
+        fe_mul(&v, &v, g->y, &FR); fe_add(&v, &v, &t, &FR);
+        g->acc[i] = v;
+    }
+}
+void orc_quotient_lookup(fe *acc, const fe *z, const fe *input, const fe *table, const fe *ap, const fe *sp, const fe *l0, const fe *l_last,
+                         const fe *l_active, size_t ne, size_t step, const fe *beta, const fe *gamma, const fe *y, int threads) {
+    lk_arg g = {acc, z, input, table, ap, sp, l0, l_last, l_active, ne, step, beta, gamma, y};
+    parallel_for(ne, threads, lk_range, &g);
+}
+/* EvaluationDomain::divide_by_vanishing_poly: a[i] *= t_evaluations[i mod 2^(ext_k-k)], t_evaluations[j] = 1/((zeta*w_ext^j)^n - 1) */
+typedef struct { fe *a; const fe *t; size_t mask; } van_arg;
+static void van_range(size_t lo, size_t hi, void *p) { van_arg *g = (van_arg *)p; for (size_t i = lo; i < hi; ++i) fe_mul(&g->a[i], &g->a[i], &g->t[i & g->mask], &FR); }
+void orc_divide_by_vanishing(fe *a, uint32_t ext_k, uint32_t k, const fe *ext_omega, const fe *zeta, int threads) {
+    size_t cnt = (size_t)1 << (ext_k - k);
+    fe *t = (fe *)malloc(sizeof(fe) * cnt), zn, wn, cur;
+    fe_pow_u64(&zn, zeta, (uint64_t)1 << k);
+    fe_pow_u64(&wn, ext_omega, (uint64_t)1 << k);
+    cur = zn;
+    for (size_t j = 0; j < cnt; ++j) { fe_sub(&t[j], &cur, &FR.r1, &FR); fe_inv(&t[j], &t[j], &FR); fe_mul(&cur, &cur, &wn, &FR); }
+    van_arg g = {a, t, cnt - 1};
+    parallel_for((size_t)1 << ext_k, threads, van_range, &g);
+    free(t);
+}
