@@ -489,6 +489,20 @@ int h2hip_fr_axpy_dev(h2hip_ctx *ctx, void *y, const void *a, const void *x, siz
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
 }
+// y[i] = s*y[i] + a*x[i]
+int h2hip_fr_axpby_dev(h2hip_ctx *ctx, void *y, const void *s, const void *a, const void *x, size_t n) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && a && s && (n == 0 || (y && x)), "NULL argument");
+    if (!n) return H2HIP_OK;
+    Fr av, sv;
+    memcpy(&av, a, sizeof(Fr));
+    memcpy(&sv, s, sizeof(Fr));
+    prof_begin(ctx, "fr_axpby_kernel");
+    hipLaunchKernelGGL(fr_axpby_kernel, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (Fr *)y, sv, true, (const Fr *)x, av, n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
 int h2hip_fr_scale_dev(h2hip_ctx *ctx, void *y, const void *s, size_t n) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && s && (n == 0 || y), "NULL argument");

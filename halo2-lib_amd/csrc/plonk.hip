@@ -1,0 +1,1062 @@
+// plonk::create_proof for halo2-base circuits with every polynomial resident in HBM.
+//
+// What the reference runs at halo2-base/src/utils/testing.rs:32-50
+//     create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<'_, Bn256>, Challenge255<_>, _, Blake2bWrite<Vec<u8>, G1Affine, _>, _>
+// lives in the un-vendored halo2-axiom 0.5.3 (Cargo.lock:1063-1065); the protocol below restates it [UPSTREAM-RECALL, SURVEY.md §3.2
+// and Appendix A] for the one constraint system halo2-lib builds, BaseConfig::configure (halo2-base/src/gates/circuit/mod.rs:70-96):
+//     FlexGateConfig   one selector + the gate q*(a + b*c - d) at rotations 0..3 per advice column, constants columns with equality
+//                      (halo2-base/src/gates/flex_gate/mod.rs:61-91,120-146)
+//     RangeConfig      table column first; with a single advice column the lookup is (q_lookup * a, table) on that column, else
+//                      dedicated lookup-advice columns (a, table)  (halo2-base/src/gates/range/mod.rs:71-150)
+//     instance columns with equality (gates/circuit/mod.rs:89-91)
+// This file is host code: the Blake2b transcript, the order of operations, and SHPLONK's O(#openings) bookkeeping.  All vector work
+// goes through the kernels behind the C ABI (include/h2hip.h).  First phase only.
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <vector>
+
+#include "blake2b.h"
+#include "internal.h"
+
+namespace h2 {
+namespace plonk {
+
+// ---------------------------------------------------------------------------------------------- host field helpers
+static Fr fr_from_canonical_u64x4(const uint64_t v[4]) {
+    Fr a;
+    memcpy(a.l, v, 32);
+    return fe_to_mont(a);
+}
+static Fr fr_from_u64(uint64_t v) {
+    uint64_t w[4] = {v, 0, 0, 0};
+    return fr_from_canonical_u64x4(w);
+}
+// canonical little-endian bytes (to_repr)
+static void fr_repr(const Fr &a, uint8_t out[32]) {
+    Fr c = fe_from_mont(a);
+    memcpy(out, c.l, 32);
+}
+static void fq_repr(const Fq &a, uint8_t out[32]) {
+    Fq c = fe_from_mont(a);
+    memcpy(out, c.l, 32);
+}
+// numeric order of the canonical values (Ord for Fr compares to_repr from the most significant byte)
+static int fr_cmp(const Fr &a, const Fr &b) {
+    Fr x = fe_from_mont(a), y = fe_from_mont(b);
+    for (int i = 7; i >= 0; --i)
+        if (x.l[i] != y.l[i]) return x.l[i] < y.l[i] ? -1 : 1;
+    return 0;
+}
+struct FrLess {
+    bool operator()(const Fr &a, const Fr &b) const { return fr_cmp(a, b) < 0; }
+};
+// Fr::from_uniform_bytes: 512-bit little-endian integer mod r = d0 + d1 * 2^256
+static Fr fr_from_uniform_bytes(const uint8_t b[64]) {
+    Fr d0, d1;
+    memcpy(d0.l, b, 32);
+    memcpy(d1.l, b + 32, 32);
+    const Fr r2 = Fr::r2(), r3 = fe_mul(r2, r2);
+    return fe_add(fe_mul(d0, r2), fe_mul(d1, r3));
+}
+static const uint64_t ROOT_OF_UNITY[4] = {0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL};   // 7^((r-1)/2^28)
+static const uint64_t ZETA[4] = {0xb8ca0b2d36636f23ULL, 0xcc37a73fec2bc5e9ULL, 0x048b6e193fd84104ULL, 0x30644e72e131a029ULL};            // 7^(2(r-1)/3)
+static const uint64_t DELTA[4] = {0x870e56bbe533e9a2ULL, 0x5b5f898e5e963f25ULL, 0x64ec26aad4c86e71ULL, 0x09226b6e22c6f0caULL};           // 7^(2^28)
+
+// ---------------------------------------------------------------------------------------------- constraint-system shape
+struct Lookup {
+    int q_col;   // fixed column of the complex selector, or -1
+    int advice_col, table_col;
+};
+struct ColumnRef {
+    int kind;   // 0 = fixed, 1 = advice, 2 = instance
+    int index;
+};
+struct Shape {
+    h2hip_base_circuit_params p;
+    uint32_t k, n;
+    bool with_range, single;
+    int table_col = -1, q_lookup_col = -1, first_constant_col = -1, first_q_enable_col = -1;
+    uint32_t num_advice_total, num_fixed_total;
+    std::vector<Lookup> lookups;
+    std::vector<ColumnRef> perm_columns;
+    std::vector<std::pair<int, int>> advice_queries, fixed_queries;   // (column, rotation) in first-query order
+    uint32_t degree, blinding_factors, usable_rows, chunk_len, quotient_pieces, extended_k, num_perm_sets;
+
+    int init(const h2hip_base_circuit_params &bp) {
+        p = bp;
+        k = bp.k;
+        H2_REQUIRE(k >= 4 && k <= 26, "k out of range (4..26)");
+        H2_REQUIRE(bp.num_advice >= 1 && bp.num_advice <= 64 && bp.num_lookup_advice <= 64 && bp.num_fixed <= 16 && bp.num_instance <= 8,
+                   "column counts out of range");
+        H2_REQUIRE(bp.lookup_bits < (int32_t)k, "lookup_bits must be less than k");
+        n = 1u << k;
+        with_range = bp.lookup_bits >= 0 && bp.num_lookup_advice != 0;
+        single = with_range && bp.num_advice == 1;   // range/mod.rs:93-95: the lookup sits on the gate column behind a complex selector
+        int nf = 0;
+        if (with_range) table_col = nf++;            // meta.lookup_table_column() is created first (range/mod.rs:82)
+        first_constant_col = bp.num_fixed ? nf : -1;
+        nf += (int)bp.num_fixed;                     // flex_gate/mod.rs:123-129
+        // selectors are compressed into fixed columns after the circuit's own ones: the complex selector keeps a column of its own, and
+        // the per-column gate selectors are enabled on common rows, so none of them can share a column either [UPSTREAM compress_selectors]
+        if (single) q_lookup_col = nf++;
+        first_q_enable_col = nf;
+        nf += (int)bp.num_advice;
+        num_fixed_total = (uint32_t)nf;
+        const uint32_t nla = (single || !with_range) ? 0 : bp.num_lookup_advice;
+        num_advice_total = bp.num_advice + nla;
+        if (single) lookups.push_back({q_lookup_col, 0, table_col});
+        for (uint32_t i = 0; i < nla; ++i) lookups.push_back({-1, (int)(bp.num_advice + i), table_col});
+        // enable_equality order: constants, gate advice, lookup advice, instance
+        for (uint32_t i = 0; i < bp.num_fixed; ++i) perm_columns.push_back({0, first_constant_col + (int)i});
+        for (uint32_t i = 0; i < num_advice_total; ++i) perm_columns.push_back({1, (int)i});
+        for (uint32_t i = 0; i < bp.num_instance; ++i) perm_columns.push_back({2, (int)i});
+        for (uint32_t a = 0; a < bp.num_advice; ++a)
+            for (int r = 0; r < 4; ++r) advice_queries.push_back({(int)a, r});
+        for (uint32_t i = 0; i < nla; ++i) advice_queries.push_back({(int)(bp.num_advice + i), 0});
+        for (uint32_t i = 0; i < bp.num_fixed; ++i) fixed_queries.push_back({first_constant_col + (int)i, 0});
+        if (with_range) fixed_queries.push_back({table_col, 0});
+        if (single) fixed_queries.push_back({q_lookup_col, 0});
+        for (uint32_t i = 0; i < bp.num_advice; ++i) fixed_queries.push_back({first_q_enable_col + (int)i, 0});
+        degree = 3;   // gate and permutation argument
+        for (const Lookup &l : lookups) degree = std::max<uint32_t>(degree, std::max<uint32_t>(4, 2 + (l.q_col >= 0 ? 2 : 1) + 1));
+        blinding_factors = std::max<uint32_t>(3, 4) + 2;   // a gate column is queried at four rotations
+        H2_REQUIRE(n > blinding_factors + 8, "k too small for the blinding rows");
+        usable_rows = n - (blinding_factors + 1);
+        chunk_len = degree - 2;
+        quotient_pieces = degree - 1;
+        extended_k = k;
+        while (((uint64_t)1 << extended_k) < (uint64_t)n * quotient_pieces) ++extended_k;
+        H2_REQUIRE(extended_k <= 28, "extended domain exceeds the 2-adicity of F_r");
+        num_perm_sets = (uint32_t)((perm_columns.size() + chunk_len - 1) / chunk_len);
+        if (bp.lookup_bits >= 0 && with_range) H2_REQUIRE(((uint64_t)1 << bp.lookup_bits) <= usable_rows, "lookup table is too large for the circuit degree plus blinding factors");
+        return H2HIP_OK;
+    }
+    uint32_t num_commitments() const {
+        return num_advice_total + 3 * (uint32_t)lookups.size() + num_perm_sets + 1 + quotient_pieces + 2;
+    }
+    uint32_t num_evals() const {
+        return (uint32_t)advice_queries.size() + (uint32_t)fixed_queries.size() + 1 + (uint32_t)perm_columns.size() +
+               (num_perm_sets ? 3 * num_perm_sets - 1 : 0) + 5 * (uint32_t)lookups.size();
+    }
+};
+
+struct Domain {
+    Fr omega, omega_inv, ext_omega, ext_omega_inv, zeta, zeta_inv, ifft_divisor, ext_ifft_divisor, delta;
+    void init(uint32_t k, uint32_t ek) {
+        ext_omega = fr_from_canonical_u64x4(ROOT_OF_UNITY);
+        for (uint32_t i = ek; i < 28; ++i) ext_omega = fe_sqr(ext_omega);
+        omega = ext_omega;
+        for (uint32_t i = k; i < ek; ++i) omega = fe_sqr(omega);
+        omega_inv = fe_inv(omega);
+        ext_omega_inv = fe_inv(ext_omega);
+        zeta = fr_from_canonical_u64x4(ZETA);
+        zeta_inv = fe_sqr(zeta);
+        ifft_divisor = fe_inv(fr_from_u64((uint64_t)1 << k));
+        ext_ifft_divisor = fe_inv(fr_from_u64((uint64_t)1 << ek));
+        delta = fr_from_canonical_u64x4(DELTA);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- device buffers
+// size-keyed pool: a proof's buffers go back to the key's pool when it is done, so a second proof allocates nothing
+struct BufPool {
+    std::multimap<size_t, void *> free_;
+    std::vector<void *> all_;
+    int take(size_t bytes, void **out) {
+        auto it = free_.find(bytes);
+        if (it != free_.end()) {
+            *out = it->second;
+            free_.erase(it);
+            return H2HIP_OK;
+        }
+        hipError_t e = hipMalloc(out, bytes ? bytes : 256);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return H2HIP_ERR_NOMEM;
+        }
+        all_.push_back(*out);
+        return H2HIP_OK;
+    }
+    void give(size_t bytes, void *p) { free_.insert({bytes, p}); }
+    void destroy() {
+        for (void *p : all_) hipFree(p);
+        all_.clear();
+        free_.clear();
+    }
+};
+// buffers taken during one call; returned to the pool on scope exit (also on the error paths)
+struct Scope {
+    BufPool *pool;
+    std::vector<std::pair<size_t, void *>> held;
+    explicit Scope(BufPool *p) : pool(p) {}
+    ~Scope() {
+        for (auto &h : held) pool->give(h.first, h.second);
+    }
+    int take(size_t elems, Fr **out) {
+        void *p = nullptr;
+        H2_CHK(pool->take(sizeof(Fr) * elems, &p));
+        held.push_back({sizeof(Fr) * elems, p});
+        *out = (Fr *)p;
+        return H2HIP_OK;
+    }
+    void release(Fr *p) {   // early return of one buffer
+        for (size_t i = 0; i < held.size(); ++i)
+            if (held[i].second == (void *)p) {
+                pool->give(held[i].first, held[i].second);
+                held.erase(held.begin() + (long)i);
+                return;
+            }
+    }
+};
+
+}  // namespace plonk
+}  // namespace h2
+
+using namespace h2;
+using namespace h2::plonk;
+
+struct h2hip_plonk_pk {
+    Shape sh;
+    Domain dom;
+    h2hip_ctx *ctx = nullptr;
+    const h2hip_bases *g = nullptr, *g_lagrange = nullptr;
+    std::vector<Fr *> fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets;
+    Fr *l0 = nullptr, *l_last = nullptr, *l_blind = nullptr;   // extended-domain evaluations
+    std::vector<G1Affine> fixed_commitments, permutation_commitments;
+    Fr transcript_repr;
+    bool have_repr = false;
+    BufPool pool;
+    std::vector<void *> owned;
+};
+
+namespace h2 {
+namespace plonk {
+
+// ---------------------------------------------------------------------------------------------- transcript
+static const unsigned SIGN_BIT = 6, INF_BIT = 7;   // compressed G1: sign(y) and identity flags in the top byte (halo2curves new_curve_impl!; the
+                                                   // positions are UNVERIFIED for halo2curves-axiom 0.7.3, see oracle/transcript.py)
+struct Transcript {   // Blake2bWrite<Vec<u8>, G1Affine, Challenge255<_>>  
+    Blake2b st;
+    std::vector<uint8_t> proof;
+    Transcript() : st(64, "Halo2-Transcript") {}
+    void common_scalar(const Fr &s) {
+        uint8_t b[33];
+        b[0] = 0x02;
+        fr_repr(s, b + 1);
+        st.update(b, 33);
+    }
+    void write_scalar(const Fr &s) {
+        common_scalar(s);
+        uint8_t b[32];
+        fr_repr(s, b);
+        proof.insert(proof.end(), b, b + 32);
+    }
+    int write_point(const G1Affine &p) {
+        if (p.x.is_zero() && p.y.is_zero()) {   // upstream: io::Error "cannot write points at infinity to the transcript"
+            set_error("create_proof: a commitment is the point at infinity and cannot be written to the transcript");
+            return H2HIP_ERR_INVALID;
+        }
+        uint8_t b[65];
+        b[0] = 0x01;
+        fq_repr(p.x, b + 1);
+        fq_repr(p.y, b + 33);
+        st.update(b, 65);
+        uint8_t c[32];
+        memcpy(c, b + 1, 32);
+        c[31] |= (uint8_t)((b[33] & 1) << SIGN_BIT);
+        proof.insert(proof.end(), c, c + 32);
+        return H2HIP_OK;
+    }
+    Fr squeeze_challenge() {
+        uint8_t z = 0x00, d[64];
+        st.update(&z, 1);
+        st.digest(d);
+        return fr_from_uniform_bytes(d);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- permutation keygen
+// permutation::keygen::Assembly [UPSTREAM-RECALL]: cycles merged by `copy`; sigma_i(omega^j) = delta^i' * omega^j' for mapping[i][j] = (i', j')
+struct Assembly {
+    uint32_t m, n;
+    std::vector<uint32_t> map_c, map_r, aux_c, aux_r, sizes;
+    Assembly(uint32_t m_, uint32_t n_) : m(m_), n(n_), map_c((size_t)m_ * n_), map_r((size_t)m_ * n_), aux_c((size_t)m_ * n_), aux_r((size_t)m_ * n_), sizes((size_t)m_ * n_, 1) {
+        for (uint32_t c = 0; c < m; ++c)
+            for (uint32_t r = 0; r < n; ++r) {
+                size_t i = (size_t)c * n + r;
+                map_c[i] = aux_c[i] = c;
+                map_r[i] = aux_r[i] = r;
+            }
+    }
+    void copy(uint32_t lc, uint32_t lr, uint32_t rc, uint32_t rr) {
+        size_t li = (size_t)lc * n + lr, ri = (size_t)rc * n + rr;
+        uint32_t lcy_c = aux_c[li], lcy_r = aux_r[li], rcy_c = aux_c[ri], rcy_r = aux_r[ri];
+        if (lcy_c == rcy_c && lcy_r == rcy_r) return;
+        size_t lcy = (size_t)lcy_c * n + lcy_r, rcy = (size_t)rcy_c * n + rcy_r;
+        if (sizes[lcy] < sizes[rcy]) {
+            std::swap(lcy, rcy);
+            std::swap(lcy_c, rcy_c);
+            std::swap(lcy_r, rcy_r);
+        }
+        sizes[lcy] += sizes[rcy];
+        size_t i = rcy;
+        do {
+            aux_c[i] = lcy_c;
+            aux_r[i] = lcy_r;
+            i = (size_t)map_c[i] * n + map_r[i];
+        } while (i != rcy);
+        std::swap(map_c[li], map_c[ri]);
+        std::swap(map_r[li], map_r[ri]);
+    }
+};
+
+static int dev_alloc(h2hip_plonk_pk *pk, size_t elems, Fr **out) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, sizeof(Fr) * (elems ? elems : 1));
+    if (e != hipSuccess) {
+        set_error("hipMalloc for the proving key failed: %s", hipGetErrorString(e));
+        return H2HIP_ERR_NOMEM;
+    }
+    pk->owned.push_back(p);
+    *out = (Fr *)p;
+    return H2HIP_OK;
+}
+
+// values (n, resident) -> (poly, coset): lagrange_to_coeff then coeff_to_extended
+static int to_poly_and_coset(h2hip_plonk_pk *pk, const Fr *values, Fr **poly, Fr **coset) {
+    h2hip_ctx *ctx = pk->ctx;
+    const Shape &sh = pk->sh;
+    const Domain &d = pk->dom;
+    H2_CHK(dev_alloc(pk, sh.n, poly));
+    H2_CHK(dev_alloc(pk, (size_t)1 << sh.extended_k, coset));
+    H2_HIPCHK(hipMemcpyAsync(*poly, values, sizeof(Fr) * sh.n, hipMemcpyDeviceToDevice, ctx->stream));
+    H2_CHK(h2hip_ifft_dev(ctx, *poly, &d.omega_inv, sh.k, &d.ifft_divisor));
+    return h2hip_coeff_to_extended_dev(ctx, *poly, sh.k, *coset, sh.extended_k, &d.ext_omega, &d.zeta);
+}
+
+static int keygen_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *const *fixed_host, const uint32_t *copies, size_t ncopies) {
+    const Shape &sh = pk->sh;
+    const uint32_t n = sh.n, m = (uint32_t)sh.perm_columns.size();
+    // ---- fixed columns
+    for (uint32_t c = 0; c < sh.num_fixed_total; ++c) {
+        H2_REQUIRE(fixed_host[c], "NULL fixed column");
+        Fr *v = nullptr, *p = nullptr, *e = nullptr;
+        H2_CHK(dev_alloc(pk, n, &v));
+        H2_HIPCHK(hipMemcpyAsync(v, fixed_host[c], sizeof(Fr) * n, hipMemcpyHostToDevice, ctx->stream));
+        H2_CHK(to_poly_and_coset(pk, v, &p, &e));
+        pk->fixed_values.push_back(v);
+        pk->fixed_polys.push_back(p);
+        pk->fixed_cosets.push_back(e);
+    }
+    // ---- permutation: cycles on the host, sigma values delta^c' * omega^r'
+    Assembly as(m, n);
+    for (size_t i = 0; i < ncopies; ++i) {
+        const uint32_t *c = copies + 4 * i;
+        H2_REQUIRE(c[0] < m && c[2] < m, "copy constraint names a column outside the permutation");
+        H2_REQUIRE(c[1] < sh.usable_rows && c[3] < sh.usable_rows, "copy constraint outside the usable rows (NotEnoughRowsAvailable)");
+        as.copy(c[0], c[1], c[2], c[3]);
+    }
+    std::vector<Fr> wpow(n), dpow(m ? m : 1), col(n);
+    wpow[0] = Fr::one();
+    for (uint32_t j = 1; j < n; ++j) wpow[j] = fe_mul(wpow[j - 1], pk->dom.omega);
+    dpow[0] = Fr::one();
+    for (uint32_t i = 1; i < m; ++i) dpow[i] = fe_mul(dpow[i - 1], pk->dom.delta);
+    for (uint32_t c = 0; c < m; ++c) {
+        for (uint32_t r = 0; r < n; ++r) {
+            size_t i = (size_t)c * n + r;
+            col[r] = as.map_c[i] == 0 ? wpow[as.map_r[i]] : fe_mul(dpow[as.map_c[i]], wpow[as.map_r[i]]);
+        }
+        Fr *v = nullptr, *p = nullptr, *e = nullptr;
+        H2_CHK(dev_alloc(pk, n, &v));
+        H2_HIPCHK(hipMemcpyAsync(v, col.data(), sizeof(Fr) * n, hipMemcpyHostToDevice, ctx->stream));
+        H2_HIPCHK(hipStreamSynchronize(ctx->stream));   // `col` is reused
+        H2_CHK(to_poly_and_coset(pk, v, &p, &e));
+        pk->sigma_values.push_back(v);
+        pk->sigma_polys.push_back(p);
+        pk->sigma_cosets.push_back(e);
+    }
+    // ---- commitments of the verifying key
+    std::vector<const void *> cols;
+    for (Fr *v : pk->fixed_values) cols.push_back(v);
+    for (Fr *v : pk->sigma_values) cols.push_back(v);
+    std::vector<G1Affine> comm(cols.size());
+    if (!cols.empty()) H2_CHK(h2hip_msm_g1_batch_dev(ctx, pk->g_lagrange, cols.data(), n, cols.size(), H2HIP_POINT_AFFINE, comm.data()));
+    pk->fixed_commitments.assign(comm.begin(), comm.begin() + sh.num_fixed_total);
+    pk->permutation_commitments.assign(comm.begin() + sh.num_fixed_total, comm.end());
+    // ---- l_0, l_last, l_blind on the extended domain
+    Fr *tmp = nullptr, *tp = nullptr;
+    H2_CHK(dev_alloc(pk, n, &tmp));
+    std::vector<Fr> lv(n);
+    const Fr one = Fr::one(), zero = Fr::zero();
+    const uint32_t bf = sh.blinding_factors;
+    Fr **dst[3] = {&pk->l0, &pk->l_last, &pk->l_blind};
+    for (int which = 0; which < 3; ++which) {
+        for (uint32_t r = 0; r < n; ++r) lv[r] = zero;
+        if (which == 0) lv[0] = one;
+        if (which == 1) lv[n - bf - 1] = one;
+        if (which == 2)
+            for (uint32_t r = n - bf; r < n; ++r) lv[r] = one;
+        H2_HIPCHK(hipMemcpyAsync(tmp, lv.data(), sizeof(Fr) * n, hipMemcpyHostToDevice, ctx->stream));
+        H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+        H2_CHK(to_poly_and_coset(pk, tmp, &tp, dst[which]));
+    }
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- SHPLONK bookkeeping
+struct Query {
+    int poly;   // index into the prover's polynomial list
+    Fr point, eval;
+};
+struct RotationSet {
+    std::vector<Fr> points;                          // ascending
+    std::vector<int> polys;                          // in order of first appearance
+    std::vector<std::vector<Fr>> evals;              // [poly][point]
+};
+// poly/kzg/multiopen/shplonk.rs::construct_intermediate_sets [UPSTREAM-RECALL]
+static void construct_intermediate_sets(const std::vector<Query> &queries, std::vector<RotationSet> &sets, std::vector<Fr> &super_points) {
+    std::vector<Fr> pts;
+    for (const Query &q : queries) pts.push_back(q.point);
+    std::sort(pts.begin(), pts.end(), FrLess());
+    super_points.clear();
+    for (const Fr &p : pts)
+        if (super_points.empty() || fr_cmp(super_points.back(), p) != 0) super_points.push_back(p);
+    // polynomial -> its point set, polynomials in order of first appearance
+    std::vector<int> order;
+    std::map<int, std::vector<Fr>> pset;
+    for (const Query &q : queries) {
+        auto it = pset.find(q.poly);
+        if (it == pset.end()) {
+            order.push_back(q.poly);
+            pset[q.poly] = {q.point};
+        } else {
+            bool have = false;
+            for (const Fr &p : it->second) have |= fr_cmp(p, q.point) == 0;
+            if (!have) it->second.push_back(q.point);
+        }
+    }
+    for (auto &kv : pset) std::sort(kv.second.begin(), kv.second.end(), FrLess());
+    auto same = [](const std::vector<Fr> &a, const std::vector<Fr> &b) {
+        if (a.size() != b.size()) return false;
+        for (size_t i = 0; i < a.size(); ++i)
+            if (fr_cmp(a[i], b[i]) != 0) return false;
+        return true;
+    };
+    sets.clear();
+    for (int poly : order) {
+        const std::vector<Fr> &ps = pset[poly];
+        RotationSet *rs = nullptr;
+        for (RotationSet &s : sets)
+            if (same(s.points, ps)) rs = &s;
+        if (!rs) {
+            sets.push_back(RotationSet());
+            rs = &sets.back();
+            rs->points = ps;
+        }
+        rs->polys.push_back(poly);
+        std::vector<Fr> ev;
+        for (const Fr &p : ps)
+            for (const Query &q : queries)
+                if (q.poly == poly && fr_cmp(q.point, p) == 0) {
+                    ev.push_back(q.eval);
+                    break;
+                }
+        rs->evals.push_back(ev);
+    }
+}
+// coefficients (low to high) of the polynomial of degree < m through (points[i], evals[i])
+static std::vector<Fr> lagrange_interpolate(const std::vector<Fr> &points, const std::vector<Fr> &evals) {
+    const size_t m = points.size();
+    std::vector<Fr> out(m, Fr::zero());
+    if (m == 1) {
+        out[0] = evals[0];
+        return out;
+    }
+    for (size_t j = 0; j < m; ++j) {
+        std::vector<Fr> num(1, Fr::one());
+        Fr den = Fr::one();
+        for (size_t i = 0; i < m; ++i) {
+            if (i == j) continue;
+            std::vector<Fr> nxt(num.size() + 1, Fr::zero());
+            for (size_t t = 0; t < num.size(); ++t) {
+                nxt[t] = fe_sub(nxt[t], fe_mul(num[t], points[i]));
+                nxt[t + 1] = fe_add(nxt[t + 1], num[t]);
+            }
+            num.swap(nxt);
+            den = fe_mul(den, fe_sub(points[j], points[i]));
+        }
+        Fr scale = fe_mul(evals[j], fe_inv(den));
+        for (size_t t = 0; t < num.size(); ++t) out[t] = fe_add(out[t], fe_mul(num[t], scale));
+    }
+    return out;
+}
+static Fr eval_small(const std::vector<Fr> &c, const Fr &x) {
+    Fr acc = Fr::zero();
+    for (size_t i = c.size(); i-- > 0;) acc = fe_add(fe_mul(acc, x), c[i]);
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------- create_proof
+static const char *STAGE_NAMES[H2HIP_PLONK_STAGES] = {
+    "advice_upload_blinding", "commit_advice", "lookup_permute", "commit_lookup_permuted", "grand_products", "commit_grand_products",
+    "random_poly_commit", "lagrange_to_coeff", "coeff_to_extended", "quotient_terms", "quotient_to_coeff", "commit_h_pieces", "evaluations",
+    "multiopen_shplonk"};
+
+struct Laps {
+    h2hip_ctx *ctx;
+    double *ms;
+    std::chrono::steady_clock::time_point t;
+    Laps(h2hip_ctx *c, double *m) : ctx(c), ms(m) {
+        if (ms) {
+            for (int i = 0; i < H2HIP_PLONK_STAGES; ++i) ms[i] = 0;
+            t = std::chrono::steady_clock::now();
+        }
+    }
+    void lap(int stage) {
+        if (!ms) return;
+        hipStreamSynchronize(ctx->stream);
+        auto now = std::chrono::steady_clock::now();
+        ms[stage] += std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
+    }
+};
+
+static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *const *advice, bool advice_on_device, const void *const *instances,
+                             const size_t *instance_lens, h2hip_rng_fill_fn rng, void *rng_user, std::vector<uint8_t> &proof_out, double *stage_ms) {
+    const Shape &sh = pk->sh;
+    const Domain &dom = pk->dom;
+    const uint32_t n = sh.n, k = sh.k, ek = sh.extended_k, bf = sh.blinding_factors, u = sh.usable_rows;
+    const size_t ne = (size_t)1 << ek;
+    hipStream_t st = ctx->stream;
+    Scope sc(&pk->pool);
+    Laps laps(ctx, stage_ms);
+    Transcript tr;
+    std::vector<Fr> rnd;   // host staging of blinding values
+    auto draw = [&](size_t cnt) -> const Fr * {
+        rnd.resize(cnt ? cnt : 1);
+        if (cnt) rng(rng_user, rnd.data(), cnt);
+        return rnd.data();
+    };
+    auto put = [&](Fr *dst, const Fr *src, size_t cnt) -> int {   // pageable host -> device; the copy returns once `src` is consumed
+        if (cnt) H2_HIPCHK(hipMemcpyAsync(dst, src, sizeof(Fr) * cnt, hipMemcpyHostToDevice, st));
+        return H2HIP_OK;
+    };
+    auto commit_batch = [&](const h2hip_bases *bases, const std::vector<const void *> &cols, size_t len) -> int {
+        std::vector<G1Affine> pts(cols.size());
+        if (cols.size() == 1)
+            H2_CHK(h2hip_msm_g1_dev(ctx, bases, cols[0], len, H2HIP_POINT_AFFINE, pts.data()));
+        else if (!cols.empty())
+            H2_CHK(h2hip_msm_g1_batch_dev(ctx, bases, cols.data(), len, cols.size(), H2HIP_POINT_AFFINE, pts.data()));
+        for (const G1Affine &p : pts) H2_CHK(tr.write_point(p));
+        return H2HIP_OK;
+    };
+
+    tr.common_scalar(pk->transcript_repr);   // vk.hash_into(transcript)
+    // ---- instance columns: values are hashed, not committed (KZG: QUERY_INSTANCE = false)
+    std::vector<Fr *> inst_values(sh.p.num_instance), adv(sh.num_advice_total);
+    for (uint32_t i = 0; i < sh.p.num_instance; ++i) {
+        const size_t len = instance_lens ? instance_lens[i] : 0;
+        H2_REQUIRE(len <= u, "InstanceTooLarge");
+        H2_REQUIRE(len == 0 || (instances && instances[i]), "NULL instance column");
+        std::vector<Fr> vals(len ? len : 1);   // the caller's buffer need not be aligned like Fr
+        if (len) memcpy(vals.data(), instances[i], sizeof(Fr) * len);
+        for (size_t j = 0; j < len; ++j) tr.common_scalar(vals[j]);
+        H2_CHK(sc.take(n, &inst_values[i]));
+        H2_HIPCHK(hipMemsetAsync(inst_values[i], 0, sizeof(Fr) * n, st));
+        H2_CHK(put(inst_values[i], vals.data(), len));
+        H2_HIPCHK(hipStreamSynchronize(st));
+    }
+    // ---- advice columns: witness rows from the caller, blinding rows from the RNG
+    for (uint32_t c = 0; c < sh.num_advice_total; ++c) {
+        H2_REQUIRE(advice[c], "NULL advice column");
+        H2_CHK(sc.take(n, &adv[c]));
+        H2_HIPCHK(hipMemcpyAsync(adv[c], advice[c], sizeof(Fr) * u, advice_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        const Fr *tail = draw(n - u);
+        H2_CHK(put(adv[c] + u, tail, n - u));
+        H2_HIPCHK(hipStreamSynchronize(st));   // `rnd` is reused by the next draw
+    }
+    draw(sh.num_advice_total);   // Blind(Fr::random) per column: drawn, unused by KZG
+    laps.lap(0);
+    {
+        std::vector<const void *> cols(adv.begin(), adv.end());
+        H2_CHK(commit_batch(pk->g_lagrange, cols, n));
+    }
+    laps.lap(1);
+    const Fr theta = tr.squeeze_challenge();
+    (void)theta;   // every lookup of halo2-base compresses a single expression pair: theta does not enter the values
+    // ---- lookups: permuted input / table columns
+    struct LookupState {
+        Fr *inp, *ap, *sp, *z;
+        bool own_inp;
+    };
+    std::vector<LookupState> lks(sh.lookups.size());
+    {
+        std::vector<const void *> cols;
+        for (size_t li = 0; li < sh.lookups.size(); ++li) {
+            const Lookup &l = sh.lookups[li];
+            LookupState &s = lks[li];
+            s.own_inp = l.q_col >= 0;
+            if (s.own_inp) {
+                H2_CHK(sc.take(n, &s.inp));
+                H2_CHK(h2hip_fr_mul_batch_dev(ctx, s.inp, pk->fixed_values[l.q_col], adv[l.advice_col], n));
+            } else {
+                s.inp = adv[l.advice_col];
+            }
+            H2_CHK(sc.take(n, &s.ap));
+            H2_CHK(sc.take(n, &s.sp));
+            H2_CHK(h2hip_lookup_permute_dev(ctx, s.inp, pk->fixed_values[l.table_col], u, s.ap, s.sp));
+            const Fr *t1 = draw(bf + 1);
+            H2_CHK(put(s.ap + u, t1, bf + 1));
+            H2_HIPCHK(hipStreamSynchronize(st));
+            const Fr *t2 = draw(bf + 1);
+            H2_CHK(put(s.sp + u, t2, bf + 1));
+            H2_HIPCHK(hipStreamSynchronize(st));
+            draw(2);   // the two commitment blinds
+            cols.push_back(s.ap);
+            cols.push_back(s.sp);
+        }
+        laps.lap(2);
+        if (!cols.empty()) H2_CHK(commit_batch(pk->g_lagrange, cols, n));
+        laps.lap(3);
+    }
+    const Fr beta = tr.squeeze_challenge();
+    const Fr gamma = tr.squeeze_challenge();
+    // ---- grand products: permutation sets (chained through the last usable row), then the lookups
+    Fr *num = nullptr, *den = nullptr;
+    H2_CHK(sc.take(n, &num));
+    H2_CHK(sc.take(n, &den));
+    auto column_values = [&](const ColumnRef &c) -> const Fr * {
+        return c.kind == 0 ? pk->fixed_values[c.index] : c.kind == 1 ? adv[c.index] : inst_values[c.index];
+    };
+    std::vector<Fr *> perm_z(sh.num_perm_sets);
+    {
+        Fr last_z = Fr::one();
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
+            const uint32_t c0 = si * sh.chunk_len, c1 = std::min<uint32_t>(c0 + sh.chunk_len, (uint32_t)sh.perm_columns.size());
+            const void *cols[8], *sigs[8];
+            for (uint32_t c = c0; c < c1; ++c) {
+                cols[c - c0] = column_values(sh.perm_columns[c]);
+                sigs[c - c0] = pk->sigma_values[c];
+            }
+            H2_CHK(h2hip_permutation_product_terms_dev(ctx, num, den, cols, sigs, c1 - c0, c0, u, &beta, &gamma, &dom.delta, &dom.omega));
+            H2_CHK(sc.take(n, &perm_z[si]));
+            H2_CHK(h2hip_fr_grand_product_dev(ctx, perm_z[si], num, den, u));   // z[0] = 1 ... z[u]
+            if (si) H2_CHK(h2hip_fr_scale_dev(ctx, perm_z[si], &last_z, (size_t)u + 1));
+            const Fr *tail = draw(bf);
+            H2_CHK(put(perm_z[si] + (n - bf), tail, bf));
+            if (si + 1 < sh.num_perm_sets) H2_HIPCHK(hipMemcpyAsync(&last_z, perm_z[si] + u, sizeof(Fr), hipMemcpyDeviceToHost, st));
+            H2_HIPCHK(hipStreamSynchronize(st));
+            draw(1);   // blind
+        }
+        for (size_t li = 0; li < lks.size(); ++li) {
+            LookupState &s = lks[li];
+            H2_CHK(h2hip_lookup_product_terms_dev(ctx, num, den, s.inp, pk->fixed_values[sh.lookups[li].table_col], s.ap, s.sp, u, &beta, &gamma));
+            H2_CHK(sc.take(n, &s.z));
+            H2_CHK(h2hip_fr_grand_product_dev(ctx, s.z, num, den, u));
+            const Fr *tail = draw(bf);
+            H2_CHK(put(s.z + (n - bf), tail, bf));
+            H2_HIPCHK(hipStreamSynchronize(st));
+            draw(1);   // blind
+        }
+        laps.lap(4);
+        std::vector<const void *> cols(perm_z.begin(), perm_z.end());
+        for (LookupState &s : lks) cols.push_back(s.z);
+        if (!cols.empty()) H2_CHK(commit_batch(pk->g_lagrange, cols, n));
+        laps.lap(5);
+    }
+    // ---- vanishing argument: the random polynomial
+    Fr *random_poly = nullptr;
+    H2_CHK(sc.take(n, &random_poly));
+    {
+        const Fr *vals = draw(n);
+        H2_CHK(put(random_poly, vals, n));
+        H2_HIPCHK(hipStreamSynchronize(st));
+        draw(1);   // random_blind
+        std::vector<const void *> cols(1, random_poly);
+        H2_CHK(commit_batch(pk->g, cols, n));
+    }
+    laps.lap(6);
+    const Fr y = tr.squeeze_challenge();
+    // ---- coefficient form (in place: the Lagrange values are not needed again)
+    auto to_coeff = [&](Fr *a) -> int { return h2hip_ifft_dev(ctx, a, &dom.omega_inv, k, &dom.ifft_divisor); };
+    for (Fr *a : adv) H2_CHK(to_coeff(a));
+    for (Fr *a : inst_values) H2_CHK(to_coeff(a));
+    for (Fr *a : perm_z) H2_CHK(to_coeff(a));
+    for (LookupState &s : lks) {
+        if (s.own_inp) {
+            sc.release(s.inp);
+            s.inp = nullptr;
+        }
+        H2_CHK(to_coeff(s.ap));
+        H2_CHK(to_coeff(s.sp));
+        H2_CHK(to_coeff(s.z));
+    }
+    laps.lap(7);
+    // ---- h(X) numerator on the extended domain
+    auto to_ext = [&](const Fr *poly, Fr **out) -> int {
+        H2_CHK(sc.take(ne, out));
+        return h2hip_coeff_to_extended_dev(ctx, poly, k, *out, ek, &dom.ext_omega, &dom.zeta);
+    };
+    std::vector<Fr *> adv_cos(adv.size()), inst_cos(inst_values.size());
+    for (size_t i = 0; i < adv.size(); ++i) H2_CHK(to_ext(adv[i], &adv_cos[i]));
+    for (size_t i = 0; i < inst_values.size(); ++i) H2_CHK(to_ext(inst_values[i], &inst_cos[i]));
+    Fr *acc = nullptr;
+    H2_CHK(sc.take(ne, &acc));
+    H2_HIPCHK(hipMemsetAsync(acc, 0, sizeof(Fr) * ne, st));
+    laps.lap(8);
+    for (uint32_t a = 0; a < sh.p.num_advice; ++a)
+        H2_CHK(h2hip_quotient_flex_gate_dev(ctx, acc, pk->fixed_cosets[sh.first_q_enable_col + (int)a], adv_cos[a], ek, k, &y));
+    laps.lap(9);
+    if (sh.num_perm_sets) {
+        std::vector<Fr *> zc(sh.num_perm_sets);
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(to_ext(perm_z[si], &zc[si]));
+        laps.lap(8);
+        auto column_coset = [&](const ColumnRef &c) -> const Fr * {
+            return c.kind == 0 ? pk->fixed_cosets[c.index] : c.kind == 1 ? adv_cos[c.index] : inst_cos[c.index];
+        };
+        auto perm_terms = [&](uint32_t si, uint32_t terms) -> int {
+            const uint32_t c0 = si * sh.chunk_len, c1 = std::min<uint32_t>(c0 + sh.chunk_len, (uint32_t)sh.perm_columns.size());
+            const void *cols[8], *sigs[8];
+            for (uint32_t c = c0; c < c1; ++c) {
+                cols[c - c0] = column_coset(sh.perm_columns[c]);
+                sigs[c - c0] = pk->sigma_cosets[c];
+            }
+            return h2hip_quotient_permutation_set_dev(ctx, acc, zc[si], si ? zc[si - 1] : nullptr, cols, sigs, c1 - c0, c0, pk->l0, pk->l_last, pk->l_blind,
+                                                      ek, k, terms, -(int32_t)(bf + 1), &beta, &gamma, &dom.delta, &dom.zeta, &dom.ext_omega, &y);
+        };
+        // evaluate_h's order: first set's l_0 term, last set's l_last term, the chaining terms, then every set's product identity
+        H2_CHK(perm_terms(0, H2HIP_PERM_FIRST));
+        H2_CHK(perm_terms(sh.num_perm_sets - 1, H2HIP_PERM_LAST));
+        for (uint32_t si = 1; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_CHAIN));
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_PRODUCT));
+        for (Fr *p : zc) sc.release(p);
+        laps.lap(9);
+    }
+    for (size_t li = 0; li < lks.size(); ++li) {
+        const Lookup &l = sh.lookups[li];
+        LookupState &s = lks[li];
+        Fr *zc = nullptr, *apc = nullptr, *spc = nullptr, *inpc = nullptr;
+        H2_CHK(to_ext(s.z, &zc));
+        H2_CHK(to_ext(s.ap, &apc));
+        H2_CHK(to_ext(s.sp, &spc));
+        laps.lap(8);
+        const Fr *inp = adv_cos[l.advice_col];
+        if (l.q_col >= 0) {   // the product of the cosets is the coset of the product polynomial q_lookup(X) * a(X)
+            H2_CHK(sc.take(ne, &inpc));
+            H2_CHK(h2hip_fr_mul_batch_dev(ctx, inpc, pk->fixed_cosets[l.q_col], adv_cos[l.advice_col], ne));
+            inp = inpc;
+        }
+        H2_CHK(h2hip_quotient_lookup_dev(ctx, acc, zc, inp, pk->fixed_cosets[l.table_col], apc, spc, pk->l0, pk->l_last, pk->l_blind, ek, k, &beta, &gamma,
+                                         &y));
+        sc.release(zc);
+        sc.release(apc);
+        sc.release(spc);
+        if (inpc) sc.release(inpc);
+        laps.lap(9);
+    }
+    for (Fr *p : adv_cos) sc.release(p);
+    for (Fr *p : inst_cos) sc.release(p);
+    // ---- vanishing.construct: h = numerator / (X^n - 1), back to coefficients, split into pieces, commit
+    H2_CHK(h2hip_divide_by_vanishing_poly_dev(ctx, acc, ek, k, &dom.ext_omega, &dom.zeta));
+    H2_CHK(h2hip_extended_to_coeff_dev(ctx, acc, ek, &dom.ext_omega_inv, &dom.ext_ifft_divisor, &dom.zeta_inv));
+    laps.lap(10);
+    draw(sh.quotient_pieces);   // h_blinds
+    {
+        std::vector<const void *> cols;
+        for (uint32_t i = 0; i < sh.quotient_pieces; ++i) cols.push_back(acc + (size_t)i * n);
+        H2_CHK(commit_batch(pk->g, cols, n));
+    }
+    laps.lap(11);
+    const Fr x = tr.squeeze_challenge();
+    const Fr xn = fe_pow_u64(x, n);
+    // ---- evaluations
+    auto rotate = [&](int rot) -> Fr {
+        int64_t r = ((int64_t)rot % (int64_t)n + (int64_t)n) % (int64_t)n;
+        return fe_mul(x, fe_pow_u64(dom.omega, (uint64_t)r));
+    };
+    auto ev = [&](const Fr *poly, size_t len, const Fr &point, Fr *out) -> int { return h2hip_fr_eval_polynomial_dev(ctx, poly, len, &point, out); };
+    std::vector<const Fr *> polys;     // SHPLONK's polynomial list; Query.poly indexes it
+    auto poly_id = [&](const Fr *p) -> int {
+        for (size_t i = 0; i < polys.size(); ++i)
+            if (polys[i] == p) return (int)i;
+        polys.push_back(p);
+        return (int)polys.size() - 1;
+    };
+    std::vector<Query> q_adv, q_fixed, q_sigma, q_perm_a, q_perm_b, q_lookup;
+    for (auto &aq : sh.advice_queries) {
+        Query q{poly_id(adv[aq.first]), rotate(aq.second), Fr::zero()};
+        H2_CHK(ev(adv[aq.first], n, q.point, &q.eval));
+        tr.write_scalar(q.eval);
+        q_adv.push_back(q);
+    }
+    for (auto &fq : sh.fixed_queries) {
+        Query q{-1, rotate(fq.second), Fr::zero()};
+        H2_CHK(ev(pk->fixed_polys[fq.first], n, q.point, &q.eval));
+        tr.write_scalar(q.eval);
+        q.poly = -2 - fq.first;   // registered after the lookups' polynomials (query order), resolved below
+        q_fixed.push_back(q);
+    }
+    // vanishing.evaluate: h(X) = sum_i x^(n i) h_i(X) (its evaluation is not written); the random polynomial's is
+    Fr *h_poly = nullptr;
+    H2_CHK(sc.take(n, &h_poly));
+    H2_HIPCHK(hipMemcpyAsync(h_poly, acc + (size_t)(sh.quotient_pieces - 1) * n, sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
+    {
+        const Fr one = Fr::one();
+        for (int i = (int)sh.quotient_pieces - 2; i >= 0; --i) H2_CHK(h2hip_fr_axpby_dev(ctx, h_poly, &xn, &one, acc + (size_t)i * n, n));
+    }
+    Fr random_eval;
+    H2_CHK(ev(random_poly, n, x, &random_eval));
+    tr.write_scalar(random_eval);
+    for (size_t j = 0; j < pk->sigma_polys.size(); ++j) {
+        Query q{-1, x, Fr::zero()};
+        H2_CHK(ev(pk->sigma_polys[j], n, x, &q.eval));
+        tr.write_scalar(q.eval);
+        q.poly = -100 - (int)j;
+        q_sigma.push_back(q);
+    }
+    const Fr x_next = rotate(1), x_last = rotate(-(int)(bf + 1)), x_inv = rotate(-1);
+    for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
+        Query a{poly_id(perm_z[si]), x, Fr::zero()}, b{poly_id(perm_z[si]), x_next, Fr::zero()};
+        H2_CHK(ev(perm_z[si], n, x, &a.eval));
+        H2_CHK(ev(perm_z[si], n, x_next, &b.eval));
+        tr.write_scalar(a.eval);
+        tr.write_scalar(b.eval);
+        q_perm_a.push_back(a);
+        q_perm_a.push_back(b);
+        if (si + 1 != sh.num_perm_sets) {
+            Query c{poly_id(perm_z[si]), x_last, Fr::zero()};
+            H2_CHK(ev(perm_z[si], n, x_last, &c.eval));
+            tr.write_scalar(c.eval);
+            q_perm_b.push_back(c);
+        }
+    }
+    for (LookupState &s : lks) {
+        Query pe{poly_id(s.z), x, Fr::zero()}, ae{poly_id(s.ap), x, Fr::zero()}, se{poly_id(s.sp), x, Fr::zero()};
+        Query aie{ae.poly, x_inv, Fr::zero()}, pne{pe.poly, x_next, Fr::zero()};
+        H2_CHK(ev(s.z, n, x, &pe.eval));
+        H2_CHK(ev(s.z, n, x_next, &pne.eval));
+        H2_CHK(ev(s.ap, n, x, &ae.eval));
+        H2_CHK(ev(s.ap, n, x_inv, &aie.eval));
+        H2_CHK(ev(s.sp, n, x, &se.eval));
+        tr.write_scalar(pe.eval);
+        tr.write_scalar(pne.eval);
+        tr.write_scalar(ae.eval);
+        tr.write_scalar(aie.eval);
+        tr.write_scalar(se.eval);
+        q_lookup.push_back(pe);
+        q_lookup.push_back(ae);
+        q_lookup.push_back(se);
+        q_lookup.push_back(aie);
+        q_lookup.push_back(pne);
+    }
+    // the multiopen's query list in upstream's order: advice, permutation (sets at x / x_next, then sets.rev().skip(1) at x_last), lookups,
+    // fixed, permutation polynomials, h, random
+    std::vector<Query> queries(q_adv);
+    queries.insert(queries.end(), q_perm_a.begin(), q_perm_a.end());
+    queries.insert(queries.end(), q_perm_b.rbegin(), q_perm_b.rend());
+    queries.insert(queries.end(), q_lookup.begin(), q_lookup.end());
+    for (Query q : q_fixed) {
+        q.poly = poly_id(pk->fixed_polys[-2 - q.poly]);
+        queries.push_back(q);
+    }
+    for (Query q : q_sigma) {
+        q.poly = poly_id(pk->sigma_polys[-100 - q.poly]);
+        queries.push_back(q);
+    }
+    {
+        Query hq{poly_id(h_poly), x, Fr::zero()};
+        H2_CHK(ev(h_poly, n, x, &hq.eval));
+        queries.push_back(hq);
+        queries.push_back(Query{poly_id(random_poly), x, random_eval});
+    }
+    laps.lap(12);
+    // ---- ProverSHPLONK::create_proof [UPSTREAM-RECALL poly/kzg/multiopen/shplonk/prover.rs]
+    {
+        const Fr yq = tr.squeeze_challenge();
+        std::vector<RotationSet> sets;
+        std::vector<Fr> super_points;
+        construct_intermediate_sets(queries, sets, super_points);
+        const Fr v = tr.squeeze_challenge();
+        // S_i(X) = sum_j y^j P_ij(X) (kept for the linearisation), r_i(X) = sum_j y^j * interpolant of P_ij on the set's points
+        std::vector<Fr *> S(sets.size());
+        std::vector<std::vector<Fr>> low(sets.size());
+        Fr *buf_a = nullptr, *buf_b = nullptr, *h_x = nullptr;
+        H2_CHK(sc.take(n, &buf_a));
+        H2_CHK(sc.take(n, &buf_b));
+        H2_CHK(sc.take(n, &h_x));
+        H2_HIPCHK(hipMemsetAsync(h_x, 0, sizeof(Fr) * n, st));
+        Fr vpow = Fr::one();
+        for (size_t i = 0; i < sets.size(); ++i) {
+            const RotationSet &rs = sets[i];
+            H2_REQUIRE(rs.points.size() <= 8, "more than 8 rotations in one opening set");
+            H2_CHK(sc.take(n, &S[i]));
+            low[i].assign(rs.points.size(), Fr::zero());
+            Fr ypow = Fr::one();
+            for (size_t j = 0; j < rs.polys.size(); ++j) {
+                if (j == 0)
+                    H2_HIPCHK(hipMemcpyAsync(S[i], polys[rs.polys[j]], sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
+                else
+                    H2_CHK(h2hip_fr_axpy_dev(ctx, S[i], &ypow, polys[rs.polys[j]], n));
+                std::vector<Fr> r = lagrange_interpolate(rs.points, rs.evals[j]);
+                for (size_t t = 0; t < r.size(); ++t) low[i][t] = fe_add(low[i][t], fe_mul(ypow, r[t]));
+                ypow = fe_mul(ypow, yq);
+            }
+            // (S_i - r_i) / prod (X - point): exact divisions, one root at a time
+            H2_HIPCHK(hipMemcpyAsync(buf_a, S[i], sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
+            H2_CHK(h2hip_fr_sub_low_dev(ctx, buf_a, low[i].data(), (uint32_t)low[i].size()));
+            Fr *cur = buf_a, *oth = buf_b;
+            size_t len = n;
+            for (const Fr &root : rs.points) {
+                H2_CHK(h2hip_fr_kate_division_dev(ctx, oth, cur, len, &root));
+                std::swap(cur, oth);
+                --len;
+            }
+            H2_CHK(h2hip_fr_axpy_dev(ctx, h_x, &vpow, cur, len));
+            vpow = fe_mul(vpow, v);
+        }
+        {
+            std::vector<const void *> cols(1, h_x);
+            H2_CHK(commit_batch(pk->g, cols, n));
+        }
+        const Fr uq = tr.squeeze_challenge();
+        // linearisation L(X) = sum_i v^i Z_{T\S_i}(u) (S_i(X) - r_i(u)) - Z_T(u) h(X), which vanishes at u
+        Fr *l_x = buf_a;
+        H2_HIPCHK(hipMemsetAsync(l_x, 0, sizeof(Fr) * n, st));
+        Fr const0 = Fr::zero(), z_diff_0 = Fr::one();
+        vpow = Fr::one();
+        for (size_t i = 0; i < sets.size(); ++i) {
+            Fr z_i = Fr::one();
+            for (const Fr &p : super_points) {
+                bool in_set = false;
+                for (const Fr &sp : sets[i].points) in_set |= fr_cmp(sp, p) == 0;
+                if (!in_set) z_i = fe_mul(z_i, fe_sub(uq, p));
+            }
+            if (i == 0) z_diff_0 = z_i;
+            const Fr c_i = fe_mul(vpow, z_i);
+            H2_CHK(h2hip_fr_axpy_dev(ctx, l_x, &c_i, S[i], n));
+            const0 = fe_add(const0, fe_mul(c_i, eval_small(low[i], uq)));
+            vpow = fe_mul(vpow, v);
+        }
+        H2_CHK(h2hip_fr_sub_low_dev(ctx, l_x, &const0, 1));
+        Fr zt = Fr::one();
+        for (const Fr &p : super_points) zt = fe_mul(zt, fe_sub(uq, p));
+        const Fr neg_zt = fe_neg(zt);
+        H2_CHK(h2hip_fr_axpy_dev(ctx, l_x, &neg_zt, h_x, n));
+        H2_CHK(h2hip_fr_kate_division_dev(ctx, buf_b, l_x, n, &uq));
+        const Fr inv0 = fe_inv(z_diff_0);
+        H2_CHK(h2hip_fr_scale_dev(ctx, buf_b, &inv0, (size_t)n - 1));
+        std::vector<const void *> cols(1, buf_b);
+        H2_CHK(commit_batch(pk->g, cols, (size_t)n - 1));
+    }
+    laps.lap(13);
+    proof_out.swap(tr.proof);
+    return H2HIP_OK;
+}
+
+}  // namespace plonk
+}  // namespace h2
+
+extern "C" {
+
+int h2hip_plonk_shape_of(const h2hip_base_circuit_params *params, h2hip_plonk_shape *out) {
+    H2_REQUIRE(params && out, "NULL argument");
+    Shape sh;
+    H2_CHK(sh.init(*params));
+    out->num_advice_total = sh.num_advice_total;
+    out->num_fixed_total = sh.num_fixed_total;
+    out->table_col = sh.table_col;
+    out->first_constant_col = sh.first_constant_col;
+    out->q_lookup_col = sh.q_lookup_col;
+    out->first_q_enable_col = sh.first_q_enable_col;
+    out->num_lookups = (uint32_t)sh.lookups.size();
+    out->num_perm_columns = (uint32_t)sh.perm_columns.size();
+    out->num_perm_sets = sh.num_perm_sets;
+    out->degree = sh.degree;
+    out->extended_k = sh.extended_k;
+    out->blinding_factors = sh.blinding_factors;
+    out->usable_rows = sh.usable_rows;
+    out->quotient_pieces = sh.quotient_pieces;
+    out->num_commitments = sh.num_commitments();
+    out->num_evals = sh.num_evals();
+    return H2HIP_OK;
+}
+
+int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, const h2hip_bases *g, const h2hip_bases *g_lagrange,
+                       const void *const *fixed_host, const uint32_t *copies, size_t ncopies, h2hip_plonk_pk **out) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && params && g && g_lagrange && fixed_host && out && (ncopies == 0 || copies), "NULL argument");
+    h2hip_plonk_pk *pk = new h2hip_plonk_pk();
+    int rc = pk->sh.init(*params);
+    if (rc == H2HIP_OK && (g->n < pk->sh.n || g_lagrange->n < pk->sh.n)) {
+        set_error("h2hip_plonk_keygen: the SRS holds fewer than 2^k bases");
+        rc = H2HIP_ERR_INVALID;
+    }
+    if (rc == H2HIP_OK) {
+        pk->ctx = ctx;
+        pk->g = g;
+        pk->g_lagrange = g_lagrange;
+        pk->dom.init(pk->sh.k, pk->sh.extended_k);
+        rc = keygen_impl(ctx, pk, fixed_host, copies, ncopies);
+    }
+    if (rc != H2HIP_OK) {
+        h2hip_plonk_pk_free(ctx, pk);
+        return rc;
+    }
+    *out = pk;
+    return H2HIP_OK;
+}
+
+void h2hip_plonk_pk_free(h2hip_ctx *ctx, h2hip_plonk_pk *pk) {
+    H2_DEVICE_GUARD(ctx);
+    if (!pk) return;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    for (void *p : pk->owned) hipFree(p);
+    pk->pool.destroy();
+    delete pk;
+}
+
+int h2hip_plonk_pk_commitments(const h2hip_plonk_pk *pk, void *fixed_out, void *permutation_out) {
+    H2_REQUIRE(pk, "NULL argument");
+    if (fixed_out && !pk->fixed_commitments.empty()) memcpy(fixed_out, pk->fixed_commitments.data(), sizeof(G1Affine) * pk->fixed_commitments.size());
+    if (permutation_out && !pk->permutation_commitments.empty())
+        memcpy(permutation_out, pk->permutation_commitments.data(), sizeof(G1Affine) * pk->permutation_commitments.size());
+    return H2HIP_OK;
+}
+
+int h2hip_plonk_pk_set_transcript_repr(h2hip_plonk_pk *pk, const void *fr) {
+    H2_REQUIRE(pk && fr, "NULL argument");
+    memcpy(&pk->transcript_repr, fr, sizeof(Fr));
+    pk->have_repr = true;
+    return H2HIP_OK;
+}
+
+const char *h2hip_plonk_stage_name(int stage) { return stage >= 0 && stage < H2HIP_PLONK_STAGES ? STAGE_NAMES[stage] : ""; }
+
+int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *const *advice, int advice_on_device, const void *const *instances_host,
+                             const size_t *instance_lens, h2hip_rng_fill_fn rng, void *rng_user, uint8_t *proof_out, size_t proof_cap,
+                             size_t *proof_len, double *stage_ms) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && pk && advice && rng && proof_out && proof_len, "NULL argument");
+    H2_REQUIRE(pk->ctx == ctx, "the proving key belongs to another context");
+    H2_REQUIRE(pk->have_repr, "h2hip_plonk_pk_set_transcript_repr has not been called");
+    H2_REQUIRE(pk->sh.p.num_instance == 0 || instance_lens, "instance_lens is required");
+    const size_t need = 32 * (size_t)(pk->sh.num_commitments() + pk->sh.num_evals());
+    H2_REQUIRE(proof_cap >= need, "proof buffer too small");
+    std::vector<uint8_t> proof;
+    int rc = create_proof_impl(ctx, pk, advice, advice_on_device != 0, instances_host, instance_lens, rng, rng_user, proof, stage_ms);
+    if (rc != H2HIP_OK) {
+        hipStreamSynchronize(ctx->stream);   // nothing of the failed proof may still run on buffers that go back to the pool
+        return rc;
+    }
+    if (proof.size() != need) {
+        set_error("create_proof: internal error: proof has %zu bytes, expected %zu", proof.size(), need);
+        return H2HIP_ERR_INVALID;
+    }
+    memcpy(proof_out, proof.data(), need);
+    *proof_len = need;
+    return H2HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// Device steps of create_proof that sit between the big kernels: the factors of the permutation
+// and lookup grand products, and the resolution of Assigned::Rational advice cells.  What they compute is fixed by halo2-base's
+// constraint system — the equality-enabled columns of FlexGateConfig / RangeConfig (reference halo2-base/src/gates/flex_gate/mod.rs:
+// 69,124-128, halo2-base/src/gates/range/mod.rs:104) and RangeConfig's lookups (range/mod.rs:131-150) — the argument formulas are
+// upstream halo2's (permutation/prover.rs, lookup/prover.rs [UPSTREAM]).
+#include "internal.h"
+
+namespace h2 {
+
+constexpr int PP_MAX_COLS = 8;
+struct PermProductArgs {
+    const Fr *cols[PP_MAX_COLS], *sigmas[PP_MAX_COLS];
+    uint32_t ncols;
+    Fr beta, gamma, delta;
+    Fr x0;      // beta * delta^(first column index of the set): the identity-permutation term at row 0
+    Fr omega;   // row generator
+    Fr xstep;   // omega^(grid stride)
+};
+// num[i] = prod_j (v_j[i] + beta*delta^(c0+j)*omega^i + gamma),  den[i] = prod_j (v_j[i] + beta*sigma_j[i] + gamma),  i < rows
+__global__ __launch_bounds__(256) void perm_product_terms_kernel(Fr *__restrict__ num, Fr *__restrict__ den, PermProductArgs g, size_t rows) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= rows) return;
+    Fr xbase = fe_mul(g.x0, fe_pow_u64(g.omega, (uint64_t)i0));
+    for (size_t i = i0; i < rows; i += stride, xbase = fe_mul(xbase, g.xstep)) {
+        Fr nu = Fr::one(), de = Fr::one(), xterm = xbase;
+        for (uint32_t j = 0; j < g.ncols; ++j) {
+            Fr v = g.cols[j][i];
+            Fr a = fe_add(fe_add(v, xterm), g.gamma);
+            Fr b = fe_add(fe_add(v, fe_mul(g.beta, g.sigmas[j][i])), g.gamma);
+            nu = j ? fe_mul(nu, a) : a;
+            de = j ? fe_mul(de, b) : b;
+            xterm = fe_mul(xterm, g.delta);
+        }
+        num[i] = nu;
+        den[i] = de;
+    }
+}
+
+// num[i] = (a[i] + beta)(s[i] + gamma),  den[i] = (a'[i] + beta)(s'[i] + gamma)
+__global__ __launch_bounds__(256) void lookup_product_terms_kernel(Fr *__restrict__ num, Fr *__restrict__ den, const Fr *__restrict__ a,
+                                                                   const Fr *__restrict__ s, const Fr *__restrict__ ap, const Fr *__restrict__ sp,
+                                                                   Fr beta, Fr gamma, size_t rows) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride) {
+        num[i] = fe_mul(fe_add(a[i], beta), fe_add(s[i], gamma));
+        den[i] = fe_mul(fe_add(ap[i], beta), fe_add(sp[i], gamma));
+    }
+}
+
+struct SmallPoly {
+    Fr c[8];
+};
+__global__ void fr_sub_low_kernel(Fr *__restrict__ y, SmallPoly p, uint32_t m) {
+    uint32_t i = threadIdx.x;
+    if (i < m) y[i] = fe_sub(y[i], p.c[i]);
+}
+
+static uint32_t grid_rows(h2hip_ctx *ctx, size_t n, size_t per_lane) {
+    size_t blocks = (n / per_lane + 255) / 256, cap = (size_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    return (uint32_t)(blocks ? blocks : 1);
+}
+static Fr ld(const void *p) {
+    Fr r;
+    memcpy(&r, p, sizeof(Fr));
+    return r;
+}
+
+}  // namespace h2
+
+using namespace h2;
+
+extern "C" {
+
+int h2hip_permutation_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
+                                        uint32_t ncols, uint32_t first_col_index, size_t rows, const void *beta, const void *gamma, const void *delta,
+                                        const void *omega) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && beta && gamma && delta && omega && cols_dev && sigmas_dev && (rows == 0 || (num_dev && den_dev)), "NULL argument");
+    H2_REQUIRE(ncols >= 1 && ncols <= PP_MAX_COLS, "1..8 columns per permutation set");
+    if (!rows) return H2HIP_OK;
+    PermProductArgs g;
+    memset(&g, 0, sizeof(g));
+    for (uint32_t j = 0; j < ncols; ++j) {
+        H2_REQUIRE(cols_dev[j] && sigmas_dev[j], "NULL column");
+        g.cols[j] = (const Fr *)cols_dev[j];
+        g.sigmas[j] = (const Fr *)sigmas_dev[j];
+    }
+    g.ncols = ncols;
+    g.beta = ld(beta); g.gamma = ld(gamma); g.delta = ld(delta); g.omega = ld(omega);
+    g.x0 = fe_mul(g.beta, fe_pow_u64(g.delta, first_col_index));
+    uint32_t grid = grid_rows(ctx, rows, 4);
+    g.xstep = fe_pow_u64(g.omega, (uint64_t)grid * 256);
+    prof_begin(ctx, "perm_product_terms_kernel");
+    hipLaunchKernelGGL(perm_product_terms_kernel, dim3(grid), dim3(256), 0, ctx->stream, (Fr *)num_dev, (Fr *)den_dev, g, rows);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+int h2hip_lookup_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *a_dev, const void *s_dev, const void *a_perm_dev,
+                                   const void *s_perm_dev, size_t rows, const void *beta, const void *gamma) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && beta && gamma && (rows == 0 || (num_dev && den_dev && a_dev && s_dev && a_perm_dev && s_perm_dev)), "NULL argument");
+    if (!rows) return H2HIP_OK;
+    prof_begin(ctx, "lookup_product_terms_kernel");
+    hipLaunchKernelGGL(lookup_product_terms_kernel, dim3(grid_rows(ctx, rows, 1)), dim3(256), 0, ctx->stream, (Fr *)num_dev, (Fr *)den_dev,
+                       (const Fr *)a_dev, (const Fr *)s_dev, (const Fr *)a_perm_dev, (const Fr *)s_perm_dev, ld(beta), ld(gamma), rows);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+// y[i] -= low[i] for i < m <= 8: subtracting the low-degree interpolant r(X) of an opening set from a resident polynomial
+// (ProverSHPLONK: P(X) - r(X) before the division by the set's vanishing polynomial); `low_host`: m Montgomery elements
+int h2hip_fr_sub_low_dev(h2hip_ctx *ctx, void *y_dev, const void *low_host, uint32_t m) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && m <= 8 && (m == 0 || (y_dev && low_host)), "bad argument (m <= 8)");
+    if (!m) return H2HIP_OK;
+    SmallPoly p;
+    memset(&p, 0, sizeof(p));
+    memcpy(p.c, low_host, sizeof(Fr) * m);
+    hipLaunchKernelGGL(fr_sub_low_kernel, dim3(1), dim3(64), 0, ctx->stream, (Fr *)y_dev, p, m);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+// Assigned::Rational(num, den) -> num * den^-1 with 0^-1 := 0 (Assigned::evaluate / batch_invert_assigned [UPSTREAM]): one batch
+// inversion of the denominators and one product, the column never leaves HBM.
+int h2hip_assigned_resolve_dev(h2hip_ctx *ctx, void *out_dev, const void *num_dev, const void *den_dev, size_t n) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && (n == 0 || (out_dev && num_dev && den_dev)), "NULL argument");
+    H2_REQUIRE(out_dev != num_dev || n == 0, "out must not alias num");
+    if (!n) return H2HIP_OK;
+    if (out_dev != den_dev) H2_HIPCHK(hipMemcpyAsync(out_dev, den_dev, sizeof(Fr) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    H2_CHK(h2hip_fr_batch_invert_dev(ctx, out_dev, n));
+    return h2hip_fr_mul_batch_dev(ctx, out_dev, out_dev, num_dev, n);
+}
+
+}  // extern "C"

@@ -74,6 +74,19 @@ _PROTOS = {
                                                   C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2hip_fr_axpy_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "h2hip_fr_scale_dev": (_int, [_vp, _vp, _vp, _sz]),
+    "h2hip_fr_axpby_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _sz]),
+    "h2hip_fr_sub_low_dev": (_int, [_vp, _vp, _vp, _u32]),
+    "h2hip_assigned_resolve_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "h2hip_permutation_product_terms_dev": (_int, [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
+    "h2hip_lookup_product_terms_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "h2hip_plonk_shape_of": (_int, [_vp, _vp]),
+    "h2hip_plonk_keygen": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), _vp, _sz, C.POINTER(_vp)]),
+    "h2hip_plonk_pk_free": (None, [_vp, _vp]),
+    "h2hip_plonk_pk_commitments": (_int, [_vp, _vp, _vp]),
+    "h2hip_plonk_pk_set_transcript_repr": (_int, [_vp, _vp]),
+    "h2hip_plonk_stage_name": (C.c_char_p, [_int]),
+    "h2hip_plonk_create_proof": (_int, [_vp, _vp, C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_sz), _vp, _vp, _vp, _sz, C.POINTER(_sz),
+                                        C.POINTER(C.c_double)]),
     "h2hip_divide_by_vanishing_poly_dev": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "h2hip_lookup_permute_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),

@@ -152,15 +152,35 @@ int h2hip_fr_mul_add_batch_dev(h2hip_ctx *ctx, void *out_dev, const void *a_dev,
  * y[i] += a * x[i]   and   y[i] *= s ; a, s: host pointers to one Montgomery Fr */
 int h2hip_fr_axpy_dev(h2hip_ctx *ctx, void *y_dev, const void *a, const void *x_dev, size_t n);
 int h2hip_fr_scale_dev(h2hip_ctx *ctx, void *y_dev, const void *s, size_t n);
+/* y[i] = s * y[i] + a * x[i]  (Horner steps over polynomial pieces, e.g. h(X) = sum_i x^(n i) h_i(X)) */
+int h2hip_fr_axpby_dev(h2hip_ctx *ctx, void *y_dev, const void *s, const void *a, const void *x_dev, size_t n);
+/* y[i] -= low[i] for i < m <= 8 (`low_host`: m elements): P(X) - r(X) for the low-degree interpolant r of an opening set */
+int h2hip_fr_sub_low_dev(h2hip_ctx *ctx, void *y_dev, const void *low_host, uint32_t m);
 
 /* ---- K4: BatchInvert, in place, 0 -> 0 (ff::BatchInvert / batch_invert_assigned [UPSTREAM]; the deferred
  *      denominators come from reference halo2-base/src/gates/flex_gate/mod.rs:677-681,791-795) ---------- */
 int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a_dev, size_t n);
 
+/* a5/a6: advice cells arrive as Assigned<F> — Trivial values and Rational(num, den) with the inversion deferred (reference
+ * halo2-base/src/gates/flex_gate/mod.rs:677-681,791-795; columns laid out by threads/single_phase.rs:273-312).  out = num * den^-1
+ * with 0^-1 := 0 (batch_invert_assigned [UPSTREAM]); Trivial cells carry den = 1.  out may alias den. */
+int h2hip_assigned_resolve_dev(h2hip_ctx *ctx, void *out_dev, const void *num_dev, const void *den_dev, size_t n);
+
 /* ---- K5: permutation / lookup grand products: out[i] = prod_{j<=i} in[j], and
  *      z[0] = 1, z[i+1] = z[i]*num[i]/den[i] (z has n+1 elements) ---------------------------------------- */
 int h2hip_fr_prefix_product_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, size_t n);
 int h2hip_fr_grand_product_dev(h2hip_ctx *ctx, void *z_dev, const void *num_dev, const void *den_dev, size_t n);
+
+/* factors of ONE permutation set's grand product over rows [0, rows) (columns = the equality-enabled columns of
+ * halo2-base's configs, flex_gate/mod.rs:69,124-128, range/mod.rs:104):  num[i] = prod_j (v_j[i] + beta*delta^(first_col_index+j)*omega^i
+ * + gamma),  den[i] = prod_j (v_j[i] + beta*sigma_j[i] + gamma);  cols / sigmas: host arrays of ncols (<= 8) device pointers.
+ * z = h2hip_fr_grand_product_dev(num, den), scaled by the previous set's last value. */
+int h2hip_permutation_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
+                                        uint32_t ncols, uint32_t first_col_index, size_t rows, const void *beta, const void *gamma, const void *delta,
+                                        const void *omega);
+/* factors of a lookup's grand product: num[i] = (a[i]+beta)(s[i]+gamma), den[i] = (a'[i]+beta)(s'[i]+gamma) */
+int h2hip_lookup_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *a_dev, const void *s_dev, const void *a_perm_dev,
+                                   const void *s_perm_dev, size_t rows, const void *beta, const void *gamma);
 
 /* ---- K7: arithmetic::eval_polynomial and arithmetic::kate_division [UPSTREAM] ------------------------- */
 int h2hip_fr_eval_polynomial_dev(h2hip_ctx *ctx, const void *coeffs_dev, size_t n, const void *x, void *out_host);
@@ -215,6 +235,62 @@ int h2hip_lookup_permute_dev(h2hip_ctx *ctx, const void *a_dev, const void *s_de
  *      after the last input when num_inputs < t-1. -------------------------------------------------------- */
 int h2hip_poseidon_set_spec(h2hip_ctx *ctx, uint32_t t, uint32_t r_f, uint32_t r_p, const void *round_constants, const void *mds);
 int h2hip_poseidon_permute_batch_dev(h2hip_ctx *ctx, void *states_dev, const void *inputs_dev, uint32_t num_inputs, size_t n);
+
+/* ---- a1: plonk::create_proof for halo2-base circuits, resident on the GPU -------------------------------------------------
+ * Replaces create_proof::<KZGCommitmentScheme<Bn256>, ProverSHPLONK<_>, Challenge255<_>, _, Blake2bWrite<_, _, _>, _> as the
+ * reference calls it (halo2-base/src/utils/testing.rs:32-50) for circuits configured by BaseConfig::configure
+ * (halo2-base/src/gates/circuit/mod.rs:70-96: FlexGateConfig's gate q*(a + b*c - d), RangeConfig's lookups, the equality-enabled
+ * columns) — the only constraint system halo2-lib builds.  First phase only (halo2-ecc's ECDSA / pairing circuits use no
+ * challenge phases).  The Rust side keeps what it owns: circuit synthesis (it hands over the advice columns assign_witnesses
+ * produced, halo2-base/src/gates/flex_gate/threads/single_phase.rs:273-312), the RNG (called back for every Fr::random the
+ * prover draws, in upstream's order), the verifying key's transcript representation, and the proof bytes.
+ * Everything between — 12 MSMs, ~11 NTTs, the lookup sort, grand products, h(X), evaluations, SHPLONK — runs on the device with
+ * every polynomial resident in HBM; the host part is the Blake2b transcript and the O(#openings) bookkeeping of the multiopen. */
+typedef struct {
+    uint32_t k;                 /* BaseCircuitParams (gates/circuit/mod.rs:25-45), first phase */
+    uint32_t num_advice;        /* num_advice_per_phase[0] */
+    uint32_t num_lookup_advice; /* num_lookup_advice_per_phase[0] */
+    uint32_t num_fixed;
+    uint32_t num_instance;      /* num_instance_columns */
+    int32_t lookup_bits;        /* < 0: None (no RangeConfig table / lookups) */
+} h2hip_base_circuit_params;
+
+/* the ConstraintSystem BaseConfig::configure derives from the params (column order = creation order in the reference's configure) */
+typedef struct {
+    uint32_t num_advice_total;   /* gate advice columns, then dedicated lookup-advice columns (none when num_advice == 1: range/mod.rs:93-95) */
+    uint32_t num_fixed_total;    /* [table] [constants...] [q_lookup] [q_enable per gate column] */
+    int32_t table_col, first_constant_col, q_lookup_col, first_q_enable_col;   /* fixed-column indices, -1 = absent */
+    uint32_t num_lookups, num_perm_columns, num_perm_sets;   /* permutation columns: constants, gate advice, lookup advice, instance */
+    uint32_t degree, extended_k, blinding_factors, usable_rows, quotient_pieces;
+    uint32_t num_commitments, num_evals;   /* what one proof carries: proof bytes = 32 * (num_commitments + num_evals) */
+} h2hip_plonk_shape;
+int h2hip_plonk_shape_of(const h2hip_base_circuit_params *params, h2hip_plonk_shape *out);
+
+typedef struct h2hip_plonk_pk h2hip_plonk_pk;
+/* keygen_vk + keygen_pk [UPSTREAM], reference halo2-base/src/utils/testing.rs:224-227.  fixed_host: num_fixed_total columns of 2^k
+ * Montgomery Fr (Lagrange values, as the circuit's synthesize assigned them).  copies: ncopies x 4 u32 = (column, row, column, row)
+ * with `column` indexing the permutation columns — the copy constraints in the order the circuit emitted them (the cycle
+ * representation depends on it).  g / g_lagrange: ParamsKZG's resident base sets (borrowed: they must outlive the key).
+ * Builds sigma polynomials, all coefficient / extended-domain forms and the l_0 / l_last / l_blind cosets on the device. */
+int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, const h2hip_bases *g, const h2hip_bases *g_lagrange,
+                       const void *const *fixed_host, const uint32_t *copies, size_t ncopies, h2hip_plonk_pk **out);
+void h2hip_plonk_pk_free(h2hip_ctx *ctx, h2hip_plonk_pk *pk);
+/* VerifyingKey contents: fixed_commitments (num_fixed_total x 64 B affine) and permutation commitments (num_perm_columns x 64 B) */
+int h2hip_plonk_pk_commitments(const h2hip_plonk_pk *pk, void *fixed_out, void *permutation_out);
+/* vk.transcript_repr — upstream hashes the Debug rendering of the pinned key; it is computed by the Rust side and handed over */
+int h2hip_plonk_pk_set_transcript_repr(h2hip_plonk_pk *pk, const void *fr);
+
+/* `Fr::random(rng)` x n into out (Montgomery limbs); called in upstream's draw order */
+typedef void (*h2hip_rng_fill_fn)(void *user, void *out_fr, size_t n);
+#define H2HIP_PLONK_STAGES 14
+const char *h2hip_plonk_stage_name(int stage);
+/* advice: num_advice_total columns of 2^k Montgomery Fr (host pointers, or device pointers when advice_on_device != 0); rows >=
+ * usable_rows are ignored (blinding rows).  instances: num_instance host arrays of instance_lens[i] Fr.  proof_out: capacity
+ * proof_cap bytes, *proof_len receives 32 * (num_commitments + num_evals).  stage_ms (optional, H2HIP_PLONK_STAGES doubles):
+ * host wall-clock per stage, synchronising the stream at stage boundaries. */
+int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *const *advice, int advice_on_device, const void *const *instances_host,
+                             const size_t *instance_lens, h2hip_rng_fill_fn rng, void *rng_user, uint8_t *proof_out, size_t proof_cap,
+                             size_t *proof_len, double *stage_ms);
 
 /* ---- diagnostics: 254-bit Montgomery multiplier throughput (the integer roofline bench.py quotes) ------ */
 int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);

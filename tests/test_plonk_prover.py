@@ -1,0 +1,193 @@
+"""create_proof for halo2-base circuits (include/h2hip.h "a1", halo2-lib_amd/csrc/plonk.hip) against the oracle's restatement
+(oracle/plonk.py) of what the reference runs at halo2-base/src/utils/testing.rs:32-50 (prove) and :64-88 (verify):
+
+  * proof BYTES equal to the oracle prover's on the same SRS, circuit and RNG stream (BASELINE.json: "proof bytes equal to CPU");
+  * the oracle's verifier — transcript replay, quotient identity at x, SHPLONK with a real pairing — accepts the HIP proof and
+    rejects tampered ones;
+  * shapes: the k=19 ECDSA configuration of halo2-ecc/configs/secp256k1/bench_ecdsa.config:1 (1 advice, lookup on the gate column
+    behind q_lookup, 1 constants column, no instances), multi-column shapes with dedicated lookup-advice columns (the form of
+    halo2-ecc/configs/bn254/bench_pairing.config), instance columns, and circuits without a range table.
+"""
+import numpy as np
+import pytest
+
+import halo2_lib_amd as H
+from halo2_lib_amd import halo2_proofs as HP
+from halo2_lib_amd import plonk as PL
+from halo2_lib_amd import testing as T
+from oracle import bn254 as O
+from oracle import c_oracle as CO
+from oracle import plonk as P
+from tests.util import PreDrawnRng, R
+
+
+class _OracleBackend:
+    mul = staticmethod(CO.fr_mul)
+    add = staticmethod(CO.fr_add)
+
+
+def _rng_budget(sh):
+    """how many Fr::random draws one proof consumes"""
+    n, bf = sh.n, sh.blinding_factors
+    return (sh.num_advice_total * (bf + 2) + len(sh.lookups) * (2 * (bf + 1) + 2 + bf + 1) + sh.num_perm_sets * (bf + 1) + n + 1 +
+            sh.quotient_poly_degree + 16)
+
+
+def _setup(ctx, k, na, nl, nf, ni, lb, seed, threads, precompute):
+    sh = P.Shape(k, na, nl, nf, ni, lb)
+    s_toxic = 0x1D0C0FFEE1234567890ABCDEF + seed
+    kzg = HP.ParamsKZG.setup(ctx, k, s_toxic, precompute=precompute)
+    # the oracle uses the SAME SRS (downloaded; the GPU setup itself is tested against the definition in test_host_mirror.py)
+    params = P.Params.setup(k, s_toxic, g=ctx.bases_download(kzg.g), g_lagrange=ctx.bases_download(kzg.g_lagrange))
+    circ = T.build_circuit(sh, seed, _OracleBackend)
+    bp = PL.BaseCircuitParams.new(k, na, nl, nf, ni, lb)
+    gpk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
+    return sh, kzg, params, circ, gpk
+
+
+def _oracle_pk(sh, params, circ, threads):
+    asm = P.PermutationAssembly(sh)
+    for l, r in circ.copies:
+        asm.copy(l, r)
+    return P.keygen(params, sh, circ.fixed, asm, threads)
+
+
+def _vk_from_gpu(sh, gpk):
+    """a VerifyingKey for the oracle verifier from the HIP keygen's commitments (large k: the oracle keygen is skipped)"""
+    pts = lambda a: O.limbs_to_points(np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 8))
+    return P.VerifyingKey(sh, pts(gpk.fixed_commitments), pts(gpk.permutation_commitments) if len(gpk.permutation_commitments) else [],
+                          gpk.transcript_repr)
+
+
+def _check(ctx, k, na, nl, nf, ni, lb, seed=3, threads=4, oracle_prover=True, precompute=False, second_proof=True):
+    sh, kzg, params, circ, gpk = _setup(ctx, k, na, nl, nf, ni, lb, seed, threads, precompute)
+    try:
+        shape = gpk.shape
+        assert (shape.degree, shape.extended_k, shape.blinding_factors, shape.usable_rows, shape.num_perm_sets, shape.num_fixed_total) == (
+            sh.degree, sh.extended_k, sh.blinding_factors, sh.usable_rows, sh.num_perm_sets, sh.num_fixed_total)
+        inst = [O.limbs_to_ints(v, R) for v in circ.instances]
+        budget = _rng_budget(sh)
+        timings = {}
+        got = PL.create_proof(gpk, circ.advice, circ.instances, PreDrawnRng(budget, 1000 + seed), timings)
+        assert len(got) == gpk.proof_size() and set(timings) == {ctx.lib.h2hip_plonk_stage_name(i).decode() for i in range(PL.PLONK_STAGES)}
+        if oracle_prover:
+            pk = _oracle_pk(sh, params, circ, threads)
+            assert gpk.transcript_repr == pk.vk.transcript_repr, "verifying keys differ (fixed / permutation commitments)"
+            want = P.create_proof(params, pk, circ.advice, inst, PreDrawnRng(budget, 1000 + seed), threads)
+            assert got == want, "proof bytes differ from the oracle prover's"
+            vk = pk.vk
+        else:
+            vk = _vk_from_gpu(sh, gpk)
+        assert P.verify_proof(params, vk, inst, got), "the oracle verifier rejects the HIP proof"
+        # a second proof from the same key (pooled buffers reused) with another RNG stream: different bytes, still valid
+        if second_proof:
+            again = PL.create_proof(gpk, circ.advice, circ.instances, PreDrawnRng(budget, 2000 + seed))
+            assert again != got and P.verify_proof(params, vk, inst, again)
+        return sh, params, vk, inst, got, circ, gpk, kzg
+    except Exception:
+        gpk.free()
+        kzg.free()
+        raise
+
+
+def _tamper_checks(sh, params, vk, inst, proof, circ, gpk, forge=True):
+    # an evaluation flipped -> the quotient identity or the opening fails
+    first_eval = 32 * (sh.num_advice_total + 3 * len(sh.lookups) + sh.num_perm_sets + 1 + sh.quotient_poly_degree)
+    bad = bytearray(proof)
+    bad[first_eval] ^= 1
+    try:
+        assert not P.verify_proof(params, vk, inst, bytes(bad))
+    except P.VerifyError:
+        pass
+    # a witness that violates the gate: the prover still produces bytes (like upstream), the verifier rejects them
+    if forge:
+        adv = [np.array(c) for c in circ.advice]
+        adv[0][3] = CO.fr_add(adv[0][3:4], O.ints_to_limbs([1], R))[0]
+        forged = PL.create_proof(gpk, adv, circ.instances, PreDrawnRng(_rng_budget(sh), 7))
+        assert not P.verify_proof(params, vk, inst, forged)
+    if inst and len(inst[0]):
+        wrong = [list(v) for v in inst]
+        wrong[0][0] = (wrong[0][0] + 1) % R
+        assert not P.verify_proof(params, vk, wrong, proof)
+
+
+SMALL_SHAPES = [(6, 1, 1, 1, 0, 4), (7, 2, 1, 1, 1, 5), (6, 1, 0, 1, 0, None), (6, 2, 2, 2, 1, 3)]
+
+
+@pytest.mark.parametrize("shape", SMALL_SHAPES)
+def test_create_proof_emulated(shape):
+    """the prover's host logic and kernels on the CPU-emulated build: byte equality, verification, tampering"""
+    from tests.emu_util import emu_context
+
+    ctx = emu_context()
+    try:
+        full = shape == SMALL_SHAPES[0]   # the emulated kernels are slow: the extra proofs run for one shape here, for all on the GPU
+        sh, params, vk, inst, proof, circ, gpk, kzg = _check(ctx, *shape, threads=2, second_proof=full)
+        _tamper_checks(sh, params, vk, inst, proof, circ, gpk, forge=full)
+        gpk.free()
+        kzg.free()
+    finally:
+        ctx.close()
+
+
+def test_create_proof_argument_errors_emulated():
+    from tests.emu_util import emu_context
+
+    ctx = emu_context()
+    try:
+        sh, kzg, params, circ, gpk = _setup(ctx, 6, 1, 1, 1, 0, 4, 1, 1, False)
+        with pytest.raises(ValueError):
+            PL.create_proof(gpk, [], [], PreDrawnRng(8, 1))
+        with pytest.raises(RuntimeError):      # the RNG runs dry: reported, nothing hangs
+            PL.create_proof(gpk, circ.advice, [], PreDrawnRng(8, 1))
+        bad_copy = np.array([[0, sh.usable_rows, 1, 0]], dtype=np.uint32)   # a copy constraint in the blinding rows
+        with pytest.raises(H.H2HipError):
+            PL.keygen(kzg, PL.BaseCircuitParams.new(6, 1, 1, 1, 0, 4), circ.fixed, bad_copy)
+        with pytest.raises(H.H2HipError):      # lookup table larger than the usable rows
+            PL.shape_of(ctx, PL.BaseCircuitParams.new(6, 1, 1, 1, 0, 6))
+        missing = [np.array(c) for c in circ.advice]
+        missing[0][0] = O.ints_to_limbs([(1 << 4) + 5], R)[0]              # a range-checked cell outside the table
+        with pytest.raises(H.H2HipError):
+            PL.create_proof(gpk, missing, [], PreDrawnRng(_rng_budget(sh), 1))
+        gpk.free()
+        kzg.free()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(9, 1, 1, 1, 0, 8), (12, 1, 1, 1, 1, 11), (12, 2, 1, 1, 1, 11), (13, 4, 2, 2, 2, 10), (10, 1, 0, 1, 0, None)])
+def test_create_proof_gpu(shape):
+    ctx = H.Context()
+    try:
+        sh, params, vk, inst, proof, circ, gpk, kzg = _check(ctx, *shape, threads=8, precompute=shape[0] >= 12)
+        _tamper_checks(sh, params, vk, inst, proof, circ, gpk)
+        gpk.free()
+        kzg.free()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_create_proof_gpu_k16_bytes_equal():
+    ctx = H.Context()
+    try:
+        *_, gpk, kzg = _check(ctx, 16, 1, 1, 1, 0, 15, threads=16, precompute=True)
+        gpk.free()
+        kzg.free()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_create_proof_gpu_k19_ecdsa_shape():
+    """BASELINE.json configs[3]: the k = 19 secp256k1-ECDSA configuration (halo2-ecc/configs/secp256k1/bench_ecdsa.config:1).  The HIP
+    proof is checked by the oracle verifier; bench.py compares the bytes with the oracle prover's at this size (its cpu_baseline leg)."""
+    ctx = H.Context()
+    try:
+        sh, params, vk, inst, proof, circ, gpk, kzg = _check(ctx, 19, 1, 1, 1, 0, 18, threads=16, oracle_prover=False, precompute=True)
+        assert (sh.degree, sh.extended_k, gpk.shape.num_commitments) == (5, 21, 12)
+        gpk.free()
+        kzg.free()
+    finally:
+        ctx.close()

@@ -44,3 +44,28 @@ def domain_consts(k):
     """(omega, omega_inv, 2^-k) as (1,4) limb arrays."""
     w = O.omega_for(k)
     return fr([w]), fr([O.inv_mod(w, R)]), fr([O.inv_mod(1 << k, R)])
+
+
+class PreDrawnRng:
+    """The prover's `Fr::random(rng)` stream as a pre-drawn array, served identically to the oracle prover (fill / next_fr, oracle/plonk.py)
+    and to the HIP prover (fill_into, halo2-lib_amd/plonk.py): both sides consume the same values in the same order."""
+
+    def __init__(self, count, seed):
+        self.values = rand_fr(count, seed)
+        self.pos = 0
+
+    def fill(self, m):
+        if self.pos + m > len(self.values):
+            raise RuntimeError("PreDrawnRng exhausted")
+        out = self.values[self.pos:self.pos + m]
+        self.pos += m
+        return out
+
+    def next_fr(self):
+        return O.limbs_to_ints(self.fill(1), R)[0]
+
+    def fill_into(self, dst, m):
+        import ctypes
+
+        a = self.fill(m)
+        ctypes.memmove(dst, a.ctypes.data, 32 * m)
