@@ -218,6 +218,62 @@ __global__ __launch_bounds__(256) void fr_eval_final_kernel(const Fr *__restrict
     if (tid == 0) out[0] = sh[0];
 }
 
+// Batched form: `count` (polynomial, point) pairs in two launches and one copy-out — the prover's evaluation round (every queried
+// polynomial at x and its rotations) instead of one launch pair + one synchronising copy per evaluation.
+struct EvalJob {
+    const Fr *coeffs;
+    size_t n;
+    Fr x;
+    PowTable pw;
+};
+__global__ __launch_bounds__(256) void fr_eval_tile_batch_kernel(const EvalJob *__restrict__ jobs, uint32_t ntiles_max, Fr *__restrict__ tile_val) {
+    __shared__ Fr sh[256];
+    const EvalJob &job = jobs[blockIdx.y];
+    const size_t n = job.n;
+    const uint32_t tid = threadIdx.x;
+    const size_t base = ((size_t)blockIdx.x * 256 + tid) * EVAL_J;
+    if ((size_t)blockIdx.x * 256 * EVAL_J >= n && blockIdx.x) return;   // tile past the end of this polynomial (uniform per workgroup)
+    const Fr x = job.x;
+    const Fr *__restrict__ coeffs = job.coeffs;
+    Fr acc = Fr::zero();
+    for (int k = EVAL_J - 1; k >= 0; --k) {
+        acc = fe_mul(acc, x);
+        if (base + k < n) acc = fe_add(acc, coeffs[base + k]);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t d = 1, l = 0; d < 256; d <<= 1, ++l) {
+        if ((tid & (2 * d - 1)) == 0) sh[tid] = fe_add(sh[tid], fe_mul(sh[tid + d], job.pw.p[l]));
+        __syncthreads();
+    }
+    if (tid == 0) tile_val[(size_t)blockIdx.y * ntiles_max + blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void fr_eval_final_batch_kernel(const EvalJob *__restrict__ jobs, uint32_t ntiles_max, const Fr *__restrict__ tile_val,
+                                                                  Fr *__restrict__ out) {
+    __shared__ Fr sh[256];
+    const EvalJob &job = jobs[blockIdx.x];
+    const Fr *tv = tile_val + (size_t)blockIdx.x * ntiles_max;
+    uint32_t ntiles = (uint32_t)((job.n + 256 * EVAL_J - 1) / (256 * EVAL_J));
+    if (!ntiles) ntiles = 1;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (ntiles + 255) / 256, lo = tid * per;
+    const Fr X = job.pw.p[8];
+    Fr acc = Fr::zero();
+    for (int k = (int)per - 1; k >= 0; --k) {
+        acc = fe_mul(acc, X);
+        if (lo + k < ntiles) acc = fe_add(acc, tv[lo + k]);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    Fr Y = fe_pow_u64(X, per);
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        if ((tid & (2 * d - 1)) == 0) sh[tid] = fe_add(sh[tid], fe_mul(sh[tid + d], Y));
+        Y = fe_sqr(Y);
+        __syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = sh[0];
+}
+
 // kate_division: q[m] = sum_{j>m} c_j b^(j-m-1), m = 0..n-2  (suffix Horner).  Stage 1 computes every
 // workgroup's head H = sum_{j in tile} c_j b^(j-lo); stage 2 turns heads into carries
 // carry[blk] = sum_{blk'>blk} H[blk'] * (b^TILE)^(blk'-blk-1); stage 3 replays the tile with its carry.
@@ -601,6 +657,41 @@ int h2hip_fr_eval_polynomial_dev(h2hip_ctx *ctx, const void *coeffs, size_t n, c
     H2_HIPCHK(hipGetLastError());
     H2_HIPCHK(hipMemcpyAsync(out_host, tv + ntiles, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs_dev, const size_t *lens, const void *points, size_t count,
+                                       void *out_host) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && (count == 0 || (coeffs_dev && lens && points && out_host)), "NULL argument");
+    if (!count) return H2HIP_OK;
+    H2_REQUIRE(count <= 4096, "too many evaluations in one batch");
+    std::vector<EvalJob> jobs(count);
+    size_t nmax = 0;
+    for (size_t j = 0; j < count; ++j) {
+        H2_REQUIRE(lens[j] == 0 || coeffs_dev[j], "NULL polynomial");
+        jobs[j].coeffs = (const Fr *)coeffs_dev[j];
+        jobs[j].n = lens[j];
+        memcpy(&jobs[j].x, (const char *)points + sizeof(Fr) * j, sizeof(Fr));
+        if (j && jobs[j].x == jobs[j - 1].x) jobs[j].pw = jobs[j - 1].pw;   // queries arrive grouped by point
+        else pow_table(jobs[j].x, EVAL_J, jobs[j].pw);
+        if (lens[j] > nmax) nmax = lens[j];
+    }
+    const uint32_t tile = 256 * EVAL_J;
+    uint32_t ntiles = (uint32_t)((nmax + tile - 1) / tile);
+    if (!ntiles) ntiles = 1;
+    char *buf = nullptr;
+    const size_t jobs_bytes = (sizeof(EvalJob) * count + 255) / 256 * 256;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, jobs_bytes + sizeof(Fr) * ((size_t)ntiles * count + count), (void **)&buf));
+    EvalJob *djobs = (EvalJob *)buf;
+    Fr *tv = (Fr *)(buf + jobs_bytes), *res = tv + (size_t)ntiles * count;
+    H2_HIPCHK(hipMemcpyAsync(djobs, jobs.data(), sizeof(EvalJob) * count, hipMemcpyHostToDevice, ctx->stream));
+    prof_begin(ctx, "fr_eval_kernels");
+    hipLaunchKernelGGL(fr_eval_tile_batch_kernel, dim3(ntiles, (uint32_t)count), dim3(256), 0, ctx->stream, (const EvalJob *)djobs, ntiles, tv);
+    hipLaunchKernelGGL(fr_eval_final_batch_kernel, dim3((uint32_t)count), dim3(256), 0, ctx->stream, (const EvalJob *)djobs, ntiles, (const Fr *)tv, res);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_HIPCHK(hipMemcpyAsync(out_host, res, sizeof(Fr) * count, hipMemcpyDeviceToHost, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));   // also keeps `jobs` alive until the upload has been consumed
     return H2HIP_OK;
 }
 // q[0..n-1) = (f(X) - f(b)) / (X - b)   [UPSTREAM arithmetic::kate_division]

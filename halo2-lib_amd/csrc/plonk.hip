@@ -228,6 +228,8 @@ struct h2hip_plonk_pk {
     bool have_repr = false;
     BufPool pool;
     std::vector<void *> owned;
+    Fr *host_stage = nullptr;   // pinned staging for the RNG-drawn scalars (the n coefficients of the random polynomial, the blinding rows)
+    size_t host_stage_elems = 0;
 };
 
 namespace h2 {
@@ -275,6 +277,19 @@ struct Transcript {   // Blake2bWrite<Vec<u8>, G1Affine, Challenge255<_>>  (SURV
         return fr_from_uniform_bytes(d);
     }
 };
+
+static G1Affine jacobian_to_affine(const G1Jac &p) {
+    G1Affine r;
+    if (p.z.is_zero()) {
+        r.x = Fq::zero();
+        r.y = Fq::zero();
+        return r;
+    }
+    const Fq zi = fe_inv(p.z), zi2 = fe_sqr(zi);
+    r.x = fe_mul(p.x, zi2);
+    r.y = fe_mul(p.y, fe_mul(zi2, zi));
+    return r;
+}
 
 // ---------------------------------------------------------------------------------------------- permutation keygen
 // permutation::keygen::Assembly [UPSTREAM-RECALL]: cycles merged by `copy`; sigma_i(omega^j) = delta^i' * omega^j' for mapping[i][j] = (i', j')
@@ -500,9 +515,10 @@ static Fr eval_small(const std::vector<Fr> &c, const Fr &x) {
 
 // ---------------------------------------------------------------------------------------------- create_proof
 static const char *STAGE_NAMES[H2HIP_PLONK_STAGES] = {
-    "advice_upload_blinding", "commit_advice", "lookup_permute", "commit_lookup_permuted", "grand_products", "commit_grand_products",
-    "random_poly_commit", "lagrange_to_coeff", "coeff_to_extended", "quotient_terms", "quotient_to_coeff", "commit_h_pieces", "evaluations",
-    "multiopen_shplonk"};
+    "advice_upload_blinding", "lookup_permute", "commit_advice_lookup_permuted", "grand_products", "commit_grand_products", "random_poly_commit",
+    "lagrange_to_coeff", "coeff_to_extended", "quotient_terms", "quotient_to_coeff", "commit_h_pieces", "evaluations", "multiopen_shplonk"};
+enum { ST_UPLOAD = 0, ST_LOOKUP_PERMUTE, ST_COMMIT_ROUND1, ST_PRODUCTS, ST_COMMIT_PRODUCTS, ST_RANDOM, ST_TO_COEFF, ST_TO_EXT, ST_QUOTIENT, ST_H_COEFF,
+       ST_COMMIT_H, ST_EVALS, ST_MULTIOPEN };
 
 struct Laps {
     h2hip_ctx *ctx;
@@ -533,22 +549,37 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     Scope sc(&pk->pool);
     Laps laps(ctx, stage_ms);
     Transcript tr;
-    std::vector<Fr> rnd;   // host staging of blinding values
+    // the RNG writes straight into pinned host memory, from where the DMA engine takes it (n scalars for the random polynomial)
+    if (pk->host_stage_elems < n) {
+        if (pk->host_stage) hipHostFree(pk->host_stage);
+        pk->host_stage = nullptr;
+        pk->host_stage_elems = 0;
+        H2_HIPCHK(hipHostMalloc((void **)&pk->host_stage, sizeof(Fr) * n, 0));
+        pk->host_stage_elems = n;
+    }
     auto draw = [&](size_t cnt) -> const Fr * {
-        rnd.resize(cnt ? cnt : 1);
-        if (cnt) rng(rng_user, rnd.data(), cnt);
-        return rnd.data();
+        if (cnt) rng(rng_user, pk->host_stage, cnt);   // cnt <= n by construction
+        return pk->host_stage;
     };
     auto put = [&](Fr *dst, const Fr *src, size_t cnt) -> int {   // pageable host -> device; the copy returns once `src` is consumed
         if (cnt) H2_HIPCHK(hipMemcpyAsync(dst, src, sizeof(Fr) * cnt, hipMemcpyHostToDevice, st));
         return H2HIP_OK;
     };
-    auto commit_batch = [&](const h2hip_bases *bases, const std::vector<const void *> &cols, size_t len) -> int {
-        std::vector<G1Affine> pts(cols.size());
+    // commitments come back as Jacobian points (C::Curve, like best_multiexp) and are normalised here: one field inversion on the host
+    // costs microseconds, on a single GPU lane ~0.1 ms of an otherwise idle chip
+    auto commit_points = [&](const h2hip_bases *bases, const std::vector<const void *> &cols, size_t len, std::vector<G1Affine> &pts) -> int {
+        std::vector<G1Jac> jac(cols.size());
         if (cols.size() == 1)
-            H2_CHK(h2hip_msm_g1_dev(ctx, bases, cols[0], len, H2HIP_POINT_AFFINE, pts.data()));
+            H2_CHK(h2hip_msm_g1_dev(ctx, bases, cols[0], len, H2HIP_POINT_JACOBIAN, jac.data()));
         else if (!cols.empty())
-            H2_CHK(h2hip_msm_g1_batch_dev(ctx, bases, cols.data(), len, cols.size(), H2HIP_POINT_AFFINE, pts.data()));
+            H2_CHK(h2hip_msm_g1_batch_dev(ctx, bases, cols.data(), len, cols.size(), H2HIP_POINT_JACOBIAN, jac.data()));
+        pts.resize(cols.size());
+        for (size_t i = 0; i < jac.size(); ++i) pts[i] = jacobian_to_affine(jac[i]);
+        return H2HIP_OK;
+    };
+    auto commit_batch = [&](const h2hip_bases *bases, const std::vector<const void *> &cols, size_t len) -> int {
+        std::vector<G1Affine> pts;
+        H2_CHK(commit_points(bases, cols, len, pts));
         for (const G1Affine &p : pts) H2_CHK(tr.write_point(p));
         return H2HIP_OK;
     };
@@ -578,22 +609,17 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_HIPCHK(hipStreamSynchronize(st));   // `rnd` is reused by the next draw
     }
     draw(sh.num_advice_total);   // Blind(Fr::random) per column: drawn, unused by KZG
-    laps.lap(0);
-    {
-        std::vector<const void *> cols(adv.begin(), adv.end());
-        H2_CHK(commit_batch(pk->g_lagrange, cols, n));
-    }
-    laps.lap(1);
-    const Fr theta = tr.squeeze_challenge();
-    (void)theta;   // every lookup of halo2-base compresses a single expression pair: theta does not enter the values
-    // ---- lookups: permuted input / table columns
+    laps.lap(ST_UPLOAD);
+    // ---- lookups: permuted input / table columns.  Every lookup of halo2-base compresses a single (input, table) expression pair, so
+    // theta does not enter the values: the permuted columns are computed before the advice commitments are out, and all of this round's
+    // and the next round's commitments go through ONE batched MSM call (the transcript still sees them in upstream's order)
     struct LookupState {
         Fr *inp, *ap, *sp, *z;
         bool own_inp;
     };
     std::vector<LookupState> lks(sh.lookups.size());
     {
-        std::vector<const void *> cols;
+        std::vector<const void *> cols(adv.begin(), adv.end());
         for (size_t li = 0; li < sh.lookups.size(); ++li) {
             const Lookup &l = sh.lookups[li];
             LookupState &s = lks[li];
@@ -617,9 +643,14 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             cols.push_back(s.ap);
             cols.push_back(s.sp);
         }
-        laps.lap(2);
-        if (!cols.empty()) H2_CHK(commit_batch(pk->g_lagrange, cols, n));
-        laps.lap(3);
+        laps.lap(ST_LOOKUP_PERMUTE);
+        std::vector<G1Affine> pts;
+        H2_CHK(commit_points(pk->g_lagrange, cols, n, pts));
+        for (size_t i = 0; i < adv.size(); ++i) H2_CHK(tr.write_point(pts[i]));
+        const Fr theta = tr.squeeze_challenge();
+        (void)theta;
+        for (size_t i = adv.size(); i < pts.size(); ++i) H2_CHK(tr.write_point(pts[i]));
+        laps.lap(ST_COMMIT_ROUND1);
     }
     const Fr beta = tr.squeeze_challenge();
     const Fr gamma = tr.squeeze_challenge();
@@ -660,11 +691,11 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             H2_HIPCHK(hipStreamSynchronize(st));
             draw(1);   // blind
         }
-        laps.lap(4);
+        laps.lap(ST_PRODUCTS);
         std::vector<const void *> cols(perm_z.begin(), perm_z.end());
         for (LookupState &s : lks) cols.push_back(s.z);
         if (!cols.empty()) H2_CHK(commit_batch(pk->g_lagrange, cols, n));
-        laps.lap(5);
+        laps.lap(ST_COMMIT_PRODUCTS);
     }
     // ---- vanishing argument: the random polynomial
     Fr *random_poly = nullptr;
@@ -677,7 +708,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         std::vector<const void *> cols(1, random_poly);
         H2_CHK(commit_batch(pk->g, cols, n));
     }
-    laps.lap(6);
+    laps.lap(ST_RANDOM);
     const Fr y = tr.squeeze_challenge();
     // ---- coefficient form (in place: the Lagrange values are not needed again)
     auto to_coeff = [&](Fr *a) -> int { return h2hip_ifft_dev(ctx, a, &dom.omega_inv, k, &dom.ifft_divisor); };
@@ -693,7 +724,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(to_coeff(s.sp));
         H2_CHK(to_coeff(s.z));
     }
-    laps.lap(7);
+    laps.lap(ST_TO_COEFF);
     // ---- h(X) numerator on the extended domain
     auto to_ext = [&](const Fr *poly, Fr **out) -> int {
         H2_CHK(sc.take(ne, out));
@@ -705,14 +736,14 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     Fr *acc = nullptr;
     H2_CHK(sc.take(ne, &acc));
     H2_HIPCHK(hipMemsetAsync(acc, 0, sizeof(Fr) * ne, st));
-    laps.lap(8);
+    laps.lap(ST_TO_EXT);
     for (uint32_t a = 0; a < sh.p.num_advice; ++a)
         H2_CHK(h2hip_quotient_flex_gate_dev(ctx, acc, pk->fixed_cosets[sh.first_q_enable_col + (int)a], adv_cos[a], ek, k, &y));
-    laps.lap(9);
+    laps.lap(ST_QUOTIENT);
     if (sh.num_perm_sets) {
         std::vector<Fr *> zc(sh.num_perm_sets);
         for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(to_ext(perm_z[si], &zc[si]));
-        laps.lap(8);
+        laps.lap(ST_TO_EXT);
         auto column_coset = [&](const ColumnRef &c) -> const Fr * {
             return c.kind == 0 ? pk->fixed_cosets[c.index] : c.kind == 1 ? adv_cos[c.index] : inst_cos[c.index];
         };
@@ -727,12 +758,16 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                                                       ek, k, terms, -(int32_t)(bf + 1), &beta, &gamma, &dom.delta, &dom.zeta, &dom.ext_omega, &y);
         };
         // evaluate_h's order: first set's l_0 term, last set's l_last term, the chaining terms, then every set's product identity
-        H2_CHK(perm_terms(0, H2HIP_PERM_FIRST));
-        H2_CHK(perm_terms(sh.num_perm_sets - 1, H2HIP_PERM_LAST));
-        for (uint32_t si = 1; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_CHAIN));
-        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_PRODUCT));
+        if (sh.num_perm_sets == 1) {   // the kernel folds a mask's terms in this same order: one pass over the extended domain
+            H2_CHK(perm_terms(0, H2HIP_PERM_FIRST | H2HIP_PERM_LAST | H2HIP_PERM_PRODUCT));
+        } else {
+            H2_CHK(perm_terms(0, H2HIP_PERM_FIRST));
+            H2_CHK(perm_terms(sh.num_perm_sets - 1, H2HIP_PERM_LAST));
+            for (uint32_t si = 1; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_CHAIN));
+            for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_PRODUCT));
+        }
         for (Fr *p : zc) sc.release(p);
-        laps.lap(9);
+        laps.lap(ST_QUOTIENT);
     }
     for (size_t li = 0; li < lks.size(); ++li) {
         const Lookup &l = sh.lookups[li];
@@ -741,7 +776,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(to_ext(s.z, &zc));
         H2_CHK(to_ext(s.ap, &apc));
         H2_CHK(to_ext(s.sp, &spc));
-        laps.lap(8);
+        laps.lap(ST_TO_EXT);
         const Fr *inp = adv_cos[l.advice_col];
         if (l.q_col >= 0) {   // the product of the cosets is the coset of the product polynomial q_lookup(X) * a(X)
             H2_CHK(sc.take(ne, &inpc));
@@ -754,29 +789,29 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         sc.release(apc);
         sc.release(spc);
         if (inpc) sc.release(inpc);
-        laps.lap(9);
+        laps.lap(ST_QUOTIENT);
     }
     for (Fr *p : adv_cos) sc.release(p);
     for (Fr *p : inst_cos) sc.release(p);
     // ---- vanishing.construct: h = numerator / (X^n - 1), back to coefficients, split into pieces, commit
     H2_CHK(h2hip_divide_by_vanishing_poly_dev(ctx, acc, ek, k, &dom.ext_omega, &dom.zeta));
     H2_CHK(h2hip_extended_to_coeff_dev(ctx, acc, ek, &dom.ext_omega_inv, &dom.ext_ifft_divisor, &dom.zeta_inv));
-    laps.lap(10);
+    laps.lap(ST_H_COEFF);
     draw(sh.quotient_pieces);   // h_blinds
     {
         std::vector<const void *> cols;
         for (uint32_t i = 0; i < sh.quotient_pieces; ++i) cols.push_back(acc + (size_t)i * n);
         H2_CHK(commit_batch(pk->g, cols, n));
     }
-    laps.lap(11);
+    laps.lap(ST_COMMIT_H);
     const Fr x = tr.squeeze_challenge();
     const Fr xn = fe_pow_u64(x, n);
-    // ---- evaluations
+    // ---- evaluations: every (polynomial, point) pair of the round goes through ONE batched launch; the transcript then takes the
+    // values in upstream's order
     auto rotate = [&](int rot) -> Fr {
         int64_t r = ((int64_t)rot % (int64_t)n + (int64_t)n) % (int64_t)n;
         return fe_mul(x, fe_pow_u64(dom.omega, (uint64_t)r));
     };
-    auto ev = [&](const Fr *poly, size_t len, const Fr &point, Fr *out) -> int { return h2hip_fr_eval_polynomial_dev(ctx, poly, len, &point, out); };
     std::vector<const Fr *> polys;     // SHPLONK's polynomial list; Query.poly indexes it
     auto poly_id = [&](const Fr *p) -> int {
         for (size_t i = 0; i < polys.size(); ++i)
@@ -784,21 +819,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         polys.push_back(p);
         return (int)polys.size() - 1;
     };
-    std::vector<Query> q_adv, q_fixed, q_sigma, q_perm_a, q_perm_b, q_lookup;
-    for (auto &aq : sh.advice_queries) {
-        Query q{poly_id(adv[aq.first]), rotate(aq.second), Fr::zero()};
-        H2_CHK(ev(adv[aq.first], n, q.point, &q.eval));
-        tr.write_scalar(q.eval);
-        q_adv.push_back(q);
-    }
-    for (auto &fq : sh.fixed_queries) {
-        Query q{-1, rotate(fq.second), Fr::zero()};
-        H2_CHK(ev(pk->fixed_polys[fq.first], n, q.point, &q.eval));
-        tr.write_scalar(q.eval);
-        q.poly = -2 - fq.first;   // registered after the lookups' polynomials (query order), resolved below
-        q_fixed.push_back(q);
-    }
-    // vanishing.evaluate: h(X) = sum_i x^(n i) h_i(X) (its evaluation is not written); the random polynomial's is
+    // vanishing.evaluate: h(X) = sum_i x^(n i) h_i(X) (its evaluation is not written to the proof; the multiopen needs it)
     Fr *h_poly = nullptr;
     H2_CHK(sc.take(n, &h_poly));
     H2_HIPCHK(hipMemcpyAsync(h_poly, acc + (size_t)(sh.quotient_pieces - 1) * n, sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
@@ -806,72 +827,78 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         const Fr one = Fr::one();
         for (int i = (int)sh.quotient_pieces - 2; i >= 0; --i) H2_CHK(h2hip_fr_axpby_dev(ctx, h_poly, &xn, &one, acc + (size_t)i * n, n));
     }
-    Fr random_eval;
-    H2_CHK(ev(random_poly, n, x, &random_eval));
-    tr.write_scalar(random_eval);
-    for (size_t j = 0; j < pk->sigma_polys.size(); ++j) {
-        Query q{-1, x, Fr::zero()};
-        H2_CHK(ev(pk->sigma_polys[j], n, x, &q.eval));
-        tr.write_scalar(q.eval);
-        q.poly = -100 - (int)j;
-        q_sigma.push_back(q);
-    }
     const Fr x_next = rotate(1), x_last = rotate(-(int)(bf + 1)), x_inv = rotate(-1);
+    std::vector<Query> evq;            // in the order the values are written: advice, fixed, random, sigma, permutation sets, lookups; then h
+    std::vector<const void *> ev_polys;
+    auto want = [&](const Fr *poly, const Fr &point) -> size_t {
+        evq.push_back(Query{-1, point, Fr::zero()});
+        ev_polys.push_back(poly);
+        return evq.size() - 1;
+    };
+    const size_t i_adv = evq.size();
+    for (auto &aq : sh.advice_queries) want(adv[aq.first], rotate(aq.second));
+    const size_t i_fixed = evq.size();
+    for (auto &fq : sh.fixed_queries) want(pk->fixed_polys[fq.first], rotate(fq.second));
+    const size_t i_random = want(random_poly, x);
+    const size_t i_sigma = evq.size();
+    for (Fr *sp_ : pk->sigma_polys) want(sp_, x);
+    const size_t i_perm = evq.size();
     for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
-        Query a{poly_id(perm_z[si]), x, Fr::zero()}, b{poly_id(perm_z[si]), x_next, Fr::zero()};
-        H2_CHK(ev(perm_z[si], n, x, &a.eval));
-        H2_CHK(ev(perm_z[si], n, x_next, &b.eval));
-        tr.write_scalar(a.eval);
-        tr.write_scalar(b.eval);
-        q_perm_a.push_back(a);
-        q_perm_a.push_back(b);
-        if (si + 1 != sh.num_perm_sets) {
-            Query c{poly_id(perm_z[si]), x_last, Fr::zero()};
-            H2_CHK(ev(perm_z[si], n, x_last, &c.eval));
-            tr.write_scalar(c.eval);
-            q_perm_b.push_back(c);
-        }
+        want(perm_z[si], x);
+        want(perm_z[si], x_next);
+        if (si + 1 != sh.num_perm_sets) want(perm_z[si], x_last);
     }
-    for (LookupState &s : lks) {
-        Query pe{poly_id(s.z), x, Fr::zero()}, ae{poly_id(s.ap), x, Fr::zero()}, se{poly_id(s.sp), x, Fr::zero()};
-        Query aie{ae.poly, x_inv, Fr::zero()}, pne{pe.poly, x_next, Fr::zero()};
-        H2_CHK(ev(s.z, n, x, &pe.eval));
-        H2_CHK(ev(s.z, n, x_next, &pne.eval));
-        H2_CHK(ev(s.ap, n, x, &ae.eval));
-        H2_CHK(ev(s.ap, n, x_inv, &aie.eval));
-        H2_CHK(ev(s.sp, n, x, &se.eval));
-        tr.write_scalar(pe.eval);
-        tr.write_scalar(pne.eval);
-        tr.write_scalar(ae.eval);
-        tr.write_scalar(aie.eval);
-        tr.write_scalar(se.eval);
-        q_lookup.push_back(pe);
-        q_lookup.push_back(ae);
-        q_lookup.push_back(se);
-        q_lookup.push_back(aie);
-        q_lookup.push_back(pne);
+    const size_t i_lookup = evq.size();
+    for (LookupState &s : lks) {   // product_eval, product_next_eval, permuted_input_eval, permuted_input_inv_eval, permuted_table_eval
+        want(s.z, x);
+        want(s.z, x_next);
+        want(s.ap, x);
+        want(s.ap, x_inv);
+        want(s.sp, x);
     }
-    // the multiopen's query list in upstream's order: advice, permutation (sets at x / x_next, then sets.rev().skip(1) at x_last), lookups,
-    // fixed, permutation polynomials, h, random
-    std::vector<Query> queries(q_adv);
-    queries.insert(queries.end(), q_perm_a.begin(), q_perm_a.end());
-    queries.insert(queries.end(), q_perm_b.rbegin(), q_perm_b.rend());
-    queries.insert(queries.end(), q_lookup.begin(), q_lookup.end());
-    for (Query q : q_fixed) {
-        q.poly = poly_id(pk->fixed_polys[-2 - q.poly]);
-        queries.push_back(q);
-    }
-    for (Query q : q_sigma) {
-        q.poly = poly_id(pk->sigma_polys[-100 - q.poly]);
-        queries.push_back(q);
-    }
+    const size_t n_written = evq.size();
+    const size_t i_h = want(h_poly, x);
     {
-        Query hq{poly_id(h_poly), x, Fr::zero()};
-        H2_CHK(ev(h_poly, n, x, &hq.eval));
-        queries.push_back(hq);
-        queries.push_back(Query{poly_id(random_poly), x, random_eval});
+        std::vector<size_t> lens(evq.size(), n);
+        std::vector<Fr> points(evq.size()), vals(evq.size());
+        for (size_t i = 0; i < evq.size(); ++i) points[i] = evq[i].point;
+        H2_CHK(h2hip_fr_eval_polynomial_batch_dev(ctx, ev_polys.data(), lens.data(), points.data(), evq.size(), vals.data()));
+        for (size_t i = 0; i < evq.size(); ++i) evq[i].eval = vals[i];
     }
-    laps.lap(12);
+    for (size_t i = 0; i < n_written; ++i) tr.write_scalar(evq[i].eval);
+    // the multiopen's query list in upstream's order: advice, permutation (sets at x / x_next, then sets.rev().skip(1) at x_last), lookups
+    // (product, permuted input, permuted table at x; permuted input at x_inv; product at x_next), fixed, permutation polynomials, h, random
+    std::vector<Query> queries;
+    auto ask = [&](size_t i) {
+        Query q = evq[i];
+        q.poly = poly_id((const Fr *)ev_polys[i]);
+        queries.push_back(q);
+    };
+    for (size_t i = i_adv; i < i_fixed; ++i) ask(i);
+    {
+        std::vector<size_t> tail;
+        size_t i = i_perm;
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
+            ask(i);
+            ask(i + 1);
+            i += 2;
+            if (si + 1 != sh.num_perm_sets) tail.push_back(i++);
+        }
+        for (size_t t = tail.size(); t-- > 0;) ask(tail[t]);
+    }
+    for (size_t li = 0; li < lks.size(); ++li) {
+        const size_t i = i_lookup + 5 * li;
+        ask(i);       // product at x
+        ask(i + 2);   // permuted input at x
+        ask(i + 4);   // permuted table at x
+        ask(i + 3);   // permuted input at x_inv
+        ask(i + 1);   // product at x_next
+    }
+    for (size_t i = i_fixed; i < i_random; ++i) ask(i);
+    for (size_t i = i_sigma; i < i_perm; ++i) ask(i);
+    ask(i_h);
+    ask(i_random);
+    laps.lap(ST_EVALS);
     // ---- ProverSHPLONK::create_proof [UPSTREAM-RECALL poly/kzg/multiopen/shplonk/prover.rs]
     {
         const Fr yq = tr.squeeze_challenge();
@@ -950,7 +977,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         std::vector<const void *> cols(1, buf_b);
         H2_CHK(commit_batch(pk->g, cols, (size_t)n - 1));
     }
-    laps.lap(13);
+    laps.lap(ST_MULTIOPEN);
     proof_out.swap(tr.proof);
     return H2HIP_OK;
 }
@@ -1013,6 +1040,7 @@ void h2hip_plonk_pk_free(h2hip_ctx *ctx, h2hip_plonk_pk *pk) {
     if (!pk) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
     for (void *p : pk->owned) hipFree(p);
+    if (pk->host_stage) hipHostFree(pk->host_stage);
     pk->pool.destroy();
     delete pk;
 }

@@ -67,6 +67,7 @@ _PROTOS = {
     "h2hip_fr_prefix_product_dev": (_int, [_vp, _vp, _vp, _sz]),
     "h2hip_fr_grand_product_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "h2hip_fr_eval_polynomial_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "h2hip_fr_eval_polynomial_batch_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, _vp]),
     "h2hip_fr_kate_division_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_quotient_flex_gate_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),

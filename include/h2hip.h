@@ -184,6 +184,10 @@ int h2hip_lookup_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev,
 
 /* ---- K7: arithmetic::eval_polynomial and arithmetic::kate_division [UPSTREAM] ------------------------- */
 int h2hip_fr_eval_polynomial_dev(h2hip_ctx *ctx, const void *coeffs_dev, size_t n, const void *x, void *out_host);
+/* `count` evaluations in one pass: out[j] = poly_j(points[j]); coeffs_dev / lens: host arrays of device pointers and lengths, points: count
+ * Montgomery elements (host), out_host: count elements — the prover's whole evaluation round with one synchronisation */
+int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs_dev, const size_t *lens, const void *points, size_t count,
+                                       void *out_host);
 /* q[0..n-1) = (f(X) - f(b)) / (X - b); q_dev must not alias coeffs_dev */
 int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_dev, size_t n, const void *b);
 
@@ -282,7 +286,7 @@ int h2hip_plonk_pk_set_transcript_repr(h2hip_plonk_pk *pk, const void *fr);
 
 /* `Fr::random(rng)` x n into out (Montgomery limbs); called in upstream's draw order */
 typedef void (*h2hip_rng_fill_fn)(void *user, void *out_fr, size_t n);
-#define H2HIP_PLONK_STAGES 14
+#define H2HIP_PLONK_STAGES 13
 const char *h2hip_plonk_stage_name(int stage);
 /* advice: num_advice_total columns of 2^k Montgomery Fr (host pointers, or device pointers when advice_on_device != 0); rows >=
  * usable_rows are ignored (blinding rows).  instances: num_instance host arrays of instance_lens[i] Fr.  proof_out: capacity

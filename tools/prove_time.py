@@ -5,7 +5,9 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import halo2_lib_amd as H
 from halo2_lib_amd import halo2_proofs as HP
 from halo2_lib_amd import plonk as PL
