@@ -462,6 +462,82 @@ class Context:
             self.free(d)
             self.free(q)
 
+    # -- prover steps between the big kernels (host-array conveniences for tests)
+    def assigned_resolve(self, num: np.ndarray, den: np.ndarray) -> np.ndarray:
+        """Assigned::Rational columns -> values: num * den^-1, 0^-1 := 0"""
+        num, den = _fe(num), _fe(den)
+        assert num.shape == den.shape
+        dn, dd, do = self.to_device(num), self.to_device(den), self.malloc(max(num.nbytes, 32))
+        try:
+            self._chk(self.lib.h2hip_assigned_resolve_dev(self.handle, _vp(do), _vp(dn), _vp(dd), len(num)))
+            return self.download(do, num.shape)
+        finally:
+            for d in (dn, dd, do):
+                self.free(d)
+
+    def fr_axpby(self, y: np.ndarray, s: np.ndarray, a: np.ndarray, x: np.ndarray) -> np.ndarray:
+        """s*y + a*x"""
+        y, x = _fe(y), _fe(x)
+        dy, dx = self.to_device(y), self.to_device(x)
+        try:
+            self._chk(self.lib.h2hip_fr_axpby_dev(self.handle, _vp(dy), _ptr(_fe(s)), _ptr(_fe(a)), _vp(dx), len(y)))
+            return self.download(dy, y.shape)
+        finally:
+            self.free(dy)
+            self.free(dx)
+
+    def fr_sub_low(self, y: np.ndarray, low: np.ndarray) -> np.ndarray:
+        y, low = _fe(y), _fe(low)
+        dy = self.to_device(y)
+        try:
+            self._chk(self.lib.h2hip_fr_sub_low_dev(self.handle, _vp(dy), _ptr(low), len(low)))
+            return self.download(dy, y.shape)
+        finally:
+            self.free(dy)
+
+    def fr_eval_polynomial_batch(self, polys, points: np.ndarray) -> np.ndarray:
+        """[poly_j(points[j])]: one pass over all pairs"""
+        cols = [_fe(p) for p in polys]
+        pts = _fe(points)
+        assert len(cols) == len(pts)
+        d = [self.to_device(c) if len(c) else self.malloc(32) for c in cols]
+        out = np.zeros((len(cols), 4), dtype=np.uint64)
+        try:
+            arr = (_vp * max(len(d), 1))(*[_vp(p) for p in d])
+            lens = (_sz * max(len(d), 1))(*[len(c) for c in cols])
+            self._chk(self.lib.h2hip_fr_eval_polynomial_batch_dev(self.handle, arr, lens, _ptr(pts), len(cols), _ptr(out)))
+            return out
+        finally:
+            for p in d:
+                self.free(p)
+
+    def permutation_product_terms(self, cols, sigmas, first_col_index: int, beta, gamma, delta, omega):
+        """(num, den) of one permutation set over all rows of the given columns"""
+        cols, sigmas = [_fe(c) for c in cols], [_fe(c) for c in sigmas]
+        rows, m = len(cols[0]), len(cols)
+        dc, ds = [self.to_device(c) for c in cols], [self.to_device(c) for c in sigmas]
+        dn, dd = self.malloc(32 * max(rows, 1)), self.malloc(32 * max(rows, 1))
+        try:
+            pc, ps = (_vp * m)(*[_vp(p) for p in dc]), (_vp * m)(*[_vp(p) for p in ds])
+            self._chk(self.lib.h2hip_permutation_product_terms_dev(self.handle, _vp(dn), _vp(dd), pc, ps, m, first_col_index, rows, _ptr(_fe(beta)),
+                                                                   _ptr(_fe(gamma)), _ptr(_fe(delta)), _ptr(_fe(omega))))
+            return self.download(dn, (rows, 4)), self.download(dd, (rows, 4))
+        finally:
+            for p in dc + ds + [dn, dd]:
+                self.free(p)
+
+    def lookup_product_terms(self, a, s, a_perm, s_perm, beta, gamma):
+        arrs = [_fe(v) for v in (a, s, a_perm, s_perm)]
+        rows = len(arrs[0])
+        d = [self.to_device(v) for v in arrs]
+        dn, dd = self.malloc(32 * max(rows, 1)), self.malloc(32 * max(rows, 1))
+        try:
+            self._chk(self.lib.h2hip_lookup_product_terms_dev(self.handle, _vp(dn), _vp(dd), *[_vp(p) for p in d], rows, _ptr(_fe(beta)), _ptr(_fe(gamma))))
+            return self.download(dn, (rows, 4)), self.download(dd, (rows, 4))
+        finally:
+            for p in d + [dn, dd]:
+                self.free(p)
+
     def quotient_flex_gate(self, acc: np.ndarray, q: np.ndarray, a: np.ndarray, ext_k: int, k: int, y: np.ndarray) -> np.ndarray:
         acc, q, a = _fe(acc), _fe(q), _fe(a)
         da, dq, dv = self.to_device(acc), self.to_device(q), self.to_device(a)

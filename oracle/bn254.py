@@ -211,6 +211,63 @@ def g1_mul(P, k: int):
     return _from_jac(acc)
 
 
+# ---- a second, structurally different G1 implementation: COMPLETE addition in homogeneous projective coordinates
+# (Renes-Costello-Batina 2015, algorithm 7 for y^2 = x^3 + b, a = 0; b3 = 3*b = 9).  One formula covers doubling, the identity
+# (0 : 1 : 0) and inverse points, so it shares no case analysis and no coordinate system with g1_add / _jac_add above.  Used by the
+# tests as an independent anchor for every closed-form MSM check (the reference holds no MSM vectors).
+_B3 = 3 * CURVE_B
+
+
+def _proj_add_complete(P, Q):
+    X1, Y1, Z1 = P
+    X2, Y2, Z2 = Q
+    q = Q_MOD
+    t0, t1, t2 = X1 * X2 % q, Y1 * Y2 % q, Z1 * Z2 % q
+    t3 = (X1 + Y1) * (X2 + Y2) % q
+    t3 = (t3 - t0 - t1) % q
+    t4 = (Y1 + Z1) * (Y2 + Z2) % q
+    t4 = (t4 - t1 - t2) % q
+    Y3 = (X1 + Z1) * (X2 + Z2) % q
+    Y3 = (Y3 - t0 - t2) % q
+    X3 = 3 * t0 % q
+    t2 = _B3 * t2 % q
+    Z3 = (t1 + t2) % q
+    t1 = (t1 - t2) % q
+    Y3 = _B3 * Y3 % q
+    Xo = (t3 * t1 - t4 * Y3) % q
+    Yo = (Y3 * X3 + t1 * Z3) % q
+    Zo = (Z3 * t4 + X3 * t3) % q
+    return (Xo, Yo, Zo)
+
+
+def g1_mul_complete(P, k: int):
+    """k*P with the complete formula only (left-to-right double-and-add; no special cases anywhere)"""
+    acc = (0, 1, 0)
+    base = (0, 1, 0) if P is None else (P[0], P[1], 1)
+    for bit in bin(k % R_MOD)[2:] if k % R_MOD else "":
+        acc = _proj_add_complete(acc, acc)
+        if bit == "1":
+            acc = _proj_add_complete(acc, base)
+    X, Y, Z = acc
+    if Z == 0:
+        return None
+    zi = inv_mod(Z, Q_MOD)
+    return (X * zi % Q_MOD, Y * zi % Q_MOD)
+
+
+def msm_complete(scalars, points):
+    """sum_i scalars[i]*points[i] through the complete projective formulas"""
+    acc = (0, 1, 0)
+    for k, P in zip(scalars, points):
+        term = g1_mul_complete(P, k)
+        acc = _proj_add_complete(acc, (0, 1, 0) if term is None else (term[0], term[1], 1))
+    X, Y, Z = acc
+    if Z == 0:
+        return None
+    zi = inv_mod(Z, Q_MOD)
+    return (X * zi % Q_MOD, Y * zi % Q_MOD)
+
+
 def msm_naive(scalars, points):
     """sum_i s_i * P_i by independent scalar multiplications (small n only)."""
     acc = (1, 1, 0)

@@ -88,3 +88,65 @@ def check_c_oracle_against_golden():
     assert O.limbs_to_ints(CO.fr_kate_division(c, x), R) == ints(p["kate_division"])
     cv = ints(p["coeffs"])
     assert O.limbs_to_ints(CO.fr_grand_product(fr(cv[:16]), fr(cv[16:32])), R) == ints(p["grand_product"])
+
+
+def check_prover_steps(ctx, n, seed=5):
+    """the device steps of create_proof that sit between the big kernels, against big-int arithmetic: Assigned::Rational resolution
+    (zero denominators included, reference halo2-base/src/gates/flex_gate/mod.rs:677-681), the factors of the permutation and lookup grand
+    products, the Horner step over h's pieces, P(X) - r(X), and the batched evaluation round"""
+    from tests.util import rand_fr
+
+    g = np.random.default_rng(seed)
+    to_i = lambda a: O.limbs_to_ints(np.asarray(a).reshape(-1, 4), R)
+    # Assigned::Rational -> value, 0^-1 := 0; Trivial cells carry den = 1
+    num, den = rand_fr(n, seed), rand_fr(n, seed + 1)
+    den[:: 7] = 0
+    den[1:: 5] = fr([1])[0]
+    got = to_i(ctx.assigned_resolve(num, den))
+    ni, di = to_i(num), to_i(den)
+    assert got == [a * (O.inv_mod(d, R) if d else 0) % R for a, d in zip(ni, di)]
+    # permutation set factors
+    beta, gamma = [int(v) for v in g.integers(1, 1 << 62, size=2)]
+    omega = O.omega_for(max(1, (n - 1).bit_length()))
+    cols, sigs = [rand_fr(n, seed + 10 + j) for j in range(3)], [rand_fr(n, seed + 20 + j) for j in range(3)]
+    first = 2
+    gn, gd = ctx.permutation_product_terms(cols, sigs, first, fr([beta]), fr([gamma]), fr([O.DELTA]), fr([omega]))
+    ci, si = [to_i(c) for c in cols], [to_i(c) for c in sigs]
+    wn, wd, wpow = [], [], 1
+    for i in range(n):
+        a = b = 1
+        for j in range(3):
+            a = a * (ci[j][i] + beta * pow(O.DELTA, first + j, R) % R * wpow + gamma) % R
+            b = b * (ci[j][i] + beta * si[j][i] + gamma) % R
+        wn.append(a)
+        wd.append(b)
+        wpow = wpow * omega % R
+    assert to_i(gn) == wn and to_i(gd) == wd
+    # lookup factors
+    a_, s_, ap, sp = (rand_fr(n, seed + 30 + j) for j in range(4))
+    gn, gd = ctx.lookup_product_terms(a_, s_, ap, sp, fr([beta]), fr([gamma]))
+    ai, si_, api, spi = to_i(a_), to_i(s_), to_i(ap), to_i(sp)
+    assert to_i(gn) == [(x + beta) * (y + gamma) % R for x, y in zip(ai, si_)]
+    assert to_i(gd) == [(x + beta) * (y + gamma) % R for x, y in zip(api, spi)]
+    # s*y + a*x and y - low
+    sc, ac = [int(v) for v in g.integers(1, 1 << 62, size=2)]
+    assert to_i(ctx.fr_axpby(a_, fr([sc]), fr([ac]), s_)) == [(sc * y + ac * x) % R for y, x in zip(ai, si_)]
+    m = min(n, 5)
+    low = rand_fr(m, seed + 40)
+    want = list(ai)
+    for i, v in enumerate(to_i(low)):
+        want[i] = (want[i] - v) % R
+    assert to_i(ctx.fr_sub_low(a_, low)) == want
+    # batched evaluations: different polynomials / lengths / points, repeated points (the kernel shares their power tables)
+    polys = [a_, s_, ap[: max(1, n // 3)], sp[:1], a_]
+    pts = [int(v) for v in g.integers(1, 1 << 62, size=3)]
+    points = [pts[0], pts[0], pts[1], pts[2], pts[2]]
+    got = to_i(ctx.fr_eval_polynomial_batch(polys, fr(points)))
+
+    def horner(c, x):
+        acc = 0
+        for v in reversed(c):
+            acc = (acc * x + v) % R
+        return acc
+
+    assert got == [horner(to_i(p), x) for p, x in zip(polys, points)]

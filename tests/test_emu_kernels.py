@@ -388,3 +388,10 @@ def test_divide_by_vanishing_poly(ctx, k, ek):
     got = ctx.divide_by_vanishing_poly(fr(a), ek, k, fr([we]), fr([O.ZETA]))
     want = [v * O.inv_mod((pow(O.ZETA * pow(we, i, R) % R, n, R) - 1) % R, R) % R for i, v in enumerate(a)]
     assert O.limbs_to_ints(got, R) == want
+
+
+@pytest.mark.parametrize("n", [1, 37, 2500])
+def test_prover_steps_emulated(ctx, n):
+    from tests.golden_checks import check_prover_steps
+
+    check_prover_steps(ctx, n)

@@ -77,7 +77,7 @@ def test_msm_2_20_bit_exact_and_closed_form(ctx, kind):
     assert np.array_equal(got, CO.best_multiexp(s, bases, threads=NT))
     si = O.limbs_to_ints(s, R)
     total = sum(v * (k0 + i * d) for i, v in enumerate(si)) % R
-    assert O.limbs_to_points(got) == [O.g1_mul(O.G1_GEN, total)]
+    assert O.limbs_to_points(got) == [O.g1_mul(O.G1_GEN, total)] == [O.g1_mul_complete(O.G1_GEN, total)]   # two independent G1 implementations
     # device-resident scalars give the same answer (the bench path)
     ds = ctx.to_device(s)
     assert [jac_to_affine_ints(ctx.msm_dev(b, ds, n, H.POINT_JACOBIAN))] == O.limbs_to_points(got)
@@ -156,7 +156,7 @@ def test_msm_2_20_precomputed_closed_form(ctx):
         got = ctx.msm(b, s, H.POINT_AFFINE)
         si = O.limbs_to_ints(s, R)
         total = sum(v * (k0 + i * d) for i, v in enumerate(si)) % R
-        assert O.limbs_to_points(got) == [O.g1_mul(O.G1_GEN, total)]
+        assert O.limbs_to_points(got) == [O.g1_mul(O.G1_GEN, total)] == [O.g1_mul_complete(O.G1_GEN, total)]
     b.free()
 
 
@@ -244,7 +244,7 @@ def test_msm_batch_bench_path_closed_form(ctx, log_n, batch):
     assert ctx.get_param("msm_defer_reduce") == 1 and ctx.get_param("msm_fuse_cols") == 0
     got = ctx.msm_batch_dev(b, [t.data_ptr() for t in dcols], n, H.POINT_JACOBIAN)
     for j in range(batch):
-        assert B.jac_to_affine(got[j]) == O.g1_mul(O.G1_GEN, B.closed_form_dlog(cols[j], k0, d)), (log_n, batch, j)
+        assert B.jac_to_affine(got[j]) == O.g1_mul_complete(O.G1_GEN, B.closed_form_dlog(cols[j], k0, d)), (log_n, batch, j)
     assert [B.jac_to_affine(got[0])] == O.limbs_to_points(CO.best_multiexp(cols[0], host_pts, threads=NT))
     b.free()
 
@@ -302,3 +302,11 @@ def test_msm_randomized_shapes(ctx):
         for d in dptrs:
             ctx.free(d)
         b.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 37, 2500, 70001])
+def test_prover_steps(ctx, n):
+    from tests.golden_checks import check_prover_steps
+
+    check_prover_steps(ctx, n)

@@ -177,3 +177,34 @@ def test_c_oracle_and_python_oracle_match_committed_golden_fixtures():
     for key in ("t3", "t5"):
         kat = kats[key]
         assert Spec(kat["t"], kat["r_f"], kat["r_p"]).absorb_and_permute(kat["state_in"], kat["inputs"]) == [int(v) for v in kat["state_out"]]
+
+
+def test_second_g1_implementation_agrees():
+    """complete projective formulas (RCB15) vs the affine / Jacobian oracle arithmetic, including the identity, doubling, inverse points,
+    and the closed forms the large-size MSM tests rely on ((sum_i s_i*(k0+i*d))*G and p(s)*G)"""
+    import random
+
+    from oracle import c_oracle as CO
+
+    rnd = random.Random(11)
+    G = O.G1_GEN
+    pts = [O.g1_mul(G, rnd.randrange(1, R)) for _ in range(6)]
+    for P in pts:
+        k = rnd.randrange(R)
+        assert O.g1_mul_complete(P, k) == O.g1_mul(P, k)
+        assert O.g1_mul_complete(P, R - 1) == O.g1_neg(P) and O.g1_mul_complete(P, 0) is None and O.g1_mul_complete(P, 2) == O.g1_add(P, P)
+    assert O.msm_complete([1, R - 1], [pts[0], pts[0]]) is None                    # P + (-P)
+    scal = [rnd.randrange(R) for _ in range(6)] + [0, 1]
+    assert O.msm_complete(scal, pts + [pts[0], None]) == O.msm_naive(scal, pts + [pts[0], None])
+    # closed form over known-dlog bases: the C oracle's MSM, the Python Pippenger and the complete-formula scalar multiplication agree
+    n, k0, d = 64, 31337, 7
+    bases = O.known_dlog_bases(n, k0, d)
+    s = [rnd.randrange(R) for _ in range(n)]
+    want = O.g1_mul_complete(G, sum(si * (k0 + i * d) for i, si in enumerate(s)) % R)
+    assert O.multiexp_serial(s, bases) == want
+    assert O.limbs_to_points(CO.best_multiexp(O.ints_to_limbs(s, R), O.points_to_limbs(bases), threads=2))[0] == want
+    # SRS-shaped bases g_i = tau^i G: a commitment is p(tau)*G
+    tau = rnd.randrange(R)
+    srs = [O.g1_mul(G, pow(tau, i, R)) for i in range(16)]
+    p = [rnd.randrange(R) for _ in range(16)]
+    assert O.msm_complete(p, srs) == O.g1_mul_complete(G, O.eval_polynomial(p, tau))
