@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank owns a 2^log_n-point slice of an N*2^log_n-point MSM (default); strong = ONE 2^log_n-point MSM "
+                         "split into N point ranges (2^log_n / N points per GPU)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (exchange staged through the host; testing)")
     ap.add_argument("--share-device", action="store_true", help="testing on a 1-GPU box: every rank uses GPU 0 (requires --dist-backend gloo)")
     ap.add_argument("--param", action="append", default=[], help="name=value tuning knob passed to h2hip_set_param (repeatable)")
@@ -178,7 +181,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     xdev = dev if args.dist_backend == "nccl" else None   # where the all-gather tensors live
 
-    n = 1 << args.log_n
+    n_total = 1 << args.log_n
+    n = n_total // world if args.scaling == "strong" else n_total   # points per rank
     # a non-default torch stream: the legacy null stream adds implicit synchronisation to every launch
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
@@ -254,7 +258,7 @@ def main():
         # (scalar, window) pair, plus the running-sum reduction of ONE bucket set with precomputed 2^(c*w) tables (all windows share
         # it) or of W bucket sets with plain bases
         adds_per_msm = n * W + 2 * (1 if args.precompute else W) * (1 << (c - 1))
-        units = world * args.steps * adds_per_msm
+        units = world * args.steps * adds_per_msm   # strong scaling: N ranks x their n/N-point share = the adds of the one MSM (+ N bucket sets)
         ms_per_step = elapsed / args.steps * 1e3
         # dominant kernel, timed with HIP events on the launch stream inside the timed region
         k_ms, k_cnt = ctx.profile_get("msm_accum_kernel")
@@ -301,13 +305,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32x8 (254-bit Montgomery integers)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 2^%d-point BN254 G1 MSM, uniform random scalars (distinct column per MSM of a batch), 2^%d distinct random-looking bases (known-dlog multiples of G built on the GPU) resident in HBM" % (args.log_n, args.log_n),
                        "points_per_gpu": n, "bases": "precomputed 2^(c*w) tables" if args.precompute else "plain", "window_bits": c, "windows": W, "adds_per_msm": adds_per_msm,
-                       "sharding": "point-range, one 2^%d slice per GPU, all-gather of 96 B partials" % args.log_n},
+                       "sharding": ("point-range, one 2^%d slice per GPU (weak scaling), all-gather of 96 B partials" % args.log_n) if args.scaling == "weak" else
+                                   ("point-range, ONE 2^%d-point MSM split into %d ranges of %d points (strong scaling), all-gather of 96 B partials" % (args.log_n, world, n))},
             "pairs_per_sec": world * args.steps * n / elapsed, "batch": args.batch, "result_verified": "last timed batch == (sum_i s_i*dlog_i)*G for every column (closed form, known-dlog bases)", "sync_ms_per_msm": sync_ms,
             "kernel_ms_per_msm": breakdown,
             "roofline": {"bound": "hbm", "kernel": "msm_accum_kernel", "achieved": (alg_bytes / k_busy_s / 1e9) if k_busy_s > 0 else achieved_gbs, "peak": 8000.0, "unit": "GB/s",
@@ -347,6 +352,14 @@ def main():
                 out["create_proof_k19"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx.bases_download(bases), scal_h, adds_per_msm)
+    if world > 1 and not args.no_replay:   # every rank takes part: the k=19 create_proof with point-range-sharded commitments
+        try:
+            sharded = create_proof_k19_sharded(ctx, dist, xdev)
+        except Exception as e:
+            sharded = {"error": repr(e)}
+        if rank == 0:
+            out["create_proof_k19_sharded"] = sharded
+    if rank == 0:
         print(json.dumps(out), flush=True)
     bases.free()
     ctx.close()
@@ -456,6 +469,52 @@ def create_proof_k19(ctx, with_cpu_baseline: bool, reps: int = 10):
     pk.free()
     kzg.free()
     return out
+
+
+def create_proof_k19_sharded(ctx, dist, device, reps: int = 5):
+    """N > 1: the same k = 19 create_proof on every rank with its commitments sharded by point range (h2hip_plonk_pk_set_msm_sharding): each of
+    the five MSM rounds is a partial MSM over 2^19 / N points of the rank's SRS slice + one all-gather of 96-byte partials; the NTT / quotient
+    work is replicated (strong scaling of the MSM share only).  seconds = max over ranks."""
+    import hashlib
+
+    import torch
+
+    from halo2_lib_amd import halo2_proofs as HP
+    from halo2_lib_amd import plonk as PL
+    from halo2_lib_amd import testing as T
+    from halo2_lib_amd.multi_gpu import shard_proving_key
+
+    k = 19
+    kzg = HP.ParamsKZG.setup(ctx, k, 0x1D0C0FFEE1234567890ABCDEF, precompute=False)   # only the rank's slice gets window tables
+    bp = PL.BaseCircuitParams.new(k, 1, 1, 1, 0, 18)
+    sh = PL.shape_of(ctx, bp)
+
+    class Backend:
+        mul = staticmethod(ctx.fr_mul)
+        add = staticmethod(ctx.fr_add)
+
+    circ = T.build_circuit(_ShapeView(bp, sh), 19, Backend)
+    pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
+    sk = shard_proving_key(pk, ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange), device=device, precompute=True)
+    draws = synthetic_scalars((1 << k) + 4096, 4242)
+    proof = PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        proof = PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))
+    dist.barrier()
+    sec = (time.perf_counter() - t0) / reps
+    te = torch.tensor([sec], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    digests = [None] * dist.get_world_size()
+    dist.all_gather_object(digests, hashlib.sha256(proof).hexdigest())
+    sk.free()
+    pk.free()
+    kzg.free()
+    return {"seconds": float(te.item()), "reps": reps, "ranks": dist.get_world_size(), "proof_bytes": len(proof),
+            "all_ranks_emit_the_same_proof": len(set(digests)) == 1, "proof_sha256": digests[0],
+            "what": "k=19 ECDSA-configuration create_proof, commitments point-range sharded over the ranks (one all-gather of 96 B partials per "
+                    "MSM round), NTT / quotient work replicated"}
 
 
 def _cpu_threads():

@@ -228,6 +228,12 @@ struct h2hip_plonk_pk {
     bool have_repr = false;
     BufPool pool;
     std::vector<void *> owned;
+    // multi-GPU: point-range sharding of every commitment (h2hip_plonk_pk_set_msm_sharding)
+    const h2hip_bases *g_shard = nullptr, *g_lagrange_shard = nullptr;
+    size_t shard_offset = 0, shard_len = 0;
+    uint32_t shard_world = 1;
+    h2hip_allgather_fn allgather = nullptr;
+    void *allgather_user = nullptr;
     Fr *host_stage = nullptr;   // pinned staging for the RNG-drawn scalars (the n coefficients of the random polynomial, the blinding rows)
     size_t host_stage_elems = 0;
 };
@@ -569,6 +575,40 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // costs microseconds, on a single GPU lane ~0.1 ms of an otherwise idle chip
     auto commit_points = [&](const h2hip_bases *bases, const std::vector<const void *> &cols, size_t len, std::vector<G1Affine> &pts) -> int {
         std::vector<G1Jac> jac(cols.size());
+        if (pk->shard_world > 1) {
+            // point-range sharding: this rank's partial MSM over its resident slice of the SRS, one all-gather of the
+            // 96-byte partials per round (RCCL has no group-law reduction), the N-term sums on the host.  Every rank ends up with every
+            // commitment, so the replicated transcripts stay in lock step and all ranks emit the same proof bytes.
+            const h2hip_bases *sb = bases == pk->g ? pk->g_shard : pk->g_lagrange_shard;
+            const size_t lo = std::min(pk->shard_offset, len), hi = std::min(pk->shard_offset + pk->shard_len, len);
+            std::vector<const void *> local(cols.size());
+            for (size_t i = 0; i < cols.size(); ++i) local[i] = (const Fr *)cols[i] + lo;
+            if (cols.size() == 1)
+                H2_CHK(h2hip_msm_g1_dev(ctx, sb, local[0], hi - lo, H2HIP_POINT_JACOBIAN, jac.data()));
+            else if (!cols.empty())
+                H2_CHK(h2hip_msm_g1_batch_dev(ctx, sb, local.data(), hi - lo, cols.size(), H2HIP_POINT_JACOBIAN, jac.data()));
+            std::vector<G1Jac> all(cols.size() * pk->shard_world);
+            if (pk->allgather(pk->allgather_user, jac.data(), sizeof(G1Jac) * cols.size(), all.data()) != 0) {
+                set_error("create_proof: the all-gather callback failed");
+                return H2HIP_ERR_INVALID;
+            }
+            pts.resize(cols.size());
+            for (size_t i = 0; i < cols.size(); ++i) {
+                XYZZ acc = XYZZ::identity();
+                for (uint32_t r = 0; r < pk->shard_world; ++r) {
+                    const G1Jac &p = all[(size_t)r * cols.size() + i];
+                    if (p.z.is_zero()) continue;
+                    XYZZ q;
+                    q.x = p.x;
+                    q.y = p.y;
+                    q.zz = fe_sqr(p.z);
+                    q.zzz = fe_mul(q.zz, p.z);
+                    xyzz_add(acc, q);
+                }
+                pts[i] = xyzz_to_affine(acc);
+            }
+            return H2HIP_OK;
+        }
         if (cols.size() == 1)
             H2_CHK(h2hip_msm_g1_dev(ctx, bases, cols[0], len, H2HIP_POINT_JACOBIAN, jac.data()));
         else if (!cols.empty())
@@ -1057,6 +1097,27 @@ int h2hip_plonk_pk_set_transcript_repr(h2hip_plonk_pk *pk, const void *fr) {
     H2_REQUIRE(pk && fr, "NULL argument");
     memcpy(&pk->transcript_repr, fr, sizeof(Fr));
     pk->have_repr = true;
+    return H2HIP_OK;
+}
+
+int h2hip_plonk_pk_set_msm_sharding(h2hip_plonk_pk *pk, const h2hip_bases *g_shard, const h2hip_bases *g_lagrange_shard, size_t offset, size_t len,
+                                    uint32_t world, h2hip_allgather_fn allgather, void *user) {
+    H2_REQUIRE(pk, "NULL argument");
+    if (world <= 1) {
+        pk->shard_world = 1;
+        pk->g_shard = pk->g_lagrange_shard = nullptr;
+        pk->allgather = nullptr;
+        return H2HIP_OK;
+    }
+    H2_REQUIRE(g_shard && g_lagrange_shard && allgather, "NULL argument");
+    H2_REQUIRE(offset + len <= pk->sh.n && g_shard->n >= len && g_lagrange_shard->n >= len, "shard range outside the SRS / shard base sets too small");
+    pk->g_shard = g_shard;
+    pk->g_lagrange_shard = g_lagrange_shard;
+    pk->shard_offset = offset;
+    pk->shard_len = len;
+    pk->shard_world = world;
+    pk->allgather = allgather;
+    pk->allgather_user = user;
     return H2HIP_OK;
 }
 

@@ -85,6 +85,7 @@ _PROTOS = {
     "h2hip_plonk_pk_free": (None, [_vp, _vp]),
     "h2hip_plonk_pk_commitments": (_int, [_vp, _vp, _vp]),
     "h2hip_plonk_pk_set_transcript_repr": (_int, [_vp, _vp]),
+    "h2hip_plonk_pk_set_msm_sharding": (_int, [_vp, _vp, _vp, _sz, _sz, _u32, _vp, _vp]),
     "h2hip_plonk_stage_name": (C.c_char_p, [_int]),
     "h2hip_plonk_create_proof": (_int, [_vp, _vp, C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_sz), _vp, _vp, _vp, _sz, C.POINTER(_sz),
                                         C.POINTER(C.c_double)]),

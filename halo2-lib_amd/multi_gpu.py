@@ -5,7 +5,11 @@ over xGMI on ROCm; "gloo" in CPU tests).
   scalar slice; it computes a full partial MSM locally (no data-path collective).  The only exchange is an
   all-gather of the N partial results (96 B Jacobian each — RCCL has no elliptic-curve reduction op), after
   which every rank sums the N points on its own GPU (h2hip_g1_sum_jacobian_dev).
-* NTT — independent columns are dealt round-robin to ranks (`columns_for_rank`); no communication.
+* NTT — independent columns are dealt round-robin to ranks (`columns_for_rank`); `sharded_ntt_columns` runs each rank's transforms
+  on its own GPU and leaves the results there (where the matching commitments / quotient terms are computed), or, on request,
+  all-gathers them so that every rank holds every transformed column.
+* create_proof — `shard_proving_key` switches a proving key's commitments to point-range sharding (h2hip_plonk_pk_set_msm_sharding):
+  all ranks run the same create_proof call; each MSM round costs one all-gather of 96-byte partials.
 """
 from __future__ import annotations
 
@@ -91,3 +95,99 @@ def sharded_msm_batch(ctx: Context, bases: Bases, scalar_dptrs, n_local: int, gr
     dist.all_gather(gathered, t, group=group)
     allp = torch.cat(gathered, dim=0).permute(1, 0, 2).contiguous()   # (count, world, 12)
     return _sum_gathered(ctx, allp, world, count, POINT_JACOBIAN, device)
+
+
+def sharded_ntt_columns(ctx: Context, columns, transform, group=None, gather: bool = False, device=None):
+    """Column-sharded NTTs: `columns` is the full list of independent polynomials (host (n,4) arrays, every rank passes
+    the same list); rank r transforms columns r, r+N, ... with `transform(ctx, dptr)` — any of the in-place `_dev` NTT entry points,
+    e.g. `lambda c, p: c.ifft_dev(p, omega_inv, k, divisor)` — on its own GPU.  Returns {column index: device pointer} of the columns this
+    rank owns (resident: the caller frees them with ctx.free), or with gather=True a list of ALL transformed columns as host arrays
+    (one all-gather per column slot; ranks without a column in the last slot contribute a dummy)."""
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    mine = columns_for_rank(len(columns), rank, world)
+    owned = {}
+    for j in mine:
+        col = np.ascontiguousarray(columns[j], dtype=np.uint64).reshape(-1, 4)
+        d = ctx.to_device(col)
+        transform(ctx, d)
+        owned[j] = (d, col.shape)
+    if not gather:
+        ctx.sync()
+        return {j: d for j, (d, _) in owned.items()}
+    out = [None] * len(columns)
+    slots = (len(columns) + world - 1) // world
+    for slot in range(slots):
+        j = slot * world + rank
+        shape = np.ascontiguousarray(columns[min(j, len(columns) - 1)]).reshape(-1, 4).shape
+        local = ctx.download(owned[j][0], owned[j][1]) if j in owned else np.zeros(shape, dtype=np.uint64)
+        if not distributed:
+            out[j] = local
+            continue
+        t = torch.from_numpy(local.view(np.int64).copy())
+        if device is not None:
+            t = t.to(device)
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t, group=group)
+        for r in range(world):
+            jj = slot * world + r
+            if jj < len(columns):
+                out[jj] = gathered[r].cpu().numpy().view(np.uint64).reshape(-1, 4)
+    for d, _ in owned.values():
+        ctx.free(d)
+    return out
+
+
+class ShardedKey:
+    """keeps the shard base sets and the all-gather callback of a sharded proving key alive"""
+
+    def __init__(self, pk, g_shard, g_lagrange_shard, callback):
+        self.pk, self.g_shard, self.g_lagrange_shard, self.callback = pk, g_shard, g_lagrange_shard, callback
+
+    def free(self):
+        self.pk.ctx._chk(self.pk.ctx.lib.h2hip_plonk_pk_set_msm_sharding(self.pk.handle, None, None, 0, 0, 1, None, None))
+        self.g_shard.free()
+        self.g_lagrange_shard.free()
+
+
+def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, group=None, device=None, precompute: bool = True) -> ShardedKey:
+    """Point-range sharding of a proving key's commitments over the process group: this rank uploads ONLY its slice of the SRS
+    (g_points / g_lagrange_points: the full (n, 8) affine arrays or anything sliceable that yields them) as base sets with their own window
+    tables, and installs an all-gather over torch.distributed ("nccl" = RCCL with `device`, "gloo" on the CPU) as the exchange step."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from .h2hip import BASES_PLAIN, BASES_PRECOMPUTE
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = 1 << pk.params.k
+    lo, hi = shard_range(n, rank, world)
+    ctx = pk.ctx
+    flags = BASES_PRECOMPUTE if precompute else BASES_PLAIN
+    gs = ctx.bases_upload(np.ascontiguousarray(g_points[lo:hi]), flags)
+    gls = ctx.bases_upload(np.ascontiguousarray(g_lagrange_points[lo:hi]), flags)
+
+    def _allgather(_user, local, nbytes, out):
+        try:
+            buf = (C.c_uint8 * nbytes).from_address(local)
+            t = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+            if device is not None:
+                t = t.to(device)
+            gathered = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t, group=group)
+            flat = torch.cat(gathered).cpu().numpy()
+            C.memmove(out, flat.ctypes.data, nbytes * world)
+            return 0
+        except BaseException:   # never unwind through the C frames
+            return 1
+
+    cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)(_allgather)
+    ctx._chk(ctx.lib.h2hip_plonk_pk_set_msm_sharding(pk.handle, gs.handle, gls.handle, lo, hi - lo, world, C.cast(cb, C.c_void_p), None))
+    return ShardedKey(pk, gs, gls, cb)

@@ -284,6 +284,16 @@ int h2hip_plonk_pk_commitments(const h2hip_plonk_pk *pk, void *fixed_out, void *
 /* vk.transcript_repr — upstream hashes the Debug rendering of the pinned key; it is computed by the Rust side and handed over */
 int h2hip_plonk_pk_set_transcript_repr(h2hip_plonk_pk *pk, const void *fr);
 
+/* Multi-GPU (one process per GPU): every commitment of create_proof becomes a partial MSM over this rank's point range
+ * [offset, offset + len) of the SRS — g_shard / g_lagrange_shard hold just that slice (1/N of the table memory) — followed by ONE
+ * all-gather of the 96-byte Jacobian partials per commitment round and an N-term sum on the host (RCCL has no group-law reduction).
+ * allgather(user, local, bytes, all): gather `bytes` from every rank into all[rank * bytes ...], return 0; the host library above
+ * implements it with its collective of choice (torch.distributed / RCCL over xGMI).  All ranks run the same create_proof call on the
+ * same inputs and emit identical proof bytes.  world <= 1 switches sharding off. */
+typedef int (*h2hip_allgather_fn)(void *user, const void *local, size_t bytes, void *all);
+int h2hip_plonk_pk_set_msm_sharding(h2hip_plonk_pk *pk, const h2hip_bases *g_shard, const h2hip_bases *g_lagrange_shard, size_t offset, size_t len,
+                                    uint32_t world, h2hip_allgather_fn allgather, void *user);
+
 /* `Fr::random(rng)` x n into out (Montgomery limbs); called in upstream's draw order */
 typedef void (*h2hip_rng_fill_fn)(void *user, void *out_fr, size_t n);
 #define H2HIP_PLONK_STAGES 13

@@ -77,3 +77,70 @@ def test_shard_range_covers_everything():
             spans = [shard_range(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def _worker_prover(rank, world, port, q):
+    """world-2 create_proof with point-range-sharded commitments + column-sharded NTTs on the emulated kernels"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from halo2_lib_amd import halo2_proofs as HP
+        from halo2_lib_amd import plonk as PL
+        from halo2_lib_amd import testing as T
+        from halo2_lib_amd.multi_gpu import shard_proving_key, sharded_ntt_columns
+        from oracle import c_oracle as CO
+        from oracle import plonk as P
+        from tests.emu_util import emu_context
+        from tests.test_plonk_prover import _OracleBackend, _rng_budget
+        from tests.util import PreDrawnRng, domain_consts, rand_fr
+
+        ctx = emu_context()
+        k, shape = 6, (6, 2, 1, 1, 1, 4)
+        sh = P.Shape(*shape)
+        kzg = HP.ParamsKZG.setup(ctx, k, 0xABCDEF0123, precompute=False)
+        circ = T.build_circuit(sh, 4, _OracleBackend)
+        pk = PL.keygen(kzg, PL.BaseCircuitParams.new(*shape), circ.fixed, circ.copies)
+        budget = _rng_budget(sh)
+        single = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9))
+        sk = shard_proving_key(pk, ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange), precompute=False)
+        sharded = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9))
+        sk.free()
+        after = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9))
+        ok_proof = sharded == single == after
+        # column-sharded NTTs: 5 columns over 2 ranks, values checked against the oracle on every rank
+        log_n = 7
+        cols = [rand_fr(1 << log_n, 100 + j) for j in range(5)]
+        w, winv, div = domain_consts(log_n)
+        got = sharded_ntt_columns(ctx, cols, lambda c, p: c.ifft_dev(p, winv, log_n, div), gather=True)
+        ok_ntt = all(np.array_equal(got[j], CO.ifft(cols[j], log_n, w)) for j in range(5))
+        owned = sharded_ntt_columns(ctx, cols, lambda c, p: c.best_fft_dev(p, w, log_n))
+        ok_owned = sorted(owned) == list(range(rank, 5, world)) and all(
+            np.array_equal(ctx.download(d, (1 << log_n, 4)), CO.best_fft(cols[j], log_n, w)) for j, d in owned.items())
+        for d in owned.values():
+            ctx.free(d)
+        q.put((rank, ok_proof, ok_ntt, ok_owned, sharded.hex()[:32]))
+        pk.free()
+        kzg.free()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_create_proof_and_ntt_columns_world2():
+    from tests.emu_util import emu_context
+
+    emu_context().close()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_prover, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] and r[3] for r in res), res
+    assert res[0][4] == res[1][4]   # both ranks emit the same proof
