@@ -13,6 +13,44 @@ pub struct h2hip_ctx {
 pub struct h2hip_bases {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct h2hip_plonk_pk {
+    _private: [u8; 0],
+}
+/// BaseCircuitParams, first phase (halo2-base/src/gates/circuit/mod.rs:25-45); `lookup_bits < 0` = None
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct h2hip_base_circuit_params {
+    pub k: u32,
+    pub num_advice: u32,
+    pub num_lookup_advice: u32,
+    pub num_fixed: u32,
+    pub num_instance: u32,
+    pub lookup_bits: i32,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct h2hip_plonk_shape {
+    pub num_advice_total: u32,
+    pub num_fixed_total: u32,
+    pub table_col: i32,
+    pub first_constant_col: i32,
+    pub q_lookup_col: i32,
+    pub first_q_enable_col: i32,
+    pub num_lookups: u32,
+    pub num_perm_columns: u32,
+    pub num_perm_sets: u32,
+    pub degree: u32,
+    pub extended_k: u32,
+    pub blinding_factors: u32,
+    pub usable_rows: u32,
+    pub quotient_pieces: u32,
+    pub num_commitments: u32,
+    pub num_evals: u32,
+}
+pub type h2hip_rng_fill_fn = Option<unsafe extern "C" fn(user: *mut c_void, out_fr: *mut c_void, n: usize)>;
+pub type h2hip_allgather_fn = Option<unsafe extern "C" fn(user: *mut c_void, local: *const c_void, bytes: usize, all: *mut c_void) -> c_int>;
+pub const H2HIP_PLONK_STAGES: usize = 13;
 
 pub const H2HIP_OK: c_int = 0;
 pub const H2HIP_ERR_INVALID: c_int = -1;
@@ -93,6 +131,31 @@ extern "C" {
                                               zeta: *const c_void, ext_omega: *const c_void, y: *const c_void) -> c_int;
     pub fn h2hip_lookup_permute_dev(ctx: *mut h2hip_ctx, a_dev: *const c_void, s_dev: *const c_void, usable_rows: usize, a_perm_dev: *mut c_void,
                                     s_perm_dev: *mut c_void) -> c_int;
+    // prover steps between the big kernels
+    pub fn h2hip_fr_axpby_dev(ctx: *mut h2hip_ctx, y_dev: *mut c_void, s: *const c_void, a: *const c_void, x_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_fr_sub_low_dev(ctx: *mut h2hip_ctx, y_dev: *mut c_void, low_host: *const c_void, m: u32) -> c_int;
+    pub fn h2hip_assigned_resolve_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, num_dev: *const c_void, den_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_permutation_product_terms_dev(ctx: *mut h2hip_ctx, num_dev: *mut c_void, den_dev: *mut c_void, cols_dev: *const *const c_void,
+                                               sigmas_dev: *const *const c_void, ncols: u32, first_col_index: u32, rows: usize, beta: *const c_void,
+                                               gamma: *const c_void, delta: *const c_void, omega: *const c_void) -> c_int;
+    pub fn h2hip_lookup_product_terms_dev(ctx: *mut h2hip_ctx, num_dev: *mut c_void, den_dev: *mut c_void, a_dev: *const c_void, s_dev: *const c_void,
+                                          a_perm_dev: *const c_void, s_perm_dev: *const c_void, rows: usize, beta: *const c_void,
+                                          gamma: *const c_void) -> c_int;
+    pub fn h2hip_fr_eval_polynomial_batch_dev(ctx: *mut h2hip_ctx, coeffs_dev: *const *const c_void, lens: *const usize, points: *const c_void,
+                                              count: usize, out_host: *mut c_void) -> c_int;
+    // a1 — plonk::{keygen_vk, keygen_pk, create_proof} for BaseConfig circuits, resident on the GPU
+    pub fn h2hip_plonk_shape_of(params: *const h2hip_base_circuit_params, out: *mut h2hip_plonk_shape) -> c_int;
+    pub fn h2hip_plonk_keygen(ctx: *mut h2hip_ctx, params: *const h2hip_base_circuit_params, g: *const h2hip_bases, g_lagrange: *const h2hip_bases,
+                              fixed_host: *const *const c_void, copies: *const u32, ncopies: usize, out: *mut *mut h2hip_plonk_pk) -> c_int;
+    pub fn h2hip_plonk_pk_free(ctx: *mut h2hip_ctx, pk: *mut h2hip_plonk_pk);
+    pub fn h2hip_plonk_pk_commitments(pk: *const h2hip_plonk_pk, fixed_out: *mut c_void, permutation_out: *mut c_void) -> c_int;
+    pub fn h2hip_plonk_pk_set_transcript_repr(pk: *mut h2hip_plonk_pk, fr: *const c_void) -> c_int;
+    pub fn h2hip_plonk_pk_set_msm_sharding(pk: *mut h2hip_plonk_pk, g_shard: *const h2hip_bases, g_lagrange_shard: *const h2hip_bases, offset: usize,
+                                           len: usize, world: u32, allgather: h2hip_allgather_fn, user: *mut c_void) -> c_int;
+    pub fn h2hip_plonk_stage_name(stage: c_int) -> *const c_char;
+    pub fn h2hip_plonk_create_proof(ctx: *mut h2hip_ctx, pk: *mut h2hip_plonk_pk, advice: *const *const c_void, advice_on_device: c_int,
+                                    instances_host: *const *const c_void, instance_lens: *const usize, rng: h2hip_rng_fill_fn, rng_user: *mut c_void,
+                                    proof_out: *mut u8, proof_cap: usize, proof_len: *mut usize, stage_ms: *mut f64) -> c_int;
     // timing / diagnostics
     pub fn h2hip_profile_enable(ctx: *mut h2hip_ctx, on: c_int) -> c_int;
     pub fn h2hip_profile_reset(ctx: *mut h2hip_ctx) -> c_int;

@@ -99,3 +99,213 @@ pub fn extended_to_coeff(be: &Backend, mut a: Vec<Fr>, extended_k: u32, extended
     a.truncate(n * quotient_poly_degree);
     Ok(a)
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The rest of INTEGRATION.md §2's call-site table.  Polynomials that stay on the device between calls are `DeviceVec`s.
+
+/// A column / polynomial resident in HBM.
+pub struct DeviceVec<'b> {
+    be: &'b Backend,
+    ptr: *mut c_void,
+    len: usize,
+}
+impl<'b> DeviceVec<'b> {
+    pub fn zeroed(be: &'b Backend, len: usize) -> Result<Self, HipError> {
+        let mut ptr = ptr::null_mut();
+        check(unsafe { h2hip_malloc(be.ctx, 32 * len.max(1), &mut ptr) })?;
+        let v = Self { be, ptr, len };
+        v.upload(&vec![Fr::zero(); len])?;
+        Ok(v)
+    }
+    pub fn from_slice(be: &'b Backend, values: &[Fr]) -> Result<Self, HipError> {
+        let mut ptr = ptr::null_mut();
+        check(unsafe { h2hip_malloc(be.ctx, 32 * values.len().max(1), &mut ptr) })?;
+        let v = Self { be, ptr, len: values.len() };
+        v.upload(values)?;
+        Ok(v)
+    }
+    pub fn upload(&self, values: &[Fr]) -> Result<(), HipError> {
+        assert_eq!(values.len(), self.len);
+        check(unsafe { h2hip_upload(self.be.ctx, self.ptr, values.as_ptr().cast(), 32 * self.len) })
+    }
+    pub fn to_vec(&self) -> Result<Vec<Fr>, HipError> {
+        let mut out = vec![Fr::zero(); self.len];
+        check(unsafe { h2hip_download(self.be.ctx, out.as_mut_ptr().cast(), self.ptr, 32 * self.len) })?;
+        Ok(out)
+    }
+    pub fn len(&self) -> usize {
+        self.len
+    }
+}
+impl Drop for DeviceVec<'_> {
+    fn drop(&mut self) {
+        unsafe { h2hip_free(self.be.ctx, self.ptr) };
+    }
+}
+fn fr_ptr(v: &Fr) -> *const c_void {
+    (v as *const Fr).cast()
+}
+
+impl<'b> ResidentBases<'b> {
+    /// all commitments of one prover round (`advice.iter().map(|p| params.commit_lagrange(p))` upstream) as ONE pipelined batch
+    pub fn multiexp_many(&self, columns: &[&DeviceVec<'b>]) -> Result<Vec<G1>, HipError> {
+        let n = columns.first().map_or(0, |c| c.len);
+        assert!(columns.iter().all(|c| c.len == n));
+        let ptrs: Vec<*const c_void> = columns.iter().map(|c| c.ptr as *const c_void).collect();
+        let mut out = vec![G1::default(); columns.len()];
+        check(unsafe { h2hip_msm_g1_batch_dev(self.be.ctx, self.h, ptrs.as_ptr(), n, columns.len(), H2HIP_POINT_JACOBIAN, out.as_mut_ptr().cast()) })?;
+        Ok(out)
+    }
+}
+
+/// `batch_invert_assigned`: Assigned::Rational(num, den) columns -> values, 0^-1 := 0 (halo2-base/src/gates/flex_gate/mod.rs:677-681)
+pub fn assigned_resolve<'b>(be: &'b Backend, num: &DeviceVec<'b>, den: &DeviceVec<'b>) -> Result<DeviceVec<'b>, HipError> {
+    assert_eq!(num.len, den.len);
+    let out = DeviceVec::zeroed(be, num.len)?;
+    check(unsafe { h2hip_assigned_resolve_dev(be.ctx, out.ptr, num.ptr, den.ptr, num.len) })?;
+    Ok(out)
+}
+/// `ff::BatchInvert` on a resident column, in place
+pub fn batch_invert(be: &Backend, a: &mut DeviceVec) -> Result<(), HipError> {
+    check(unsafe { h2hip_fr_batch_invert_dev(be.ctx, a.ptr, a.len) })
+}
+/// permutation argument: z over the usable rows of one column set, starting at `first` (the previous set's last value)
+pub fn permutation_product<'b>(be: &'b Backend, columns: &[&DeviceVec<'b>], sigmas: &[&DeviceVec<'b>], first_col_index: u32, usable_rows: usize,
+                               beta: Fr, gamma: Fr, delta: Fr, omega: Fr, first: Fr) -> Result<DeviceVec<'b>, HipError> {
+    assert_eq!(columns.len(), sigmas.len());
+    let (num, den) = (DeviceVec::zeroed(be, usable_rows)?, DeviceVec::zeroed(be, usable_rows)?);
+    let c: Vec<*const c_void> = columns.iter().map(|v| v.ptr as *const c_void).collect();
+    let s: Vec<*const c_void> = sigmas.iter().map(|v| v.ptr as *const c_void).collect();
+    check(unsafe {
+        h2hip_permutation_product_terms_dev(be.ctx, num.ptr, den.ptr, c.as_ptr(), s.as_ptr(), c.len() as u32, first_col_index, usable_rows,
+                                            fr_ptr(&beta), fr_ptr(&gamma), fr_ptr(&delta), fr_ptr(&omega))
+    })?;
+    let z = DeviceVec::zeroed(be, usable_rows + 1)?;
+    check(unsafe { h2hip_fr_grand_product_dev(be.ctx, z.ptr, num.ptr, den.ptr, usable_rows) })?;
+    check(unsafe { h2hip_fr_scale_dev(be.ctx, z.ptr, fr_ptr(&first), usable_rows + 1) })?;
+    Ok(z)
+}
+/// lookup argument: `permute_expression_pair` over the usable rows (Err = upstream's ConstraintSystemFailure)
+pub fn permute_expression_pair<'b>(be: &'b Backend, input: &DeviceVec<'b>, table: &DeviceVec<'b>, usable_rows: usize)
+                                   -> Result<(DeviceVec<'b>, DeviceVec<'b>), HipError> {
+    let (a, s) = (DeviceVec::zeroed(be, input.len)?, DeviceVec::zeroed(be, input.len)?);
+    check(unsafe { h2hip_lookup_permute_dev(be.ctx, input.ptr, table.ptr, usable_rows, a.ptr, s.ptr) })?;
+    Ok((a, s))
+}
+/// lookup argument: the grand product z over the usable rows
+pub fn lookup_product<'b>(be: &'b Backend, input: &DeviceVec<'b>, table: &DeviceVec<'b>, permuted_input: &DeviceVec<'b>,
+                          permuted_table: &DeviceVec<'b>, usable_rows: usize, beta: Fr, gamma: Fr) -> Result<DeviceVec<'b>, HipError> {
+    let (num, den) = (DeviceVec::zeroed(be, usable_rows)?, DeviceVec::zeroed(be, usable_rows)?);
+    check(unsafe {
+        h2hip_lookup_product_terms_dev(be.ctx, num.ptr, den.ptr, input.ptr, table.ptr, permuted_input.ptr, permuted_table.ptr, usable_rows,
+                                       fr_ptr(&beta), fr_ptr(&gamma))
+    })?;
+    let z = DeviceVec::zeroed(be, usable_rows + 1)?;
+    check(unsafe { h2hip_fr_grand_product_dev(be.ctx, z.ptr, num.ptr, den.ptr, usable_rows) })?;
+    Ok(z)
+}
+/// evaluate_h, gate term: acc = acc*y + q*(a + a(wX)*a(w^2 X) - a(w^3 X)) on the extended domain
+pub fn quotient_flex_gate(be: &Backend, acc: &mut DeviceVec, q: &DeviceVec, a: &DeviceVec, extended_k: u32, k: u32, y: Fr) -> Result<(), HipError> {
+    check(unsafe { h2hip_quotient_flex_gate_dev(be.ctx, acc.ptr, q.ptr, a.ptr, extended_k, k, fr_ptr(&y)) })
+}
+/// evaluate_h, the lookup argument's five identities
+#[allow(clippy::too_many_arguments)]
+pub fn quotient_lookup(be: &Backend, acc: &mut DeviceVec, z: &DeviceVec, input: &DeviceVec, table: &DeviceVec, permuted_input: &DeviceVec,
+                       permuted_table: &DeviceVec, l0: &DeviceVec, l_last: &DeviceVec, l_blind: &DeviceVec, extended_k: u32, k: u32, beta: Fr,
+                       gamma: Fr, y: Fr) -> Result<(), HipError> {
+    check(unsafe {
+        h2hip_quotient_lookup_dev(be.ctx, acc.ptr, z.ptr, input.ptr, table.ptr, permuted_input.ptr, permuted_table.ptr, l0.ptr, l_last.ptr,
+                                  l_blind.ptr, extended_k, k, fr_ptr(&beta), fr_ptr(&gamma), fr_ptr(&y))
+    })
+}
+/// evaluate_h, one permutation set's terms (`terms`: mask of H2HIP_PERM_*)
+#[allow(clippy::too_many_arguments)]
+pub fn quotient_permutation_set(be: &Backend, acc: &mut DeviceVec, z: &DeviceVec, z_prev: Option<&DeviceVec>, columns: &[&DeviceVec],
+                                sigmas: &[&DeviceVec], first_col_index: u32, l0: &DeviceVec, l_last: &DeviceVec, l_blind: &DeviceVec,
+                                extended_k: u32, k: u32, terms: u32, last_rotation: i32, beta: Fr, gamma: Fr, delta: Fr, zeta: Fr,
+                                extended_omega: Fr, y: Fr) -> Result<(), HipError> {
+    let c: Vec<*const c_void> = columns.iter().map(|v| v.ptr as *const c_void).collect();
+    let s: Vec<*const c_void> = sigmas.iter().map(|v| v.ptr as *const c_void).collect();
+    check(unsafe {
+        h2hip_quotient_permutation_set_dev(be.ctx, acc.ptr, z.ptr, z_prev.map_or(ptr::null(), |v| v.ptr as *const c_void), c.as_ptr(), s.as_ptr(),
+                                           c.len() as u32, first_col_index, l0.ptr, l_last.ptr, l_blind.ptr, extended_k, k, terms, last_rotation,
+                                           fr_ptr(&beta), fr_ptr(&gamma), fr_ptr(&delta), fr_ptr(&zeta), fr_ptr(&extended_omega), fr_ptr(&y))
+    })
+}
+/// `EvaluationDomain::divide_by_vanishing_poly`
+pub fn divide_by_vanishing_poly(be: &Backend, a: &mut DeviceVec, extended_k: u32, k: u32, extended_omega: Fr, zeta: Fr) -> Result<(), HipError> {
+    check(unsafe { h2hip_divide_by_vanishing_poly_dev(be.ctx, a.ptr, extended_k, k, fr_ptr(&extended_omega), fr_ptr(&zeta)) })
+}
+/// `arithmetic::eval_polynomial` for a whole evaluation round: out[j] = polys[j](points[j])
+pub fn eval_polynomials(be: &Backend, polys: &[&DeviceVec], points: &[Fr]) -> Result<Vec<Fr>, HipError> {
+    assert_eq!(polys.len(), points.len());
+    let p: Vec<*const c_void> = polys.iter().map(|v| v.ptr as *const c_void).collect();
+    let l: Vec<usize> = polys.iter().map(|v| v.len).collect();
+    let mut out = vec![Fr::zero(); polys.len()];
+    check(unsafe { h2hip_fr_eval_polynomial_batch_dev(be.ctx, p.as_ptr(), l.as_ptr(), points.as_ptr().cast(), polys.len(), out.as_mut_ptr().cast()) })?;
+    Ok(out)
+}
+/// `arithmetic::kate_division`: (f(X) - f(b)) / (X - b)
+pub fn kate_division<'b>(be: &'b Backend, f: &DeviceVec<'b>, b: Fr) -> Result<DeviceVec<'b>, HipError> {
+    let q = DeviceVec::zeroed(be, f.len.saturating_sub(1))?;
+    check(unsafe { h2hip_fr_kate_division_dev(be.ctx, q.ptr, f.ptr, f.len, fr_ptr(&b)) })?;
+    Ok(q)
+}
+/// `poly * scalar` / `poly += other * scalar` of the multiopen argument
+pub fn axpy(be: &Backend, y: &mut DeviceVec, a: Fr, x: &DeviceVec) -> Result<(), HipError> {
+    check(unsafe { h2hip_fr_axpy_dev(be.ctx, y.ptr, fr_ptr(&a), x.ptr, x.len.min(y.len)) })
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// plonk::{keygen_pk, create_proof}: the whole prover on the device.  This is what `halo2_proofs::plonk::create_proof` becomes in the fork
+// for `ConcreteCircuit = BaseCircuitBuilder<Fr>` (the reference's only circuit type, halo2-base/src/utils/testing.rs:32-50): synthesis, the
+// RNG and the transcript's verifying-key hash stay in Rust, everything else is one FFI call.
+
+pub struct ProvingKeyHip<'b> {
+    be: &'b Backend,
+    pk: *mut h2hip_plonk_pk,
+    pub shape: h2hip_plonk_shape,
+}
+impl<'b> ProvingKeyHip<'b> {
+    /// `keygen_vk` + `keygen_pk`: `fixed` = the fixed columns after synthesis (table, constants, selector columns), `copies` = the copy
+    /// constraints as (permutation column, row, permutation column, row) in emission order.
+    pub fn keygen(be: &'b Backend, params: h2hip_base_circuit_params, g: &ResidentBases<'b>, g_lagrange: &ResidentBases<'b>, fixed: &[Vec<Fr>],
+                  copies: &[[u32; 4]], transcript_repr: impl FnOnce(&[G1Affine], &[G1Affine]) -> Fr) -> Result<Self, HipError> {
+        let mut shape = h2hip_plonk_shape::default();
+        check(unsafe { h2hip_plonk_shape_of(&params, &mut shape) })?;
+        assert_eq!(fixed.len(), shape.num_fixed_total as usize);
+        let cols: Vec<*const c_void> = fixed.iter().map(|c| c.as_ptr().cast()).collect();
+        let mut pk = ptr::null_mut();
+        check(unsafe { h2hip_plonk_keygen(be.ctx, &params, g.h, g_lagrange.h, cols.as_ptr(), copies.as_ptr().cast(), copies.len(), &mut pk) })?;
+        let mut fc = vec![G1Affine::default(); shape.num_fixed_total as usize];
+        let mut pc = vec![G1Affine::default(); shape.num_perm_columns as usize];
+        check(unsafe { h2hip_plonk_pk_commitments(pk, fc.as_mut_ptr().cast(), pc.as_mut_ptr().cast()) })?;
+        let repr = transcript_repr(&fc, &pc);   // VerifyingKey::transcript_repr, computed by the Rust side from the pinned key
+        check(unsafe { h2hip_plonk_pk_set_transcript_repr(pk, fr_ptr(&repr)) })?;
+        Ok(Self { be, pk, shape })
+    }
+    /// `create_proof(params, pk, &[circuit], &[instances], rng, &mut transcript)` after synthesis: returns what
+    /// `transcript.finalize()` would.  `rng_fill` is called for every batch of `Fr::random(rng)` draws, in upstream's order.
+    pub fn create_proof<R: FnMut(&mut [Fr])>(&self, advice: &[Vec<Fr>], instances: &[&[Fr]], mut rng_fill: R) -> Result<Vec<u8>, HipError> {
+        unsafe extern "C" fn trampoline<R: FnMut(&mut [Fr])>(user: *mut c_void, out: *mut c_void, n: usize) {
+            let f = &mut *(user as *mut R);
+            f(std::slice::from_raw_parts_mut(out as *mut Fr, n));
+        }
+        let adv: Vec<*const c_void> = advice.iter().map(|c| c.as_ptr().cast()).collect();
+        let ins: Vec<*const c_void> = instances.iter().map(|c| c.as_ptr().cast()).collect();
+        let lens: Vec<usize> = instances.iter().map(|c| c.len()).collect();
+        let mut proof = vec![0u8; 32 * (self.shape.num_commitments + self.shape.num_evals) as usize];
+        let mut len = 0usize;
+        check(unsafe {
+            h2hip_plonk_create_proof(self.be.ctx, self.pk, adv.as_ptr(), 0, ins.as_ptr(), lens.as_ptr(), Some(trampoline::<R>),
+                                     (&mut rng_fill as *mut R).cast(), proof.as_mut_ptr(), proof.len(), &mut len, ptr::null_mut())
+        })?;
+        proof.truncate(len);
+        Ok(proof)
+    }
+}
+impl Drop for ProvingKeyHip<'_> {
+    fn drop(&mut self) {
+        unsafe { h2hip_plonk_pk_free(self.be.ctx, self.pk) }
+    }
+}

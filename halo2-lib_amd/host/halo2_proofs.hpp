@@ -334,6 +334,67 @@ class ParamsKZG {
 }  // namespace poly
 
 namespace plonk {
+// keygen_vk + keygen_pk and create_proof for BaseConfig circuits (reference halo2-base/src/utils/testing.rs:224-227, :32-50): the whole
+// prover runs on the device (h2hip_plonk_*); synthesis (advice / fixed columns, copy constraints), the RNG and the verifying key's
+// transcript representation stay with the caller, exactly as in the Rust shim (ffi/rust/h2hip-sys/src/safe.rs ProvingKeyHip).
+class ProvingKey {
+  public:
+    // fixed: num_fixed_total Lagrange columns; copies: (permutation column, row, permutation column, row) in emission order
+    ProvingKey(Backend &b, const h2hip_base_circuit_params &params, const poly::kzg::ParamsKZG &kzg, const std::vector<std::vector<Fr>> &fixed,
+               const std::vector<uint32_t> &copies)
+        : be_(&b) {
+        check(h2hip_plonk_shape_of(&params, &shape_));
+        if (fixed.size() != shape_.num_fixed_total) throw Error(H2HIP_ERR_INVALID, "keygen: wrong number of fixed columns");
+        std::vector<const void *> cols;
+        for (auto &c : fixed) {
+            if (c.size() != ((size_t)1 << params.k)) throw Error(H2HIP_ERR_INVALID, "keygen: fixed column length");
+            cols.push_back(c.data());
+        }
+        check(h2hip_plonk_keygen(b.raw(), &params, kzg.get_g().raw(), kzg.get_g_lagrange().raw(), cols.data(), copies.data(), copies.size() / 4, &pk_));
+        fixed_commitments_.resize(shape_.num_fixed_total);
+        permutation_commitments_.resize(shape_.num_perm_columns ? shape_.num_perm_columns : 1);
+        check(h2hip_plonk_pk_commitments(pk_, fixed_commitments_.data(), permutation_commitments_.data()));
+        permutation_commitments_.resize(shape_.num_perm_columns);
+    }
+    ProvingKey(const ProvingKey &) = delete;
+    ~ProvingKey() {
+        if (pk_) h2hip_plonk_pk_free(be_->raw(), pk_);
+    }
+    const h2hip_plonk_shape &shape() const { return shape_; }
+    const std::vector<G1Affine> &fixed_commitments() const { return fixed_commitments_; }
+    const std::vector<G1Affine> &permutation_commitments() const { return permutation_commitments_; }
+    void set_transcript_repr(const Fr &repr) { check(h2hip_plonk_pk_set_transcript_repr(pk_, &repr)); }
+    h2hip_plonk_pk *raw() const { return pk_; }
+
+  private:
+    Backend *be_;
+    h2hip_plonk_pk *pk_ = nullptr;
+    h2hip_plonk_shape shape_;
+    std::vector<G1Affine> fixed_commitments_, permutation_commitments_;
+};
+
+// create_proof(params, pk, &[circuit], &[instances], rng, &mut transcript) after synthesis -> transcript.finalize().
+// Rng: any callable void(Fr *out, size_t n) producing `Fr::random` values in call order.
+template <class Rng>
+inline std::vector<uint8_t> create_proof(Backend &b, const ProvingKey &pk, const std::vector<std::vector<Fr>> &advice,
+                                         const std::vector<std::vector<Fr>> &instances, Rng &rng) {
+    std::vector<const void *> adv, ins;
+    std::vector<size_t> lens;
+    for (auto &c : advice) adv.push_back(c.data());
+    for (auto &c : instances) {
+        ins.push_back(c.data());
+        lens.push_back(c.size());
+    }
+    if (adv.size() != pk.shape().num_advice_total) throw Error(H2HIP_ERR_INVALID, "create_proof: wrong number of advice columns");
+    std::vector<uint8_t> proof(32 * (size_t)(pk.shape().num_commitments + pk.shape().num_evals));
+    size_t len = 0;
+    auto tramp = [](void *user, void *out, size_t n) { (*static_cast<Rng *>(user))(static_cast<Fr *>(out), n); };
+    check(h2hip_plonk_create_proof(b.raw(), pk.raw(), adv.data(), 0, ins.empty() ? nullptr : ins.data(), lens.empty() ? nullptr : lens.data(), +tramp,
+                                   &rng, proof.data(), proof.size(), &len, nullptr));
+    proof.resize(len);
+    return proof;
+}
+
 namespace lookup {
 // permute_expression_pair over the usable rows: (permuted_input, permuted_table); throws where upstream returns
 // Err(ConstraintSystemFailure) (an input value that the table does not contain)

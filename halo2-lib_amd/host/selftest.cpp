@@ -30,10 +30,67 @@ static bool jac_equal(Backend &b, const G1 &p, const G1 &q) {
     return a[0] == a[1];
 }
 
+// A small BaseConfig circuit built on the host (1 advice column with the lookup behind q_lookup, 1 constants column), proven twice:
+// the same RNG stream must give the same bytes, another stream different ones.  With --dump-proof the proof is printed in hex so that
+// tests/test_host_cpp.py can compare it with the oracle prover's bytes for the same (deterministic) circuit and RNG stream.
+static Fr draw_fr(uint64_t &s) {
+    uint64_t c[4] = {sm(s), sm(s), sm(s), sm(s) >> 4};
+    return host_fr::from_canonical(c);
+}
+struct StreamRng {
+    uint64_t state;
+    void operator()(Fr *out, size_t n) {
+        for (size_t i = 0; i < n; ++i) out[i] = draw_fr(state);
+    }
+};
+static std::vector<uint8_t> prove_small_circuit(Backend &be, uint32_t k, uint64_t rng_seed, uint64_t circuit_seed) {
+    const uint32_t lb = k - 2;
+    h2hip_base_circuit_params bp = {k, 1, 1, 1, 0, (int32_t)lb};
+    h2hip_plonk_shape sh;
+    check(h2hip_plonk_shape_of(&bp, &sh));
+    const size_t n = (size_t)1 << k, m = sh.usable_rows / 4;
+    const Fr zero = {{0, 0, 0, 0}}, one = host_fr::R1;
+    std::vector<std::vector<Fr>> fixed(sh.num_fixed_total, std::vector<Fr>(n, zero)), advice(1, std::vector<Fr>(n, zero));
+    for (size_t i = 0; i < ((size_t)1 << lb); ++i) fixed[sh.table_col][i] = host_fr::from_u64(i);
+    uint64_t s = circuit_seed;
+    for (size_t j = 0; j < m; ++j) {
+        Fr a = (j % 3 == 0) ? host_fr::from_u64(sm(s) & (((uint64_t)1 << lb) - 1)) : draw_fr(s);
+        Fr b = draw_fr(s), c = draw_fr(s);
+        if (j == 1) b = advice[0][1];   // gates 0 and 1 share their `b` input (a copy constraint between advice cells)
+        advice[0][4 * j] = a;
+        advice[0][4 * j + 1] = b;
+        advice[0][4 * j + 2] = c;
+        advice[0][4 * j + 3] = host_fr::add(a, host_fr::mul(b, c));
+        fixed[sh.first_q_enable_col][4 * j] = one;
+        if (j % 3 == 0) fixed[sh.q_lookup_col][4 * j] = one;
+    }
+    std::vector<uint32_t> copies = {1, 1, 1, 5};   // permutation columns: 0 = constants, 1 = advice
+    for (uint32_t t = 0; t < 8 && t < m; ++t) {    // constants exposed in the fixed column, tied to the cells that use them
+        fixed[sh.first_constant_col][t] = advice[0][4 * t + 2];
+        copies.insert(copies.end(), {0u, t, 1u, 4 * t + 2});
+    }
+    poly::kzg::ParamsKZG params = poly::kzg::ParamsKZG::setup(be, k, host_fr::from_u64(0x5eed5eed5eedULL), k >= 10);
+    plonk::ProvingKey pk(be, bp, params, fixed, copies);
+    pk.set_transcript_repr(host_fr::from_u64(0x1234567890abcdefULL));   // the Rust side's VerifyingKey::transcript_repr stand-in
+    StreamRng rng{rng_seed};
+    return plonk::create_proof(be, pk, advice, {}, rng);
+}
+
 int main(int argc, char **argv) {
     uint32_t k = argc > 1 ? (uint32_t)atoi(argv[1]) : 10;
     try {
         Backend be(0);
+        if (argc > 2 && std::string(argv[2]) == "--dump-proof") {
+            std::vector<uint8_t> proof = prove_small_circuit(be, k, 7, 99);
+            for (uint8_t c : proof) printf("%02x", c);
+            printf("\n");
+            return 0;
+        }
+        {
+            std::vector<uint8_t> p1 = prove_small_circuit(be, k, 7, 99), p2 = prove_small_circuit(be, k, 7, 99), p3 = prove_small_circuit(be, k, 8, 99);
+            if (p1.empty() || p1 != p2) throw Error(-1, "create_proof is not deterministic for a fixed RNG stream");
+            if (p1 == p3) throw Error(-1, "create_proof ignores the RNG");
+        }
         poly::EvaluationDomain dom(be, 5, k);
         if (dom.extended_k() != k + 2) throw Error(-1, "extended_k");
         uint64_t seed = 42;
