@@ -94,6 +94,8 @@ extern "C" {
     pub fn h2hip_g1_to_lagrange(ctx: *mut h2hip_ctx, g: *const h2hip_bases, k: u32, flags: u32, g_lagrange_out: *mut *mut h2hip_bases) -> c_int;
     pub fn h2hip_params_kzg_setup(ctx: *mut h2hip_ctx, k: u32, s_fr: *const c_void, flags: u32, g_out: *mut *mut h2hip_bases, g_lagrange_out: *mut *mut h2hip_bases) -> c_int;
     pub fn h2hip_g1_fixed_base_mul_batch_dev(ctx: *mut h2hip_ctx, base_affine: *const c_void, scalars_dev: *const c_void, n: usize, out_affine_dev: *mut c_void) -> c_int;
+    pub fn h2hip_g1_validate_dev(ctx: *mut h2hip_ctx, points_dev: *const c_void, n: usize, invalid: *mut usize) -> c_int;
+    pub fn h2hip_g1_decompress_batch_dev(ctx: *mut h2hip_ctx, compressed_dev: *const c_void, n: usize, out_affine_dev: *mut c_void, sign_bit: u32, inf_bit: u32) -> c_int;
     // K2/K3 — arithmetic::best_fft, EvaluationDomain::*
     pub fn h2hip_best_fft(ctx: *mut h2hip_ctx, a_host: *mut c_void, omega: *const c_void, log_n: u32) -> c_int;
     pub fn h2hip_best_fft_dev(ctx: *mut h2hip_ctx, a_dev: *mut c_void, omega: *const c_void, log_n: u32) -> c_int;

@@ -158,6 +158,67 @@ __global__ __launch_bounds__(256) void gl_scale_kernel(const XYZZ29 *__restrict_
 
 using namespace h2;
 
+// ---- SRS files (ParamsKZG::read, reference halo2-base/src/utils/mod.rs:401-435): point validation and decompression ------------------
+struct Exp256 {
+    uint32_t e[8];
+};
+__device__ __forceinline__ bool fq_is_canonical(const Fq &a) {   // limbs < q
+    unsigned br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) subb32(a.l[j], FqP::m(j), br);
+    return br != 0;
+}
+__device__ __forceinline__ bool g1_on_curve_mont(const Fq &x, const Fq &y) {
+    Fq b3 = fe_add(fe_add(Fq::one(), Fq::one()), Fq::one());
+    return fe_sqr(y) == fe_add(fe_mul(fe_sqr(x), x), b3);
+}
+// SerdeFormat::RawBytes points: both coordinates must be canonical Montgomery limbs (< q) and satisfy y^2 = x^3 + 3, or be (0, 0)
+__global__ __launch_bounds__(256) void g1_validate_kernel(const G1Affine *__restrict__ p, size_t n, uint32_t *__restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine a = p[i];
+    bool ok = fq_is_canonical(a.x) && fq_is_canonical(a.y) && (a.is_identity() || g1_on_curve_mont(a.x, a.y));
+    if (!ok) atomicAdd(bad, 1u);
+}
+// SerdeFormat::Processed points: 32 bytes, x little-endian canonical, sign(y) = y mod 2 and the identity flag in the top byte
+__global__ __launch_bounds__(256) void g1_decompress_kernel(const uint32_t *__restrict__ in, size_t n, G1Affine *__restrict__ out, uint32_t sign_bit,
+                                                            uint32_t inf_bit, Exp256 sqrt_exp, uint32_t *__restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fq x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x.l[j] = in[i * 8 + j];
+    const uint32_t top = x.l[7] >> 24;
+    const bool inf = (top >> inf_bit) & 1u, sign = (top >> sign_bit) & 1u;
+    x.l[7] &= ~(((1u << sign_bit) | (1u << inf_bit)) << 24);
+    G1Affine r;
+    r.x = Fq::zero();
+    r.y = Fq::zero();
+    if (inf) {
+        if (!x.is_zero() || sign) atomicAdd(bad, 1u);   // non-canonical identity encoding
+        out[i] = r;
+        return;
+    }
+    if (!fq_is_canonical(x)) {
+        atomicAdd(bad, 1u);
+        out[i] = r;
+        return;
+    }
+    const Fq xm = fe_to_mont(x);
+    const Fq b3 = fe_add(fe_add(Fq::one(), Fq::one()), Fq::one());
+    const Fq y2 = fe_add(fe_mul(fe_sqr(xm), xm), b3);
+    Fq y = fe_pow(y2, sqrt_exp.e);   // q = 3 mod 4: a square root of y2, if one exists, is y2^((q+1)/4)
+    if (!(fe_sqr(y) == y2)) {
+        atomicAdd(bad, 1u);
+        out[i] = r;
+        return;
+    }
+    if ((fe_from_mont(y).l[0] & 1u) != (sign ? 1u : 0u)) y = fe_neg(y);
+    r.x = xm;
+    r.y = y;
+    out[i] = r;
+}
+
 extern "C" {
 
 // out[i] = scalars[i] * base   (device arrays; base is a host G1Affine)
@@ -265,6 +326,59 @@ int h2hip_bases_download(h2hip_ctx *ctx, const h2hip_bases *bases, void *out_hos
     if (!bases->n) return H2HIP_OK;
     H2_HIPCHK(hipMemcpyAsync(out_host, bases->pts, sizeof(G1Affine) * bases->n, hipMemcpyDeviceToHost, ctx->stream));
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    return H2HIP_OK;
+}
+
+// ParamsKZG::read for SerdeFormat::RawBytes: *invalid = number of points that are not canonical on-curve points (or the identity)
+int h2hip_g1_validate_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, size_t *invalid) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && invalid && (n == 0 || points_dev), "NULL argument");
+    *invalid = 0;
+    if (!n) return H2HIP_OK;
+    uint32_t *bad = nullptr, host_bad = 0;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, 1024, (void **)&bad));
+    H2_HIPCHK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+    prof_begin(ctx, "g1_validate_kernel");
+    hipLaunchKernelGGL(g1_validate_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const G1Affine *)points_dev, n, bad);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_HIPCHK(hipMemcpyAsync(&host_bad, bad, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    *invalid = host_bad;
+    return H2HIP_OK;
+}
+// ParamsKZG::read for SerdeFormat::Processed: n compressed points (32 B each) -> affine Montgomery points; H2HIP_ERR_INVALID if any
+// encoding is non-canonical or not on the curve.  sign_bit / inf_bit: flag positions in the top byte (halo2curves: 6 / 7).
+int h2hip_g1_decompress_batch_dev(h2hip_ctx *ctx, const void *compressed_dev, size_t n, void *out_affine_dev, uint32_t sign_bit, uint32_t inf_bit) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && (n == 0 || (compressed_dev && out_affine_dev)), "NULL argument");
+    H2_REQUIRE(sign_bit < 8 && inf_bit < 8 && sign_bit != inf_bit && sign_bit >= 6 && inf_bit >= 6, "flag bits must be the two spare bits (6, 7) of the top byte");
+    if (!n) return H2HIP_OK;
+    Exp256 e;   // (q + 1) / 4
+    {
+        uint64_t carry = 1;
+        uint32_t t[8];
+        for (int j = 0; j < 8; ++j) {
+            uint64_t v = (uint64_t)FqP::m(j) + carry;
+            t[j] = (uint32_t)v;
+            carry = v >> 32;
+        }
+        for (int j = 0; j < 8; ++j) e.e[j] = (t[j] >> 2) | (j < 7 ? t[j + 1] << 30 : 0u);
+    }
+    uint32_t *bad = nullptr, host_bad = 0;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, 1024, (void **)&bad));
+    H2_HIPCHK(hipMemsetAsync(bad, 0, sizeof(uint32_t), ctx->stream));
+    prof_begin(ctx, "g1_decompress_kernel");
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)compressed_dev, n,
+                       (G1Affine *)out_affine_dev, sign_bit, inf_bit, e, bad);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_HIPCHK(hipMemcpyAsync(&host_bad, bad, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (host_bad) {
+        set_error("h2hip_g1_decompress_batch_dev: %u of %zu point encodings are invalid (non-canonical x, not on the curve, or a malformed identity)", host_bad, n);
+        return H2HIP_ERR_INVALID;
+    }
     return H2HIP_OK;
 }
 

@@ -50,6 +50,8 @@ _PROTOS = {
     "h2hip_params_kzg_setup": (_int, [_vp, _u32, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp)]),
     "h2hip_g1_fixed_base_mul_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_bases_download": (_int, [_vp, _vp, _vp]),
+    "h2hip_g1_validate_dev": (_int, [_vp, _vp, _sz, C.POINTER(_sz)]),
+    "h2hip_g1_decompress_batch_dev": (_int, [_vp, _vp, _sz, _vp, _u32, _u32]),
     "h2hip_g1_sum_jacobian_dev": (_int, [_vp, _vp, _sz, _int, _vp]),
     "h2hip_best_fft": (_int, [_vp, _vp, _vp, _u32]),
     "h2hip_best_fft_dev": (_int, [_vp, _vp, _vp, _u32]),

@@ -117,6 +117,13 @@ int h2hip_g1_fixed_base_mul_batch_dev(h2hip_ctx *ctx, const void *base_affine, c
 /* copy the resident affine points back to the host (n x 64 B) — ParamsKZG::write / tests */
 int h2hip_bases_download(h2hip_ctx *ctx, const h2hip_bases *bases, void *out_host);
 
+/* SRS files (ParamsKZG::read / gen_srs, reference halo2-base/src/utils/mod.rs:401-443).  RawBytes files carry 64-byte Montgomery points:
+ * validate counts the entries that are not canonical on-curve points (the identity (0,0) is allowed).  Processed files carry 32-byte
+ * compressed points: decompress fails with H2HIP_ERR_INVALID on any malformed encoding.  sign_bit / inf_bit: positions of the y-sign and
+ * identity flags in the top byte (6 / 7 in halo2curves' encoding). */
+int h2hip_g1_validate_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, size_t *invalid);
+int h2hip_g1_decompress_batch_dev(h2hip_ctx *ctx, const void *compressed_dev, size_t n, void *out_affine_dev, uint32_t sign_bit, uint32_t inf_bit);
+
 /* Sum of n Jacobian points resident on the device (multi-GPU: the all-gathered per-GPU partial MSM results;
  * RCCL has no group-law reduction). */
 int h2hip_g1_sum_jacobian_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, int point_format, void *out_host);

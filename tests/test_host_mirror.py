@@ -171,3 +171,83 @@ def test_g_to_lagrange_gpu(k):
         _g_to_lagrange_check(ctx, k)
     finally:
         ctx.close()
+
+
+def _srs_files(ctx, k, tmp_path):
+    """ParamsKZG files (reference halo2-base/src/utils/mod.rs:401-443): both element encodings, written by the product AND by an independent
+    writer on the oracle side (oracle/transcript.py's compression, big-int Montgomery conversion), round trips, corruption, gen_srs"""
+    import struct
+
+    from oracle import pairing as PR
+    from oracle import transcript as OT
+
+    n = 1 << k
+    s = HP.default_srs_secret()
+    params = HP.ParamsKZG.setup(ctx, k, s, precompute=False)
+    g, gl = ctx.bases_download(params.g), ctx.bases_download(params.g_lagrange)
+    # g[i] = s^i * G by definition (spot checks), s_g2 = s * G2 in the file tail
+    for i in (0, 1, n - 1):
+        assert O.limbs_to_points(g[i:i + 1]) == [O.g1_mul(O.G1_GEN, pow(s, i, R))]
+    raw_g2 = lambda P: b"".join(((c << 256) % O.Q_MOD).to_bytes(32, "little") for c in (P[0][0], P[0][1], P[1][0], P[1][1]))
+    assert params.g2_raw == raw_g2(PR.G2_GEN) + raw_g2(PR.g2_mul(PR.G2_GEN, s))
+    # files from an independent writer
+    pts = O.limbs_to_points(np.concatenate([g, gl]))
+    mont = lambda v: ((v << 256) % O.Q_MOD).to_bytes(32, "little")
+    oracle_raw = struct.pack("<I", k) + b"".join(bytes(64) if P is None else mont(P[0]) + mont(P[1]) for P in pts) + params.g2_raw
+    oracle_proc = struct.pack("<I", k) + b"".join(OT.g1_compress(P) for P in pts) + params.g2_raw
+    for fmt, want in (("raw", oracle_raw), ("processed", oracle_proc)):
+        path = os.path.join(tmp_path, "p_%s.srs" % fmt)
+        params.write(path, fmt)
+        assert open(path, "rb").read() == want, fmt                       # the product writes what the independent writer writes
+        for pre in (False, True):
+            again = HP.ParamsKZG.read(ctx, path, precompute=pre)
+            assert again.k == k and again.g2_raw == params.g2_raw
+            assert np.array_equal(ctx.bases_download(again.g), g) and np.array_equal(ctx.bases_download(again.g_lagrange), gl)
+            v = rand_fr(n, 3)
+            assert np.array_equal(again.commit_lagrange(v, H.POINT_AFFINE), params.commit_lagrange(v, H.POINT_AFFINE))
+            again.free()
+        # corruption: one flipped bit in a point -> rejected, not silently wrong commitments
+        bad = bytearray(want)
+        bad[4 + 64 * 3 + 5 if fmt == "raw" else 4 + 32 * 3 + 5] ^= 0x10
+        open(path, "wb").write(bytes(bad))
+        with pytest.raises(ValueError):
+            HP.ParamsKZG.read(ctx, path, precompute=False)
+        open(path, "wb").write(want[: len(want) // 3])
+        with pytest.raises(ValueError):
+            HP.ParamsKZG.read(ctx, path, precompute=False)
+    # a non-canonical coordinate (x + q) in a raw file
+    bad = bytearray(oracle_raw)
+    x = int.from_bytes(bad[4 + 64:4 + 96], "little") + O.Q_MOD
+    if x < 1 << 256:
+        bad[4 + 64:4 + 96] = x.to_bytes(32, "little")
+        path = os.path.join(tmp_path, "noncanonical.srs")
+        open(path, "wb").write(bytes(bad))
+        with pytest.raises(ValueError):
+            HP.ParamsKZG.read(ctx, path, precompute=False)
+    # gen_srs: PARAMS_DIR convention, setup with the reference's fixed seed on first use, read afterwards
+    d = os.path.join(tmp_path, "params")
+    first = HP.gen_srs(ctx, k, params_dir=d, precompute=False)
+    assert os.path.exists(os.path.join(d, "kzg_bn254_%d.srs" % k)) and np.array_equal(ctx.bases_download(first.g), g)
+    second = HP.gen_srs(ctx, k, params_dir=d, precompute=False)
+    assert np.array_equal(ctx.bases_download(second.g_lagrange), gl)
+    for p_ in (first, second, params):
+        p_.free()
+
+
+def test_srs_files_emulated(tmp_path):
+    from tests.emu_util import emu_context
+
+    ctx = emu_context()
+    try:
+        _srs_files(ctx, 5, str(tmp_path))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_srs_files_gpu(tmp_path):
+    ctx = H.Context()
+    try:
+        _srs_files(ctx, 10, str(tmp_path))
+    finally:
+        ctx.close()
