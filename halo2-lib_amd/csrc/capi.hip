@@ -227,6 +227,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_seg")) return &ctx->msm_seg;
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
     if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
+    if (!strcmp(name, "msm_table_nontemporal")) return &ctx->msm_table_nontemporal;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
@@ -499,6 +500,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *
         c->msm_chunk = ctx->msm_chunk;
         c->msm_seg = ctx->msm_seg;
         c->msm_accum_variant = ctx->msm_accum_variant;
+        c->msm_table_nontemporal = ctx->msm_table_nontemporal;
         c->msm_scatter_split = ctx->msm_scatter_split;
         c->msm_sort_threads = ctx->msm_sort_threads;
         c->msm_quad_tails = ctx->msm_quad_tails;

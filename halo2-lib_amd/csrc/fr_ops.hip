@@ -492,6 +492,36 @@ __global__ __launch_bounds__(256) void quotient_permutation_kernel(Fr *__restric
     }
 }
 
+// HBM-counter calibration probes (profiles/r02_*_pmc_*.md): a random gather of aligned ENTRY-byte table entries — the access pattern
+// of msm_accum_kernel's base-table reads (one aligned 64-byte entry per mixed addition out of a table far larger than the 256 MiB
+// Infinity Cache) — with an exactly known useful byte count, and a coalesced stream of the same volume.
+template <int ENTRY>
+__global__ __launch_bounds__(256) void gather_probe_kernel(const uint4 *__restrict__ table, uint64_t entries, uint32_t per_lane, uint4 *__restrict__ out) {
+    const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t state = lane * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    uint4 acc = {0u, 0u, 0u, 0u};
+    for (uint32_t k = 0; k < per_lane; ++k) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        const uint64_t idx = (state >> 20) % entries;
+        const uint4 *e = table + idx * (ENTRY / 16);
+#pragma unroll
+        for (int q = 0; q < ENTRY / 16; ++q) {
+            uint4 v = e[q];
+            acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        }
+    }
+    out[lane] = acc;
+}
+__global__ __launch_bounds__(256) void stream_probe_kernel(const uint4 *__restrict__ table, uint64_t vec16, uint4 *__restrict__ out) {
+    const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    uint4 acc = {0u, 0u, 0u, 0u};
+    for (uint64_t i = lane; i < vec16; i += stride) {
+        uint4 v = table[i];
+        acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+    }
+    out[lane] = acc;
+}
+
 static uint32_t grid_for(h2hip_ctx *ctx, size_t n) {
     size_t blocks = (n + 255) / 256, cap = (size_t)ctx->num_cus * 8;
     if (blocks > cap) blocks = cap;
@@ -933,6 +963,36 @@ int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t
     }
     *modmuls = (double)lanes * iters * chains;
     return H2HIP_OK;
+}
+
+// kind 0: coalesced stream of table_bytes; kind 64 / 128: lanes * per_lane random gathers of aligned 64- / 128-byte entries from a
+// table of table_bytes.  *useful_bytes = the bytes the lanes asked for.
+int h2hip_bench_gather(h2hip_ctx *ctx, uint32_t kind, size_t table_bytes, uint32_t lanes, uint32_t per_lane, double *elapsed_ms, double *useful_bytes) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && elapsed_ms && useful_bytes && table_bytes >= 4096 && lanes >= 256 && per_lane >= 1, "bad argument");
+    H2_REQUIRE(kind == 0 || kind == 64 || kind == 128, "kind must be 0 (stream), 64 or 128");
+    void *table = nullptr, *out = nullptr;
+    H2_HIPCHK(hipMalloc(&table, table_bytes));
+    if (hipMalloc(&out, sizeof(uint4) * (size_t)lanes) != hipSuccess) {
+        hipFree(table);
+        set_error("hipMalloc failed");
+        return H2HIP_ERR_NOMEM;
+    }
+    hipMemsetAsync(table, 0x5a, table_bytes, ctx->stream);
+    const uint32_t blocks = lanes / 256;
+    int rc = H2HIP_OK;
+    for (int rep = 0; rep < 2 && rc == H2HIP_OK; ++rep) {   // rep 0 = warm-up
+        rc = h2hip_timer_start(ctx);
+        if (kind == 0) hipLaunchKernelGGL(stream_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4 *)table, (uint64_t)(table_bytes / 16), (uint4 *)out);
+        if (kind == 64) hipLaunchKernelGGL(gather_probe_kernel<64>, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4 *)table, (uint64_t)(table_bytes / 64), per_lane, (uint4 *)out);
+        if (kind == 128) hipLaunchKernelGGL(gather_probe_kernel<128>, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4 *)table, (uint64_t)(table_bytes / 128), per_lane, (uint4 *)out);
+        if (rc == H2HIP_OK) rc = h2hip_timer_stop(ctx, elapsed_ms);
+    }
+    hipStreamSynchronize(ctx->stream);
+    hipFree(table);
+    hipFree(out);
+    *useful_bytes = kind == 0 ? (double)table_bytes : (double)blocks * 256.0 * per_lane * kind;
+    return rc;
 }
 
 }  // extern "C"

@@ -83,6 +83,7 @@ struct h2hip_ctx {
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
     int msm_scatter_split = 0;   // bucket sub-ranges per window in the scatter (0 = auto, power of two)
+    int msm_table_nontemporal = 1;   // accumulation: gather the base-table entries with non-temporal loads (no reuse; keeps the reused lines in L2)
     int msm_accum_variant = 3;   // accumulate kernel build: 3 / 4 = min waves per SIMD it is compiled for, 2 = registers padded to two waves per SIMD
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]
     // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled

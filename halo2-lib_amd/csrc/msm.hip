@@ -239,6 +239,30 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offset
     return lo;
 }
 
+// One aligned 64-byte table entry.  The gather has no reuse (a 1 GiB table, one entry per addition): loaded NON-TEMPORALLY it streams past
+// the L2 instead of evicting the lines the kernel does reuse — each lane's slice of the sorted entry list (32 entries per 128-byte line,
+// touched over ~32 additions) and the bucket offsets.  rocprofv3 PMC (profiles/r02_hbm_counter_calibration.md): with plain loads the
+// kernel issued 2.0 memory-side line requests per addition, one of them a re-fetch of such an evicted line.
+template <bool NT>
+__device__ __forceinline__ G1Affine load_table_entry(const G1Affine *__restrict__ p) {
+#ifdef H2_HIPEMU
+    return *p;
+#else
+    if (!NT) return *p;
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u *q = reinterpret_cast<const v4u *>(p);
+    v4u a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1), c = __builtin_nontemporal_load(q + 2),
+        d = __builtin_nontemporal_load(q + 3);
+    G1Affine r;
+    r.x.l[0] = a.x; r.x.l[1] = a.y; r.x.l[2] = a.z; r.x.l[3] = a.w;
+    r.x.l[4] = b.x; r.x.l[5] = b.y; r.x.l[6] = b.z; r.x.l[7] = b.w;
+    r.y.l[0] = c.x; r.y.l[1] = c.y; r.y.l[2] = c.z; r.y.l[3] = c.w;
+    r.y.l[4] = d.x; r.y.l[5] = d.y; r.y.l[6] = d.z; r.y.l[7] = d.w;
+    return r;
+#endif
+}
+
+template <bool NT>
 __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
                                                const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K, XYZZ29 *__restrict__ buckets,
                                                uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
@@ -257,6 +281,7 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
     uint32_t hk = KEY_INVALID;
     bool first = true;
     XYZZ29 acc = XYZZ29::identity();
+    uint4 sv4 = {0u, 0u, 0u, 0u};
     for (uint32_t e = start; e < end; ++e) {
         if (e >= next) {   // bucket boundary: close the run
             if (first) {
@@ -270,8 +295,15 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
             cur = (offsets[cur + 2] > e) ? cur + 1 : find_key(offsets, cur + 1, nkeys, e);
             next = offsets[cur + 1];
         }
-        uint32_t v = sval[e];
-        G1Affine p = bases[v & 0x7fffffffu];   // packed R'-domain point, one aligned 64-byte gather
+        uint32_t v;
+        if (NT) {   // the lane's entries 16 bytes at a time: a quarter of the loads (and of the chances to find the line evicted)
+            if ((e & 3u) == 0 || e == start) sv4 = reinterpret_cast<const uint4 *>(sval)[e >> 2];
+            const uint32_t sel = e & 3u;
+            v = sel == 0 ? sv4.x : sel == 1 ? sv4.y : sel == 2 ? sv4.z : sv4.w;
+        } else {
+            v = sval[e];
+        }
+        G1Affine p = load_table_entry<NT>(bases + (v & 0x7fffffffu));   // packed R'-domain point, one aligned 64-byte gather
         if (!p.is_identity()) xyzz29_add_affine(acc, f29_split<Q29P>(p.x), f29_split<Q29P>(p.y), (v >> 31) != 0);
     }
     // the list handed to msm_merge is sorted and hole-free: a single-run chunk emits (key, sum), (key, identity)
@@ -286,12 +318,12 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
     out_keys[2 * (size_t)t + 1] = cur;
 }
 
-template <int MINW>
+template <int MINW, bool NT>
 __global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
                                                         const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
                                                         XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
                                                         XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
-    msm_accum_body(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
+    msm_accum_body<NT>(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
 }
 // Same body with the register allocation padded to 176 per lane: two waves per SIMD instead of three, which leaves a
 // third of every SIMD's register file free at all times for the tail / sort kernels of the neighbouring pipelined MSMs
@@ -303,7 +335,7 @@ __global__ __launch_bounds__(256) void msm_accum_w2_kernel(const uint32_t *__res
 #ifndef H2_HIPEMU
     asm volatile("" ::: "v119");
 #endif
-    msm_accum_body(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
+    msm_accum_body<false>(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
 }
 
 // ------------------------------------------------------------------ 6. segmented merge of the partial list
@@ -812,7 +844,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * (nkeys + 1), (void **)&counts));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * (nkeys + 2), (void **)&offsets));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SVAL, sizeof(uint32_t) * emax, (void **)&sval));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SVAL, sizeof(uint32_t) * (emax + 4), (void **)&sval));   // + 4: the accumulation reads aligned 16-byte groups
     if (ext_buckets) buckets = ext_buckets;
     else H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(XYZZ29) * nkeys, (void **)&buckets));
     const uint32_t T1 = (uint32_t)((emax + K1 - 1) / K1);
@@ -866,10 +898,13 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         hipLaunchKernelGGL(msm_accum_w2_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
                            (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     else if (ctx->msm_accum_variant == 4)
-        hipLaunchKernelGGL(msm_accum_kernel<4>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+        hipLaunchKernelGGL((msm_accum_kernel<4, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+                           (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+    else if (ctx->msm_table_nontemporal)
+        hipLaunchKernelGGL((msm_accum_kernel<3, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
                            (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     else
-        hipLaunchKernelGGL(msm_accum_kernel<3>, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+        hipLaunchKernelGGL((msm_accum_kernel<3, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
                            (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());

@@ -95,6 +95,7 @@ _PROTOS = {
     "h2hip_lookup_permute_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
     "h2hip_poseidon_permute_batch_dev": (_int, [_vp, _vp, _vp, _u32, _sz]),
+    "h2hip_bench_gather": (_int, [_vp, _u32, _sz, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "h2hip_bench_modmul29": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "h2hip_bench_modmul": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -393,6 +394,12 @@ class Context:
         fn = self.lib.h2hip_bench_modmul29 if unsaturated else self.lib.h2hip_bench_modmul
         self._chk(fn(self.handle, blocks, iters, chains, C.byref(ms), C.byref(mm)))
         return ms.value, mm.value
+
+    def bench_gather(self, kind: int, table_bytes: int, lanes: int, per_lane: int):
+        """(elapsed_ms, useful_bytes) of the HBM calibration probe: kind 0 = stream, 64 / 128 = random gathers of aligned entries"""
+        ms, nb = C.c_double(), C.c_double()
+        self._chk(self.lib.h2hip_bench_gather(self.handle, kind, table_bytes, lanes, per_lane, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
 
     # -- K4/K5/K7 (host-array conveniences over the _dev entry points)
     def fr_axpy(self, y: np.ndarray, a: np.ndarray, x: np.ndarray) -> np.ndarray:

@@ -315,6 +315,9 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
 
 /* ---- diagnostics: 254-bit Montgomery multiplier throughput (the integer roofline bench.py quotes) ------ */
 int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);
+/* HBM-counter calibration probes: kind 0 = coalesced stream of table_bytes, kind 64 / 128 = lanes * per_lane random gathers of aligned
+ * 64- / 128-byte entries from a table of table_bytes (the base-table access pattern of the MSM's accumulation) */
+int h2hip_bench_gather(h2hip_ctx *ctx, uint32_t kind, size_t table_bytes, uint32_t lanes, uint32_t per_lane, double *elapsed_ms, double *useful_bytes);
 /* the same probe on the unsaturated 9 x 29-bit representation the MSM / NTT kernels multiply in (chains: 1 or 2) */
 int h2hip_bench_modmul29(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);
 

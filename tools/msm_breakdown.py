@@ -2,14 +2,16 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import halo2_lib_amd as H
-from bench import synthetic_bases, synthetic_scalars
+from bench import synthetic_scalars
+from halo2_lib_amd import halo2_proofs as HP
 
 NAMES = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 ctx = H.Context(0)
 for log_n in [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["19", "20"])]:
     n = 1 << log_n
     s = synthetic_scalars(n, 2); ds = ctx.to_device(s)
-    b = ctx.bases_upload(synthetic_bases(n, 1), 1)
+    params = HP.ParamsKZG.setup(ctx, log_n, 0x1234567, precompute=True)
+    b = params.g
     ctx.msm_dev(b, ds, n)
     ctx.profile_enable(True); ctx.profile_reset(); ctx.timer_start()
     reps = 8
@@ -24,4 +26,4 @@ for log_n in [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else 
             tot += t / reps
     print(f"   {'sum of kernels':28s} {tot:7.3f} ms")
     ctx.profile_enable(False)
-    b.free(); ctx.free(ds)
+    params.free(); ctx.free(ds)
