@@ -158,6 +158,10 @@ extern "C" {
     pub fn h2hip_plonk_create_proof(ctx: *mut h2hip_ctx, pk: *mut h2hip_plonk_pk, advice: *const *const c_void, advice_on_device: c_int,
                                     instances_host: *const *const c_void, instance_lens: *const usize, rng: h2hip_rng_fill_fn, rng_user: *mut c_void,
                                     proof_out: *mut u8, proof_cap: usize, proof_len: *mut usize, stage_ms: *mut f64) -> c_int;
+    pub fn h2hip_lookup_sorted_table_bytes(usable_rows: usize) -> usize;
+    pub fn h2hip_lookup_table_sort_dev(ctx: *mut h2hip_ctx, s_dev: *const c_void, usable_rows: usize, sorted_out_dev: *mut c_void) -> c_int;
+    pub fn h2hip_lookup_permute_presorted_dev(ctx: *mut h2hip_ctx, a_dev: *const c_void, sorted_table_dev: *const c_void, usable_rows: usize,
+                                              a_perm_dev: *mut c_void, s_perm_dev: *mut c_void) -> c_int;
     // timing / diagnostics
     pub fn h2hip_profile_enable(ctx: *mut h2hip_ctx, on: c_int) -> c_int;
     pub fn h2hip_profile_reset(ctx: *mut h2hip_ctx) -> c_int;

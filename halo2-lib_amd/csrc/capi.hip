@@ -255,7 +255,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->lookup_big_tile_bits) H2_REQUIRE(value >= 12 && value <= 28, "lookup_big_tile_bits must be 12..28");
     if (p == &ctx->msm_sort_threads) H2_REQUIRE(value == 256 || value == 512 || value == 1024, "msm_sort_threads must be 256, 512 or 1024");
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
-    if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 1 && value <= 4, "msm_lanes must be 1..4");
+    if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 0 && value <= 4, "msm_lanes must be 0 (auto) or 1..4");
     if (p == &ctx->msm_accum_variant) H2_REQUIRE(value >= 2 && value <= 4, "msm_accum_variant must be 2, 3 or 4");
     if (p == &ctx->ntt_min_col_bits) H2_REQUIRE(value >= 0 && value <= 5, "ntt_min_col_bits must be 0..5");
     if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
@@ -487,7 +487,12 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *
     for (size_t j = 0; j < count; ++j) H2_REQUIRE(n == 0 || scalars_in[j], "NULL scalar column");   // everything checked before the first launch
     const bool affine = point_format == H2HIP_POINT_AFFINE;
     const size_t psz = affine ? sizeof(G1Affine) : sizeof(G1Jac);
-    const int NL = ctx->msm_lanes < 1 ? 1 : ctx->msm_lanes > 4 ? 4 : ctx->msm_lanes;
+    // lanes: the kernels of one MSM are issue-bound or latency-bound, so lanes that overlap whole MSMs mostly contend (measured,
+    // tools/batch_ab.py, batches of 4 with the deferred reduction: 2^20 1.71 / 1.75 / 1.80 / 1.84 ms per MSM on 1 / 2 / 3 / 4 lanes, 2^19
+    // 0.99 / 0.95 / 0.98 / 1.00) — auto picks 1 lane from 2^20 points, 2 below, 3 for the fused small sizes
+    int NL = ctx->msm_lanes;
+    if (NL <= 0) NL = n >= ((size_t)1 << 20) ? 1 : n > ((size_t)1 << 17) ? 2 : 3;
+    if (NL > 4) NL = 4;
     for (int l = 0; l < NL; ++l) {
         if (!ctx->lane[l]) {
             h2hip_ctx *c = nullptr;

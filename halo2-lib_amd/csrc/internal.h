@@ -69,7 +69,7 @@ struct h2hip_ctx {
     int num_cus = 256;
     // scratch
     enum { WS_NTT = 0, WS_DIGITS, WS_COUNTS, WS_OFFSETS, WS_CURSOR, WS_SKEY, WS_SVAL, WS_BUCKETS, WS_PKEY0, WS_PVAL0, WS_PKEY1,
-           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_POSEIDON, WS_FBTABLE, WS_BATCH, WS_LK0, WS_LK1, WS_LK2, WS_LK3, WS_LK4, WS_VANISH, WS_BATCH_BUCKETS, WS_COUNT };
+           WS_PVAL1, WS_SEG, WS_WIN, WS_OUT, WS_SCAN, WS_TMP0, WS_TMP1, WS_TMP2, WS_STAGE, WS_POSEIDON, WS_FBTABLE, WS_BATCH, WS_LK0, WS_LK1, WS_LK2, WS_LK3, WS_LK4, WS_LK5, WS_VANISH, WS_BATCH_BUCKETS, WS_COUNT };
     h2::DevBuf ws[WS_COUNT];
     std::vector<h2::TwiddleSet> twiddles;
     // tuning knobs (h2hip_set_param)
@@ -96,7 +96,7 @@ struct h2hip_ctx {
     // batch lanes (h2hip_msm_g1_batch_dev): child contexts with their own stream + scratch
     h2hip_ctx *lane[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int msm_lanes = 3;   // lanes used by h2hip_msm_g1_batch_dev (1..4)
+    int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
     int fr_invert_run = 0;           // elements per lane (= per inversion) in h2hip_fr_batch_invert_dev; 0 = auto (n / 2^16 in 4..32)
     int lookup_big_tile_bits = 19;   // lookup sort: 4096-key LDS tiles from 2^bits padded keys (12..28), 1024-key tiles below
     int msm_quad_seg_max = 32768;   // bucket reduction: quad-lane kernels up to this many segments (latency-bound), one-lane kernels above

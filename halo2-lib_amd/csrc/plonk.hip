@@ -223,6 +223,7 @@ struct h2hip_plonk_pk {
     const h2hip_bases *g = nullptr, *g_lagrange = nullptr;
     std::vector<Fr *> fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets;
     Fr *l0 = nullptr, *l_last = nullptr, *l_blind = nullptr;   // extended-domain evaluations
+    void *table_sorted = nullptr;                               // sorted keys of the lookup table column (prepared once: the table is fixed)
     std::vector<G1Affine> fixed_commitments, permutation_commitments;
     Fr transcript_repr;
     bool have_repr = false;
@@ -396,6 +397,17 @@ static int keygen_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *const *fi
         pk->sigma_values.push_back(v);
         pk->sigma_polys.push_back(p);
         pk->sigma_cosets.push_back(e);
+    }
+    if (!sh.lookups.empty()) {   // every lookup of a BaseConfig circuit uses the one range table
+        void *ts = nullptr;
+        hipError_t e = hipMalloc(&ts, h2hip_lookup_sorted_table_bytes(sh.usable_rows));
+        if (e != hipSuccess) {
+            set_error("hipMalloc for the sorted lookup table failed: %s", hipGetErrorString(e));
+            return H2HIP_ERR_NOMEM;
+        }
+        pk->owned.push_back(ts);
+        pk->table_sorted = ts;
+        H2_CHK(h2hip_lookup_table_sort_dev(ctx, pk->fixed_values[sh.table_col], sh.usable_rows, ts));
     }
     // ---- commitments of the verifying key
     std::vector<const void *> cols;
@@ -672,7 +684,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             }
             H2_CHK(sc.take(n, &s.ap));
             H2_CHK(sc.take(n, &s.sp));
-            H2_CHK(h2hip_lookup_permute_dev(ctx, s.inp, pk->fixed_values[l.table_col], u, s.ap, s.sp));
+            H2_CHK(h2hip_lookup_permute_presorted_dev(ctx, s.inp, pk->table_sorted, u, s.ap, s.sp));
             const Fr *t1 = draw(bf + 1);
             H2_CHK(put(s.ap + u, t1, bf + 1));
             H2_HIPCHK(hipStreamSynchronize(st));

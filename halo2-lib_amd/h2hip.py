@@ -93,6 +93,9 @@ _PROTOS = {
                                         C.POINTER(C.c_double)]),
     "h2hip_divide_by_vanishing_poly_dev": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "h2hip_lookup_permute_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "h2hip_lookup_sorted_table_bytes": (_sz, [_sz]),
+    "h2hip_lookup_table_sort_dev": (_int, [_vp, _vp, _sz, _vp]),
+    "h2hip_lookup_permute_presorted_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
     "h2hip_poseidon_permute_batch_dev": (_int, [_vp, _vp, _vp, _u32, _sz]),
     "h2hip_bench_gather": (_int, [_vp, _u32, _sz, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -620,16 +623,23 @@ class Context:
             for p in [d_acc, d_z] + ([d_zp] if d_zp else []) + d_cols + d_sig + d_l:
                 self.free(p)
 
-    def lookup_permute(self, a: np.ndarray, s: np.ndarray, usable_rows: int):
-        """(a_perm, s_perm) over rows [0, usable_rows)"""
+    def lookup_permute(self, a: np.ndarray, s: np.ndarray, usable_rows: int, presort_table: bool = False):
+        """(a_perm, s_perm) over rows [0, usable_rows); presort_table: go through h2hip_lookup_table_sort_dev + _permute_presorted_dev (what a
+        prover with a cached, sorted table column does)"""
         a, s = _fe(a), _fe(s)
         if not (len(a) == len(s) and 0 <= usable_rows <= len(a)):
             raise ValueError("lookup_permute: need len(a) == len(s) >= usable_rows")
         da, ds = self.to_device(a), self.to_device(s)
         dap, dsp = self.malloc(max(a.nbytes, 32)), self.malloc(max(a.nbytes, 32))
+        dsorted = None
         try:
-            self._chk(self.lib.h2hip_lookup_permute_dev(self.handle, _vp(da), _vp(ds), usable_rows, _vp(dap), _vp(dsp)))
+            if presort_table and usable_rows:
+                dsorted = self.malloc(self.lib.h2hip_lookup_sorted_table_bytes(usable_rows))
+                self._chk(self.lib.h2hip_lookup_table_sort_dev(self.handle, _vp(ds), usable_rows, _vp(dsorted)))
+                self._chk(self.lib.h2hip_lookup_permute_presorted_dev(self.handle, _vp(da), _vp(dsorted), usable_rows, _vp(dap), _vp(dsp)))
+            else:
+                self._chk(self.lib.h2hip_lookup_permute_dev(self.handle, _vp(da), _vp(ds), usable_rows, _vp(dap), _vp(dsp)))
             return self.download(dap, a.shape)[:usable_rows], self.download(dsp, a.shape)[:usable_rows]
         finally:
-            for d in (da, ds, dap, dsp):
+            for d in (da, ds, dap, dsp) + ((dsorted,) if dsorted else ()):
                 self.free(d)

@@ -94,7 +94,7 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
 
 /* `count` independent MSMs over the same bases (all advice columns of a phase, the pieces of h(X), ...).
  * scalars_dev: host array of `count` device pointers, n scalars each; out_host: `count` points.  The MSMs are
- * pipelined over the context's lanes ("msm_lanes" internal streams, default 3) so that one MSM's sort and latency-bound tail
+ * pipelined over the context's lanes ("msm_lanes" internal streams; default: chosen by size) so that one MSM's sort and latency-bound tail
  * overlap another one's accumulation. */
 int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count,
                            int point_format, void *out_host);
@@ -237,6 +237,13 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc_dev, const void
  * run starts, the other rows take the unconsumed table elements (ascending) from the last repeated row backwards.
  * Rows >= usable_rows are left untouched (blinding).  H2HIP_ERR_INVALID if an input value is missing from the table. */
 int h2hip_lookup_permute_dev(h2hip_ctx *ctx, const void *a_dev, const void *s_dev, size_t usable_rows, void *a_perm_dev, void *s_perm_dev);
+
+/* The table of a lookup is a FIXED column: its sorted keys can be prepared once (keygen) and reused by every proof.
+ * sorted_out_dev: h2hip_lookup_sorted_table_bytes(usable_rows) bytes of device memory. */
+size_t h2hip_lookup_sorted_table_bytes(size_t usable_rows);
+int h2hip_lookup_table_sort_dev(h2hip_ctx *ctx, const void *s_dev, size_t usable_rows, void *sorted_out_dev);
+int h2hip_lookup_permute_presorted_dev(h2hip_ctx *ctx, const void *a_dev, const void *sorted_table_dev, size_t usable_rows, void *a_perm_dev,
+                                       void *s_perm_dev);
 
 /* ---- K8: Poseidon permutation batches (halo2-base PoseidonState::permutation, reference
  *      halo2-base/src/poseidon/hasher/state.rs:35-83,124-160).  The caller supplies the spec its

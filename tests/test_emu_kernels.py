@@ -312,7 +312,9 @@ def test_msm_quad_and_serial_tails_agree(ctx):
         b.free()
 
 
-def _lookup_permute_checks(ctx, sizes):
+def _lookup_permute_checks(ctx, sizes, big=True, presort=False):
+    """big: a few full-size field elements among the keys (forces the bitonic network); without them every key is small and the counting
+    sort runs.  presort: the table's keys are sorted once up front (h2hip_lookup_table_sort_dev), as the prover does at keygen."""
     rng = np.random.default_rng(5)
     for u, tbits in sizes:
         table = list(range(1 << tbits)) + [0] * max(0, u - (1 << tbits))   # range table padded with zeros, like halo2-base's
@@ -321,15 +323,15 @@ def _lookup_permute_checks(ctx, sizes):
             table += [0] * (u - len(table))
         vals = [int(x) for x in rng.integers(0, 1 << tbits, size=u)]
         vals[: u // 4] = [0] * (u // 4)            # many repeats of one value
-        if u >= 8:
-            big = O.random_scalars(3, 9)
-            vals[-3:], table[-3:] = big, big[::-1]  # a few full-size field elements
+        if u >= 8 and big:
+            bigv = O.random_scalars(3, 9)
+            vals[-3:], table[-3:] = bigv, bigv[::-1]  # a few full-size field elements
         tset = set(table)
         vals = [v if v in tset else 0 for v in vals]   # every input must occur in the (truncated / overwritten) table
         want_a, want_s = O.permute_expression_pair(vals, table)
         a = np.concatenate([fr(vals), rand_fr(7, 1)])   # rows beyond `usable` must be ignored
         s = np.concatenate([fr(table), rand_fr(7, 2)])
-        got_a, got_s = ctx.lookup_permute(a, s, u)
+        got_a, got_s = ctx.lookup_permute(a, s, u, presort_table=presort)
         assert O.limbs_to_ints(got_a, R) == want_a
         assert O.limbs_to_ints(got_s, R) == want_s
     with pytest.raises(H.H2HipError):
@@ -338,6 +340,9 @@ def _lookup_permute_checks(ctx, sizes):
 
 def test_lookup_permute_expression_pair(ctx):
     _lookup_permute_checks(ctx, [(1, 1), (5, 2), (300, 5), (1024, 8), (3001, 9)])
+    _lookup_permute_checks(ctx, [(1, 1), (300, 5), (1024, 8), (3001, 9), (3001, 11)], big=False)                 # counting sort (small keys)
+    _lookup_permute_checks(ctx, [(5, 2), (3001, 9)], big=False, presort=True)
+    _lookup_permute_checks(ctx, [(3001, 9)], big=True, presort=True)
     ctx.set_param("lookup_big_tile_bits", 12)      # the 4096-key LDS tile (default: from 2^19 keys) on 4096 / 8192 padded keys
     try:
         _lookup_permute_checks(ctx, [(4000, 9), (5000, 10)])

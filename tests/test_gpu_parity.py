@@ -259,6 +259,9 @@ def test_lookup_permute_expression_pair(ctx):
     from tests.test_emu_kernels import _lookup_permute_checks
 
     _lookup_permute_checks(ctx, [(5, 2), (3001, 9), ((1 << 17) - 20, 15), ((1 << 19) - 6, 18)])   # the last one sorts with 4096-key tiles
+    _lookup_permute_checks(ctx, [(3001, 9), ((1 << 17) - 20, 15), ((1 << 19) - 7, 18)], big=False)                  # counting sort
+    _lookup_permute_checks(ctx, [((1 << 19) - 7, 18)], big=False, presort=True)
+    _lookup_permute_checks(ctx, [((1 << 16) - 7, 12)], big=True, presort=True)
 
 
 def test_gpu_matches_committed_golden_fixtures(ctx):
