@@ -119,11 +119,40 @@ def library_path() -> str:
 _LIBS = {}
 
 
+_TORCH_HIP_PRELOADED = False
+
+
+def _initialise_torch_hip_runtime_first():
+    """PyTorch's ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (unversioned SONAMEs), libh2hip.so links the system
+    ROCm's (libamdhip64.so.7): a process that uses both holds two HSA runtimes, and the one that initialises SECOND must not be torch's
+    (measured on the GPU box: libh2hip first, then torch.cuda -> "No HIP GPUs are available"; the other order works).  So when a torch
+    installation is present, its HIP runtime is loaded and initialised here, before libh2hip.so is opened — without importing torch."""
+    global _TORCH_HIP_PRELOADED
+    if _TORCH_HIP_PRELOADED:
+        return
+    _TORCH_HIP_PRELOADED = True
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if not spec or not spec.origin:
+            return
+        lib = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if not os.path.exists(lib):
+            return
+        n = C.c_int(0)
+        C.CDLL(lib, mode=C.RTLD_GLOBAL).hipGetDeviceCount(C.byref(n))
+    except Exception:   # no torch, or a CPU-only box: nothing to order
+        pass
+
+
 def load_library(path: Optional[str] = None):
     """dlopen libh2hip.so and attach prototypes.  Fails loudly when the HIP extension has not been built."""
     path = os.path.abspath(path or library_path())
     if path in _LIBS:
         return _LIBS[path]
+    if os.path.basename(path) == "libh2hip.so":
+        _initialise_torch_hip_runtime_first()
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'); "
