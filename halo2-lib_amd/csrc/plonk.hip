@@ -235,6 +235,8 @@ struct h2hip_plonk_pk {
     uint32_t shard_world = 1;
     h2hip_allgather_fn allgather = nullptr;
     void *allgather_user = nullptr;
+    hipStream_t copy_stream = nullptr;   // the RNG-drawn random polynomial is uploaded on its own stream, next to the NTTs
+    hipEvent_t copy_ev = nullptr;
     Fr *host_stage = nullptr;   // pinned staging for the RNG-drawn scalars (the n coefficients of the random polynomial, the blinding rows)
     size_t host_stage_elems = 0;
 };
@@ -568,6 +570,10 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     Laps laps(ctx, stage_ms);
     Transcript tr;
     // the RNG writes straight into pinned host memory, from where the DMA engine takes it (n scalars for the random polynomial)
+    if (!pk->copy_stream) {
+        H2_HIPCHK(hipStreamCreateWithFlags(&pk->copy_stream, hipStreamNonBlocking));
+        H2_HIPCHK(hipEventCreateWithFlags(&pk->copy_ev, hipEventDisableTiming));
+    }
     if (pk->host_stage_elems < n) {
         if (pk->host_stage) hipHostFree(pk->host_stage);
         pk->host_stage = nullptr;
@@ -749,20 +755,10 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         if (!cols.empty()) H2_CHK(commit_batch(pk->g_lagrange, cols, n));
         laps.lap(ST_COMMIT_PRODUCTS);
     }
-    // ---- vanishing argument: the random polynomial
-    Fr *random_poly = nullptr;
+    // ---- everything of h(X)'s inputs that does not depend on y is queued BEFORE the random polynomial is drawn: the GPU transforms the
+    // columns to coefficient and extended form while the host runs the RNG for 2^k scalars and the DMA engine uploads them (own stream)
+    Fr *random_poly = nullptr;   // taken while the stream is idle (the commitments above synchronised it): the copy stream writes into it unordered
     H2_CHK(sc.take(n, &random_poly));
-    {
-        const Fr *vals = draw(n);
-        H2_CHK(put(random_poly, vals, n));
-        H2_HIPCHK(hipStreamSynchronize(st));
-        draw(1);   // random_blind
-        std::vector<const void *> cols(1, random_poly);
-        H2_CHK(commit_batch(pk->g, cols, n));
-    }
-    laps.lap(ST_RANDOM);
-    const Fr y = tr.squeeze_challenge();
-    // ---- coefficient form (in place: the Lagrange values are not needed again)
     auto to_coeff = [&](Fr *a) -> int { return h2hip_ifft_dev(ctx, a, &dom.omega_inv, k, &dom.ifft_divisor); };
     for (Fr *a : adv) H2_CHK(to_coeff(a));
     for (Fr *a : inst_values) H2_CHK(to_coeff(a));
@@ -776,26 +772,53 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(to_coeff(s.sp));
         H2_CHK(to_coeff(s.z));
     }
-    laps.lap(ST_TO_COEFF);
-    // ---- h(X) numerator on the extended domain
+    if (stage_ms) laps.lap(ST_TO_COEFF);
     auto to_ext = [&](const Fr *poly, Fr **out) -> int {
         H2_CHK(sc.take(ne, out));
         return h2hip_coeff_to_extended_dev(ctx, poly, k, *out, ek, &dom.ext_omega, &dom.zeta);
     };
-    std::vector<Fr *> adv_cos(adv.size()), inst_cos(inst_values.size());
+    std::vector<Fr *> adv_cos(adv.size()), inst_cos(inst_values.size()), perm_cos(sh.num_perm_sets);
+    struct LookupCosets {
+        Fr *z, *ap, *sp, *inp;
+    };
+    std::vector<LookupCosets> lk_cos(lks.size());
     for (size_t i = 0; i < adv.size(); ++i) H2_CHK(to_ext(adv[i], &adv_cos[i]));
     for (size_t i = 0; i < inst_values.size(); ++i) H2_CHK(to_ext(inst_values[i], &inst_cos[i]));
+    for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(to_ext(perm_z[si], &perm_cos[si]));
+    for (size_t li = 0; li < lks.size(); ++li) {
+        const Lookup &l = sh.lookups[li];
+        LookupCosets &c = lk_cos[li];
+        H2_CHK(to_ext(lks[li].z, &c.z));
+        H2_CHK(to_ext(lks[li].ap, &c.ap));
+        H2_CHK(to_ext(lks[li].sp, &c.sp));
+        c.inp = nullptr;
+        if (l.q_col >= 0) {   // the product of the cosets is the coset of the product polynomial q_lookup(X) * a(X)
+            H2_CHK(sc.take(ne, &c.inp));
+            H2_CHK(h2hip_fr_mul_batch_dev(ctx, c.inp, pk->fixed_cosets[l.q_col], adv_cos[l.advice_col], ne));
+        }
+    }
     Fr *acc = nullptr;
     H2_CHK(sc.take(ne, &acc));
     H2_HIPCHK(hipMemsetAsync(acc, 0, sizeof(Fr) * ne, st));
-    laps.lap(ST_TO_EXT);
+    if (stage_ms) laps.lap(ST_TO_EXT);
+    // ---- vanishing argument: the random polynomial
+    {
+        const Fr *vals = draw(n);
+        H2_HIPCHK(hipMemcpyAsync(random_poly, vals, sizeof(Fr) * n, hipMemcpyHostToDevice, pk->copy_stream));
+        H2_HIPCHK(hipEventRecord(pk->copy_ev, pk->copy_stream));
+        H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));
+        H2_HIPCHK(hipStreamSynchronize(pk->copy_stream));   // the staging buffer is reused by the next draw
+        draw(1);   // random_blind
+        std::vector<const void *> cols(1, random_poly);
+        H2_CHK(commit_batch(pk->g, cols, n));
+    }
+    laps.lap(ST_RANDOM);
+    const Fr y = tr.squeeze_challenge();
+    // ---- h(X) numerator on the extended domain: the pointwise identities, folded by y in evaluate_h's order
     for (uint32_t a = 0; a < sh.p.num_advice; ++a)
         H2_CHK(h2hip_quotient_flex_gate_dev(ctx, acc, pk->fixed_cosets[sh.first_q_enable_col + (int)a], adv_cos[a], ek, k, &y));
-    laps.lap(ST_QUOTIENT);
     if (sh.num_perm_sets) {
-        std::vector<Fr *> zc(sh.num_perm_sets);
-        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(to_ext(perm_z[si], &zc[si]));
-        laps.lap(ST_TO_EXT);
+        const std::vector<Fr *> &zc = perm_cos;
         auto column_coset = [&](const ColumnRef &c) -> const Fr * {
             return c.kind == 0 ? pk->fixed_cosets[c.index] : c.kind == 1 ? adv_cos[c.index] : inst_cos[c.index];
         };
@@ -818,30 +841,20 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             for (uint32_t si = 1; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_CHAIN));
             for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_PRODUCT));
         }
-        for (Fr *p : zc) sc.release(p);
-        laps.lap(ST_QUOTIENT);
     }
     for (size_t li = 0; li < lks.size(); ++li) {
         const Lookup &l = sh.lookups[li];
-        LookupState &s = lks[li];
-        Fr *zc = nullptr, *apc = nullptr, *spc = nullptr, *inpc = nullptr;
-        H2_CHK(to_ext(s.z, &zc));
-        H2_CHK(to_ext(s.ap, &apc));
-        H2_CHK(to_ext(s.sp, &spc));
-        laps.lap(ST_TO_EXT);
-        const Fr *inp = adv_cos[l.advice_col];
-        if (l.q_col >= 0) {   // the product of the cosets is the coset of the product polynomial q_lookup(X) * a(X)
-            H2_CHK(sc.take(ne, &inpc));
-            H2_CHK(h2hip_fr_mul_batch_dev(ctx, inpc, pk->fixed_cosets[l.q_col], adv_cos[l.advice_col], ne));
-            inp = inpc;
-        }
-        H2_CHK(h2hip_quotient_lookup_dev(ctx, acc, zc, inp, pk->fixed_cosets[l.table_col], apc, spc, pk->l0, pk->l_last, pk->l_blind, ek, k, &beta, &gamma,
-                                         &y));
-        sc.release(zc);
-        sc.release(apc);
-        sc.release(spc);
-        if (inpc) sc.release(inpc);
-        laps.lap(ST_QUOTIENT);
+        const LookupCosets &c = lk_cos[li];
+        H2_CHK(h2hip_quotient_lookup_dev(ctx, acc, c.z, c.inp ? c.inp : adv_cos[l.advice_col], pk->fixed_cosets[l.table_col], c.ap, c.sp, pk->l0, pk->l_last,
+                                         pk->l_blind, ek, k, &beta, &gamma, &y));
+    }
+    laps.lap(ST_QUOTIENT);
+    for (Fr *p : perm_cos) sc.release(p);
+    for (LookupCosets &c : lk_cos) {
+        sc.release(c.z);
+        sc.release(c.ap);
+        sc.release(c.sp);
+        if (c.inp) sc.release(c.inp);
     }
     for (Fr *p : adv_cos) sc.release(p);
     for (Fr *p : inst_cos) sc.release(p);
@@ -1093,6 +1106,8 @@ void h2hip_plonk_pk_free(h2hip_ctx *ctx, h2hip_plonk_pk *pk) {
     if (ctx) hipStreamSynchronize(ctx->stream);
     for (void *p : pk->owned) hipFree(p);
     if (pk->host_stage) hipHostFree(pk->host_stage);
+    if (pk->copy_ev) hipEventDestroy(pk->copy_ev);
+    if (pk->copy_stream) hipStreamDestroy(pk->copy_stream);
     pk->pool.destroy();
     delete pk;
 }
