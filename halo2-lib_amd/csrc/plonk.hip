@@ -87,7 +87,8 @@ struct Shape {
         p = bp;
         k = bp.k;
         H2_REQUIRE(k >= 4 && k <= 26, "k out of range (4..26)");
-        H2_REQUIRE(bp.num_advice >= 1 && bp.num_advice <= 64 && bp.num_lookup_advice <= 64 && bp.num_fixed <= 16 && bp.num_instance <= 8,
+        // the reference's configurations go up to 291 gate + 53 lookup advice columns (halo2-ecc/configs/secp256k1/bench_ecdsa.config:9)
+        H2_REQUIRE(bp.num_advice >= 1 && bp.num_advice <= 1024 && bp.num_lookup_advice <= 256 && bp.num_fixed <= 16 && bp.num_instance <= 8,
                    "column counts out of range");
         H2_REQUIRE(bp.lookup_bits < (int32_t)k, "lookup_bits must be less than k");
         n = 1u << k;
@@ -574,16 +575,26 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_HIPCHK(hipStreamCreateWithFlags(&pk->copy_stream, hipStreamNonBlocking));
         H2_HIPCHK(hipEventCreateWithFlags(&pk->copy_ev, hipEventDisableTiming));
     }
-    if (pk->host_stage_elems < n) {
+    const size_t stage_cap = (size_t)n + ((size_t)1 << 14);   // the blinding tails of a proof and the n random-polynomial scalars without wrapping
+    if (pk->host_stage_elems < stage_cap) {
         if (pk->host_stage) hipHostFree(pk->host_stage);
         pk->host_stage = nullptr;
         pk->host_stage_elems = 0;
-        H2_HIPCHK(hipHostMalloc((void **)&pk->host_stage, sizeof(Fr) * n, 0));
-        pk->host_stage_elems = n;
+        H2_HIPCHK(hipHostMalloc((void **)&pk->host_stage, sizeof(Fr) * stage_cap, 0));
+        pk->host_stage_elems = stage_cap;
     }
+    // bump allocation over the staging buffer: a draw's values stay where they are until the buffer wraps, so the (asynchronous) uploads
+    // that read them need no synchronisation per draw — wide circuits draw hundreds of small tails
+    size_t stage_off = 0;
     auto draw = [&](size_t cnt) -> const Fr * {
-        if (cnt) rng(rng_user, pk->host_stage, cnt);   // cnt <= n by construction
-        return pk->host_stage;
+        if (stage_off + cnt > pk->host_stage_elems) {
+            hipStreamSynchronize(st);
+            stage_off = 0;
+        }
+        Fr *p = pk->host_stage + stage_off;
+        if (cnt) rng(rng_user, p, cnt);   // cnt <= n <= capacity by construction
+        stage_off += cnt;
+        return p;
     };
     auto put = [&](Fr *dst, const Fr *src, size_t cnt) -> int {   // pageable host -> device; the copy returns once `src` is consumed
         if (cnt) H2_HIPCHK(hipMemcpyAsync(dst, src, sizeof(Fr) * cnt, hipMemcpyHostToDevice, st));
@@ -664,7 +675,6 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_HIPCHK(hipMemcpyAsync(adv[c], advice[c], sizeof(Fr) * u, advice_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         const Fr *tail = draw(n - u);
         H2_CHK(put(adv[c] + u, tail, n - u));
-        H2_HIPCHK(hipStreamSynchronize(st));   // `rnd` is reused by the next draw
     }
     draw(sh.num_advice_total);   // Blind(Fr::random) per column: drawn, unused by KZG
     laps.lap(ST_UPLOAD);
@@ -693,10 +703,8 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             H2_CHK(h2hip_lookup_permute_presorted_dev(ctx, s.inp, pk->table_sorted, u, s.ap, s.sp));
             const Fr *t1 = draw(bf + 1);
             H2_CHK(put(s.ap + u, t1, bf + 1));
-            H2_HIPCHK(hipStreamSynchronize(st));
             const Fr *t2 = draw(bf + 1);
             H2_CHK(put(s.sp + u, t2, bf + 1));
-            H2_HIPCHK(hipStreamSynchronize(st));
             draw(2);   // the two commitment blinds
             cols.push_back(s.ap);
             cols.push_back(s.sp);
@@ -721,7 +729,9 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     };
     std::vector<Fr *> perm_z(sh.num_perm_sets);
     {
-        Fr last_z = Fr::one();
+        // every set's product is first computed from 1; the chain z_i(0) = z_{i-1}(last usable row) is then a prefix product over the sets'
+        // last values on the host and one scaling launch per set — one synchronisation for the whole argument instead of one per set
+        std::vector<Fr> local_last(sh.num_perm_sets);
         for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
             const uint32_t c0 = si * sh.chunk_len, c1 = std::min<uint32_t>(c0 + sh.chunk_len, (uint32_t)sh.perm_columns.size());
             const void *cols[8], *sigs[8];
@@ -732,12 +742,18 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             H2_CHK(h2hip_permutation_product_terms_dev(ctx, num, den, cols, sigs, c1 - c0, c0, u, &beta, &gamma, &dom.delta, &dom.omega));
             H2_CHK(sc.take(n, &perm_z[si]));
             H2_CHK(h2hip_fr_grand_product_dev(ctx, perm_z[si], num, den, u));   // z[0] = 1 ... z[u]
-            if (si) H2_CHK(h2hip_fr_scale_dev(ctx, perm_z[si], &last_z, (size_t)u + 1));
+            if (si + 1 < sh.num_perm_sets) H2_HIPCHK(hipMemcpyAsync(&local_last[si], perm_z[si] + u, sizeof(Fr), hipMemcpyDeviceToHost, st));
             const Fr *tail = draw(bf);
             H2_CHK(put(perm_z[si] + (n - bf), tail, bf));
-            if (si + 1 < sh.num_perm_sets) H2_HIPCHK(hipMemcpyAsync(&last_z, perm_z[si] + u, sizeof(Fr), hipMemcpyDeviceToHost, st));
-            H2_HIPCHK(hipStreamSynchronize(st));
             draw(1);   // blind
+        }
+        if (sh.num_perm_sets > 1) {
+            H2_HIPCHK(hipStreamSynchronize(st));
+            Fr carry = Fr::one();
+            for (uint32_t si = 1; si < sh.num_perm_sets; ++si) {
+                carry = fe_mul(carry, local_last[si - 1]);   // = the true z_{si-1}(last usable row)
+                H2_CHK(h2hip_fr_scale_dev(ctx, perm_z[si], &carry, (size_t)u + 1));
+            }
         }
         for (size_t li = 0; li < lks.size(); ++li) {
             LookupState &s = lks[li];
@@ -746,7 +762,6 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             H2_CHK(h2hip_fr_grand_product_dev(ctx, s.z, num, den, u));
             const Fr *tail = draw(bf);
             H2_CHK(put(s.z + (n - bf), tail, bf));
-            H2_HIPCHK(hipStreamSynchronize(st));
             draw(1);   // blind
         }
         laps.lap(ST_PRODUCTS);
@@ -803,7 +818,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     if (stage_ms) laps.lap(ST_TO_EXT);
     // ---- vanishing argument: the random polynomial
     {
-        const Fr *vals = draw(n);
+        const Fr *vals = draw(n);   // (wraps the staging buffer: synchronises the stream once if the earlier tails are still in it)
         H2_HIPCHK(hipMemcpyAsync(random_poly, vals, sizeof(Fr) * n, hipMemcpyHostToDevice, pk->copy_stream));
         H2_HIPCHK(hipEventRecord(pk->copy_ev, pk->copy_stream));
         H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));
