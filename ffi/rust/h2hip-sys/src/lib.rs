@@ -50,7 +50,7 @@ pub struct h2hip_plonk_shape {
 }
 pub type h2hip_rng_fill_fn = Option<unsafe extern "C" fn(user: *mut c_void, out_fr: *mut c_void, n: usize)>;
 pub type h2hip_allgather_fn = Option<unsafe extern "C" fn(user: *mut c_void, local: *const c_void, bytes: usize, all: *mut c_void) -> c_int>;
-pub const H2HIP_PLONK_STAGES: usize = 13;
+pub const H2HIP_PLONK_STAGES: usize = 12;
 
 pub const H2HIP_OK: c_int = 0;
 pub const H2HIP_ERR_INVALID: c_int = -1;
@@ -89,6 +89,7 @@ extern "C" {
     pub fn h2hip_msm_g1_dev(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_dev: *const c_void, n: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     pub fn h2hip_msm_g1_batch(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_host: *const *const c_void, n: usize, count: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     pub fn h2hip_msm_g1_batch_dev(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_dev: *const *const c_void, n: usize, count: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
+    pub fn h2hip_msm_g1_multi_dev(ctx: *mut h2hip_ctx, bases_per_column: *const *const h2hip_bases, scalars_dev: *const *const c_void, n: usize, count: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     pub fn h2hip_g1_sum_jacobian_dev(ctx: *mut h2hip_ctx, points_dev: *const c_void, n: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     // a2 — ParamsKZG::setup
     pub fn h2hip_g1_to_lagrange(ctx: *mut h2hip_ctx, g: *const h2hip_bases, k: u32, flags: u32, g_lagrange_out: *mut *mut h2hip_bases) -> c_int;

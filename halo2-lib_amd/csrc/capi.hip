@@ -478,9 +478,21 @@ static void join_lanes(h2hip_ctx *ctx, int nl) {
             return r__;           \
         }                         \
     } while (0)
-static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_in, bool scalars_on_host, size_t n, size_t count,
-                          int point_format, void *out_host) {
+// bases_per_col (optional): a base set per column — columns over different sets (e.g. a Lagrange-basis and a monomial-basis commitment of
+// the same prover round) share the lanes and, when their window tables match, the deferred bucket reduction
+static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_bases *const *bases_per_col, const void *const *scalars_in,
+                          bool scalars_on_host, size_t n, size_t count, int point_format, void *out_host) {
+    if (bases_per_col && count) bases = bases_per_col[0];
     H2_REQUIRE(ctx && bases && (count == 0 || (scalars_in && out_host)), "NULL argument");
+    bool mixed = false;
+    if (bases_per_col)
+        for (size_t j = 0; j < count; ++j) {
+            H2_REQUIRE(bases_per_col[j] && n <= bases_per_col[j]->n, "NULL base set / more scalars than bases");
+            if (bases_per_col[j] != bases) mixed = true;
+            H2_REQUIRE((bases_per_col[j]->tables > 1) == (bases->tables > 1) && bases_per_col[j]->window_bits == bases->window_bits,
+                       "the base sets of one batch must share their table layout (plain, or precomputed with the same window)");
+        }
+    auto bases_of = [&](size_t j) -> const h2hip_bases * { return bases_per_col ? bases_per_col[j] : bases; };
     H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
     if (!count) return H2HIP_OK;
     H2_REQUIRE(n <= bases->n, "more scalars than bases");
@@ -546,16 +558,18 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *
         for (size_t j = 0; j < count; ++j) staged[j] = stage + sizeof(Fr) * n * j;
         scalars_dev = staged.data();
     }
+    if (mixed) fuse = 1;   // a fused multi-column MSM reads one table
     const size_t ngroups = (count + fuse - 1) / fuse;
     for (size_t g = 0, j0 = 0; g < ngroups; ++g) {
         const size_t gsize = (count - j0 + (ngroups - g) - 1) / (ngroups - g);   // balanced group sizes
         h2hip_ctx *c = ctx->lane[g % NL];
+        const h2hip_bases *gb = bases_of(j0);
         for (size_t j = j0; j < j0 + gsize; ++j) {
             if (scalars_on_host && n) H2_LANES(hipMemcpyAsync((void *)staged[j], scalars_in[j], sizeof(Fr) * n, hipMemcpyHostToDevice, c->stream));
         }
         char *outbuf = nullptr;
         H2_LANES_RC(ws_reserve(c, h2hip_ctx::WS_OUT, 2048, (void **)&outbuf));
-        H2_LANES_RC(msm_run_cols(c, bases, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
+        H2_LANES_RC(msm_run_cols(c, gb, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
                                  deferred ? all_buckets + keys_per_col * j0 : nullptr));
         if (!deferred) {
             prof_begin(c, "point_finish_kernel");
@@ -599,12 +613,19 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const void *
 int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count, int point_format,
                            void *out_host) {
     H2_DEVICE_GUARD(ctx);
-    return msm_batch_impl(ctx, bases, scalars_dev, false, n, count, point_format, out_host);
+    return msm_batch_impl(ctx, bases, nullptr, scalars_dev, false, n, count, point_format, out_host);
+}
+int h2hip_msm_g1_multi_dev(h2hip_ctx *ctx, const h2hip_bases *const *bases_per_column, const void *const *scalars_dev, size_t n, size_t count,
+                           int point_format, void *out_host) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && (count == 0 || bases_per_column), "NULL argument");
+    if (!count) return H2HIP_OK;
+    return msm_batch_impl(ctx, nullptr, bases_per_column, scalars_dev, false, n, count, point_format, out_host);
 }
 int h2hip_msm_g1_batch(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_host, size_t n, size_t count, int point_format,
                        void *out_host) {
     H2_DEVICE_GUARD(ctx);
-    return msm_batch_impl(ctx, bases, scalars_host, true, n, count, point_format, out_host);
+    return msm_batch_impl(ctx, bases, nullptr, scalars_host, true, n, count, point_format, out_host);
 }
 
 int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_host, size_t n, int point_format, void *out_host) {

@@ -536,10 +536,10 @@ static Fr eval_small(const std::vector<Fr> &c, const Fr &x) {
 
 // ---------------------------------------------------------------------------------------------- create_proof
 static const char *STAGE_NAMES[H2HIP_PLONK_STAGES] = {
-    "advice_upload_blinding", "lookup_permute", "commit_advice_lookup_permuted", "grand_products", "commit_grand_products", "random_poly_commit",
+    "advice_upload_blinding", "lookup_permute", "commit_advice_lookup_permuted", "grand_products", "ntt_round1_columns_and_commit_products_random",
     "lagrange_to_coeff", "coeff_to_extended", "quotient_terms", "quotient_to_coeff", "commit_h_pieces", "evaluations", "multiopen_shplonk"};
-enum { ST_UPLOAD = 0, ST_LOOKUP_PERMUTE, ST_COMMIT_ROUND1, ST_PRODUCTS, ST_COMMIT_PRODUCTS, ST_RANDOM, ST_TO_COEFF, ST_TO_EXT, ST_QUOTIENT, ST_H_COEFF,
-       ST_COMMIT_H, ST_EVALS, ST_MULTIOPEN };
+enum { ST_UPLOAD = 0, ST_LOOKUP_PERMUTE, ST_COMMIT_ROUND1, ST_PRODUCTS, ST_COMMIT_PRODUCTS, ST_TO_COEFF, ST_TO_EXT, ST_QUOTIENT, ST_H_COEFF, ST_COMMIT_H,
+       ST_EVALS, ST_MULTIOPEN };
 
 struct Laps {
     h2hip_ctx *ctx;
@@ -600,28 +600,33 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         if (cnt) H2_HIPCHK(hipMemcpyAsync(dst, src, sizeof(Fr) * cnt, hipMemcpyHostToDevice, st));
         return H2HIP_OK;
     };
-    // commitments come back as Jacobian points (C::Curve, like best_multiexp) and are normalised here: one field inversion on the host
-    // costs microseconds, on a single GPU lane ~0.1 ms of an otherwise idle chip
-    auto commit_points = [&](const h2hip_bases *bases, const std::vector<const void *> &cols, size_t len, std::vector<G1Affine> &pts) -> int {
+    // `bases_per_col`: empty = all columns over `bases`
+    auto commit_points_multi = [&](const h2hip_bases *bases, const std::vector<const h2hip_bases *> &bases_per_col, const std::vector<const void *> &cols,
+                                   size_t len, std::vector<G1Affine> &pts) -> int {
         std::vector<G1Jac> jac(cols.size());
-        if (pk->shard_world > 1) {
-            // point-range sharding: this rank's partial MSM over its resident slice of the SRS, one all-gather of the
-            // 96-byte partials per round (RCCL has no group-law reduction), the N-term sums on the host.  Every rank ends up with every
-            // commitment, so the replicated transcripts stay in lock step and all ranks emit the same proof bytes.
-            const h2hip_bases *sb = bases == pk->g ? pk->g_shard : pk->g_lagrange_shard;
-            const size_t lo = std::min(pk->shard_offset, len), hi = std::min(pk->shard_offset + pk->shard_len, len);
-            std::vector<const void *> local(cols.size());
-            for (size_t i = 0; i < cols.size(); ++i) local[i] = (const Fr *)cols[i] + lo;
-            if (cols.size() == 1)
-                H2_CHK(h2hip_msm_g1_dev(ctx, sb, local[0], hi - lo, H2HIP_POINT_JACOBIAN, jac.data()));
-            else if (!cols.empty())
-                H2_CHK(h2hip_msm_g1_batch_dev(ctx, sb, local.data(), hi - lo, cols.size(), H2HIP_POINT_JACOBIAN, jac.data()));
+        const bool sharded = pk->shard_world > 1;
+        std::vector<const h2hip_bases *> bpc(cols.size());
+        for (size_t i = 0; i < cols.size(); ++i) {
+            const h2hip_bases *b = bases_per_col.empty() ? bases : bases_per_col[i];
+            bpc[i] = sharded ? (b == pk->g ? pk->g_shard : pk->g_lagrange_shard) : b;
+        }
+        // sharded: point-range sharding: this rank's partial MSM over its resident slice of the SRS, one all-gather of the
+        // 96-byte partials per round (RCCL has no group-law reduction), the N-term sums on the host.  Every rank ends up with every
+        // commitment, so the replicated transcripts stay in lock step and all ranks emit the same proof bytes.
+        const size_t lo = sharded ? std::min(pk->shard_offset, len) : 0, hi = sharded ? std::min(pk->shard_offset + pk->shard_len, len) : len;
+        std::vector<const void *> local(cols.size());
+        for (size_t i = 0; i < cols.size(); ++i) local[i] = (const Fr *)cols[i] + lo;
+        if (cols.size() == 1)
+            H2_CHK(h2hip_msm_g1_dev(ctx, bpc[0], local[0], hi - lo, H2HIP_POINT_JACOBIAN, jac.data()));
+        else if (!cols.empty())
+            H2_CHK(h2hip_msm_g1_multi_dev(ctx, bpc.data(), local.data(), hi - lo, cols.size(), H2HIP_POINT_JACOBIAN, jac.data()));
+        pts.resize(cols.size());
+        if (sharded) {
             std::vector<G1Jac> all(cols.size() * pk->shard_world);
             if (pk->allgather(pk->allgather_user, jac.data(), sizeof(G1Jac) * cols.size(), all.data()) != 0) {
                 set_error("create_proof: the all-gather callback failed");
                 return H2HIP_ERR_INVALID;
             }
-            pts.resize(cols.size());
             for (size_t i = 0; i < cols.size(); ++i) {
                 XYZZ acc = XYZZ::identity();
                 for (uint32_t r = 0; r < pk->shard_world; ++r) {
@@ -638,13 +643,13 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             }
             return H2HIP_OK;
         }
-        if (cols.size() == 1)
-            H2_CHK(h2hip_msm_g1_dev(ctx, bases, cols[0], len, H2HIP_POINT_JACOBIAN, jac.data()));
-        else if (!cols.empty())
-            H2_CHK(h2hip_msm_g1_batch_dev(ctx, bases, cols.data(), len, cols.size(), H2HIP_POINT_JACOBIAN, jac.data()));
-        pts.resize(cols.size());
+        // commitments come back as Jacobian points (C::Curve, like best_multiexp) and are normalised here: one field inversion on the
+        // host costs microseconds, on a single GPU lane ~0.1 ms of an otherwise idle chip
         for (size_t i = 0; i < jac.size(); ++i) pts[i] = jacobian_to_affine(jac[i]);
         return H2HIP_OK;
+    };
+    auto commit_points = [&](const h2hip_bases *bases, const std::vector<const void *> &cols, size_t len, std::vector<G1Affine> &pts) -> int {
+        return commit_points_multi(bases, std::vector<const h2hip_bases *>(), cols, len, pts);
     };
     auto commit_batch = [&](const h2hip_bases *bases, const std::vector<const void *> &cols, size_t len) -> int {
         std::vector<G1Affine> pts;
@@ -764,20 +769,25 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             H2_CHK(put(s.z + (n - bf), tail, bf));
             draw(1);   // blind
         }
-        laps.lap(ST_PRODUCTS);
-        std::vector<const void *> cols(perm_z.begin(), perm_z.end());
-        for (LookupState &s : lks) cols.push_back(s.z);
-        if (!cols.empty()) H2_CHK(commit_batch(pk->g_lagrange, cols, n));
-        laps.lap(ST_COMMIT_PRODUCTS);
+        if (stage_ms) laps.lap(ST_PRODUCTS);
     }
-    // ---- everything of h(X)'s inputs that does not depend on y is queued BEFORE the random polynomial is drawn: the GPU transforms the
-    // columns to coefficient and extended form while the host runs the RNG for 2^k scalars and the DMA engine uploads them (own stream)
-    Fr *random_poly = nullptr;   // taken while the stream is idle (the commitments above synchronised it): the copy stream writes into it unordered
+    // ---- this round's commitments are the grand products AND the vanishing argument's random polynomial (nothing is squeezed between
+    // them): one batched call over two base sets.  Before the host draws the 2^k random scalars, the GPU is given everything that no longer
+    // needs the Lagrange values of the first-round columns: their coefficient and extended forms — RNG, upload (own stream) and NTTs overlap.
+    Fr *random_poly = nullptr;
     H2_CHK(sc.take(n, &random_poly));
     auto to_coeff = [&](Fr *a) -> int { return h2hip_ifft_dev(ctx, a, &dom.omega_inv, k, &dom.ifft_divisor); };
+    auto to_ext = [&](const Fr *poly, Fr **out) -> int {
+        H2_CHK(sc.take(ne, out));
+        return h2hip_coeff_to_extended_dev(ctx, poly, k, *out, ek, &dom.ext_omega, &dom.zeta);
+    };
+    struct LookupCosets {
+        Fr *z, *ap, *sp, *inp;
+    };
+    std::vector<Fr *> adv_cos(adv.size()), inst_cos(inst_values.size()), perm_cos(sh.num_perm_sets);
+    std::vector<LookupCosets> lk_cos(lks.size());
     for (Fr *a : adv) H2_CHK(to_coeff(a));
     for (Fr *a : inst_values) H2_CHK(to_coeff(a));
-    for (Fr *a : perm_z) H2_CHK(to_coeff(a));
     for (LookupState &s : lks) {
         if (s.own_inp) {
             sc.release(s.inp);
@@ -785,25 +795,13 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         }
         H2_CHK(to_coeff(s.ap));
         H2_CHK(to_coeff(s.sp));
-        H2_CHK(to_coeff(s.z));
     }
-    if (stage_ms) laps.lap(ST_TO_COEFF);
-    auto to_ext = [&](const Fr *poly, Fr **out) -> int {
-        H2_CHK(sc.take(ne, out));
-        return h2hip_coeff_to_extended_dev(ctx, poly, k, *out, ek, &dom.ext_omega, &dom.zeta);
-    };
-    std::vector<Fr *> adv_cos(adv.size()), inst_cos(inst_values.size()), perm_cos(sh.num_perm_sets);
-    struct LookupCosets {
-        Fr *z, *ap, *sp, *inp;
-    };
-    std::vector<LookupCosets> lk_cos(lks.size());
     for (size_t i = 0; i < adv.size(); ++i) H2_CHK(to_ext(adv[i], &adv_cos[i]));
     for (size_t i = 0; i < inst_values.size(); ++i) H2_CHK(to_ext(inst_values[i], &inst_cos[i]));
-    for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(to_ext(perm_z[si], &perm_cos[si]));
     for (size_t li = 0; li < lks.size(); ++li) {
         const Lookup &l = sh.lookups[li];
         LookupCosets &c = lk_cos[li];
-        H2_CHK(to_ext(lks[li].z, &c.z));
+        c.z = nullptr;
         H2_CHK(to_ext(lks[li].ap, &c.ap));
         H2_CHK(to_ext(lks[li].sp, &c.sp));
         c.inp = nullptr;
@@ -812,23 +810,38 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             H2_CHK(h2hip_fr_mul_batch_dev(ctx, c.inp, pk->fixed_cosets[l.q_col], adv_cos[l.advice_col], ne));
         }
     }
+    G1Affine random_commitment;
+    {
+        const Fr *vals = draw(n);
+        H2_HIPCHK(hipMemcpyAsync(random_poly, vals, sizeof(Fr) * n, hipMemcpyHostToDevice, pk->copy_stream));
+        H2_HIPCHK(hipEventRecord(pk->copy_ev, pk->copy_stream));
+        H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));
+        draw(1);   // random_blind
+        std::vector<const void *> cols(perm_z.begin(), perm_z.end());
+        std::vector<const h2hip_bases *> bases(cols.size(), pk->g_lagrange);
+        for (LookupState &s : lks) {
+            cols.push_back(s.z);
+            bases.push_back(pk->g_lagrange);
+        }
+        cols.push_back(random_poly);
+        bases.push_back(pk->g);
+        std::vector<G1Affine> pts;
+        H2_CHK(commit_points_multi(nullptr, bases, cols, n, pts));
+        for (size_t i = 0; i + 1 < pts.size(); ++i) H2_CHK(tr.write_point(pts[i]));
+        random_commitment = pts.back();
+        laps.lap(ST_COMMIT_PRODUCTS);
+    }
+    H2_CHK(tr.write_point(random_commitment));
+    const Fr y = tr.squeeze_challenge();
+    for (Fr *a : perm_z) H2_CHK(to_coeff(a));
+    for (LookupState &s : lks) H2_CHK(to_coeff(s.z));
+    if (stage_ms) laps.lap(ST_TO_COEFF);
+    for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(to_ext(perm_z[si], &perm_cos[si]));
+    for (size_t li = 0; li < lks.size(); ++li) H2_CHK(to_ext(lks[li].z, &lk_cos[li].z));
     Fr *acc = nullptr;
     H2_CHK(sc.take(ne, &acc));
     H2_HIPCHK(hipMemsetAsync(acc, 0, sizeof(Fr) * ne, st));
     if (stage_ms) laps.lap(ST_TO_EXT);
-    // ---- vanishing argument: the random polynomial
-    {
-        const Fr *vals = draw(n);   // (wraps the staging buffer: synchronises the stream once if the earlier tails are still in it)
-        H2_HIPCHK(hipMemcpyAsync(random_poly, vals, sizeof(Fr) * n, hipMemcpyHostToDevice, pk->copy_stream));
-        H2_HIPCHK(hipEventRecord(pk->copy_ev, pk->copy_stream));
-        H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));
-        H2_HIPCHK(hipStreamSynchronize(pk->copy_stream));   // the staging buffer is reused by the next draw
-        draw(1);   // random_blind
-        std::vector<const void *> cols(1, random_poly);
-        H2_CHK(commit_batch(pk->g, cols, n));
-    }
-    laps.lap(ST_RANDOM);
-    const Fr y = tr.squeeze_challenge();
     // ---- h(X) numerator on the extended domain: the pointwise identities, folded by y in evaluate_h's order
     for (uint32_t a = 0; a < sh.p.num_advice; ++a)
         H2_CHK(h2hip_quotient_flex_gate_dev(ctx, acc, pk->fixed_cosets[sh.first_q_enable_col + (int)a], adv_cos[a], ek, k, &y));

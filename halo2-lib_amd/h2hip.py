@@ -46,6 +46,7 @@ _PROTOS = {
     "h2hip_msm_g1_dev": (_int, [_vp, _vp, _vp, _sz, _int, _vp]),
     "h2hip_msm_g1_batch": (_int, [_vp, _vp, C.POINTER(_vp), _sz, _sz, _int, _vp]),
     "h2hip_msm_g1_batch_dev": (_int, [_vp, _vp, C.POINTER(_vp), _sz, _sz, _int, _vp]),
+    "h2hip_msm_g1_multi_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _sz, _sz, _int, _vp]),
     "h2hip_g1_to_lagrange": (_int, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),
     "h2hip_params_kzg_setup": (_int, [_vp, _u32, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp)]),
     "h2hip_g1_fixed_base_mul_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
@@ -341,6 +342,16 @@ class Context:
         arr = (_vp * count)(*[_vp(int(p)) for p in scalar_dptrs])
         out = np.zeros((count, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
         self._chk(self.lib.h2hip_msm_g1_batch_dev(self.handle, bases.handle, arr, n, count, point_format, _ptr(out)))
+        return out
+
+    def msm_multi_dev(self, bases_per_column, scalar_dptrs, n: int, point_format: int = POINT_JACOBIAN) -> np.ndarray:
+        """one pipelined call for columns over different base sets (a Bases per column)"""
+        count = len(scalar_dptrs)
+        assert len(bases_per_column) == count
+        barr = (_vp * max(count, 1))(*[b.handle for b in bases_per_column])
+        arr = (_vp * max(count, 1))(*[_vp(int(p)) for p in scalar_dptrs])
+        out = np.zeros((count, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
+        self._chk(self.lib.h2hip_msm_g1_multi_dev(self.handle, barr, arr, n, count, point_format, _ptr(out)))
         return out
 
     def msm_batch(self, bases: Bases, scalar_columns, point_format: int = POINT_JACOBIAN) -> np.ndarray:

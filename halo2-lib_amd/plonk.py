@@ -23,7 +23,7 @@ from .h2hip import Context, _fe, _ptr
 from .halo2_proofs import ParamsKZG, R_MOD, fr_limbs
 
 _vp = C.c_void_p
-PLONK_STAGES = 13
+PLONK_STAGES = 12
 
 
 class BaseCircuitParams(C.Structure):

@@ -98,6 +98,11 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
  * overlap another one's accumulation. */
 int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count,
                            int point_format, void *out_host);
+/* the same with a base set PER COLUMN: the commitments of one prover round that live over different SRS columns (Lagrange-basis and
+ * monomial-basis polynomials) in one pipelined call.  The sets must share their table layout (all plain, or all precomputed with the same
+ * window — true for the g / g_lagrange of one ParamsKZG). */
+int h2hip_msm_g1_multi_dev(h2hip_ctx *ctx, const h2hip_bases *const *bases_per_column, const void *const *scalars_dev, size_t n, size_t count,
+                           int point_format, void *out_host);
 /* the same for scalar columns in HOST memory (an unmodified prover's Vec<Fr>): each column is uploaded on its lane's stream
  * right before its kernels are queued, so the upload of column j+1 overlaps the GPU work of column j */
 int h2hip_msm_g1_batch(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_host, size_t n, size_t count, int point_format,
@@ -310,7 +315,7 @@ int h2hip_plonk_pk_set_msm_sharding(h2hip_plonk_pk *pk, const h2hip_bases *g_sha
 
 /* `Fr::random(rng)` x n into out (Montgomery limbs); called in upstream's draw order */
 typedef void (*h2hip_rng_fill_fn)(void *user, void *out_fr, size_t n);
-#define H2HIP_PLONK_STAGES 13
+#define H2HIP_PLONK_STAGES 12
 const char *h2hip_plonk_stage_name(int stage);
 /* advice: num_advice_total columns of 2^k Montgomery Fr (host pointers, or device pointers when advice_on_device != 0); rows >=
  * usable_rows are ignored (blinding rows).  instances: num_instance host arrays of instance_lens[i] Fr.  proof_out: capacity
