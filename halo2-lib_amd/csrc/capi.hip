@@ -229,6 +229,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
     if (!strcmp(name, "msm_table_nontemporal")) return &ctx->msm_table_nontemporal;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
+    if (!strcmp(name, "ntt_wave_local")) return &ctx->ntt_wave_local;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;

@@ -79,6 +79,9 @@ struct h2hip_ctx {
     int ntt_tile_bits = 10;
     int ntt_min_col_bits = 2;    // log2 of the minimum number of adjacent columns per tile (coalescing vs number of passes)
     int ntt_full_table = 1;      // first pass reads a full omega^e table instead of composing two table entries
+    int ntt_wave_local = 0;      // 1: full tiles with >= 4 columns are stored column-major, every wave owns whole columns and the stage pairs are separated by
+                                 // wave-level ordering points instead of block barriers.  Bit-exact, measured neutral (tools/ntt_ab.py: 2^22 0.518 vs 0.527 ms,
+                                 // coset 2^19->2^21 0.267 vs 0.257 ms): the barriers are not what the pass kernel waits for.  Off by default.
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)

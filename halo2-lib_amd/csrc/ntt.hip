@@ -18,6 +18,19 @@
 
 namespace h2 {
 
+// ordering point between LDS writes and reads of the lanes of ONE wave: the wave issues its LDS operations in order, so only the
+// compiler has to be kept from moving them across (the emulated build, where lanes are fibers, needs a real barrier)
+#ifdef H2_HIPEMU
+#define H2_WAVE_SYNC() __syncthreads()
+#else
+#define H2_WAVE_SYNC()                                         \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#endif
+
 // LDS / table element: 9 limbs padded to 48 B so that it moves as three 16-byte accesses (ds_read_b128 /
 // global_load_dwordx4); a 12-word stride is bank-conflict free for 16-lane b128 groups
 struct alignas(16) Fr29L {
@@ -58,12 +71,16 @@ constexpr uint32_t NTT_EPT = 4;   // elements per lane per tile (tile <= 1024 el
 __global__ __launch_bounds__(256) void ntt_pass_kernel(const Fr *__restrict__ x, Fr *__restrict__ y, uint32_t log_n, uint32_t m,
                                                        uint32_t log_s, uint32_t cb, const Fr29L *__restrict__ t1,
                                                        const Fr29L *__restrict__ t2, uint32_t lo_bits, const Fr29L *__restrict__ tdirect,
-                                                       uint64_t in_len, int in_mul, int out_mul, NttScale sc, int debug_skip) {
+                                                       uint64_t in_len, int in_mul, int out_mul, NttScale sc, int debug_skip, int wave_local) {
     HIP_DYNAMIC_SHARED(Fr29L, lds)
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << m, C = 1u << cb;
     const uint32_t elems = R << cb;
-    Fr29L *tw_s = lds + elems;                          // omega_R^k, k < R/2
+    // wave_local (full 1024-element tiles with >= 4 columns): the tile is stored column-major (column c at c*(R+1): the odd stride keeps
+    // the fill / read-out conflict-free) and every wave owns C/4 whole columns, so all butterfly stages of a tile stay inside one wave —
+    // the block barriers between the stage pairs (four waves waiting for each other every two stages) become wave-level ordering points
+    const uint32_t col_stride = wave_local ? R + 1 : 0;
+    Fr29L *tw_s = lds + (wave_local ? C * (R + 1) : elems);   // omega_R^k, k < R/2
     Fr29L *scale_s = tw_s + (R >> 1) + 1;               // [0..3) input scales, [3..6) output scales (R' form)
     const uint64_t rows_stride = 1ull << (log_n - m);   // N/R
     const uint32_t ntiles = 1u << (log_n - m - cb);
@@ -100,13 +117,52 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const Fr *__restrict__ x,
                     uint64_t idx = j0 + c + (uint64_t)t * rows_stride;
                     v = f29_mul(v, scale_s[idx % 3].v);   // zero padding stays zero
                 }
-                lds[(bitrev_m(t, m) << cb) + c].v = v;   // DIT: bit-reversed rows in, natural rows out
+                lds[wave_local ? c * col_stride + bitrev_m(t, m) : (bitrev_m(t, m) << cb) + c].v = v;   // DIT: bit-reversed rows in, natural rows out
             }
         }
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);   // next tile's loads overlap this tile's arithmetic
 
         uint32_t st = (debug_skip & 1) ? m : 0;
-        if ((m & 1) && !(debug_skip & 1)) {   // odd number of stages: one radix-2 stage (twiddle 1), then radix-4 rounds
+        if (wave_local && !(debug_skip & 1)) {
+            const uint32_t wave = tid >> 6, lane = tid & 63u;
+            const uint32_t cwb = cb - 2;                       // log2(columns per wave)
+            __syncthreads();                                   // the cooperative fill is complete
+            if (m & 1) {   // one radix-2 stage (twiddle 1): C/4 * R/2 = 128 butterflies per wave
+#pragma unroll
+                for (uint32_t it = 0; it < 2; ++it) {
+                    const uint32_t idx = lane + 64 * it;
+                    const uint32_t cc = idx & ((1u << cwb) - 1), p = idx >> cwb;
+                    const uint32_t e0 = ((wave << cwb) + cc) * col_stride + (p << 1), e1 = e0 + 1;
+                    Fr29 a = lds[e0].v, t = lds[e1].v;
+                    lds[e0].v = f29_norm(f29_add(a, t));
+                    lds[e1].v = f29_sub<2>(a, t);
+                }
+                st = 1;
+            }
+            const uint32_t cc = lane & ((1u << cwb) - 1), p = lane >> cwb;   // C/4 * R/4 = 64 radix-4 groups per wave: one per lane
+            const uint32_t cbase = ((wave << cwb) + cc) * col_stride;
+            for (; st < m; st += 2) {
+                const uint32_t h = 1u << st;
+                H2_WAVE_SYNC();
+                const uint32_t i = p & (h - 1), blk = p >> st;
+                const uint32_t e0 = cbase + (blk << (st + 2)) + i, stride = h;
+                Fr29 x0 = lds[e0].v, x1 = lds[e0 + stride].v, x2 = lds[e0 + 2 * stride].v, x3 = lds[e0 + 3 * stride].v;
+                if (st) {
+                    Fr29 w1 = tw_s[i << (m - 1 - st)].v;
+                    x1 = f29_mul(x1, w1);
+                    x3 = f29_mul(x3, w1);
+                }
+                Fr29 y0 = f29_add(x0, x1), y1 = f29_sub_lazy<2>(x0, x1);
+                Fr29 y2 = f29_mul_wide(f29_add(x2, x3), tw_s[i << (m - 2 - st)].v);
+                Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), tw_s[(i + h) << (m - 2 - st)].v);
+                lds[e0].v = f29_norm(f29_add(y0, y2));
+                lds[e0 + 2 * stride].v = f29_sub<2>(y0, y2);
+                lds[e0 + stride].v = f29_norm(f29_add(y1, y3));
+                lds[e0 + 3 * stride].v = f29_sub<2>(y1, y3);
+            }
+            st = m;
+        }
+        if (!wave_local && (m & 1) && !(debug_skip & 1)) {   // odd number of stages: one radix-2 stage (twiddle 1), then radix-4 rounds
             __syncthreads();
             for (uint32_t b = tid; b < (elems >> 1); b += 256) {
                 uint32_t c = b & (C - 1), p = b >> cb;
@@ -154,7 +210,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const Fr *__restrict__ x,
                 c = e & (C - 1);
             }
             uint64_t j = j0 + c, q = j & smask, jq = j - q;
-            Fr29 v = lds[(u << cb) + c].v;
+            Fr29 v = lds[wave_local ? c * col_stride + u : (u << cb) + c].v;
             uint64_t oidx = (jq << m) + q + ((uint64_t)u << log_s);
             if (has_tw && !(debug_skip & 2)) {
                 // omega^(jq*u): jq is a multiple of s, so a direct table of omega^(s*t), t < N/s, serves later passes
@@ -275,11 +331,12 @@ int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in
         const uint32_t grid = tiles < (uint32_t)ctx->num_cus * 3 ? tiles : (uint32_t)ctx->num_cus * 3;
         const Fr29L *tdirect = nullptr;
         if (i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
-        const size_t shmem = sizeof(Fr29L) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)) + 8);
+        const int wave_local = (ctx->ntt_wave_local && cb >= 2 && m + cb == 10 && m >= 2) ? 1 : 0;
+        const size_t shmem = sizeof(Fr29L) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)) + 8 + (wave_local ? ((size_t)1 << cb) : 0));
         const bool first = (i == 0), last = (i == P - 1);
         prof_begin(ctx, "ntt_pass_kernel");
         hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid), dim3(256), shmem, ctx->stream, cur, dst, log_n, m, log_s, cb, (const Fr29L *)tw->t1, (const Fr29L *)tw->t2,
-                           tw->lo_bits, tdirect, first ? in_len : N, (first && in_scale3) ? 1 : 0, (last && out_scale3) ? 1 : 0, sc, ctx->ntt_debug_skip);
+                           tw->lo_bits, tdirect, first ? in_len : N, (first && in_scale3) ? 1 : 0, (last && out_scale3) ? 1 : 0, sc, ctx->ntt_debug_skip, wave_local);
         prof_end(ctx);
         H2_HIPCHK(hipGetLastError());
         cur = dst;

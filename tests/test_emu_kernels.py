@@ -27,6 +27,24 @@ def test_ntt_matches_oracle(ctx, log_n):
     assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
 
 
+def test_ntt_wave_local_variant(ctx):
+    """ntt_wave_local = 1: column-major tiles, stage pairs inside one wave (bit-exact with the default pass kernel)"""
+    ctx.set_param("ntt_wave_local", 1)
+    try:
+        for log_n in (11, 13, 15):
+            a = rand_fr(1 << log_n, 40 + log_n)
+            w, winv, div = domain_consts(log_n)
+            got = ctx.best_fft(a, w, log_n)
+            assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=4))
+            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
+        a = rand_fr(1 << 12, 7)
+        we, weinv, ediv = domain_consts(14)
+        z = fr([O.ZETA])
+        assert np.array_equal(ctx.coeff_to_extended(a, 12, 14, we, z), CO.coeff_to_extended(a, 12, 14, we, z, threads=4))
+    finally:
+        ctx.set_param("ntt_wave_local", 0)
+
+
 @pytest.mark.parametrize("tile", [4, 6, 8])
 def test_ntt_small_tiles_force_many_passes(ctx, tile):
     ctx.set_param("ntt_tile_bits", tile)
