@@ -355,6 +355,96 @@ __global__ __launch_bounds__(256) void fr_kate_apply_kernel(const Fr *__restrict
     kate_tile_scan(c, n, (size_t)blockIdx.x * KATE_TILE, b, pw, sh, carry[blockIdx.x], q);
 }
 
+// Division by the vanishing polynomial of SEVERAL points in one pass (ProverSHPLONK's per-rotation-set quotient): by partial fractions,
+//   (f(X) - r(X)) / prod_j (X - b_j)  =  sum_j w_j * (f(X) - f(b_j)) / (X - b_j),   w_j = 1 / prod_{i != j} (b_j - b_i),
+// where r is the interpolant of f on the b_j — so the quotient is a weighted sum of independent kate divisions of the SAME polynomial: the
+// heads / carries of all points are computed side by side and one pass over f writes the combined quotient (instead of one
+// heads-carry-apply triple per root on a shrinking intermediate).
+struct KateJob {
+    Fr b, w;
+    PowTable pw;
+};
+__global__ __launch_bounds__(256) void fr_kate_heads_multi_kernel(const Fr *__restrict__ c, size_t n, const KateJob *__restrict__ jobs, uint32_t ntiles,
+                                                                  Fr *__restrict__ heads) {
+    __shared__ Fr sh[256];
+    const KateJob &job = jobs[blockIdx.y];
+    Fr h = kate_tile_scan(c, n, (size_t)blockIdx.x * KATE_TILE, job.b, job.pw, sh, Fr::zero(), nullptr);
+    if (threadIdx.x == 0) heads[(size_t)blockIdx.y * (ntiles + 1) + blockIdx.x] = h;
+}
+__global__ __launch_bounds__(256) void fr_kate_carry_multi_kernel(const Fr *__restrict__ heads, Fr *__restrict__ carry, uint32_t ntiles,
+                                                                  const KateJob *__restrict__ jobs) {
+    __shared__ Fr sh[256];
+    const uint32_t tid = threadIdx.x;
+    const Fr *hd = heads + (size_t)blockIdx.x * (ntiles + 1);
+    Fr *cr = carry + (size_t)blockIdx.x * (ntiles + 1);
+    const PowTable &pw = jobs[blockIdx.x].pw;
+    const uint32_t per = (ntiles + 255) / 256, lo = tid * per;
+    const Fr B = pw.p[8];
+    Fr h = Fr::zero();
+    for (int k = (int)per - 1; k >= 0; --k) {
+        h = fe_mul(h, B);
+        if (lo + k < ntiles) h = fe_add(h, hd[lo + k]);
+    }
+    sh[tid] = h;
+    __syncthreads();
+    Fr Y = fe_pow_u64(B, per);
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        Fr o = Fr::zero();
+        if (tid + d < 256) o = sh[tid + d];
+        __syncthreads();
+        if (tid + d < 256) sh[tid] = fe_add(sh[tid], fe_mul(o, Y));
+        Y = fe_sqr(Y);
+        __syncthreads();
+    }
+    Fr car = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
+    for (int k = (int)per - 1; k >= 0; --k) {
+        if (lo + k < ntiles) {
+            cr[lo + k] = car;
+            car = fe_add(hd[lo + k], fe_mul(car, B));
+        }
+    }
+}
+__global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__restrict__ c, size_t n, const KateJob *__restrict__ jobs, uint32_t m,
+                                                                  uint32_t ntiles, const Fr *__restrict__ carry, Fr *__restrict__ q) {
+    __shared__ Fr sh[256];
+    const uint32_t tid = threadIdx.x;
+    const size_t lo = (size_t)blockIdx.x * KATE_TILE, base = lo + (size_t)tid * KATE_J;
+    Fr cv[KATE_J], acc[KATE_J];
+#pragma unroll
+    for (uint32_t k = 0; k < KATE_J; ++k) {
+        cv[k] = base + k < n ? c[base + k] : Fr::zero();
+        acc[k] = Fr::zero();
+    }
+    for (uint32_t j = 0; j < m; ++j) {
+        const Fr b = jobs[j].b, w = jobs[j].w;
+        const PowTable &pw = jobs[j].pw;
+        Fr h = Fr::zero();
+#pragma unroll
+        for (int k = KATE_J - 1; k >= 0; --k) h = fe_add(fe_mul(h, b), cv[k]);   // coefficients past n are zero
+        __syncthreads();   // the previous point's scan has been read
+        sh[tid] = h;
+        __syncthreads();
+        for (uint32_t d = 1, l = 0; d < 256; d <<= 1, ++l) {   // inclusive suffix scan: I_t = h_t + b^J * I_{t+1}
+            Fr o = Fr::zero();
+            if (tid + d < 256) o = sh[tid + d];
+            __syncthreads();
+            if (tid + d < 256) sh[tid] = fe_add(sh[tid], fe_mul(o, pw.p[l]));
+            __syncthreads();
+        }
+        Fr car = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
+        car = fe_add(car, fe_mul(fe_pow_u64(pw.p[0], 255 - tid), carry[(size_t)j * (ntiles + 1) + blockIdx.x]));
+        Fr tmp = car;
+#pragma unroll
+        for (int k = KATE_J - 1; k >= 0; --k) {
+            tmp = fe_add(cv[k], fe_mul(tmp, b));             // = quotient coefficient of index base + k - 1
+            acc[k] = fe_add(acc[k], fe_mul(w, tmp));
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < KATE_J; ++k)
+        if (base + k < n && base + k >= 1) q[base + k - 1] = acc[k];
+}
+
 // ------------------------------------------------------------------ K8: Poseidon permutation batches
 // One lane per instance, textbook rounds (ARK, x^5, MDS) with the caller's spec — algebraically equal to
 // halo2-base's optimised PoseidonState::permutation (reference halo2-base/src/poseidon/hasher/state.rs:35-83,
@@ -744,6 +834,36 @@ int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size
     hipLaunchKernelGGL(fr_kate_apply_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, bv, pw, (const Fr *)carry, (Fr *)q);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+// q[0..n-1) = sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j]),  m <= 8 points; q_dev must not alias coeffs_dev
+int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && points && weights && n >= 1 && coeffs && (n == 1 || q) && m >= 1 && m <= 8, "bad argument (1..8 points)");
+    H2_REQUIRE(q != coeffs, "q must not alias coeffs");
+    if (n == 1) return H2HIP_OK;
+    const uint32_t ntiles = (uint32_t)((n + KATE_TILE - 1) / KATE_TILE);
+    std::vector<KateJob> jobs(m);
+    for (uint32_t j = 0; j < m; ++j) {
+        memcpy(&jobs[j].b, (const char *)points + sizeof(Fr) * j, sizeof(Fr));
+        memcpy(&jobs[j].w, (const char *)weights + sizeof(Fr) * j, sizeof(Fr));
+        pow_table(jobs[j].b, KATE_J, jobs[j].pw);
+    }
+    char *buf = nullptr;
+    const size_t jobs_bytes = (sizeof(KateJob) * m + 255) / 256 * 256;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, jobs_bytes + sizeof(Fr) * 2 * (size_t)m * (ntiles + 1), (void **)&buf));
+    KateJob *djobs = (KateJob *)buf;
+    Fr *heads = (Fr *)(buf + jobs_bytes), *carry = heads + (size_t)m * (ntiles + 1);
+    H2_HIPCHK(hipMemcpyAsync(djobs, jobs.data(), sizeof(KateJob) * m, hipMemcpyHostToDevice, ctx->stream));
+    prof_begin(ctx, "fr_kate_kernels");
+    hipLaunchKernelGGL(fr_kate_heads_multi_kernel, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, ntiles, heads);
+    hipLaunchKernelGGL(fr_kate_carry_multi_kernel, dim3(m), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles, (const KateJob *)djobs);
+    hipLaunchKernelGGL(fr_kate_apply_multi_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, m, ntiles,
+                       (const Fr *)carry, (Fr *)q);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));   // `jobs` is uploaded from pageable memory
     return H2HIP_OK;
 }
 

@@ -502,14 +502,12 @@ static void construct_intermediate_sets(const std::vector<Query> &queries, std::
         rs->evals.push_back(ev);
     }
 }
-// coefficients (low to high) of the polynomial of degree < m through (points[i], evals[i])
-static std::vector<Fr> lagrange_interpolate(const std::vector<Fr> &points, const std::vector<Fr> &evals) {
+// Lagrange basis of a point set: basis[j] = coefficients (low to high) of L_j(X) = prod_{i != j} (X - x_i) / (x_j - x_i).  Computed once
+// per rotation set (its m field inversions are the expensive part on the host), then shared by all polynomials opened on that set.
+static std::vector<std::vector<Fr>> lagrange_basis(const std::vector<Fr> &points, std::vector<Fr> &weights) {
     const size_t m = points.size();
-    std::vector<Fr> out(m, Fr::zero());
-    if (m == 1) {
-        out[0] = evals[0];
-        return out;
-    }
+    std::vector<std::vector<Fr>> basis(m);
+    weights.assign(m, Fr::one());   // weights[j] = 1 / prod_{i != j} (x_j - x_i)
     for (size_t j = 0; j < m; ++j) {
         std::vector<Fr> num(1, Fr::one());
         Fr den = Fr::one();
@@ -523,9 +521,19 @@ static std::vector<Fr> lagrange_interpolate(const std::vector<Fr> &points, const
             num.swap(nxt);
             den = fe_mul(den, fe_sub(points[j], points[i]));
         }
-        Fr scale = fe_mul(evals[j], fe_inv(den));
-        for (size_t t = 0; t < num.size(); ++t) out[t] = fe_add(out[t], fe_mul(num[t], scale));
+        const Fr scale = m == 1 ? Fr::one() : fe_inv(den);
+        weights[j] = scale;
+        for (Fr &c : num) c = fe_mul(c, scale);
+        basis[j] = num;
     }
+    return basis;
+}
+// coefficients (low to high) of the polynomial of degree < m through (points[j], evals[j])
+static std::vector<Fr> lagrange_interpolate(const std::vector<std::vector<Fr>> &basis, const std::vector<Fr> &evals) {
+    const size_t m = basis.size();
+    std::vector<Fr> out(m, Fr::zero());
+    for (size_t j = 0; j < m; ++j)
+        for (size_t t = 0; t < m; ++t) out[t] = fe_add(out[t], fe_mul(basis[j][t], evals[j]));
     return out;
 }
 static Fr eval_small(const std::vector<Fr> &c, const Fr &x) {
@@ -1014,25 +1022,22 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             H2_CHK(sc.take(n, &S[i]));
             low[i].assign(rs.points.size(), Fr::zero());
             Fr ypow = Fr::one();
+            std::vector<Fr> pf_weights;
+            const std::vector<std::vector<Fr>> basis = lagrange_basis(rs.points, pf_weights);
             for (size_t j = 0; j < rs.polys.size(); ++j) {
                 if (j == 0)
                     H2_HIPCHK(hipMemcpyAsync(S[i], polys[rs.polys[j]], sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
                 else
                     H2_CHK(h2hip_fr_axpy_dev(ctx, S[i], &ypow, polys[rs.polys[j]], n));
-                std::vector<Fr> r = lagrange_interpolate(rs.points, rs.evals[j]);
+                std::vector<Fr> r = lagrange_interpolate(basis, rs.evals[j]);
                 for (size_t t = 0; t < r.size(); ++t) low[i][t] = fe_add(low[i][t], fe_mul(ypow, r[t]));
                 ypow = fe_mul(ypow, yq);
             }
-            // (S_i - r_i) / prod (X - point): exact divisions, one root at a time
-            H2_HIPCHK(hipMemcpyAsync(buf_a, S[i], sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
-            H2_CHK(h2hip_fr_sub_low_dev(ctx, buf_a, low[i].data(), (uint32_t)low[i].size()));
-            Fr *cur = buf_a, *oth = buf_b;
-            size_t len = n;
-            for (const Fr &root : rs.points) {
-                H2_CHK(h2hip_fr_kate_division_dev(ctx, oth, cur, len, &root));
-                std::swap(cur, oth);
-                --len;
-            }
+            // (S_i - r_i) / prod_j (X - point_j) = sum_j w_j (S_i(X) - S_i(point_j)) / (X - point_j) (partial fractions; r_i interpolates S_i
+            // on the points by construction): all roots in ONE pass over S_i, no copy and no explicit subtraction of r_i
+            H2_CHK(h2hip_fr_kate_division_multi_dev(ctx, buf_b, S[i], n, rs.points.data(), pf_weights.data(), (uint32_t)rs.points.size()));
+            Fr *cur = buf_b;
+            const size_t len = (size_t)n - 1;   // the coefficients above degree n - 1 - #points come out as zeros
             H2_CHK(h2hip_fr_axpy_dev(ctx, h_x, &vpow, cur, len));
             vpow = fe_mul(vpow, v);
         }

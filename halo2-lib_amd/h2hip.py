@@ -72,6 +72,7 @@ _PROTOS = {
     "h2hip_fr_eval_polynomial_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "h2hip_fr_eval_polynomial_batch_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, _vp]),
     "h2hip_fr_kate_division_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "h2hip_fr_kate_division_multi_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _u32]),
     "h2hip_quotient_flex_gate_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),
     "h2hip_quotient_permutation_set_dev": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp, _vp, _u32, _u32, _u32,
@@ -590,6 +591,17 @@ class Context:
         finally:
             for p in d + [dn, dd]:
                 self.free(p)
+
+    def fr_kate_division_multi(self, coeffs: np.ndarray, points: np.ndarray, weights: np.ndarray) -> np.ndarray:
+        """sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j])"""
+        c, pts, w = _fe(coeffs), _fe(points), _fe(weights)
+        d, q = self.to_device(c), self.malloc(32 * max(len(c) - 1, 1))
+        try:
+            self._chk(self.lib.h2hip_fr_kate_division_multi_dev(self.handle, _vp(q), _vp(d), len(c), _ptr(pts), _ptr(w), len(pts)))
+            return self.download(q, (len(c) - 1, 4))
+        finally:
+            self.free(d)
+            self.free(q)
 
     def quotient_flex_gate(self, acc: np.ndarray, q: np.ndarray, a: np.ndarray, ext_k: int, k: int, y: np.ndarray) -> np.ndarray:
         acc, q, a = _fe(acc), _fe(q), _fe(a)

@@ -203,6 +203,11 @@ int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs
 /* q[0..n-1) = (f(X) - f(b)) / (X - b); q_dev must not alias coeffs_dev */
 int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_dev, size_t n, const void *b);
 
+/* q[0..n-1) = sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j]) for m <= 8 points (host arrays of m elements).  With weights[j] =
+ * 1 / prod_{i != j} (points[j] - points[i]) this is (f(X) - r(X)) / prod_j (X - points[j]), r the interpolant of f on the points: the
+ * quotient of one SHPLONK rotation set in a single pass over f. */
+int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_dev, size_t n, const void *points, const void *weights, uint32_t m);
+
 /* ---- K6: the halo2-base custom gate's term of the quotient numerator on the extended domain:
  *      acc[i] = acc[i]*y + q[i]*(a[i] + a[i+s]*a[i+2s] - a[i+3s]), s = 2^(ext_k-k)
  *      (gate q*(a+b*c-d) at rotations 0..3, reference halo2-base/src/gates/flex_gate/mod.rs:80-91) ----- */

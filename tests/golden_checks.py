@@ -150,3 +150,23 @@ def check_prover_steps(ctx, n, seed=5):
         return acc
 
     assert got == [horner(to_i(p), x) for p, x in zip(polys, points)]
+    # multi-point division: (f - r) / prod (X - b_j) via the weighted sum of kate divisions, against sequential exact divisions
+    if n >= 6:
+        f = to_i(a_)
+        for m in (1, 2, 4):
+            bs = [int(v) for v in g.integers(2, 1 << 62, size=m)]
+            ws = []
+            for j in range(m):
+                d = 1
+                for i in range(m):
+                    if i != j:
+                        d = d * (bs[j] - bs[i]) % R
+                ws.append(O.inv_mod(d, R))
+            want = None
+            for j in range(m):                       # sum_j w_j * kate(f, b_j), big-int
+                qj = O.kate_division(f, bs[j])
+                want = [w_ * ws[j] % R for w_ in qj] if want is None else [(a0 + w_ * ws[j]) % R for a0, w_ in zip(want, qj)]
+            got = to_i(ctx.fr_kate_division_multi(a_, fr(bs), fr(ws)))
+            assert got == want
+            if m > 1:                                # ... and it IS the quotient by the product of the roots: top m-1 coefficients vanish
+                assert got[len(got) - (m - 1):] == [0] * (m - 1)
