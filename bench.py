@@ -585,7 +585,25 @@ def ntt_config3(ctx, torch, dev, modmul_peak):
     inv_ms = ctx.timer_stop() / reps
     alg_bytes = 64.0 * n
     alg_mul = (n / 2) * log_n
+    # the transforms create_proof actually runs at k = 19: lagrange_to_coeff (iNTT 2^19), coeff_to_extended (coset NTT 2^19 -> 2^21),
+    # extended_to_coeff (coset iNTT 2^21)
+    d19, d21 = HP.EvaluationDomain(ctx, 5, 19), None
+    src = torch.from_numpy(synthetic_scalars(1 << 19, 78).view(np.int64)).to(dev)
+    ext = torch.empty((1 << 21) * 4, dtype=torch.int64, device=dev)
+    work = {}
+    for name, fn in (("intt_2_19", lambda: ctx.ifft_dev(src.data_ptr(), d19.omega_inv, 19, d19.ifft_divisor)),
+                     ("coset_ntt_2_19_to_2_21", lambda: ctx.coeff_to_extended_dev(src.data_ptr(), 19, ext.data_ptr(), 21, d19.extended_omega, d19.g_coset)),
+                     ("coset_intt_2_21", lambda: ctx.extended_to_coeff_dev(ext.data_ptr(), 21, d19.extended_omega_inv, d19.extended_ifft_divisor, d19.g_coset_inv))):
+        fn()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        ms = ctx.timer_stop() / reps
+        out_n, lg = (1 << 19, 19) if name == "intt_2_19" else (1 << 21, 21)
+        in_n = 1 << 19 if name != "coset_intt_2_21" else 1 << 21
+        work[name] = {"ms": ms, "hbm_frac": 32.0 * (in_n + out_n) / (ms * 1e-3) / 8e12, "int_frac": (out_n / 2) * lg / (ms * 1e-3) / modmul_peak}
     return {"workload": "BASELINE configs[2]: 2^22-length radix-2 NTT and iNTT over F_r, data resident in HBM", "ntt_ms": fwd_ms, "intt_ms": inv_ms,
+            "k19_workhorses": work,
             "roundtrip_bit_exact": roundtrip_ok, "passes": int(k_cnt // reps), "avg_pass_kernel_ms": k_ms / max(k_cnt, 1),
             "roofline": {"bound": "hbm", "kernel": "ntt_pass_kernel (3 launches per transform)", "achieved": alg_bytes / (fwd_ms * 1e-3) / 1e9, "peak": 8000.0,
                          "unit": "GB/s", "frac": alg_bytes / (fwd_ms * 1e-3) / 8e12, "algorithmic_bytes_per_transform": alg_bytes},

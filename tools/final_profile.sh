@@ -16,7 +16,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py --no-cpu-baseline --no-replay --steps 64 > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- python $REPO/bench.py --no-cpu-baseline --no-replay --steps 8 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- python $REPO/bench.py --no-cpu-baseline --no-replay --steps 8 > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ptrace -o t -- python $REPO/tools/prove_time.py 19 1 1 1 0 18 4 > $OUT/prove_time.log 2>&1
 cd $REPO
+python tools/rocprof_proof.py $(find $OUT/ptrace -name "*.db" | head -1) > $OUT/create_proof_kernels.md 2>&1
+rm -rf $OUT/ptrace
 python tools/rocprof_summary.py $(ls $OUT/trace/*.db | head -1) > $OUT/kernel_trace.md 2>&1
 python tools/rocprof_pmc.py $(ls $OUT/pmc_fetch/*.db | head -1) $(ls $OUT/pmc_write/*.db | head -1) $OUT/pmc_hbm.md $OUT/pmc_hbm.json > /dev/null 2>&1
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
