@@ -13,15 +13,9 @@ def main():
     cur = db.cursor()
     rows = cur.execute("select name, start, end from kernels order by start").fetchall()
     rows = [(n.split("(")[0].replace("void ", "").replace("h2::", ""), s, e) for n, s, e in rows]
-    idx = [i for i, r in enumerate(rows) if "lk_keys_kernel" in r[0]]
-    # the proofs of prove_time.py: consecutive lk_keys occurrences come in pairs (input, table); the last proof starts at the pair's first
-    last = idx[-2]
-    # walk back to the advice commitment's first kernel: the proof's first kernels are msm_digits of the advice MSM, preceded by a host gap
-    i = last
-    while i > 0 and rows[i][1] - rows[i - 1][2] < 300e3 * 1 and i > last - 60:
-        i -= 1
-    # refine: first msm_digits_kernel at or after i
-    first = next(j for j in range(i, last) if "msm_digits" in rows[j][0]) if any("msm_digits" in rows[j][0] for j in range(i, last)) else i
+    # a proof's first kernel is the q_lookup * advice product (fr_binop_kernel<2>) right before the lookup's key extraction (lk_keys_kernel)
+    last_keys = max(i for i, r in enumerate(rows) if "lk_keys_kernel" in r[0])
+    first = max(i for i, r in enumerate(rows[:last_keys]) if "fr_binop_kernel<2>" in r[0])
     sel = rows[first:]
     t0, t1 = sel[0][1], max(r[2] for r in sel)
     agg = {}
