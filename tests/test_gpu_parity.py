@@ -313,3 +313,49 @@ def test_prover_steps(ctx, n):
     from tests.golden_checks import check_prover_steps
 
     check_prover_steps(ctx, n)
+
+
+@pytest.mark.gpu
+def test_two_contexts_interleaved_and_second_thread(ctx):
+    """Two contexts (own streams, scratch and twiddle caches) used alternately and one of them from a second host thread — the C ABI's
+    contract is one thread at a time PER CONTEXT; every entry point makes its context's device current (H2_DEVICE_GUARD).  With more than
+    one GPU visible the second context sits on the last device."""
+    import threading
+
+    ndev = ctx.lib.h2hip_device_count
+    cnt = __import__("ctypes").c_int(0)
+    assert ndev(__import__("ctypes").byref(cnt)) == 0 and cnt.value >= 1
+    other = H.Context(device=cnt.value - 1)
+    try:
+        log_n, n = 14, 1 << 12
+        a = rand_fr(1 << log_n, 91)
+        w, _, _ = domain_consts(log_n)
+        bases = CO.known_dlog_bases(n, fr([4242]), fr([11]))
+        s = rand_fr(n, 92)
+        want_ntt, want_msm = CO.best_fft(a, log_n, w, threads=NT), CO.best_multiexp(s, bases, threads=NT)
+        b_main, b_other = ctx.bases_upload(bases), other.bases_upload(bases, 1)
+        out = {}
+
+        def worker():
+            try:
+                for _ in range(6):
+                    out["msm"] = other.msm(b_other, s, H.POINT_AFFINE)
+                    out["ntt"] = other.best_fft(a, w, log_n)
+            except Exception as e:   # surfaced by the assertion below
+                out["err"] = e
+
+        t = threading.Thread(target=worker)
+        t.start()
+        for _ in range(6):   # the main thread keeps the first context busy meanwhile, alternating entry points
+            assert np.array_equal(ctx.best_fft(a, w, log_n), want_ntt)
+            assert np.array_equal(ctx.msm(b_main, s, H.POINT_AFFINE), want_msm)
+        t.join()
+        assert "err" not in out, out.get("err")
+        assert np.array_equal(out["msm"], want_msm) and np.array_equal(out["ntt"], want_ntt)
+        # and strictly interleaved from one thread
+        for c, b in ((ctx, b_main), (other, b_other), (ctx, b_main)):
+            assert np.array_equal(c.msm(b, s, H.POINT_AFFINE), want_msm)
+        b_main.free()
+        b_other.free()
+    finally:
+        other.close()
