@@ -493,10 +493,21 @@ def create_proof_k19_sharded(ctx, dist, device, reps: int = 5):
         mul = staticmethod(ctx.fr_mul)
         add = staticmethod(ctx.fr_add)
 
-    circ = T.build_circuit(_ShapeView(bp, sh), 19, Backend)
-    pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
-    sk = shard_proving_key(pk, ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange), device=device, precompute=True)
-    draws = synthetic_scalars((1 << k) + 4096, 4242)
+    # set-up without collectives; the ranks then agree that all of them got through it before the first sharded proof (a rank that failed
+    # here would leave the others waiting in the proof's all-gathers)
+    err = None
+    try:
+        circ = T.build_circuit(_ShapeView(bp, sh), 19, Backend)
+        pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
+        g_pts, gl_pts = ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange)
+        draws = synthetic_scalars((1 << k) + 4096, 4242)
+    except Exception as e:
+        err = repr(e)
+    oks = [None] * dist.get_world_size()
+    dist.all_gather_object(oks, err)
+    if any(o is not None for o in oks):
+        raise RuntimeError("sharded create_proof set-up failed on some rank: %r" % (oks,))
+    sk = shard_proving_key(pk, g_pts, gl_pts, device=device, precompute=True)
     proof = PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))
     dist.barrier()
     t0 = time.perf_counter()

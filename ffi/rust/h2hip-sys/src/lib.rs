@@ -79,6 +79,8 @@ extern "C" {
     pub fn h2hip_free(ctx: *mut h2hip_ctx, dptr: *mut c_void) -> c_int;
     pub fn h2hip_upload(ctx: *mut h2hip_ctx, dst_dev: *mut c_void, src_host: *const c_void, bytes: usize) -> c_int;
     pub fn h2hip_download(ctx: *mut h2hip_ctx, dst_host: *mut c_void, src_dev: *const c_void, bytes: usize) -> c_int;
+    pub fn h2hip_host_register(ctx: *mut h2hip_ctx, host_ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn h2hip_host_unregister(ctx: *mut h2hip_ctx, host_ptr: *mut c_void) -> c_int;
     // K1 — arithmetic::best_multiexp / ParamsKZG::{commit, commit_lagrange}
     pub fn h2hip_bases_upload(ctx: *mut h2hip_ctx, g1_affine_host: *const c_void, n: usize, flags: u32, out: *mut *mut h2hip_bases) -> c_int;
     pub fn h2hip_bases_from_device(ctx: *mut h2hip_ctx, g1_affine_dev: *const c_void, n: usize, flags: u32, out: *mut *mut h2hip_bases) -> c_int;

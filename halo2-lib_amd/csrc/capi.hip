@@ -290,6 +290,20 @@ int h2hip_free(h2hip_ctx *ctx, void *dptr) {
     H2_HIPCHK(hipFree(dptr));
     return H2HIP_OK;
 }
+// Page-locks a caller-owned host buffer (e.g. the Vec<Fr> columns a prover re-uses across proofs): uploads from it then run on the DMA
+// engines asynchronously instead of through the runtime's pageable staging copies.
+int h2hip_host_register(h2hip_ctx *ctx, void *host_ptr, size_t bytes) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && host_ptr && bytes, "NULL argument");
+    H2_HIPCHK(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return H2HIP_OK;
+}
+int h2hip_host_unregister(h2hip_ctx *ctx, void *host_ptr) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && host_ptr, "NULL argument");
+    H2_HIPCHK(hipHostUnregister(host_ptr));
+    return H2HIP_OK;
+}
 int h2hip_upload(h2hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (bytes == 0 || (dst_dev && src_host)), "NULL argument");

@@ -32,6 +32,8 @@ _PROTOS = {
     "h2hip_free": (_int, [_vp, _vp]),
     "h2hip_upload": (_int, [_vp, _vp, _vp, _sz]),
     "h2hip_download": (_int, [_vp, _vp, _vp, _sz]),
+    "h2hip_host_register": (_int, [_vp, _vp, _sz]),
+    "h2hip_host_unregister": (_int, [_vp, _vp]),
     "h2hip_profile_enable": (_int, [_vp, _int]),
     "h2hip_profile_reset": (_int, [_vp]),
     "h2hip_profile_get_busy": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
@@ -243,6 +245,13 @@ class Context:
     def upload(self, dptr: int, host: np.ndarray):
         host = np.ascontiguousarray(host)
         self._chk(self.lib.h2hip_upload(self.handle, _vp(dptr), _ptr(host), host.nbytes))
+
+    def host_register(self, arr: np.ndarray):
+        """page-lock a numpy array that will be uploaded repeatedly (keep the array alive until host_unregister)"""
+        self._chk(self.lib.h2hip_host_register(self.handle, _ptr(arr), arr.nbytes))
+
+    def host_unregister(self, arr: np.ndarray):
+        self._chk(self.lib.h2hip_host_unregister(self.handle, _ptr(arr)))
 
     def to_device(self, host: np.ndarray) -> int:
         host = np.ascontiguousarray(host)

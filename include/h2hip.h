@@ -66,6 +66,10 @@ int h2hip_malloc(h2hip_ctx *ctx, size_t bytes, void **dptr);
 int h2hip_free(h2hip_ctx *ctx, void *dptr);
 int h2hip_upload(h2hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* synchronous */
 int h2hip_download(h2hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* synchronous */
+/* page-lock / release a caller-owned host buffer (a prover's long-lived Vec<Fr> columns): transfers from registered memory are true
+ * asynchronous DMA; unregistered (pageable) buffers work everywhere too, through the runtime's staging copies */
+int h2hip_host_register(h2hip_ctx *ctx, void *host_ptr, size_t bytes);
+int h2hip_host_unregister(h2hip_ctx *ctx, void *host_ptr);
 
 /* ---- per-kernel timing (HIP events on the context's stream around every launch) ------------------- */
 int h2hip_profile_enable(h2hip_ctx *ctx, int on);

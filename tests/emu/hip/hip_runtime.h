@@ -227,6 +227,9 @@ template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMall
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+enum { hipHostRegisterDefault = 0 };
+inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }

@@ -13,7 +13,7 @@ from halo2_lib_amd import halo2_proofs as HP
 from halo2_lib_amd import plonk as PL
 from halo2_lib_amd import testing as T
 
-a = [int(v) for v in sys.argv[1:]]
+a = [int(v) for v in sys.argv[1:] if not v.startswith('--')]
 k, na, nl, nf, ni, lb, reps = (a + [19, 1, 1, 1, 0, 18, 5][len(a):])[:7]
 ctx = H.Context()
 
@@ -53,6 +53,9 @@ n = 1 << k
 g = np.random.default_rng(1)
 vals = g.integers(0, 2**63, size=(n + 4096, 4), dtype=np.uint64)
 vals[:, 3] &= np.uint64((1 << 60) - 1)
+if "--register" in sys.argv:   # page-lock the advice columns (a prover keeps them across proofs)
+    for c in circ.advice:
+        ctx.host_register(c)
 for rep in range(reps):
     tm = {}
     t = time.time()
