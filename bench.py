@@ -455,12 +455,16 @@ def create_proof_k19(ctx, with_cpu_baseline: bool, reps: int = 10):
     seconds = (time.perf_counter() - t0) / reps
     stages = {}
     PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws), stages)    # per-stage laps (adds a stream sync per stage)
+    t0 = time.perf_counter()
+    verified = PL.verify_proof(pk, circ.instances, proof)     # libh2hip's own verifier (host code): the reference's check_proof
+    verify_s = time.perf_counter() - t0
     cells = 4 * (sh.usable_rows // 4)    # assigned advice cells: `constraints` of SURVEY.md §8d (total_advice of the circuit)
     out = {"what": "h2hip_plonk_create_proof, k=19 ECDSA configuration (bench_ecdsa.config:1), synthetic circuit-like witness; wall clock incl. "
                    "host staging of the advice column (16 MiB) and of the RNG-drawn scalars (16 MiB); witness generation (CPU gadgets) excluded",
            "seconds": seconds, "reps": reps, "proof_bytes": len(proof), "constraints": cells, "constraints_per_sec": cells / seconds,
            "msm_count": sh.num_commitments, "msm_size": n, "extended_k": sh.extended_k, "degree": sh.degree,
            "stage_ms": {k_: round(v, 3) for k_, v in stages.items()}, "stage_ms_sum": round(sum(stages.values()), 3), "keygen_seconds": keygen_s,
+           "verified_by_h2hip_plonk_verify_proof": bool(verified), "verify_seconds": verify_s,
            "reference_published_total_proof_time_s": 7.6,
            "reference_source": "/root/reference/README.md:242 (32 vCPU r6a / M2 Max, end-to-end incl. witness generation; other hardware)"}
     if with_cpu_baseline:

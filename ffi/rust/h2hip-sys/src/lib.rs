@@ -166,6 +166,10 @@ extern "C" {
     pub fn h2hip_lookup_table_sort_dev(ctx: *mut h2hip_ctx, s_dev: *const c_void, usable_rows: usize, sorted_out_dev: *mut c_void) -> c_int;
     pub fn h2hip_lookup_permute_presorted_dev(ctx: *mut h2hip_ctx, a_dev: *const c_void, sorted_table_dev: *const c_void, usable_rows: usize,
                                               a_perm_dev: *mut c_void, s_perm_dev: *mut c_void) -> c_int;
+    pub fn h2hip_plonk_verify_proof(params: *const h2hip_base_circuit_params, fixed_commitments: *const c_void, permutation_commitments: *const c_void,
+                                    transcript_repr: *const c_void, g1: *const c_void, g2: *const c_void, s_g2: *const c_void,
+                                    instances_host: *const *const c_void, instance_lens: *const usize, proof: *const u8, proof_len: usize,
+                                    accepted: *mut c_int) -> c_int;
     // timing / diagnostics
     pub fn h2hip_profile_enable(ctx: *mut h2hip_ctx, on: c_int) -> c_int;
     pub fn h2hip_profile_reset(ctx: *mut h2hip_ctx) -> c_int;

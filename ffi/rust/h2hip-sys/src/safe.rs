@@ -304,6 +304,21 @@ impl<'b> ProvingKeyHip<'b> {
         Ok(proof)
     }
 }
+/// `verify_proof(params, vk, SingleStrategy::new(params), &[instances], &mut Blake2bRead::init(proof))` (check_proof,
+/// halo2-base/src/utils/testing.rs:64-88): `g1` = params.get_g()[0], `g2` / `s_g2` = the verifier half of the SRS in RawBytes form.
+pub fn verify_proof(params: h2hip_base_circuit_params, fixed_commitments: &[G1Affine], permutation_commitments: &[G1Affine], transcript_repr: Fr,
+                    g1: G1Affine, g2: &[u8; 128], s_g2: &[u8; 128], instances: &[&[Fr]], proof: &[u8]) -> Result<bool, HipError> {
+    let ins: Vec<*const c_void> = instances.iter().map(|c| c.as_ptr().cast()).collect();
+    let lens: Vec<usize> = instances.iter().map(|c| c.len()).collect();
+    let mut ok: c_int = 0;
+    check(unsafe {
+        h2hip_plonk_verify_proof(&params, fixed_commitments.as_ptr().cast(), permutation_commitments.as_ptr().cast(), fr_ptr(&transcript_repr),
+                                 (&g1 as *const G1Affine).cast(), g2.as_ptr().cast(), s_g2.as_ptr().cast(), ins.as_ptr(), lens.as_ptr(), proof.as_ptr(),
+                                 proof.len(), &mut ok)
+    })?;
+    Ok(ok != 0)
+}
+
 impl Drop for ProvingKeyHip<'_> {
     fn drop(&mut self) {
         unsafe { h2hip_plonk_pk_free(self.be.ctx, self.pk) }

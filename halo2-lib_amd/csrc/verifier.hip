@@ -1,0 +1,645 @@
+// verify_proof for halo2-base circuits — the check the reference runs after every proof it creates
+// (halo2-base/src/utils/testing.rs:64-88: verify_proof::<KZGCommitmentScheme<Bn256>, VerifierSHPLONK<_>, Challenge255<_>, Blake2bRead<_, _, _>,
+// SingleStrategy<_>>).  Host code (the reference verifies on the CPU as well): Blake2b transcript replay, the quotient identity rebuilt from the
+// openings, SHPLONK's folded opening and ONE pairing check e(h2, s*g2) == e(right, g2).  [UPSTREAM-RECALL for the protocol order, like
+// plonk.hip.]  The pairing is the plain ate pairing f_{t-1,Q}(P)^((q^12-1)/r) over the tower Fq2 = Fq[u]/(u^2+1), Fq6 = Fq2[v]/(v^3 - (9+u)),
+// Fq12 = Fq6[w]/(w^2 - v) — any non-degenerate pairing decides e(L, sQ) == e(R, Q), which is all a KZG verifier needs.
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "blake2b.h"
+#include "internal.h"
+
+namespace h2 {
+namespace verifier {
+
+// ---------------------------------------------------------------------------------------------- tower arithmetic (host)
+struct F2 {
+    Fq c0, c1;
+};
+static F2 f2_zero() { return {Fq::zero(), Fq::zero()}; }
+static F2 f2_one() { return {Fq::one(), Fq::zero()}; }
+static bool f2_eq(const F2 &a, const F2 &b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+static bool f2_is_zero(const F2 &a) { return a.c0.is_zero() && a.c1.is_zero(); }
+static F2 f2_add(const F2 &a, const F2 &b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
+static F2 f2_sub(const F2 &a, const F2 &b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
+static F2 f2_neg(const F2 &a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
+static F2 f2_mul(const F2 &a, const F2 &b) {
+    Fq t0 = fe_mul(a.c0, b.c0), t1 = fe_mul(a.c1, b.c1);
+    return {fe_sub(t0, t1), fe_sub(fe_sub(fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1)), t0), t1)};
+}
+static F2 f2_sqr(const F2 &a) { return {fe_mul(fe_add(a.c0, a.c1), fe_sub(a.c0, a.c1)), fe_dbl(fe_mul(a.c0, a.c1))}; }
+static F2 f2_scal(const F2 &a, const Fq &k) { return {fe_mul(a.c0, k), fe_mul(a.c1, k)}; }
+static F2 f2_inv(const F2 &a) {
+    Fq d = fe_inv(fe_add(fe_sqr(a.c0), fe_sqr(a.c1)));
+    return {fe_mul(a.c0, d), fe_neg(fe_mul(a.c1, d))};
+}
+static Fq fq_small(uint32_t v) {
+    Fq a = Fq::zero();
+    a.l[0] = v;
+    return fe_to_mont(a);
+}
+static F2 f2_mul_xi(const F2 &a) {   // * (9 + u)
+    const Fq nine = fq_small(9);
+    return {fe_sub(fe_mul(a.c0, nine), a.c1), fe_add(a.c0, fe_mul(a.c1, nine))};
+}
+struct F6 {
+    F2 c0, c1, c2;
+};
+static F6 f6_zero() { return {f2_zero(), f2_zero(), f2_zero()}; }
+static F6 f6_one() { return {f2_one(), f2_zero(), f2_zero()}; }
+static F6 f6_add(const F6 &a, const F6 &b) { return {f2_add(a.c0, b.c0), f2_add(a.c1, b.c1), f2_add(a.c2, b.c2)}; }
+static F6 f6_sub(const F6 &a, const F6 &b) { return {f2_sub(a.c0, b.c0), f2_sub(a.c1, b.c1), f2_sub(a.c2, b.c2)}; }
+static F6 f6_neg(const F6 &a) { return {f2_neg(a.c0), f2_neg(a.c1), f2_neg(a.c2)}; }
+static F6 f6_mul(const F6 &a, const F6 &b) {
+    F2 t0 = f2_mul(a.c0, b.c0), t1 = f2_mul(a.c1, b.c1), t2 = f2_mul(a.c2, b.c2);
+    F6 r;
+    r.c0 = f2_add(t0, f2_mul_xi(f2_sub(f2_sub(f2_mul(f2_add(a.c1, a.c2), f2_add(b.c1, b.c2)), t1), t2)));
+    r.c1 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c1), f2_add(b.c0, b.c1)), t0), t1), f2_mul_xi(t2));
+    r.c2 = f2_add(f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c2), f2_add(b.c0, b.c2)), t0), t2), t1);
+    return r;
+}
+static F6 f6_mul_v(const F6 &a) { return {f2_mul_xi(a.c2), a.c0, a.c1}; }
+static F6 f6_inv(const F6 &a) {
+    F2 c0 = f2_sub(f2_sqr(a.c0), f2_mul_xi(f2_mul(a.c1, a.c2)));
+    F2 c1 = f2_sub(f2_mul_xi(f2_sqr(a.c2)), f2_mul(a.c0, a.c1));
+    F2 c2 = f2_sub(f2_sqr(a.c1), f2_mul(a.c0, a.c2));
+    F2 t = f2_inv(f2_add(f2_mul(a.c0, c0), f2_mul_xi(f2_add(f2_mul(a.c2, c1), f2_mul(a.c1, c2)))));
+    return {f2_mul(c0, t), f2_mul(c1, t), f2_mul(c2, t)};
+}
+struct F12 {
+    F6 c0, c1;
+};
+static F12 f12_one() { return {f6_one(), f6_zero()}; }
+static F12 f12_mul(const F12 &a, const F12 &b) {
+    F6 t0 = f6_mul(a.c0, b.c0), t1 = f6_mul(a.c1, b.c1);
+    return {f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1)), t0), t1)};
+}
+static F12 f12_inv(const F12 &a) {
+    F6 t = f6_inv(f6_sub(f6_mul(a.c0, a.c0), f6_mul_v(f6_mul(a.c1, a.c1))));
+    return {f6_mul(a.c0, t), f6_neg(f6_mul(a.c1, t))};
+}
+static bool f12_is_one(const F12 &a) {
+    const F12 o = f12_one();
+    return f2_eq(a.c0.c0, o.c0.c0) && f2_is_zero(a.c0.c1) && f2_is_zero(a.c0.c2) && f2_is_zero(a.c1.c0) && f2_is_zero(a.c1.c1) && f2_is_zero(a.c1.c2);
+}
+
+// ---------------------------------------------------------------------------------------------- G2 (affine over Fq2) and the ate pairing
+struct G2A {
+    F2 x, y;
+    bool inf;
+};
+static G2A g2_add(const G2A &A, const G2A &B) {
+    if (A.inf) return B;
+    if (B.inf) return A;
+    F2 lam;
+    if (f2_eq(A.x, B.x)) {
+        if (f2_is_zero(f2_add(A.y, B.y))) return {f2_zero(), f2_zero(), true};
+        F2 x2 = f2_sqr(A.x);
+        lam = f2_mul(f2_add(f2_add(x2, x2), x2), f2_inv(f2_add(A.y, A.y)));
+    } else {
+        lam = f2_mul(f2_sub(B.y, A.y), f2_inv(f2_sub(B.x, A.x)));
+    }
+    F2 x3 = f2_sub(f2_sub(f2_sqr(lam), A.x), B.x);
+    return {x3, f2_sub(f2_mul(lam, f2_sub(A.x, x3)), A.y), false};
+}
+static bool g2_on_curve(const G2A &Q) {
+    if (Q.inf) return true;
+    F2 b = f2_mul({fq_small(3), Fq::zero()}, f2_inv({fq_small(9), Fq::one()}));   // 3 / (9 + u): the D-twist's constant
+    return f2_eq(f2_sqr(Q.y), f2_add(f2_mul(f2_sqr(Q.x), Q.x), b));
+}
+// line through T with twist-slope lam, evaluated at the G1 point (xP, yP) after untwisting: yP - lam*xP*w + (lam*xT - yT)*w^3
+static F12 line_eval(const G2A &T, const F2 &lam, const Fq &xP, const Fq &yP) {
+    F12 l;
+    l.c0 = {{yP, Fq::zero()}, f2_zero(), f2_zero()};
+    l.c1 = {f2_neg(f2_scal(lam, xP)), f2_sub(f2_mul(lam, T.x), T.y), f2_zero()};
+    return l;
+}
+static const uint64_t ATE_LOOP[2] = {0xf83e9682e87cfd46ULL, 0x6f4d8248eeb859fbULL};   // t - 1 = 6x^2, x = 4965661367192848881
+static F12 miller_loop(const G1Affine &P, const G2A &Q) {
+    if (P.is_identity() || Q.inf) return f12_one();
+    F12 f = f12_one();
+    G2A T = Q;
+    for (int bit = 125; bit >= 0; --bit) {   // 127 bits: the top one starts T = Q
+        F2 x2 = f2_sqr(T.x);
+        F2 lam = f2_mul(f2_add(f2_add(x2, x2), x2), f2_inv(f2_add(T.y, T.y)));
+        f = f12_mul(f12_mul(f, f), line_eval(T, lam, P.x, P.y));
+        T = g2_add(T, T);
+        if ((ATE_LOOP[bit >> 6] >> (bit & 63)) & 1) {
+            if (f2_eq(T.x, Q.x)) {   // T = -Q: only at the very end of a loop over a multiple of the order
+                T = g2_add(T, Q);
+                continue;
+            }
+            lam = f2_mul(f2_sub(Q.y, T.y), f2_inv(f2_sub(Q.x, T.x)));
+            f = f12_mul(f, line_eval(T, lam, P.x, P.y));
+            T = g2_add(T, Q);
+        }
+    }
+    return f;
+}
+// (q^6 + 1) / r, little-endian 64-bit words: the part of the final exponent left after f -> conj(f) / f  (= f^(q^6 - 1))
+static const uint64_t HARD_EXP[20] = {
+    0x5250a54036e3f812ULL, 0xa5635f1596789051ULL, 0xd1138bf54d5bd1d4ULL, 0xa8ce2533be36c7a2ULL,
+    0x94f69f6b84e09bf6ULL, 0x42ad1f5e50ef3644ULL, 0x0fcc420e48c3454cULL, 0x758e4408ecc9952cULL,
+    0xc901bf1887c6042cULL, 0xa733cd65b14bb3b5ULL, 0xdf6d76bdcf51b0d8ULL, 0xca64c0fd82eb59e1ULL,
+    0x1d2e5726e39276a1ULL, 0xc2d1ea74a391cae9ULL, 0x07409206c82d647eULL, 0x051c6d1aa5afdd17ULL,
+    0xb37f601919667af5ULL, 0x150e578c5084015bULL, 0xfbdea556c23998e4ULL, 0x000fd14cc52f5b83ULL};
+static F12 final_exponentiation(const F12 &f) {
+    F12 conj = {f.c0, f6_neg(f.c1)};
+    F12 g = f12_mul(conj, f12_inv(f));
+    F12 r = f12_one();
+    bool started = false;
+    for (int bit = 20 * 64 - 1; bit >= 0; --bit) {
+        if (started) r = f12_mul(r, r);
+        if ((HARD_EXP[bit >> 6] >> (bit & 63)) & 1) {
+            r = started ? f12_mul(r, g) : g;
+            started = true;
+        }
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------- G1 on the host
+static XYZZ g1_scalar_mul(const G1Affine &p, const Fr &k_mont) {
+    XYZZ acc = XYZZ::identity();
+    if (p.is_identity()) return acc;
+    const Fr k = fe_from_mont(k_mont);
+    bool started = false;
+    for (int bit = 255; bit >= 0; --bit) {
+        if (started) acc = xyzz_double(acc);
+        if ((k.l[bit >> 5] >> (bit & 31)) & 1u) {
+            xyzz_add_affine(acc, p.x, p.y);
+            started = true;
+        }
+    }
+    return acc;
+}
+static G1Affine g1_neg(const G1Affine &p) {
+    G1Affine r = p;
+    if (!p.is_identity()) r.y = fe_neg(p.y);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------- transcript (Blake2bRead)
+static const unsigned SIGN_BIT = 6, INF_BIT = 7;
+static void fr_repr(const Fr &a, uint8_t out[32]) {
+    Fr c = fe_from_mont(a);
+    memcpy(out, c.l, 32);
+}
+static Fr fr_from_uniform_bytes(const uint8_t b[64]) {
+    Fr d0, d1;
+    memcpy(d0.l, b, 32);
+    memcpy(d1.l, b + 32, 32);
+    const Fr r2 = Fr::r2(), r3 = fe_mul(r2, r2);
+    return fe_add(fe_mul(d0, r2), fe_mul(d1, r3));
+}
+template <class P>
+static bool canonical(const Fe<P> &a) {
+    unsigned br = 0;
+    for (int j = 0; j < 8; ++j) subb32(a.l[j], P::m(j), br);
+    return br != 0;
+}
+struct Reader {
+    Blake2b st;
+    const uint8_t *p;
+    size_t len, pos = 0;
+    bool ok = true;
+    Reader(const uint8_t *proof, size_t n) : st(64, "Halo2-Transcript"), p(proof), len(n) {}
+    void common_scalar(const Fr &s) {
+        uint8_t b[33];
+        b[0] = 0x02;
+        fr_repr(s, b + 1);
+        st.update(b, 33);
+    }
+    Fr read_scalar() {
+        Fr c = Fr::zero();
+        if (pos + 32 > len) {
+            ok = false;
+            return c;
+        }
+        memcpy(c.l, p + pos, 32);
+        pos += 32;
+        if (!canonical(c)) {
+            ok = false;
+            return Fr::zero();
+        }
+        Fr m = fe_to_mont(c);
+        common_scalar(m);
+        return m;
+    }
+    G1Affine read_point() {
+        G1Affine r;
+        r.x = Fq::zero();
+        r.y = Fq::zero();
+        if (pos + 32 > len) {
+            ok = false;
+            return r;
+        }
+        Fq x;
+        memcpy(x.l, p + pos, 32);
+        pos += 32;
+        const uint32_t top = x.l[7] >> 24;
+        const bool inf = (top >> INF_BIT) & 1u, sign = (top >> SIGN_BIT) & 1u;
+        x.l[7] &= ~(((1u << SIGN_BIT) | (1u << INF_BIT)) << 24);
+        if (inf || !canonical(x)) {   // a prover cannot have written the identity (Blake2bWrite refuses it)
+            ok = false;
+            return r;
+        }
+        const Fq xm = fe_to_mont(x);
+        const Fq y2 = fe_add(fe_mul(fe_sqr(xm), xm), fq_small(3));
+        uint32_t e[8];   // (q + 1) / 4
+        {
+            uint64_t carry = 1;
+            uint32_t t[8];
+            for (int j = 0; j < 8; ++j) {
+                uint64_t v = (uint64_t)FqP::m(j) + carry;
+                t[j] = (uint32_t)v;
+                carry = v >> 32;
+            }
+            for (int j = 0; j < 8; ++j) e[j] = (t[j] >> 2) | (j < 7 ? t[j + 1] << 30 : 0u);
+        }
+        Fq y = fe_pow(y2, e);
+        if (!(fe_sqr(y) == y2)) {
+            ok = false;
+            return r;
+        }
+        if ((fe_from_mont(y).l[0] & 1u) != (sign ? 1u : 0u)) y = fe_neg(y);
+        r.x = xm;
+        r.y = y;
+        uint8_t b[65];
+        b[0] = 0x01;
+        Fq cx = fe_from_mont(r.x), cy = fe_from_mont(r.y);
+        memcpy(b + 1, cx.l, 32);
+        memcpy(b + 33, cy.l, 32);
+        st.update(b, 65);
+        return r;
+    }
+    Fr squeeze_challenge() {
+        uint8_t z = 0x00, d[64];
+        st.update(&z, 1);
+        st.digest(d);
+        return fr_from_uniform_bytes(d);
+    }
+};
+
+static int fr_cmp(const Fr &a, const Fr &b) {
+    Fr x = fe_from_mont(a), y = fe_from_mont(b);
+    for (int i = 7; i >= 0; --i)
+        if (x.l[i] != y.l[i]) return x.l[i] < y.l[i] ? -1 : 1;
+    return 0;
+}
+
+}  // namespace verifier
+}  // namespace h2
+
+using namespace h2;
+using namespace h2::verifier;
+
+namespace {
+
+struct VQuery {
+    int key;   // index into the commitment list
+    Fr point, eval;
+};
+struct VSet {
+    std::vector<Fr> points;
+    std::vector<int> keys;
+    std::vector<std::vector<Fr>> evals;
+};
+// the same grouping the prover performs (poly/kzg/multiopen/shplonk.rs::construct_intermediate_sets [UPSTREAM-RECALL])
+void intermediate_sets(const std::vector<VQuery> &queries, std::vector<VSet> &sets, std::vector<Fr> &super_points) {
+    auto less = [](const Fr &a, const Fr &b) { return fr_cmp(a, b) < 0; };
+    std::vector<Fr> pts;
+    for (auto &q : queries) pts.push_back(q.point);
+    std::sort(pts.begin(), pts.end(), less);
+    super_points.clear();
+    for (auto &p : pts)
+        if (super_points.empty() || fr_cmp(super_points.back(), p) != 0) super_points.push_back(p);
+    std::vector<int> order;
+    std::map<int, std::vector<Fr>> pset;
+    for (auto &q : queries) {
+        auto it = pset.find(q.key);
+        if (it == pset.end()) {
+            order.push_back(q.key);
+            pset[q.key] = {q.point};
+        } else {
+            bool have = false;
+            for (auto &p : it->second) have |= fr_cmp(p, q.point) == 0;
+            if (!have) it->second.push_back(q.point);
+        }
+    }
+    for (auto &kv : pset) std::sort(kv.second.begin(), kv.second.end(), less);
+    sets.clear();
+    for (int key : order) {
+        const std::vector<Fr> &ps = pset[key];
+        VSet *vs = nullptr;
+        for (auto &s : sets) {
+            bool same = s.points.size() == ps.size();
+            for (size_t i = 0; same && i < ps.size(); ++i) same = fr_cmp(s.points[i], ps[i]) == 0;
+            if (same) vs = &s;
+        }
+        if (!vs) {
+            sets.push_back(VSet());
+            vs = &sets.back();
+            vs->points = ps;
+        }
+        vs->keys.push_back(key);
+        std::vector<Fr> ev;
+        for (auto &p : ps)
+            for (auto &q : queries)
+                if (q.key == key && fr_cmp(q.point, p) == 0) {
+                    ev.push_back(q.eval);
+                    break;
+                }
+        vs->evals.push_back(ev);
+    }
+}
+// value at u of the polynomial of degree < m through (points[i], evals[i])
+Fr interpolate_at(const std::vector<Fr> &points, const std::vector<Fr> &evals, const Fr &u) {
+    Fr acc = Fr::zero();
+    for (size_t j = 0; j < points.size(); ++j) {
+        Fr num = Fr::one(), den = Fr::one();
+        for (size_t i = 0; i < points.size(); ++i) {
+            if (i == j) continue;
+            num = fe_mul(num, fe_sub(u, points[i]));
+            den = fe_mul(den, fe_sub(points[j], points[i]));
+        }
+        acc = fe_add(acc, fe_mul(evals[j], fe_mul(num, fe_inv(den))));
+    }
+    return acc;
+}
+Fr fr_u64(uint64_t v) {
+    Fr a = Fr::zero();
+    a.l[0] = (uint32_t)v;
+    a.l[1] = (uint32_t)(v >> 32);
+    return fe_to_mont(a);
+}
+F2 load_f2(const uint8_t *p) {
+    F2 r;
+    memcpy(r.c0.l, p, 32);
+    memcpy(r.c1.l, p + 32, 32);
+    return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+// verify_proof + VerifierSHPLONK + SingleStrategy for a BaseConfig circuit.  fixed_commitments / permutation_commitments: the verifying key
+// (h2hip_plonk_pk_commitments), transcript_repr: the key's hash into the transcript, g1: params.g[0] (the G1 generator of the SRS), g2 / s_g2:
+// 128 bytes each as SerdeFormat::RawBytes stores them (x.c0, x.c1, y.c0, y.c1 Montgomery limbs).  *accepted = 1 iff the proof verifies; a
+// malformed proof is a rejection (accepted = 0, return H2HIP_OK); H2HIP_ERR_INVALID is reserved for bad arguments.
+int h2hip_plonk_verify_proof(const h2hip_base_circuit_params *params, const void *fixed_commitments, const void *permutation_commitments,
+                             const void *transcript_repr, const void *g1, const void *g2, const void *s_g2, const void *const *instances_host,
+                             const size_t *instance_lens, const uint8_t *proof, size_t proof_len, int *accepted) {
+    H2_REQUIRE(params && fixed_commitments && transcript_repr && g1 && g2 && s_g2 && proof && accepted, "NULL argument");
+    *accepted = 0;
+    h2hip_plonk_shape sh;
+    H2_CHK(h2hip_plonk_shape_of(params, &sh));
+    H2_REQUIRE(sh.num_perm_columns == 0 || permutation_commitments, "NULL argument");
+    H2_REQUIRE(params->num_instance == 0 || (instances_host && instance_lens), "NULL argument");
+    const uint32_t k = params->k, n = 1u << k, bf = sh.blinding_factors;
+    const uint32_t num_advice = params->num_advice, nla = sh.num_advice_total - num_advice;
+    const bool with_range = sh.table_col >= 0, single = sh.q_lookup_col >= 0;
+    const uint32_t chunk = sh.degree - 2;
+    std::vector<G1Affine> fixed_comm(sh.num_fixed_total), perm_comm(sh.num_perm_columns);
+    memcpy(fixed_comm.data(), fixed_commitments, sizeof(G1Affine) * fixed_comm.size());
+    if (!perm_comm.empty()) memcpy(perm_comm.data(), permutation_commitments, sizeof(G1Affine) * perm_comm.size());
+    Fr repr;
+    memcpy(&repr, transcript_repr, sizeof(Fr));
+    G1Affine g0;
+    memcpy(&g0, g1, sizeof(G1Affine));
+    G2A Q2 = {load_f2((const uint8_t *)g2), load_f2((const uint8_t *)g2 + 64), false}, SQ2 = {load_f2((const uint8_t *)s_g2), load_f2((const uint8_t *)s_g2 + 64), false};
+    H2_REQUIRE(g2_on_curve(Q2) && g2_on_curve(SQ2), "g2 / s_g2 are not points of the twist");
+    // domain constants
+    static const uint64_t ROOT[4] = {0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL};
+    static const uint64_t DELTA[4] = {0x870e56bbe533e9a2ULL, 0x5b5f898e5e963f25ULL, 0x64ec26aad4c86e71ULL, 0x09226b6e22c6f0caULL};
+    Fr omega, delta;
+    memcpy(omega.l, ROOT, 32);
+    omega = fe_to_mont(omega);
+    for (uint32_t i = k; i < 28; ++i) omega = fe_sqr(omega);
+    memcpy(delta.l, DELTA, 32);
+    delta = fe_to_mont(delta);
+    const Fr one = Fr::one();
+
+    Reader tr(proof, proof_len);
+    tr.common_scalar(repr);
+    std::vector<std::vector<Fr>> inst(params->num_instance);
+    for (uint32_t i = 0; i < params->num_instance; ++i) {
+        if (instance_lens[i] > sh.usable_rows) return H2HIP_OK;   // InstanceTooLarge: rejected
+        inst[i].resize(instance_lens[i]);
+        if (instance_lens[i]) memcpy(inst[i].data(), instances_host[i], sizeof(Fr) * instance_lens[i]);
+        for (const Fr &v : inst[i]) tr.common_scalar(v);
+    }
+    std::vector<G1Affine> advice_comm(sh.num_advice_total);
+    for (auto &c : advice_comm) c = tr.read_point();
+    (void)tr.squeeze_challenge();   // theta
+    std::vector<G1Affine> lk_a_comm(sh.num_lookups), lk_s_comm(sh.num_lookups), lk_z_comm(sh.num_lookups), permz_comm(sh.num_perm_sets);
+    for (uint32_t i = 0; i < sh.num_lookups; ++i) {
+        lk_a_comm[i] = tr.read_point();
+        lk_s_comm[i] = tr.read_point();
+    }
+    const Fr beta = tr.squeeze_challenge(), gamma = tr.squeeze_challenge();
+    for (auto &c : permz_comm) c = tr.read_point();
+    for (auto &c : lk_z_comm) c = tr.read_point();
+    const G1Affine random_comm = tr.read_point();
+    const Fr y = tr.squeeze_challenge();
+    std::vector<G1Affine> h_comm(sh.quotient_pieces);
+    for (auto &c : h_comm) c = tr.read_point();
+    const Fr x = tr.squeeze_challenge();
+    // evaluations, in the prover's order
+    const uint32_t n_adv_q = 4 * num_advice + nla;
+    std::vector<Fr> adv_ev(n_adv_q);
+    for (auto &e : adv_ev) e = tr.read_scalar();
+    std::vector<int> fixed_q;   // fixed columns in query order: constants, table, q_lookup, q_enable
+    for (uint32_t i = 0; i < params->num_fixed; ++i) fixed_q.push_back(sh.first_constant_col + (int)i);
+    if (with_range) fixed_q.push_back(sh.table_col);
+    if (single) fixed_q.push_back(sh.q_lookup_col);
+    for (uint32_t i = 0; i < num_advice; ++i) fixed_q.push_back(sh.first_q_enable_col + (int)i);
+    std::vector<Fr> fixed_ev(sh.num_fixed_total, Fr::zero());
+    for (int c : fixed_q) fixed_ev[c] = tr.read_scalar();
+    const Fr random_eval = tr.read_scalar();
+    std::vector<Fr> sigma_ev(sh.num_perm_columns);
+    for (auto &e : sigma_ev) e = tr.read_scalar();
+    struct PermEv {
+        Fr e0, e1, e2;
+    };
+    std::vector<PermEv> perm_ev(sh.num_perm_sets);
+    for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
+        perm_ev[si].e0 = tr.read_scalar();
+        perm_ev[si].e1 = tr.read_scalar();
+        perm_ev[si].e2 = si + 1 != sh.num_perm_sets ? tr.read_scalar() : Fr::zero();
+    }
+    struct LkEv {
+        Fr pe, pne, ae, aie, se;
+    };
+    std::vector<LkEv> lk_ev(sh.num_lookups);
+    for (auto &l : lk_ev) {
+        l.pe = tr.read_scalar();
+        l.pne = tr.read_scalar();
+        l.ae = tr.read_scalar();
+        l.aie = tr.read_scalar();
+        l.se = tr.read_scalar();
+    }
+    if (!tr.ok) return H2HIP_OK;   // malformed proof
+    // ---- the quotient identity at x
+    const Fr xn = fe_pow_u64(x, n);
+    auto rot = [&](int r) -> Fr {
+        int64_t rr = ((int64_t)r % (int64_t)n + (int64_t)n) % (int64_t)n;
+        return fe_mul(x, fe_pow_u64(omega, (uint64_t)rr));
+    };
+    auto l_i = [&](int r) -> Fr {   // l_r(x) = (x^n - 1) * omega^r / (n * (x - omega^r))
+        int64_t rr = ((int64_t)r % (int64_t)n + (int64_t)n) % (int64_t)n;
+        Fr wi = fe_pow_u64(omega, (uint64_t)rr);
+        return fe_mul(fe_mul(fe_sub(xn, one), wi), fe_inv(fe_mul(fr_u64(n), fe_sub(x, wi))));
+    };
+    if (fe_sub(xn, one).is_zero()) return H2HIP_OK;   // x on the domain: negligible; reject rather than divide by zero
+    std::vector<Fr> inst_ev(params->num_instance, Fr::zero());
+    for (uint32_t c = 0; c < params->num_instance; ++c)
+        for (size_t j = 0; j < inst[c].size(); ++j) inst_ev[c] = fe_add(inst_ev[c], fe_mul(inst[c][j], l_i((int)j)));
+    const Fr l_last = l_i(-(int)(bf + 1)), l_0 = l_i(0);
+    Fr l_blind = Fr::zero();
+    for (uint32_t r = 1; r <= bf; ++r) l_blind = fe_add(l_blind, l_i(-(int)(bf + 1) + (int)r));
+    const Fr active = fe_sub(fe_sub(one, l_last), l_blind);
+    auto adv_at = [&](uint32_t col, uint32_t r) -> Fr { return col < num_advice ? adv_ev[4 * col + r] : adv_ev[4 * num_advice + (col - num_advice)]; };
+    auto perm_col_eval = [&](uint32_t pc) -> Fr {   // permutation columns: constants, advice (gate then lookup), instance
+        if (pc < params->num_fixed) return fixed_ev[sh.first_constant_col + (int)pc];
+        pc -= params->num_fixed;
+        if (pc < sh.num_advice_total) return adv_at(pc, 0);
+        return inst_ev[pc - sh.num_advice_total];
+    };
+    Fr expected = Fr::zero();
+    auto fold = [&](const Fr &term) { expected = fe_add(fe_mul(expected, y), term); };
+    for (uint32_t a = 0; a < num_advice; ++a)
+        fold(fe_mul(fixed_ev[sh.first_q_enable_col + (int)a], fe_sub(fe_add(adv_at(a, 0), fe_mul(adv_at(a, 1), adv_at(a, 2))), adv_at(a, 3))));
+    if (sh.num_perm_sets) {
+        fold(fe_mul(l_0, fe_sub(one, perm_ev[0].e0)));
+        const Fr zl = perm_ev[sh.num_perm_sets - 1].e0;
+        fold(fe_mul(l_last, fe_sub(fe_sqr(zl), zl)));
+        for (uint32_t si = 1; si < sh.num_perm_sets; ++si) fold(fe_mul(l_0, fe_sub(perm_ev[si].e0, perm_ev[si - 1].e2)));
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
+            const uint32_t c0 = si * chunk, c1 = std::min<uint32_t>(c0 + chunk, sh.num_perm_columns);
+            Fr left = perm_ev[si].e1, right = perm_ev[si].e0;
+            Fr cur = fe_mul(fe_mul(beta, x), fe_pow_u64(delta, c0));
+            for (uint32_t c = c0; c < c1; ++c) left = fe_mul(left, fe_add(fe_add(perm_col_eval(c), fe_mul(beta, sigma_ev[c])), gamma));
+            for (uint32_t c = c0; c < c1; ++c) {
+                right = fe_mul(right, fe_add(fe_add(perm_col_eval(c), cur), gamma));
+                cur = fe_mul(cur, delta);
+            }
+            fold(fe_mul(active, fe_sub(left, right)));
+        }
+    }
+    for (uint32_t li = 0; li < sh.num_lookups; ++li) {
+        const LkEv &l = lk_ev[li];
+        const uint32_t acol = single ? 0 : num_advice + li;
+        const Fr inp = single ? fe_mul(fixed_ev[sh.q_lookup_col], adv_at(0, 0)) : adv_at(acol, 0);
+        const Fr tab = fixed_ev[sh.table_col];
+        fold(fe_mul(l_0, fe_sub(one, l.pe)));
+        fold(fe_mul(l_last, fe_sub(fe_sqr(l.pe), l.pe)));
+        fold(fe_mul(active, fe_sub(fe_mul(fe_mul(l.pne, fe_add(l.ae, beta)), fe_add(l.se, gamma)), fe_mul(fe_mul(l.pe, fe_add(inp, beta)), fe_add(tab, gamma)))));
+        fold(fe_mul(l_0, fe_sub(l.ae, l.se)));
+        fold(fe_mul(active, fe_mul(fe_sub(l.ae, l.se), fe_sub(l.ae, l.aie))));
+    }
+    const Fr expected_h = fe_mul(expected, fe_inv(fe_sub(xn, one)));
+    // ---- commitments and queries in the prover's order
+    std::vector<G1Affine> comm;
+    auto add_comm = [&](const G1Affine &c) -> int {
+        comm.push_back(c);
+        return (int)comm.size() - 1;
+    };
+    std::vector<VQuery> queries;
+    std::vector<int> adv_key(sh.num_advice_total);
+    for (uint32_t c = 0; c < sh.num_advice_total; ++c) adv_key[c] = add_comm(advice_comm[c]);
+    for (uint32_t a = 0; a < num_advice; ++a)
+        for (int r = 0; r < 4; ++r) queries.push_back({adv_key[a], rot(r), adv_at(a, (uint32_t)r)});
+    for (uint32_t i = 0; i < nla; ++i) queries.push_back({adv_key[num_advice + i], x, adv_at(num_advice + i, 0)});
+    const Fr x_next = rot(1), x_last = rot(-(int)(bf + 1)), x_inv = rot(-1);
+    {
+        std::vector<VQuery> tail;
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
+            int key = add_comm(permz_comm[si]);
+            queries.push_back({key, x, perm_ev[si].e0});
+            queries.push_back({key, x_next, perm_ev[si].e1});
+            if (si + 1 != sh.num_perm_sets) tail.push_back({key, x_last, perm_ev[si].e2});
+        }
+        for (size_t t = tail.size(); t-- > 0;) queries.push_back(tail[t]);
+    }
+    for (uint32_t li = 0; li < sh.num_lookups; ++li) {
+        int kz = add_comm(lk_z_comm[li]), ka = add_comm(lk_a_comm[li]), ks = add_comm(lk_s_comm[li]);
+        const LkEv &l = lk_ev[li];
+        queries.push_back({kz, x, l.pe});
+        queries.push_back({ka, x, l.ae});
+        queries.push_back({ks, x, l.se});
+        queries.push_back({ka, x_inv, l.aie});
+        queries.push_back({kz, x_next, l.pne});
+    }
+    for (int c : fixed_q) queries.push_back({add_comm(fixed_comm[c]), x, fixed_ev[c]});
+    for (uint32_t j = 0; j < sh.num_perm_columns; ++j) queries.push_back({add_comm(perm_comm[j]), x, sigma_ev[j]});
+    {   // h commitment = sum_i xn^i H_i
+        XYZZ hc = XYZZ::identity();
+        for (size_t i = h_comm.size(); i-- > 0;) {
+            G1Affine cur = xyzz_to_affine(hc);
+            hc = g1_scalar_mul(cur, xn);
+            xyzz_add_affine(hc, h_comm[i].x, h_comm[i].y);
+        }
+        queries.push_back({add_comm(xyzz_to_affine(hc)), x, expected_h});
+        queries.push_back({add_comm(random_comm), x, random_eval});
+    }
+    // ---- VerifierSHPLONK
+    std::vector<VSet> sets;
+    std::vector<Fr> super_points;
+    intermediate_sets(queries, sets, super_points);
+    const Fr y2 = tr.squeeze_challenge(), v = tr.squeeze_challenge();
+    const G1Affine h1 = tr.read_point();
+    const Fr u = tr.squeeze_challenge();
+    const G1Affine h2 = tr.read_point();
+    if (!tr.ok || tr.pos != proof_len) return H2HIP_OK;   // malformed or trailing bytes
+    XYZZ outer = XYZZ::identity();
+    Fr r_outer = Fr::zero(), z_0 = Fr::zero(), z_0_diff_inv = Fr::zero(), vpow = one;
+    for (size_t i = 0; i < sets.size(); ++i) {
+        Fr z_diff = one;
+        for (const Fr &p : super_points) {
+            bool in_set = false;
+            for (const Fr &sp : sets[i].points) in_set |= fr_cmp(sp, p) == 0;
+            if (!in_set) z_diff = fe_mul(z_diff, fe_sub(u, p));
+        }
+        if (i == 0) {
+            z_0 = one;
+            for (const Fr &p : sets[i].points) z_0 = fe_mul(z_0, fe_sub(u, p));
+            if (z_diff.is_zero()) return H2HIP_OK;
+            z_0_diff_inv = fe_inv(z_diff);
+            z_diff = one;
+        } else {
+            z_diff = fe_mul(z_diff, z_0_diff_inv);
+        }
+        XYZZ inner = XYZZ::identity();
+        Fr r_inner = Fr::zero(), ypow = one;
+        for (size_t j = 0; j < sets[i].keys.size(); ++j) {
+            r_inner = fe_add(r_inner, fe_mul(ypow, interpolate_at(sets[i].points, sets[i].evals[j], u)));
+            XYZZ t = g1_scalar_mul(comm[sets[i].keys[j]], ypow);
+            xyzz_add(inner, t);
+            ypow = fe_mul(ypow, y2);
+        }
+        const Fr scale = fe_mul(vpow, z_diff);
+        XYZZ t = g1_scalar_mul(xyzz_to_affine(inner), scale);
+        xyzz_add(outer, t);
+        r_outer = fe_add(r_outer, fe_mul(scale, r_inner));
+        vpow = fe_mul(vpow, v);
+    }
+    {
+        XYZZ t = g1_scalar_mul(g0, fe_neg(r_outer));
+        xyzz_add(outer, t);
+        t = g1_scalar_mul(h1, fe_neg(z_0));
+        xyzz_add(outer, t);
+        t = g1_scalar_mul(h2, u);
+        xyzz_add(outer, t);
+    }
+    // DualMSM::check: e(h2, s*g2) * e(-outer, g2) == 1
+    const G1Affine right = g1_neg(xyzz_to_affine(outer));
+    F12 f = f12_mul(miller_loop(h2, SQ2), miller_loop(right, Q2));
+    *accepted = f12_is_one(final_exponentiation(f)) ? 1 : 0;
+    return H2HIP_OK;
+}
+
+}  // extern "C"

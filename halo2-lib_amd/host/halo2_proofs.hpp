@@ -395,6 +395,23 @@ inline std::vector<uint8_t> create_proof(Backend &b, const ProvingKey &pk, const
     return proof;
 }
 
+// verify_proof(params, vk, SingleStrategy, &[instances], &mut Blake2bRead) — check_proof of halo2-base/src/utils/testing.rs:64-88
+inline bool verify_proof(const ProvingKey &pk, const h2hip_base_circuit_params &params, const Fr &transcript_repr, const G1Affine &g1, const uint8_t g2[128],
+                         const uint8_t s_g2[128], const std::vector<std::vector<Fr>> &instances, const std::vector<uint8_t> &proof) {
+    std::vector<const void *> ins;
+    std::vector<size_t> lens;
+    for (auto &c : instances) {
+        ins.push_back(c.data());
+        lens.push_back(c.size());
+    }
+    int ok = 0;
+    G1Affine dummy{};
+    check(h2hip_plonk_verify_proof(&params, pk.fixed_commitments().data(), pk.permutation_commitments().empty() ? &dummy : pk.permutation_commitments().data(),
+                                   &transcript_repr, &g1, g2, s_g2, ins.empty() ? nullptr : ins.data(), lens.empty() ? nullptr : lens.data(), proof.data(),
+                                   proof.size(), &ok));
+    return ok != 0;
+}
+
 namespace lookup {
 // permute_expression_pair over the usable rows: (permuted_input, permuted_table); throws where upstream returns
 // Err(ConstraintSystemFailure) (an input value that the table does not contain)

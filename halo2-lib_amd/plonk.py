@@ -199,3 +199,26 @@ def create_proof(pk: ProvingKey, advice: Sequence, instances: Sequence[np.ndarra
             timings[name] = timings.get(name, 0.0) + stage[i]
     del keep
     return proof[: plen.value].tobytes()
+
+
+def verify_proof(pk: ProvingKey, instances: Sequence[np.ndarray], proof: bytes) -> bool:
+    """verify_proof with the key's verifying half (VerifierSHPLONK, SingleStrategy) — check_proof of halo2-base/src/utils/testing.rs:64-88.
+    Host code inside libh2hip; needs the G2 half of the SRS (ParamsKZG.g2_raw)."""
+    ctx, kzg = pk.ctx, pk.kzg
+    if len(kzg.g2_raw) != 256:
+        raise ValueError("verify_proof: the ParamsKZG carries no G2 elements (g2_raw)")
+    inst = [_fe(c) for c in instances]
+    if len(inst) != pk.params.num_instance:
+        raise ValueError("verify_proof: need %d instance columns" % pk.params.num_instance)
+    ip = (_vp * max(len(inst), 1))(*[_vp(c.ctypes.data) for c in inst])
+    il = (C.c_size_t * max(len(inst), 1))(*[len(c) for c in inst])
+    g0 = ctx.bases_download(kzg.g)[:1].copy() if not hasattr(kzg, "_g0") else kzg._g0
+    kzg._g0 = g0
+    g2 = np.frombuffer(kzg.g2_raw, dtype=np.uint8).copy()
+    buf = np.frombuffer(bytes(proof), dtype=np.uint8).copy()
+    ok = C.c_int(0)
+    pc = pk.permutation_commitments if len(pk.permutation_commitments) else np.zeros((1, 8), dtype=np.uint64)
+    ctx._chk(ctx.lib.h2hip_plonk_verify_proof(C.byref(pk.params), _ptr(np.ascontiguousarray(pk.fixed_commitments)), _ptr(np.ascontiguousarray(pc)),
+                                              _ptr(fr_limbs(pk.transcript_repr)), _ptr(g0), _vp(g2.ctypes.data), _vp(g2.ctypes.data + 128), ip, il,
+                                              _vp(buf.ctypes.data), len(buf), C.byref(ok)))
+    return bool(ok.value)

@@ -334,6 +334,15 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                              const size_t *instance_lens, h2hip_rng_fill_fn rng, void *rng_user, uint8_t *proof_out, size_t proof_cap,
                              size_t *proof_len, double *stage_ms);
 
+/* verify_proof::<KZGCommitmentScheme<Bn256>, VerifierSHPLONK<_>, Challenge255<_>, Blake2bRead<_, _, _>, SingleStrategy<_>> as the reference runs
+ * it after every proof (check_proof, halo2-base/src/utils/testing.rs:64-88).  Host code (the reference verifies on the CPU too): transcript
+ * replay, the quotient identity rebuilt from the openings, SHPLONK's folded opening and one pairing check.  fixed / permutation commitments:
+ * the verifying key (h2hip_plonk_pk_commitments); g1: params.g[0] (64 B); g2, s_g2: 128 B each, SerdeFormat::RawBytes (x.c0, x.c1, y.c0, y.c1).
+ * *accepted = 1 iff the proof verifies; a malformed proof is a rejection, not an error. */
+int h2hip_plonk_verify_proof(const h2hip_base_circuit_params *params, const void *fixed_commitments, const void *permutation_commitments,
+                             const void *transcript_repr, const void *g1, const void *g2, const void *s_g2, const void *const *instances_host,
+                             const size_t *instance_lens, const uint8_t *proof, size_t proof_len, int *accepted);
+
 /* ---- diagnostics: 254-bit Montgomery multiplier throughput (the integer roofline bench.py quotes) ------ */
 int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);
 /* HBM-counter calibration probes: kind 0 = coalesced stream of table_bytes, kind 64 / 128 = lanes * per_lane random gathers of aligned

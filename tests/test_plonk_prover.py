@@ -79,6 +79,7 @@ def _check(ctx, k, na, nl, nf, ni, lb, seed=3, threads=4, oracle_prover=True, pr
         else:
             vk = _vk_from_gpu(sh, gpk)
         assert P.verify_proof(params, vk, inst, got), "the oracle verifier rejects the HIP proof"
+        assert PL.verify_proof(gpk, circ.instances, got), "libh2hip's own verifier rejects the proof"
         # a second proof from the same key (pooled buffers reused) with another RNG stream: different bytes, still valid
         if second_proof:
             again = PL.create_proof(gpk, circ.advice, circ.instances, PreDrawnRng(budget, 2000 + seed))
@@ -109,6 +110,18 @@ def _tamper_checks(sh, params, vk, inst, proof, circ, gpk, forge=True):
         wrong = [list(v) for v in inst]
         wrong[0][0] = (wrong[0][0] + 1) % R
         assert not P.verify_proof(params, vk, wrong, proof)
+        assert not PL.verify_proof(gpk, [O.ints_to_limbs(v, R) for v in wrong], proof)
+    # libh2hip's verifier (h2hip_plonk_verify_proof: the reference's check_proof) agrees with the oracle's on mutated proofs
+    g = np.random.default_rng(len(proof))
+    for pos in [0, 31, first_eval + 5, len(proof) - 1] + [int(v) for v in g.integers(0, len(proof), size=6)]:
+        mutated = bytearray(proof)
+        mutated[pos] ^= 1 << int(g.integers(0, 8))
+        try:
+            want = P.verify_proof(params, vk, inst, bytes(mutated))
+        except P.VerifyError:
+            want = False
+        assert PL.verify_proof(gpk, circ.instances, bytes(mutated)) == want == False, pos
+    assert not PL.verify_proof(gpk, circ.instances, proof[:-32]) and not PL.verify_proof(gpk, circ.instances, proof + bytes(32))
 
 
 SMALL_SHAPES = [(6, 1, 1, 1, 0, 4), (7, 2, 1, 1, 1, 5), (6, 1, 0, 1, 0, None), (6, 2, 2, 2, 1, 3)]
