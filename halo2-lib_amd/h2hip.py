@@ -49,6 +49,8 @@ _PROTOS = {
     "h2hip_msm_g1_batch": (_int, [_vp, _vp, C.POINTER(_vp), _sz, _sz, _int, _vp]),
     "h2hip_msm_g1_batch_dev": (_int, [_vp, _vp, C.POINTER(_vp), _sz, _sz, _int, _vp]),
     "h2hip_msm_g1_multi_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _sz, _sz, _int, _vp]),
+    "h2hip_msm_g2": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "h2hip_msm_g2_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_g1_to_lagrange": (_int, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),
     "h2hip_params_kzg_setup": (_int, [_vp, _u32, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp)]),
     "h2hip_g1_fixed_base_mul_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
@@ -363,6 +365,15 @@ class Context:
         arr = (_vp * max(count, 1))(*[_vp(int(p)) for p in scalar_dptrs])
         out = np.zeros((count, 8 if point_format == POINT_AFFINE else 12), dtype=np.uint64)
         self._chk(self.lib.h2hip_msm_g1_multi_dev(self.handle, barr, arr, n, count, point_format, _ptr(out)))
+        return out
+
+    def msm_g2(self, points: np.ndarray, scalars: np.ndarray) -> np.ndarray:
+        """sum_i scalars[i] * points[i] over G2; points (n, 16) u64 affine Montgomery (x.c0, x.c1, y.c0, y.c1), returns (1, 16)"""
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 16)
+        s = _fe(scalars)
+        assert len(pts) == len(s)
+        out = np.zeros((1, 16), dtype=np.uint64)
+        self._chk(self.lib.h2hip_msm_g2(self.handle, _ptr(pts), _ptr(s), len(s), _ptr(out)))
         return out
 
     def msm_batch(self, bases: Bases, scalar_columns, point_format: int = POINT_JACOBIAN) -> np.ndarray:

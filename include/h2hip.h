@@ -112,6 +112,12 @@ int h2hip_msm_g1_multi_dev(h2hip_ctx *ctx, const h2hip_bases *const *bases_per_c
 int h2hip_msm_g1_batch(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_host, size_t n, size_t count, int point_format,
                        void *out_host);
 
+/* MSM over G2 (the twist over Fq2).  The reference holds G2 elements only as the verifier half of ParamsKZG (g2, s*g2) and has no
+ * prover-side G2 commitment: supported for completeness (8-bit windows, per-bucket lanes), not tuned like the G1 path.
+ * points: n x 128 B affine (x.c0, x.c1, y.c0, y.c1 Montgomery limbs; identity all-zero); out: 128 B affine. */
+int h2hip_msm_g2(h2hip_ctx *ctx, const void *g2_affine_host, const void *scalars_host, size_t n, void *out_affine_host);
+int h2hip_msm_g2_dev(h2hip_ctx *ctx, const void *g2_affine_dev, const void *scalars_dev, size_t n, void *out_affine_host);
+
 /* ---- a2: KZG SRS (ParamsKZG::<Bn256>::setup [UPSTREAM]; reference gen_srs halo2-base/src/utils/mod.rs:439-443,
  *      halo2-base/benches/mul.rs:39).  g[i] = s^i*G1 and g_lagrange[i] = L_i(s)*G1 for i < 2^k are generated on
  *      the GPU (fixed-base window tables) and stay resident as two base sets; `flags` as in h2hip_bases_upload.

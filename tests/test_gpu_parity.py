@@ -359,3 +359,10 @@ def test_two_contexts_interleaved_and_second_thread(ctx):
         b_other.free()
     finally:
         other.close()
+
+
+@pytest.mark.gpu
+def test_msm_g2(ctx):
+    from tests.test_emu_kernels import _g2_msm_checks
+
+    _g2_msm_checks(ctx, [1, 37, 300, 5000])
