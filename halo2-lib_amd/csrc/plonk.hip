@@ -1196,6 +1196,7 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     std::vector<uint8_t> proof;
     int rc = create_proof_impl(ctx, pk, advice, advice_on_device != 0, instances_host, instance_lens, rng, rng_user, proof, stage_ms);
     if (rc != H2HIP_OK) {
+        if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
         hipStreamSynchronize(ctx->stream);   // nothing of the failed proof may still run on buffers that go back to the pool
         return rc;
     }

@@ -62,6 +62,9 @@ for rep in range(reps):
     proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(vals), tm if rep == reps - 1 else None)
     dt = time.time() - t
     print("create_proof rep %d: %.2f ms (%d bytes)" % (rep, dt * 1e3, len(proof)), flush=True)
+if "--verify" in sys.argv:
+    t = time.time()
+    print("h2hip_plonk_verify_proof:", PL.verify_proof(pk, circ.instances, proof), "%.1f ms" % ((time.time() - t) * 1e3), flush=True)
 for name, ms in tm.items():
     print("  %-26s %8.3f ms" % (name, ms))
 print("  %-26s %8.3f ms" % ("sum", sum(tm.values())))
