@@ -184,6 +184,13 @@ int h2hip_init(int device, void *hip_stream, h2hip_ctx **out) {
     return H2HIP_OK;
 }
 
+static void destroy_split_streams(h2hip_ctx *ctx) {
+    for (hipEvent_t e : ctx->split_ev) hipEventDestroy(e);
+    ctx->split_ev.clear();
+    if (ctx->split_acc) hipStreamDestroy(ctx->split_acc);
+    if (ctx->split_aux) hipStreamDestroy(ctx->split_aux);
+    ctx->split_acc = ctx->split_aux = nullptr;
+}
 void h2hip_destroy(h2hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
@@ -208,6 +215,7 @@ void h2hip_destroy(h2hip_ctx *ctx) {
             hipEventDestroy(ctx->lane_ev[l]);
         }
     if (ctx->fork_ev) hipEventDestroy(ctx->fork_ev);
+    destroy_split_streams(ctx);
     for (auto e : ctx->timer_ev)
         if (e) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -233,6 +241,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
+    if (!strcmp(name, "msm_split_streams")) return &ctx->msm_split_streams;
     if (!strcmp(name, "msm_quad_tails")) return &ctx->msm_quad_tails;
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
     if (!strcmp(name, "msm_sort_threads")) return &ctx->msm_sort_threads;
@@ -520,6 +529,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     int NL = ctx->msm_lanes;
     if (NL <= 0) NL = n >= ((size_t)1 << 20) ? 1 : n > ((size_t)1 << 17) ? 2 : 3;
     if (NL > 4) NL = 4;
+    if (NL < 2 && ctx->msm_split_streams && !scalars_on_host && count >= 2 && n > ((size_t)1 << 17)) NL = 2;   // the split-stream schedule alternates two scratch sets
     for (int l = 0; l < NL; ++l) {
         if (!ctx->lane[l]) {
             h2hip_ctx *c = nullptr;
@@ -555,6 +565,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     if (precomp && ctx->msm_fuse_cols == 0) fuse = n <= ((size_t)1 << 17) ? 4 : 1;
     if (fuse < 1) fuse = 1;
     if (fuse > MSM_MAX_COLS) fuse = MSM_MAX_COLS;
+    if (mixed) fuse = 1;   // a fused multi-column MSM reads one table
     const bool deferred = precomp && fuse == 1 && ctx->msm_defer_reduce && count >= 2 && count <= 64 && n > 0;
     XYZZ29 *all_buckets = nullptr;
     size_t keys_per_col = 0;
@@ -573,8 +584,67 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         for (size_t j = 0; j < count; ++j) staged[j] = stage + sizeof(Fr) * n * j;
         scalars_dev = staged.data();
     }
-    if (mixed) fuse = 1;   // a fused multi-column MSM reads one table
-    const size_t ngroups = (count + fuse - 1) / fuse;
+    // Split-stream schedule (deferred reduction, device-resident columns): the multiplier-bound accumulations of all MSMs run back to back on
+    // ONE stream and never compete with each other, while every latency-bound sort and merge is issued on a second, higher-priority
+    // stream — MSM i+1 is sorted and MSM i-1 merged while MSM i accumulates.  Two scratch sets (lane contexts 0 / 1) alternate.
+    const bool split = deferred && ctx->msm_split_streams && !scalars_on_host && count >= 2 && NL >= 2;
+    if (split) {
+        if (!ctx->split_acc) {
+            int lo = 0, hi = 0;   // numerically lower = higher priority
+            hipDeviceGetStreamPriorityRange(&lo, &hi);
+            H2_HIPCHK(hipStreamCreateWithPriority(&ctx->split_acc, hipStreamNonBlocking, lo));
+            H2_HIPCHK(hipStreamCreateWithPriority(&ctx->split_aux, hipStreamNonBlocking, hi));
+        }
+        while (ctx->split_ev.size() < 2 * count + 2) {
+            hipEvent_t e = nullptr;
+            H2_HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->split_ev.push_back(e);
+        }
+        hipStream_t A = ctx->split_acc, Bx = ctx->split_aux;
+        H2_HIPCHK(hipStreamWaitEvent(A, ctx->fork_ev, 0));
+        H2_HIPCHK(hipStreamWaitEvent(Bx, ctx->fork_ev, 0));
+        hipStream_t saved[2] = {ctx->lane[0]->stream, ctx->lane[1]->stream};
+        int rc = H2HIP_OK;
+        auto phase = [&](size_t j, hipStream_t stream, uint32_t mask) {
+            if (rc != H2HIP_OK) return;
+            h2hip_ctx *c = ctx->lane[j & 1];
+            c->stream = stream;
+            const Fr *col = (const Fr *)scalars_dev[j];
+            rc = msm_run_cols(c, bases_of(j), &col, 1, n, nullptr, all_buckets + keys_per_col * j, mask);
+        };
+        auto sort = [&](size_t j) {
+            phase(j, Bx, MSM_PHASE_SORT);
+            if (rc == H2HIP_OK && hipEventRecord(ctx->split_ev[2 * j], Bx) != hipSuccess) rc = H2HIP_ERR_HIP;
+        };
+        auto accumulate = [&](size_t j) {
+            if (rc == H2HIP_OK && hipStreamWaitEvent(A, ctx->split_ev[2 * j], 0) != hipSuccess) rc = H2HIP_ERR_HIP;
+            phase(j, A, MSM_PHASE_ACCUM);
+            if (rc == H2HIP_OK && hipEventRecord(ctx->split_ev[2 * j + 1], A) != hipSuccess) rc = H2HIP_ERR_HIP;
+        };
+        auto merge = [&](size_t j) {
+            if (rc == H2HIP_OK && hipStreamWaitEvent(Bx, ctx->split_ev[2 * j + 1], 0) != hipSuccess) rc = H2HIP_ERR_HIP;
+            phase(j, Bx, MSM_PHASE_MERGE);
+        };
+        sort(0);
+        accumulate(0);
+        for (size_t j = 1; j < count; ++j) {
+            sort(j);       // scratch set j & 1 was last used by MSM j - 2, whose merge precedes this on the same in-order stream
+            accumulate(j);
+            merge(j - 1);
+        }
+        merge(count - 1);
+        ctx->lane[0]->stream = saved[0];
+        ctx->lane[1]->stream = saved[1];
+        if (rc == H2HIP_OK && hipEventRecord(ctx->split_ev[2 * count], Bx) != hipSuccess) rc = H2HIP_ERR_HIP;
+        if (rc == H2HIP_OK && hipStreamWaitEvent(ctx->stream, ctx->split_ev[2 * count], 0) != hipSuccess) rc = H2HIP_ERR_HIP;
+        if (rc != H2HIP_OK) {
+            hipStreamSynchronize(A);
+            hipStreamSynchronize(Bx);
+            if (rc == H2HIP_ERR_HIP) set_error("split-stream MSM batch: a HIP stream / event call failed");
+            return rc;
+        }
+    }
+    const size_t ngroups = split ? 0 : (count + fuse - 1) / fuse;
     for (size_t g = 0, j0 = 0; g < ngroups; ++g) {
         const size_t gsize = (count - j0 + (ngroups - g) - 1) / (ngroups - g);   // balanced group sizes
         h2hip_ctx *c = ctx->lane[g % NL];

@@ -99,6 +99,12 @@ struct h2hip_ctx {
     // batch lanes (h2hip_msm_g1_batch_dev): child contexts with their own stream + scratch
     h2hip_ctx *lane[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int msm_split_streams = 0;   // 1: batch API, deferred reduction: all accumulations back to back on one stream, every sort / merge on a second,
+                                 // higher-priority one (MSM i+1 sorted and MSM i-1 merged while MSM i accumulates).  Measured SLOWER (tools/batch_ab.py, same run:
+                                 // 2^19 1.00 vs 0.95 ms per MSM in batches of 4, 2^20 1.75-1.82 vs 1.69): kernels that share the chip with an accumulation
+                                 // stretch more than the overlap hides, and stretch the accumulation.  Off by default.
+    hipStream_t split_acc = nullptr, split_aux = nullptr;
+    std::vector<hipEvent_t> split_ev;
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
     int fr_invert_run = 0;           // elements per lane (= per inversion) in h2hip_fr_batch_invert_dev; 0 = auto (n / 2^16 in 4..32)
     int lookup_big_tile_bits = 19;   // lookup sort: 4096-key LDS tiles from 2^bits padded keys (12..28), 1024-key tiles below
@@ -153,7 +159,8 @@ int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *bases, bool precompute);
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
 constexpr uint32_t MSM_MAX_COLS = 8;   // columns one fused multi-column MSM handles
 // ext_buckets != nullptr: stop after the merge and leave the column's buckets ([W][B], zeroed here) there for msm_reduce_cols
+enum { MSM_PHASE_SORT = 1u, MSM_PHASE_ACCUM = 2u, MSM_PHASE_MERGE = 4u, MSM_PHASE_REDUCE = 8u, MSM_PHASE_ALL = 15u };
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev,
-                 XYZZ29 *ext_buckets);
+                 XYZZ29 *ext_buckets, uint32_t phases = MSM_PHASE_ALL);
 int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t window_bits, const XYZZ29 *buckets, uint32_t ncols, XYZZ *out_dev);
 }  // namespace h2

@@ -803,7 +803,8 @@ int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t c, const 
     return H2HIP_OK;
 }
 
-int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out, XYZZ29 *ext_buckets) {
+int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out, XYZZ29 *ext_buckets,
+                 uint32_t phases) {
     H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..8 columns per fused MSM");
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
@@ -854,6 +855,9 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY1, sizeof(uint32_t) * 2 * (size_t)blocks1, (void **)&pkey[1]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ29) * 2 * (size_t)blocks1, (void **)&pval[1]));
 
+    // `phases` lets a caller issue the latency-bound sort and merge of one MSM and its multiplier-bound accumulation on different
+    // streams (all derived sizes and scratch pointers are recomputed identically on every call for the same arguments)
+    if (phases & MSM_PHASE_SORT) {
     H2_HIPCHK(hipMemsetAsync(counts + nkeys, 0, sizeof(uint32_t), st));
     H2_HIPCHK(hipMemsetAsync(offsets + nkeys + 1, 0xff, sizeof(uint32_t), st));   // sentinel read by the boundary walk
     H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
@@ -892,7 +896,9 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
                        precomp ? (uint32_t)bases->n : 0u, Wcol, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
+    }   // MSM_PHASE_SORT
 
+    if (phases & MSM_PHASE_ACCUM) {
     prof_begin(ctx, "msm_accum_kernel");
     if (ctx->msm_accum_variant == 2)
         hipLaunchKernelGGL(msm_accum_w2_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
@@ -908,6 +914,8 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
                            (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
+    }   // MSM_PHASE_ACCUM
+    if (phases & MSM_PHASE_MERGE) {
     uint32_t len = len1;
     int src = 0;
     for (;;) {
@@ -922,13 +930,14 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         len = 2 * blocks;
         src ^= 1;
     }
+    }   // MSM_PHASE_MERGE
 
-    if (ext_buckets) return H2HIP_OK;   // accumulation only: the caller reduces several MSMs' buckets together
+    if (ext_buckets || !(phases & MSM_PHASE_REDUCE)) return H2HIP_OK;   // the caller reduces several MSMs' buckets together
     return msm_reduce_cols(ctx, bases, c, buckets, ncols, out);
 }
 
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
-    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr);
+    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr, MSM_PHASE_ALL);
 }
 
 }  // namespace h2

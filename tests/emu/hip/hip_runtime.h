@@ -237,6 +237,8 @@ inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event(); return hipSuccess; }

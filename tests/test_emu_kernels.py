@@ -459,3 +459,38 @@ def _g2_msm_checks(ctx, sizes):
 
 def test_msm_g2_emulated(ctx):
     _g2_msm_checks(ctx, [1, 2, 37, 300])
+
+
+def test_msm_batch_split_streams_and_mixed_bases(ctx):
+    """the batch schedule with all accumulations on one stream and every sort / merge on another (msm_split_streams, deferred reduction),
+    on and off, for 2..5 columns incl. an all-zero one; and h2hip_msm_g1_multi_dev: columns over two different base sets in one call"""
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    n = 700
+    bases_a = CO.known_dlog_bases(n, fr([21]), fr([4]))
+    bases_b = CO.known_dlog_bases(n, fr([99]), fr([9]))
+    ctx.set_param("msm_window_bits", 6)
+    ba, bb = ctx.bases_upload(bases_a, BASES_PRECOMPUTE), ctx.bases_upload(bases_b, BASES_PRECOMPUTE)
+    ctx.set_param("msm_window_bits", 0)
+    cols = [rand_fr(n, 1), circuit_like_fr(n, 2), np.zeros((n, 4), dtype=np.uint64), rand_fr(n, 4), rand_fr(n, 5)]
+    dptrs = [ctx.to_device(c) for c in cols]
+    want_a = [CO.best_multiexp(c, bases_a, threads=2) for c in cols]
+    want_b = [CO.best_multiexp(c, bases_b, threads=2) for c in cols]
+    ctx.set_param("msm_fuse_cols", 1)          # per-column pipeline + deferred joint reduction (what large sizes use)
+    try:
+        for split in (1, 0):
+            ctx.set_param("msm_split_streams", split)
+            for count in (2, 3, 5):
+                got = ctx.msm_batch_dev(ba, dptrs[:count], n, H.POINT_AFFINE)
+                assert all(np.array_equal(got[j:j + 1], want_a[j]) for j in range(count)), (split, count)
+            sets = [ba, bb, bb, ba, bb]
+            got = ctx.msm_multi_dev(sets, dptrs, n, H.POINT_AFFINE)
+            for j, s in enumerate(sets):
+                assert np.array_equal(got[j:j + 1], (want_a if s is ba else want_b)[j]), (split, j)
+    finally:
+        ctx.set_param("msm_fuse_cols", 0)
+        ctx.set_param("msm_split_streams", 0)
+    for d in dptrs:
+        ctx.free(d)
+    ba.free()
+    bb.free()

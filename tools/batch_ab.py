@@ -17,11 +17,17 @@ for log_n in (19, 20):
         ctx.sync()
         return (time.perf_counter() - t) / reps * 1e3
     print("2^%d sync: %.3f ms per MSM" % (log_n, timed(lambda: ctx.msm_dev(params.g, cols[0], n))), flush=True)
-    for lanes in (1, 2, 3, 4):
-        for defer in (0, 1):
-            ctx.set_param("msm_lanes", lanes); ctx.set_param("msm_defer_reduce", defer)
-            ms = timed(lambda: ctx.msm_batch_dev(params.g, cols, n))
-            print("2^%d batch4 lanes=%d defer=%d: %.3f ms per MSM" % (log_n, lanes, defer, ms / 4), flush=True)
-    ctx.set_param("msm_lanes", 3); ctx.set_param("msm_defer_reduce", 1)
+    ctx.set_param("msm_split_streams", 0)
+    for lanes in (1, 2, 3):
+        ctx.set_param("msm_lanes", lanes)
+        ms = timed(lambda: ctx.msm_batch_dev(params.g, cols, n))
+        print("2^%d batch4 lanes=%d (no split): %.3f ms per MSM" % (log_n, lanes, ms / 4), flush=True)
+    ctx.set_param("msm_lanes", 0)
+    for split in (1, 0, 1, 0):
+        ctx.set_param("msm_split_streams", split)
+        for cnt in (2, 4):
+            ms = timed(lambda: ctx.msm_batch_dev(params.g, cols[:cnt], n))
+            print("2^%d batch%d split_streams=%d: %.3f ms per MSM" % (log_n, cnt, split, ms / cnt), flush=True)
+    ctx.set_param("msm_split_streams", 0)
     for c in cols: ctx.free(c)
     params.free()
