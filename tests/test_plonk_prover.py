@@ -170,7 +170,7 @@ def test_create_proof_argument_errors_emulated():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(9, 1, 1, 1, 0, 8), (12, 1, 1, 1, 1, 11), (12, 2, 1, 1, 1, 11), (13, 4, 2, 2, 2, 10), (10, 1, 0, 1, 0, None),
-                                   (11, 20, 4, 2, 1, 10)])   # the last: a wide shape like the reference's low-k configurations (13 chained permutation sets)
+                                   (11, 20, 4, 2, 1, 10), (9, 1, 1, 0, 0, 7), (9, 2, 0, 0, 1, None), (10, 1, 2, 1, 0, 8)])   # (11, 20, 4, ...): a wide shape like the reference's low-k configurations (13 chained permutation sets); then: no constants column, no range chip with an instance column, one advice column with num_lookup_advice > 1
 def test_create_proof_gpu(shape):
     ctx = H.Context()
     try:
