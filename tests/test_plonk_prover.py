@@ -205,3 +205,25 @@ def test_create_proof_gpu_k19_ecdsa_shape():
         kzg.free()
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_create_proof_repeatable_with_interleaved_keys():
+    """race / state-leak detector (tools/soak.py in small): two proving keys of different shapes share one context; their proofs,
+    alternated, must stay byte-identical to the first ones for a fixed RNG stream (pooled buffers, copy stream, scratch reuse)"""
+    ctx = H.Context()
+    try:
+        a = _setup(ctx, 14, 1, 1, 1, 0, 13, 5, 8, True)
+        b = _setup(ctx, 12, 3, 1, 1, 1, 11, 6, 8, True)
+        (sha, _, _, ca, pka), (shb, _, _, cb, pkb) = a, b
+        ra = PL.create_proof(pka, ca.advice, ca.instances, PreDrawnRng(_rng_budget(sha), 1))
+        rb = PL.create_proof(pkb, cb.advice, cb.instances, PreDrawnRng(_rng_budget(shb), 2))
+        assert PL.verify_proof(pka, ca.instances, ra) and PL.verify_proof(pkb, cb.instances, rb)
+        for _ in range(12):
+            assert PL.create_proof(pka, ca.advice, ca.instances, PreDrawnRng(_rng_budget(sha), 1)) == ra
+            assert PL.create_proof(pkb, cb.advice, cb.instances, PreDrawnRng(_rng_budget(shb), 2)) == rb
+        for pk, kzg in ((pka, a[1]), (pkb, b[1])):
+            pk.free()
+            kzg.free()
+    finally:
+        ctx.close()
