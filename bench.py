@@ -353,6 +353,12 @@ def main():
                 out["create_proof_k19"] = create_proof_k19(ctx, with_cpu_baseline=not args.no_cpu_baseline)
             except Exception as e:   # never let the second half of the metric break the contract line
                 out["create_proof_k19"] = {"error": repr(e)}
+            try:
+                out["create_proof_k21_pairing_shape"] = create_proof_shape(ctx, 21, 2, 1, 1, 0, 20, reps=3,
+                                                                           what="BASELINE configs[4] on ONE GPU: the k=21 BN254-pairing configuration "
+                                                                                "(halo2-ecc/configs/bn254/bench_pairing.config:8), 14 MSMs of 2^21, extended_k 23")
+            except Exception as e:
+                out["create_proof_k21_pairing_shape"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx.bases_download(bases), scal_h, adds_per_msm)
     if world > 1 and args.sharded_proof:   # every rank takes part: the k=19 create_proof with point-range-sharded commitments
@@ -476,6 +482,40 @@ def create_proof_k19(ctx, with_cpu_baseline: bool, reps: int = 10):
     pk.free()
     kzg.free()
     return out
+
+
+def create_proof_shape(ctx, k, na, nl, nf, ni, lb, reps, what):
+    """create_proof for another BaseCircuitParams shape (no CPU leg): seconds per proof, stages, verified by libh2hip's verifier"""
+    from halo2_lib_amd import halo2_proofs as HP
+    from halo2_lib_amd import plonk as PL
+    from halo2_lib_amd import testing as T
+
+    kzg = HP.ParamsKZG.setup(ctx, k, 0x1D0C0FFEE1234567890ABCDEF, precompute=True)
+    bp = PL.BaseCircuitParams.new(k, na, nl, nf, ni, lb)
+    sh = PL.shape_of(ctx, bp)
+
+    class Backend:
+        mul = staticmethod(ctx.fr_mul)
+        add = staticmethod(ctx.fr_add)
+
+    circ = T.build_circuit(_ShapeView(bp, sh), k, Backend)
+    pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
+    draws = synthetic_scalars((1 << k) + 65536, 4243)
+    PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        proof = PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))
+    seconds = (time.perf_counter() - t0) / reps
+    stages = {}
+    PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws), stages)
+    ok = PL.verify_proof(pk, circ.instances, proof)
+    cells = 4 * (sh.usable_rows // 4) * na
+    pk.free()
+    kzg.free()
+    return {"what": what, "seconds": seconds, "reps": reps, "proof_bytes": len(proof), "constraints": cells, "constraints_per_sec": cells / seconds,
+            "msm_count": sh.num_commitments, "msm_size": 1 << k, "extended_k": sh.extended_k, "stage_ms": {k_: round(v, 3) for k_, v in stages.items()},
+            "verified_by_h2hip_plonk_verify_proof": bool(ok)}
 
 
 def create_proof_k19_sharded(ctx, dist, device, reps: int = 5):

@@ -227,3 +227,18 @@ def test_create_proof_repeatable_with_interleaved_keys():
             kzg.free()
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_create_proof_gpu_k21_pairing_shape():
+    """BASELINE.json configs[4] on one GPU: the k = 21 BN254-pairing configuration (halo2-ecc/configs/bn254/bench_pairing.config:8: 2 gate advice
+    columns, 1 lookup-advice column, 1 constants column, lookup_bits 20 -> degree 4, extended_k 23, 14 commitments of 2^21 points): the proof is
+    checked by the oracle verifier and by libh2hip's own"""
+    ctx = H.Context()
+    try:
+        sh, params, vk, inst, proof, circ, gpk, kzg = _check(ctx, 21, 2, 1, 1, 0, 20, threads=16, oracle_prover=False, precompute=True, second_proof=False)
+        assert (sh.degree, sh.extended_k, gpk.shape.num_commitments) == (4, 23, 14)
+        gpk.free()
+        kzg.free()
+    finally:
+        ctx.close()
