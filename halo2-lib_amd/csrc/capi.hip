@@ -236,6 +236,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
     if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
     if (!strcmp(name, "msm_table_nontemporal")) return &ctx->msm_table_nontemporal;
+    if (!strcmp(name, "msm_fold_windows")) return &ctx->msm_fold_windows;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_wave_local")) return &ctx->ntt_wave_local;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
@@ -258,6 +259,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     int *p = param_slot(ctx, name);
     H2_REQUIRE(p, "unknown parameter name");
     if (p == &ctx->msm_window_bits) H2_REQUIRE(value == 0 || (value >= 4 && value <= 16), "msm_window_bits must be 0 (auto) or 4..16 (a window's histogram lives in LDS; at most 64 windows)");
+    if (p == &ctx->msm_fold_windows) H2_REQUIRE(value >= 0 && value <= 64, "msm_fold_windows must be 0..64");
     if (p == &ctx->msm_chunk) H2_REQUIRE(value == 0 || (value >= 2 && value <= 4096), "msm_chunk must be 0 (auto) or 2..4096");
     if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
     if (p == &ctx->msm_fuse_cols) H2_REQUIRE(value >= 0 && value <= (int)MSM_MAX_COLS, "msm_fuse_cols must be 0 (auto) or 1..8");
@@ -543,6 +545,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         c->msm_seg = ctx->msm_seg;
         c->msm_accum_variant = ctx->msm_accum_variant;
         c->msm_table_nontemporal = ctx->msm_table_nontemporal;
+        c->msm_fold_windows = ctx->msm_fold_windows;
         c->msm_scatter_split = ctx->msm_scatter_split;
         c->msm_sort_threads = ctx->msm_sort_threads;
         c->msm_quad_tails = ctx->msm_quad_tails;
@@ -571,7 +574,13 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     size_t keys_per_col = 0;
     if (deferred) {
         const uint32_t cw = bases->window_bits;
-        keys_per_col = (size_t)((255 + cw - 1) / cw) << (cw - 1);
+        const uint32_t wcol = (255 + cw - 1) / cw;
+        uint32_t sets = wcol;   // bucket sets per column: one per group of msm_fold_windows windows (msm.hip, sort_key)
+        if (ctx->msm_fold_windows > 1) {
+            const uint32_t fg = (uint32_t)ctx->msm_fold_windows < wcol ? (uint32_t)ctx->msm_fold_windows : wcol;
+            sets = (wcol + fg - 1) / fg;
+        }
+        keys_per_col = (size_t)sets << (cw - 1);
         H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH_BUCKETS, sizeof(XYZZ29) * keys_per_col * count, (void **)&all_buckets));
     }
     // host columns: one staging area for all of them; column j is copied on its lane's stream right before its kernels are

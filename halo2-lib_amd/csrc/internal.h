@@ -86,6 +86,12 @@ struct h2hip_ctx {
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
     int msm_scatter_split = 0;   // bucket sub-ranges per window in the scatter (0 = auto, power of two)
+    int msm_fold_windows = 0;    // precomputed bases: windows per shared bucket set (0 / 1 = one set per window: the default).  The sort is bucket-major inside a group of this many windows, so the
+                                 // accumulation sums the group's entries of a bucket index into one bucket ([col][groups][B] instead of [col][windows][B]);
+                                 // >= the window count: one bucket set per column and no per-index presum in the reduction.  Bit-exact, measured SLOWER
+                                 // (tools/fold_ab.py, same run: 2^19 1.29-1.40 vs 1.17 ms synchronous, 1.06-1.10 vs 0.94 per MSM in batches of 4; groups of 2..8 in
+                                 // between; create_proof k=19 16.9 vs 16.2 ms): runs 16x longer make the segmented merge of the partial sums run ~5 doubling
+                                 // steps instead of ~2.5, which costs more than the presum it removes.
     int msm_table_nontemporal = 1;   // accumulation: gather the base-table entries with non-temporal loads (no reuse; keeps the reused lines in L2)
     int msm_accum_variant = 3;   // accumulate kernel build: 3 / 4 = min waves per SIMD it is compiled for, 2 = registers padded to two waves per SIMD
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]
@@ -158,7 +164,7 @@ int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_
 int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *bases, bool precompute);
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
 constexpr uint32_t MSM_MAX_COLS = 8;   // columns one fused multi-column MSM handles
-// ext_buckets != nullptr: stop after the merge and leave the column's buckets ([W][B], zeroed here) there for msm_reduce_cols
+// ext_buckets != nullptr: stop after the merge and leave the column's buckets ([sets][B], sets = window groups of msm_fold_windows; zeroed here) there for msm_reduce_cols
 enum { MSM_PHASE_SORT = 1u, MSM_PHASE_ACCUM = 2u, MSM_PHASE_MERGE = 4u, MSM_PHASE_REDUCE = 8u, MSM_PHASE_ALL = 15u };
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev,
                  XYZZ29 *ext_buckets, uint32_t phases = MSM_PHASE_ALL);

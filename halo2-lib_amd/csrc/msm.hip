@@ -107,20 +107,36 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t *__restri
 }
 
 // ------------------------------------------------------------------ 3. prefix over chunks per (window, bucket)
-__global__ __launch_bounds__(256) void msm_hist_scan_kernel(uint32_t *__restrict__ bhist, uint32_t W, uint32_t B, uint32_t G,
+// Precomputed bases: every window of a column carries weight 1, so groups of `fg` windows can share a bucket set.  The counting sort then
+// lays its keys out BUCKET-major inside a group — key = ((col*NG + grp)*B + b)*fg + r for window grp*fg + r of column col (NG = groups per
+// column; keys of windows past the last one stay empty) — so the sorted list holds the group's entries of one bucket index next to each
+// other and the accumulation sums them into ONE bucket: the bucket array is [col][NG][B] instead of [col][Wcol][B].
+struct FoldKeys {
+    uint32_t fg, ng, wcol;   // fg == 0: plain window-major keys w*B + b
+};
+__device__ __forceinline__ uint32_t sort_key(uint32_t w, uint32_t b, uint32_t B, const FoldKeys &f) {
+    if (!f.fg) return w * B + b;
+    const uint32_t col = w / f.wcol, wc = w - col * f.wcol, grp = wc / f.fg, r = wc - grp * f.fg;
+    return ((col * f.ng + grp) * B + b) * f.fg + r;
+}
+__global__ __launch_bounds__(256) void msm_hist_scan_kernel(uint32_t *__restrict__ bhist, uint32_t W, uint32_t B, uint32_t G, FoldKeys fold_w,
                                                             uint32_t *__restrict__ counts) {
     H2_SORT_PRIORITY();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * B) return;
     uint32_t w = t / B, b = t - w * B;
     uint32_t run = 0;
-    for (uint32_t g = 0; g < G; ++g) {
-        size_t idx = ((size_t)w * G + g) * B + b;
-        uint32_t v = bhist[idx];
-        bhist[idx] = run;
-        run += v;
+    for (uint32_t g0 = 0; g0 < G; g0 += 8) {   // eight independent loads in flight, then the stores (the array is read and written in place)
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v[k] = g0 + k < G ? bhist[((size_t)w * G + g0 + k) * B + b] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            if (g0 + k < G) bhist[((size_t)w * G + g0 + k) * B + b] = run;
+            run += v[k];
+        }
     }
-    counts[t] = run;
+    counts[sort_key(w, b, B, fold_w)] = run;
 }
 
 // exclusive scan of u32 (3 kernels)
@@ -200,7 +216,7 @@ int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32
 // segment's slice of the sorted array (n*4/S bytes) fits that XCD's 4 MiB L2, so the 4-byte writes combine there
 // instead of each costing a 64-byte HBM write.
 __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
-                                                           uint32_t G, uint32_t chunk, uint32_t S, uint32_t table_stride, uint32_t Wcol,
+                                                           uint32_t G, uint32_t chunk, uint32_t S, uint32_t table_stride, uint32_t Wcol, FoldKeys fold_w,
                                                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ bhist,
                                                            uint32_t *__restrict__ sval) {
     H2_SORT_PRIORITY();
@@ -210,9 +226,8 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     if (seg >= W * S) return;
     const uint32_t w = seg / S, h = seg - w * S;
     const uint32_t Bs = B / S, b0 = h * Bs;   // this workgroup's bucket range [b0, b0 + Bs)
-    const uint32_t *off_w = offsets + (size_t)w * B + b0;
     const uint32_t *bh = bhist + ((size_t)w * G + g) * B + b0;
-    for (uint32_t b = threadIdx.x; b < Bs; b += blockDim.x) cursor[b] = off_w[b] + bh[b];
+    for (uint32_t b = threadIdx.x; b < Bs; b += blockDim.x) cursor[b] = offsets[sort_key(w, b0 + b, B, fold_w)] + bh[b];
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t *dw = digits + (size_t)w * n;
@@ -229,11 +244,12 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
 
 // ------------------------------------------------------------------ 5. chunked bucket accumulation
 // largest k in [lo, nkeys) with offsets[k] <= e   (offsets has nkeys+1 entries, e < offsets[nkeys])
-__device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offsets, uint32_t lo, uint32_t nkeys, uint32_t e) {
+// (ks = stride between consecutive run keys in `offsets`: 1, or the number of windows folded into one bucket)
+__device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offsets, uint32_t ks, uint32_t lo, uint32_t nkeys, uint32_t e) {
     uint32_t hi = nkeys;
     while (hi - lo > 1) {
         uint32_t mid = lo + ((hi - lo) >> 1);
-        if (offsets[mid] <= e) lo = mid;
+        if (offsets[(size_t)mid * ks] <= e) lo = mid;
         else hi = mid;
     }
     return lo;
@@ -264,11 +280,12 @@ __device__ __forceinline__ G1Affine load_table_entry(const G1Affine *__restrict_
 
 template <bool NT>
 __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
-                                               const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K, XYZZ29 *__restrict__ buckets,
-                                               uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
+                                               const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t ks, uint32_t K,
+                                               XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals,
+                                               uint32_t nthreads) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nthreads) return;
-    const uint32_t total = offsets[nkeys];
+    const uint32_t total = offsets[(size_t)nkeys * ks];
     uint64_t start64 = (uint64_t)t * K;
     if (start64 >= total) {
         out_keys[2 * (size_t)t] = KEY_INVALID;
@@ -276,8 +293,8 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
         return;
     }
     uint32_t start = (uint32_t)start64, end = (start64 + K > total) ? total : start + K;
-    uint32_t cur = find_key(offsets, 0, nkeys, start);
-    uint32_t next = offsets[cur + 1];
+    uint32_t cur = find_key(offsets, ks, 0, nkeys, start);
+    uint32_t next = offsets[(size_t)(cur + 1) * ks];
     uint32_t hk = KEY_INVALID;
     bool first = true;
     XYZZ29 acc = XYZZ29::identity();
@@ -292,8 +309,8 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
                 buckets[cur] = acc;
             }
             acc = XYZZ29::identity();
-            cur = (offsets[cur + 2] > e) ? cur + 1 : find_key(offsets, cur + 1, nkeys, e);
-            next = offsets[cur + 1];
+            cur = (offsets[(size_t)(cur + 2) * ks] > e) ? cur + 1 : find_key(offsets, ks, cur + 1, nkeys, e);
+            next = offsets[(size_t)(cur + 1) * ks];
         }
         uint32_t v;
         if (NT) {   // the lane's entries 16 bytes at a time: a quarter of the loads (and of the chances to find the line evicted)
@@ -320,22 +337,22 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
 
 template <int MINW, bool NT>
 __global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
-                                                        const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
+                                                        const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t ks, uint32_t K,
                                                         XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
                                                         XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
-    msm_accum_body<NT>(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
+    msm_accum_body<NT>(sval, bases, offsets, nkeys, ks, K, buckets, out_keys, out_vals, nthreads);
 }
 // Same body with the register allocation padded to 176 per lane: two waves per SIMD instead of three, which leaves a
 // third of every SIMD's register file free at all times for the tail / sort kernels of the neighbouring pipelined MSMs
 // (msm_accum_variant = 2).
 __global__ __launch_bounds__(256) void msm_accum_w2_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
-                                                           const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
+                                                           const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t ks, uint32_t K,
                                                            XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
                                                            XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
 #ifndef H2_HIPEMU
     asm volatile("" ::: "v119");
 #endif
-    msm_accum_body<false>(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
+    msm_accum_body<false>(sval, bases, offsets, nkeys, ks, K, buckets, out_keys, out_vals, nthreads);
 }
 
 // ------------------------------------------------------------------ 6. segmented merge of the partial list
@@ -738,6 +755,12 @@ __global__ __launch_bounds__(64) void msm_cols_out_kernel(const XYZZ29 *__restri
     if (col < ncols) out[col] = xyzz29_to_sat(win[col]);
 }
 
+// windows per shared bucket set (0: none) for a context's msm_fold_windows setting
+static uint32_t fold_group(const h2hip_ctx *ctx, bool precomp, uint32_t Wcol) {
+    if (!precomp || ctx->msm_fold_windows <= 1) return 0;
+    return (uint32_t)ctx->msm_fold_windows < Wcol ? (uint32_t)ctx->msm_fold_windows : Wcol;
+}
+
 // Bucket reduction for ncols bucket sets laid out [col][Wcol][B] (plain bases: one column, Wcol weighted windows):
 // per-index presum over a column's windows (precomputed tables), sum_b (b+1)*bucket[b] per set, conversion / fold.
 // All columns go through the same launches: the dependent chains are as long as for one column.
@@ -750,17 +773,23 @@ int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t c, const 
     if (L > B) L = B;
     const uint32_t Wr = precomp ? ncols : Wcol;   // bucket sets left after the optional per-index presum (one per column)
     const uint32_t nseg = Wr * (B / L);
-    const uint32_t pre_rows = (Wcol + 3) / 4;
     XYZZ29 *seg, *win, *presum = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(XYZZ29) * nseg, (void **)&seg));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(XYZZ29) * 64, (void **)&win));
-    if (precomp) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ29) * B * (size_t)ncols * (pre_rows + 1), (void **)&presum));
+    const uint32_t fg = fold_group(ctx, precomp, Wcol);
+    const uint32_t rows = precomp ? (fg ? (Wcol + fg - 1) / fg : Wcol) : 1;   // bucket sets per column the accumulation left: [col][rows][B]
+    const uint32_t pre_rows = (rows + 3) / 4;
+    if (precomp && rows > 1) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ29) * B * (size_t)ncols * (pre_rows + 1), (void **)&presum));
     const XYZZ29 *red_in = buckets;
-    if (precomp) {
+    if (precomp && rows > 1) {
         prof_begin(ctx, "msm_presum_kernel");
-        XYZZ29 *stage1 = presum + (size_t)ncols * B;   // [ncols][pre_rows][B]; the final [ncols][B] sits in front of it
-        hipLaunchKernelGGL(msm_presum_kernel, dim3((B * pre_rows + 63) / 64, ncols), dim3(64), 0, st, buckets, stage1, B, Wcol, 4u);
-        hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64, ncols), dim3(64), 0, st, (const XYZZ29 *)stage1, presum, B, pre_rows, pre_rows);
+        if (rows <= 4) {
+            hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64, ncols), dim3(64), 0, st, buckets, presum, B, rows, rows);
+        } else {
+            XYZZ29 *stage1 = presum + (size_t)ncols * B;   // [ncols][pre_rows][B]; the final [ncols][B] sits in front of it
+            hipLaunchKernelGGL(msm_presum_kernel, dim3((B * pre_rows + 63) / 64, ncols), dim3(64), 0, st, buckets, stage1, B, rows, 4u);
+            hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64, ncols), dim3(64), 0, st, (const XYZZ29 *)stage1, presum, B, pre_rows, pre_rows);
+        }
         prof_end(ctx);
         red_in = presum;
     }
@@ -824,7 +853,13 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     const uint32_t W = Wcol * ncols;           // windows the sort / accumulation see
     H2_REQUIRE(!precomp || bases->tables >= Wcol, "precomputed table has too few windows");
     const uint32_t B = 1u << (c - 1);
-    const uint32_t nkeys = W * B;
+    FoldKeys fold_w;
+    fold_w.fg = fold_group(ctx, precomp, Wcol);
+    fold_w.ng = fold_w.fg ? (Wcol + fold_w.fg - 1) / fold_w.fg : 0u;
+    fold_w.wcol = Wcol;
+    const uint32_t ks = fold_w.fg ? fold_w.fg : 1u;
+    const uint32_t nsort = fold_w.fg ? ncols * fold_w.ng * fold_w.fg * B : W * B;   // keys of the counting sort (>= W*B: a short last group is padded)
+    const uint32_t nkeys = nsort / ks;     // run keys of the accumulation = bucket slots
     const uint64_t emax = (uint64_t)n * W;
     H2_REQUIRE(emax < 0xFFFFFFF0ull, "n*W overflows 32 bits");
     uint32_t K1 = (uint32_t)ctx->msm_chunk;
@@ -843,8 +878,8 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     XYZZ29 *buckets, *pval[2];
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_DIGITS, sizeof(uint32_t) * emax, (void **)&digits));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * (nkeys + 1), (void **)&counts));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * (nkeys + 2), (void **)&offsets));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * (nsort + 1), (void **)&counts));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * ((size_t)nsort + ks + 1), (void **)&offsets));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SVAL, sizeof(uint32_t) * (emax + 4), (void **)&sval));   // + 4: the accumulation reads aligned 16-byte groups
     if (ext_buckets) buckets = ext_buckets;
     else H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(XYZZ29) * nkeys, (void **)&buckets));
@@ -858,8 +893,9 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     // `phases` lets a caller issue the latency-bound sort and merge of one MSM and its multiplier-bound accumulation on different
     // streams (all derived sizes and scratch pointers are recomputed identically on every call for the same arguments)
     if (phases & MSM_PHASE_SORT) {
-    H2_HIPCHK(hipMemsetAsync(counts + nkeys, 0, sizeof(uint32_t), st));
-    H2_HIPCHK(hipMemsetAsync(offsets + nkeys + 1, 0xff, sizeof(uint32_t), st));   // sentinel read by the boundary walk
+    if (nsort != W * B) H2_HIPCHK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nsort, st));   // padded keys: no window writes their counts
+    H2_HIPCHK(hipMemsetAsync(counts + nsort, 0, sizeof(uint32_t), st));
+    H2_HIPCHK(hipMemsetAsync(offsets + nsort + 1, 0xff, sizeof(uint32_t) * ks, st));   // sentinel offsets[(nkeys + 1) * ks] read by the boundary walk
     H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
 
     prof_begin(ctx, "msm_digits_kernel");
@@ -879,10 +915,10 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * B, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
     prof_end(ctx);
     prof_begin(ctx, "msm_hist_scan_kernel");
-    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, bhist, W, B, G, counts);
+    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nsort + 255) / 256), dim3(256), 0, st, bhist, W, B, G, fold_w, counts);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    H2_CHK(exclusive_scan_u32(ctx, counts, offsets, nkeys + 1));
+    H2_CHK(exclusive_scan_u32(ctx, counts, offsets, nsort + 1));
     prof_begin(ctx, "msm_scatter_kernel");
     uint32_t S = (uint32_t)ctx->msm_scatter_split;   // sub-ranges per window: keep a segment's output slice (n*4/S bytes) within ~2 MiB
     if (S == 0) {
@@ -893,7 +929,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     const uint32_t scatter_grid = 8 * G * ((W * S + 7) / 8);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(sort_threads), sizeof(uint32_t) * MAX_LDS_BUCKETS, st,   // full 128 KiB: one workgroup per CU keeps a segment's writes on one XCD
                        (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S,
-                       precomp ? (uint32_t)bases->n : 0u, Wcol, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
+                       precomp ? (uint32_t)bases->n : 0u, Wcol, fold_w, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     }   // MSM_PHASE_SORT
@@ -902,16 +938,16 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     prof_begin(ctx, "msm_accum_kernel");
     if (ctx->msm_accum_variant == 2)
         hipLaunchKernelGGL(msm_accum_w2_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
-                           (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     else if (ctx->msm_accum_variant == 4)
         hipLaunchKernelGGL((msm_accum_kernel<4, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
-                           (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     else if (ctx->msm_table_nontemporal)
         hipLaunchKernelGGL((msm_accum_kernel<3, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
-                           (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     else
         hipLaunchKernelGGL((msm_accum_kernel<3, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
-                           (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     }   // MSM_PHASE_ACCUM

@@ -164,13 +164,18 @@ def test_msm_precomputed_bases(ctx, c):
     try:
         b = ctx.bases_upload(bases, BASES_PRECOMPUTE)
         for s in (rand_fr(n, c), circuit_like_fr(n, c + 1)):
-            assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=4))
+            want = CO.best_multiexp(s, bases, threads=4)
+            for fold in (64, 4, 0):   # windows per shared bucket set: all (no presum) / groups of 4 (ragged last group) / one set per window
+                ctx.set_param("msm_fold_windows", fold)
+                assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), want), fold
+        ctx.set_param("msm_fold_windows", 0)
         # a prefix of the table still works (n < table size)
         s = rand_fr(100, 3)
         assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases[:100], threads=2))
         b.free()
     finally:
         ctx.set_param("msm_window_bits", 0)
+        ctx.set_param("msm_fold_windows", 0)
 
 
 @pytest.mark.parametrize("n", [1, 2, 31, 257, 5000])
@@ -389,14 +394,16 @@ def test_msm_randomized_shapes_emulated(ctx):
         b = ctx.bases_upload(bases_all[:n], flags)
         want = [CO.best_multiexp(s, bases_all[:n], threads=4) for s in cols]
         dptrs = [ctx.to_device(s) for s in cols]
-        for fuse, defer in ((0, 1), (1, 1), (1, 0)):
+        for fuse, defer, fold in ((0, 1, 64), (1, 1, 64), (1, 0, 64), (0, 1, 0), (1, 1, 3)):
             ctx.set_param("msm_fuse_cols", fuse)
             ctx.set_param("msm_defer_reduce", defer)
+            ctx.set_param("msm_fold_windows", fold)
             got = ctx.msm_batch_dev(b, dptrs, n, H.POINT_AFFINE)
             for j in range(len(cols)):
-                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, j)
+                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, fold, j)
         ctx.set_param("msm_fuse_cols", 0)
         ctx.set_param("msm_defer_reduce", 1)
+        ctx.set_param("msm_fold_windows", 0)
         for d in dptrs:
             ctx.free(d)
         b.free()

@@ -294,14 +294,16 @@ def test_msm_randomized_shapes(ctx):
         assert np.array_equal(ctx.msm(b, cols[0], H.POINT_AFFINE), want[0]), (case, n, flags)
         assert np.array_equal(ctx.msm_batch(b, cols, H.POINT_AFFINE), np.concatenate(want)), (case, n, flags, "host columns")
         dptrs = [ctx.to_device(s) for s in cols]
-        for fuse, defer in ((0, 1), (1, 1), (1, 0), (3, 1)):
+        for fuse, defer, fold in ((0, 1, 64), (1, 1, 64), (1, 0, 64), (3, 1, 64), (0, 1, 0), (1, 1, 4), (3, 0, 3)):
             ctx.set_param("msm_fuse_cols", fuse)
             ctx.set_param("msm_defer_reduce", defer)
+            ctx.set_param("msm_fold_windows", fold)   # windows per shared bucket set (64: one set per column, 0: one per window)
             got = ctx.msm_batch_dev(b, dptrs, n, H.POINT_AFFINE)
             for j in range(len(cols)):
-                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, j)
+                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, fold, j)
         ctx.set_param("msm_fuse_cols", 0)
         ctx.set_param("msm_defer_reduce", 1)
+        ctx.set_param("msm_fold_windows", 0)
         for d in dptrs:
             ctx.free(d)
         b.free()

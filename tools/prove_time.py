@@ -1,5 +1,6 @@
 """GPU: time h2hip_plonk_create_proof for a BaseCircuitParams shape (default: the k=19 ECDSA configuration) with per-stage laps.
-usage: python tools/prove_time.py [k] [num_advice] [num_lookup_advice] [num_fixed] [num_instance] [lookup_bits] [reps]"""
+usage: python tools/prove_time.py [k] [num_advice] [num_lookup_advice] [num_fixed] [num_instance] [lookup_bits] [reps]
+       [--register] [--verify] [--param=name=value ...] [--ab=name[:a,b]]   (--ab: same-run A/B of a context parameter, values a / b (default 0 / 1) alternated)"""
 import sys
 import time
 
@@ -16,6 +17,10 @@ from halo2_lib_amd import testing as T
 a = [int(v) for v in sys.argv[1:] if not v.startswith('--')]
 k, na, nl, nf, ni, lb, reps = (a + [19, 1, 1, 1, 0, 18, 5][len(a):])[:7]
 ctx = H.Context()
+for opt in sys.argv[1:]:
+    if opt.startswith("--param="):
+        name, value = opt[len("--param="):].split("=")
+        ctx.set_param(name, int(value))
 
 
 class Backend:
@@ -62,6 +67,20 @@ for rep in range(reps):
     proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(vals), tm if rep == reps - 1 else None)
     dt = time.time() - t
     print("create_proof rep %d: %.2f ms (%d bytes)" % (rep, dt * 1e3, len(proof)), flush=True)
+for opt in sys.argv[1:]:
+    if opt.startswith("--ab="):
+        import hashlib
+        name, _, pair = opt[len("--ab="):].partition(":")
+        lo, hi = [int(v) for v in (pair or "0,1").split(",")]
+        for value in (lo, hi, lo, hi):
+            ctx.set_param(name, value)
+            times = []
+            for rep in range(6):
+                t = time.time()
+                proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(vals), None)
+                times.append((time.time() - t) * 1e3)
+            print("%s=%d: create_proof min %.2f median %.2f ms  sha256 %s" % (name, value, min(times[1:]), sorted(times[1:])[2],
+                                                                             hashlib.sha256(bytes(proof)).hexdigest()[:16]), flush=True)
 if "--verify" in sys.argv:
     t = time.time()
     print("h2hip_plonk_verify_proof:", PL.verify_proof(pk, circ.instances, proof), "%.1f ms" % ((time.time() - t) * 1e3), flush=True)
