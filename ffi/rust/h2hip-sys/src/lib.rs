@@ -114,6 +114,8 @@ extern "C" {
     pub fn h2hip_fr_batch_invert_dev(ctx: *mut h2hip_ctx, a_dev: *mut c_void, n: usize) -> c_int;
     pub fn h2hip_fr_prefix_product_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, in_dev: *const c_void, n: usize) -> c_int;
     pub fn h2hip_fr_grand_product_dev(ctx: *mut h2hip_ctx, z_dev: *mut c_void, num_dev: *const c_void, den_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_fr_grand_products_dev(ctx: *mut h2hip_ctx, z_dev: *const *mut c_void, num_dev: *const c_void, den_dev: *const c_void, segments: usize,
+                                       seg_len: usize, chained: c_int) -> c_int;
     pub fn h2hip_fr_eval_polynomial_dev(ctx: *mut h2hip_ctx, coeffs_dev: *const c_void, n: usize, x: *const c_void, out_host: *mut c_void) -> c_int;
     pub fn h2hip_fr_kate_division_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, b: *const c_void) -> c_int;
     pub fn h2hip_fr_kate_division_multi_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, points: *const c_void, weights: *const c_void, m: u32) -> c_int;
@@ -137,12 +139,32 @@ extern "C" {
                                               l0_dev: *const c_void, l_last_dev: *const c_void, l_blind_dev: *const c_void, ext_k: u32, k: u32,
                                               terms: u32, last_rotation: i32, beta: *const c_void, gamma: *const c_void, delta: *const c_void,
                                               zeta: *const c_void, ext_omega: *const c_void, y: *const c_void) -> c_int;
+    pub fn h2hip_quotient_flex_gate_batch_dev(ctx: *mut h2hip_ctx, acc_dev: *mut c_void, q_dev: *const *const c_void, a_dev: *const *const c_void,
+                                              count: usize, ext_k: u32, k: u32, y: *const c_void) -> c_int;
+    pub fn h2hip_quotient_lookups_dev(ctx: *mut h2hip_ctx, acc_dev: *mut c_void, z_dev: *const *const c_void, a_dev: *const *const c_void,
+                                      s_dev: *const *const c_void, a_perm_dev: *const *const c_void, s_perm_dev: *const *const c_void, count: usize,
+                                      l0_dev: *const c_void, l_last_dev: *const c_void, l_blind_dev: *const c_void, ext_k: u32, k: u32,
+                                      beta: *const c_void, gamma: *const c_void, y: *const c_void) -> c_int;
+    pub fn h2hip_quotient_permutation_sets_dev(ctx: *mut h2hip_ctx, acc_dev: *mut c_void, z_dev: *const *const c_void, num_sets: u32,
+                                               cols_dev: *const *const c_void, sigmas_dev: *const *const c_void, num_columns: u32, chunk_len: u32,
+                                               l0_dev: *const c_void, l_last_dev: *const c_void, l_blind_dev: *const c_void, ext_k: u32, k: u32,
+                                               last_rotation: i32, beta: *const c_void, gamma: *const c_void, delta: *const c_void,
+                                               zeta: *const c_void, ext_omega: *const c_void, y: *const c_void) -> c_int;
     pub fn h2hip_lookup_permute_dev(ctx: *mut h2hip_ctx, a_dev: *const c_void, s_dev: *const c_void, usable_rows: usize, a_perm_dev: *mut c_void,
                                     s_perm_dev: *mut c_void) -> c_int;
     // prover steps between the big kernels
     pub fn h2hip_fr_axpby_dev(ctx: *mut h2hip_ctx, y_dev: *mut c_void, s: *const c_void, a: *const c_void, x_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_ifft_batch_dev(ctx: *mut h2hip_ctx, cols_dev: *const *mut c_void, count: usize, omega_inv: *const c_void, log_n: u32,
+                                divisor: *const c_void) -> c_int;
+    pub fn h2hip_coeff_to_extended_batch_dev(ctx: *mut h2hip_ctx, coeffs_dev: *const *const c_void, k: u32, outs_dev: *const *mut c_void, ext_k: u32,
+                                             count: usize, ext_omega: *const c_void, zeta: *const c_void) -> c_int;
+    pub fn h2hip_fr_linear_combination_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, polys_dev: *const *const c_void, coeffs_host: *const c_void,
+                                           count: usize, n: usize) -> c_int;
     pub fn h2hip_fr_sub_low_dev(ctx: *mut h2hip_ctx, y_dev: *mut c_void, low_host: *const c_void, m: u32) -> c_int;
     pub fn h2hip_assigned_resolve_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, num_dev: *const c_void, den_dev: *const c_void, n: usize) -> c_int;
+    pub fn h2hip_permutation_product_terms_sets_dev(ctx: *mut h2hip_ctx, num_dev: *mut c_void, den_dev: *mut c_void, cols_dev: *const *const c_void,
+                                                    sigmas_dev: *const *const c_void, num_columns: u32, chunk_len: u32, rows: usize,
+                                                    beta: *const c_void, gamma: *const c_void, delta: *const c_void, omega: *const c_void) -> c_int;
     pub fn h2hip_permutation_product_terms_dev(ctx: *mut h2hip_ctx, num_dev: *mut c_void, den_dev: *mut c_void, cols_dev: *const *const c_void,
                                                sigmas_dev: *const *const c_void, ncols: u32, first_col_index: u32, rows: usize, beta: *const c_void,
                                                gamma: *const c_void, delta: *const c_void, omega: *const c_void) -> c_int;

@@ -255,6 +255,15 @@ pub fn kate_division<'b>(be: &'b Backend, f: &DeviceVec<'b>, b: Fr) -> Result<De
 pub fn axpy(be: &Backend, y: &mut DeviceVec, a: Fr, x: &DeviceVec) -> Result<(), HipError> {
     check(unsafe { h2hip_fr_axpy_dev(be.ctx, y.ptr, fr_ptr(&a), x.ptr, x.len.min(y.len)) })
 }
+/// sum_j coeffs[j] * polys[j]: a rotation set's sum_j y^j P_j(X) of the multiopen argument in one pass
+pub fn linear_combination<'b>(be: &'b Backend, polys: &[&DeviceVec<'b>], coeffs: &[Fr]) -> Result<DeviceVec<'b>, HipError> {
+    assert_eq!(polys.len(), coeffs.len());
+    let n = polys.iter().map(|v| v.len).min().unwrap_or(0);
+    let p: Vec<*const c_void> = polys.iter().map(|v| v.ptr as *const c_void).collect();
+    let out = DeviceVec::zeroed(be, n)?;
+    check(unsafe { h2hip_fr_linear_combination_dev(be.ctx, out.ptr, p.as_ptr(), coeffs.as_ptr().cast(), polys.len(), n) })?;
+    Ok(out)
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // plonk::{keygen_pk, create_proof}: the whole prover on the device.  This is what `halo2_proofs::plonk::create_proof` becomes in the fork

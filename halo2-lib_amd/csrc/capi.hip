@@ -96,11 +96,12 @@ __global__ void point_finish_kernel(const XYZZ *__restrict__ in, G1Jac *__restri
     }
 }
 
-__global__ void point_finish_slot_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff, uint32_t slot) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        XYZZ p = in[0];
-        if (jac) jac[slot] = xyzz_to_jacobian(p);
-        if (aff) aff[slot] = xyzz_to_affine(p);
+// workgroup b: in[b] -> slot first_slot + b of the result array
+__global__ void point_finish_slot_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff, uint32_t first_slot) {
+    if (threadIdx.x == 0) {
+        XYZZ p = in[blockIdx.x];
+        if (jac) jac[first_slot + blockIdx.x] = xyzz_to_jacobian(p);
+        if (aff) aff[first_slot + blockIdx.x] = xyzz_to_affine(p);
     }
 }
 
@@ -262,7 +263,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_fold_windows) H2_REQUIRE(value >= 0 && value <= 64, "msm_fold_windows must be 0..64");
     if (p == &ctx->msm_chunk) H2_REQUIRE(value == 0 || (value >= 2 && value <= 4096), "msm_chunk must be 0 (auto) or 2..4096");
     if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
-    if (p == &ctx->msm_fuse_cols) H2_REQUIRE(value >= 0 && value <= (int)MSM_MAX_COLS, "msm_fuse_cols must be 0 (auto) or 1..8");
+    if (p == &ctx->msm_fuse_cols) H2_REQUIRE(value >= 0 && value <= (int)MSM_MAX_COLS, "msm_fuse_cols must be 0 (auto) or 1..32");
     if (p == &ctx->fr_invert_run) H2_REQUIRE(value >= 0 && value <= 1024, "fr_invert_run must be 0 (auto) or 1..1024");
     if (p == &ctx->lookup_big_tile_bits) H2_REQUIRE(value >= 12 && value <= 28, "lookup_big_tile_bits must be 12..28");
     if (p == &ctx->msm_sort_threads) H2_REQUIRE(value == 256 || value == 512 || value == 1024, "msm_sort_threads must be 256, 512 or 1024");
@@ -565,10 +566,28 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     //    bucket reduction is DEFERRED: it runs once, for all columns together, after the lanes have joined.
     const bool precomp = bases->tables > 1;
     size_t fuse = precomp ? (size_t)ctx->msm_fuse_cols : 1;
-    if (precomp && ctx->msm_fuse_cols == 0) fuse = n <= ((size_t)1 << 17) ? 4 : 1;
+    if (precomp && ctx->msm_fuse_cols == 0) {   // auto: about 2^19 scalars per fused MSM, at most 16 columns (2^17: 4, 2^16: 8, <= 2^15: 16); larger sizes run one by one
+        fuse = 1;
+        if (n <= ((size_t)1 << 17))
+            while (fuse < 16 && fuse * 2 * (n ? n : 1) <= ((size_t)1 << 19)) fuse *= 2;
+    }
     if (fuse < 1) fuse = 1;
     if (fuse > MSM_MAX_COLS) fuse = MSM_MAX_COLS;
-    if (mixed) fuse = 1;   // a fused multi-column MSM reads one table
+    // groups of columns that go through the pipeline as one fused MSM: a fused MSM reads one table, so a group never spans two base sets
+    // (runs of columns over the same set are split into balanced groups of at most `fuse`)
+    std::vector<std::pair<size_t, size_t>> groups;   // (first column, size)
+    for (size_t r0 = 0; r0 < count;) {
+        size_t r1 = r0 + 1;
+        while (r1 < count && bases_of(r1) == bases_of(r0)) ++r1;
+        const size_t run = r1 - r0, ng = (run + fuse - 1) / fuse;
+        for (size_t g = 0, j = r0; g < ng; ++g) {
+            const size_t gs = (r1 - j + (ng - g) - 1) / (ng - g);
+            groups.push_back({j, gs});
+            j += gs;
+        }
+        r0 = r1;
+    }
+    (void)mixed;
     const bool deferred = precomp && fuse == 1 && ctx->msm_defer_reduce && count >= 2 && count <= 64 && n > 0;
     XYZZ29 *all_buckets = nullptr;
     size_t keys_per_col = 0;
@@ -653,27 +672,25 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
             return rc;
         }
     }
-    const size_t ngroups = split ? 0 : (count + fuse - 1) / fuse;
-    for (size_t g = 0, j0 = 0; g < ngroups; ++g) {
-        const size_t gsize = (count - j0 + (ngroups - g) - 1) / (ngroups - g);   // balanced group sizes
+    const size_t ngroups = split ? 0 : groups.size();
+    for (size_t g = 0; g < ngroups; ++g) {
+        const size_t j0 = groups[g].first, gsize = groups[g].second;
         h2hip_ctx *c = ctx->lane[g % NL];
         const h2hip_bases *gb = bases_of(j0);
         for (size_t j = j0; j < j0 + gsize; ++j) {
             if (scalars_on_host && n) H2_LANES(hipMemcpyAsync((void *)staged[j], scalars_in[j], sizeof(Fr) * n, hipMemcpyHostToDevice, c->stream));
         }
         char *outbuf = nullptr;
-        H2_LANES_RC(ws_reserve(c, h2hip_ctx::WS_OUT, 2048, (void **)&outbuf));
+        H2_LANES_RC(ws_reserve(c, h2hip_ctx::WS_OUT, sizeof(XYZZ) * MSM_MAX_COLS, (void **)&outbuf));
         H2_LANES_RC(msm_run_cols(c, gb, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
                                  deferred ? all_buckets + keys_per_col * j0 : nullptr));
-        if (!deferred) {
+        if (!deferred) {   // the group's results, one lane each, into their slots of the batch's result array
             prof_begin(c, "point_finish_kernel");
-            for (size_t j = j0; j < j0 + gsize; ++j)
-                hipLaunchKernelGGL(point_finish_slot_kernel, dim3(1), dim3(64), 0, c->stream, (const XYZZ *)outbuf + (j - j0),
-                                   affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr, (uint32_t)j);
+            hipLaunchKernelGGL(point_finish_slot_kernel, dim3((uint32_t)gsize), dim3(64), 0, c->stream, (const XYZZ *)outbuf,
+                               affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr, (uint32_t)j0);
             prof_end(c);
         }
         H2_LANES(hipGetLastError());
-        j0 += gsize;
     }
     for (int l = 0; l < NL; ++l) {
         H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));
@@ -815,6 +832,24 @@ int h2hip_coeff_to_extended_dev(h2hip_ctx *ctx, const void *coeffs_dev, uint32_t
     Fr z = load_fr(zeta);
     Fr in3[3] = {Fr::one(), z, fe_mul(z, z)};
     return ntt_run(ctx, (Fr *)out_dev, ext_k, load_fr(ext_omega), (const Fr *)coeffs_dev, (uint64_t)1 << k, in3, nullptr);
+}
+// the same two transforms over `count` columns at once (host arrays of device pointers): 32 columns per launch
+int h2hip_ifft_batch_dev(h2hip_ctx *ctx, void *const *cols_dev, size_t count, const void *omega_inv, uint32_t log_n, const void *divisor) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && omega_inv && divisor && (count == 0 || cols_dev), "NULL argument");
+    Fr d = load_fr(divisor);
+    Fr out3[3] = {d, d, d};
+    return ntt_run_batch(ctx, (Fr *const *)cols_dev, nullptr, count, log_n, load_fr(omega_inv), 0, nullptr, out3);
+}
+int h2hip_coeff_to_extended_batch_dev(h2hip_ctx *ctx, const void *const *coeffs_dev, uint32_t k, void *const *outs_dev, uint32_t ext_k, size_t count,
+                                      const void *ext_omega, const void *zeta) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && ext_omega && zeta && (count == 0 || (coeffs_dev && outs_dev)), "NULL argument");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    for (size_t j = 0; j < count; ++j) H2_REQUIRE(coeffs_dev[j] && outs_dev[j] && (coeffs_dev[j] != outs_dev[j] || k == ext_k), "NULL column, or coeffs and out alias");
+    Fr z = load_fr(zeta);
+    Fr in3[3] = {Fr::one(), z, fe_mul(z, z)};
+    return ntt_run_batch(ctx, (Fr *const *)outs_dev, (const Fr *const *)coeffs_dev, count, ext_k, load_fr(ext_omega), (uint64_t)1 << k, in3, nullptr);
 }
 int h2hip_coeff_to_extended(h2hip_ctx *ctx, const void *coeffs_host, uint32_t k, void *out_host, uint32_t ext_k, const void *ext_omega,
                             const void *zeta) {

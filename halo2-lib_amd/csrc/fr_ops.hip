@@ -38,6 +38,34 @@ __global__ __launch_bounds__(256) void fr_axpby_kernel(Fr *__restrict__ y, Fr s,
 }
 
 // Multiplier roofline probe: every lane runs CHAINS independent dependent-multiply chains of `iters` steps.
+// out[i] = (accumulate ? out[i] : 0) + sum_j c_j * p_j[i], up to LINCOMB_MAX polynomials per pass: the multiopen argument's sum_j y^j P_j(X)
+// and its linearisation in ONE read of every operand instead of an axpy (read y, read x, write y) per term.  The data stays in its
+// saturated Montgomery form x*2^256 as a 9x29-bit integer (f29_split: no multiplication), the coefficients come in the 2^261 form, so a
+// product c'*x*2^-261 is again x-form; five products share one Montgomery reduction (f29_dot).
+constexpr uint32_t LINCOMB_MAX = 15;
+struct LinCombArgs {
+    const Fr *p[LINCOMB_MAX];
+    Fr29 c[LINCOMB_MAX];   // coefficient * 2^261, normalised, < 1.01 r
+    uint32_t count, accumulate;
+};
+__global__ __launch_bounds__(256) void fr_lincomb_kernel(Fr *out, LinCombArgs a, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Fr29 tot = a.accumulate ? f29_split<R29P>(out[i]) : Fr29::zero();
+        for (uint32_t j0 = 0; j0 < a.count; j0 += 5) {
+            Fr29 x[5], c[5];
+#pragma unroll
+            for (uint32_t t = 0; t < 5; ++t) {
+                const bool live = j0 + t < a.count;
+                x[t] = live ? f29_split<R29P>(a.p[j0 + t][i]) : Fr29::zero();
+                c[t] = live ? a.c[j0 + t] : Fr29::zero();
+            }
+            tot = f29_add(tot, f29_dot<5>(x, c));   // lazy: at most 1 + 3 normalised terms, limbs < 2^31
+        }
+        out[i] = f29_pack_canonical<FrP>(f29_weak_reduce(f29_norm(tot)));   // < r + 3 * 1.03 r -> < 2 r -> canonical
+    }
+}
+
 template <int CHAINS>
 __global__ __launch_bounds__(256) void modmul_bench_kernel(Fr *__restrict__ io, uint32_t iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,9 +139,13 @@ __global__ __launch_bounds__(256) void fr_batch_invert_kernel(Fr *__restrict__ a
 // ------------------------------------------------------------------ K5: prefix product (grand product core)
 // inclusive prefix product over tiles of 256 lanes x SCAN_J consecutive elements
 constexpr uint32_t SCAN_J = 8;
+// (blockIdx.y = segment: independent products over equal-length segments `seg_stride` elements apart go through the same three launches)
 __global__ __launch_bounds__(256) void fr_prefix_prod_tile_kernel(const Fr *__restrict__ in, Fr *__restrict__ out, Fr *__restrict__ tile_prod,
-                                                                  size_t n) {
+                                                                  size_t n, size_t seg_stride) {
     __shared__ Fr sh[256];
+    in += (size_t)blockIdx.y * seg_stride;
+    out += (size_t)blockIdx.y * seg_stride;
+    tile_prod += (size_t)blockIdx.y * gridDim.x;
     const uint32_t tid = threadIdx.x;
     const size_t base = ((size_t)blockIdx.x * 256 + tid) * SCAN_J;
     Fr acc = Fr::one();
@@ -139,6 +171,7 @@ __global__ __launch_bounds__(256) void fr_prefix_prod_tile_kernel(const Fr *__re
 // exclusive prefix product of the tile totals, one workgroup (tiles <= 1024 * per)
 __global__ __launch_bounds__(1024) void fr_prefix_prod_sums_kernel(Fr *__restrict__ tile_prod, uint32_t ntiles) {
     __shared__ Fr sh[1024];
+    tile_prod += (size_t)blockIdx.x * ntiles;   // one workgroup per segment
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (ntiles + 1023) / 1024, lo = tid * per, hi = lo + per < ntiles ? lo + per : ntiles;
     Fr acc = Fr::one();
@@ -159,16 +192,40 @@ __global__ __launch_bounds__(1024) void fr_prefix_prod_sums_kernel(Fr *__restric
         run = fe_mul(run, t);
     }
 }
-__global__ __launch_bounds__(256) void fr_prefix_prod_apply_kernel(Fr *__restrict__ out, const Fr *__restrict__ tile_excl, size_t n) {
+__global__ __launch_bounds__(256) void fr_prefix_prod_apply_kernel(Fr *__restrict__ out, const Fr *__restrict__ tile_excl, size_t n, size_t seg_stride) {
     const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * SCAN_J;
     if (blockIdx.x == 0) return;
-    Fr m = tile_excl[blockIdx.x];
+    out += (size_t)blockIdx.y * seg_stride;
+    Fr m = tile_excl[(size_t)blockIdx.y * gridDim.x + blockIdx.x];
     for (uint32_t k = 0; k < SCAN_J; ++k)
         if (base + k < n) out[base + k] = fe_mul(out[base + k], m);
 }
 // z[0] = 1 (written by the host wrapper), t[i] = num[i] * den_inv[i]
 __global__ __launch_bounds__(256) void fr_set_one_kernel(Fr *__restrict__ z) {
     if (threadIdx.x == 0 && blockIdx.x == 0) z[0] = Fr::one();
+}
+// several grand products at once: the factors num[g] * den_inv[g] of `segments` products of seg_len factors each, laid out for ONE
+// (segmented) prefix product.  chained: [1, all factors] — the prefix product over the concatenation IS the chain z_i(0) = z_{i-1}(last);
+// otherwise every segment gets its own leading 1: [1, factors of segment 0][1, factors of segment 1]...
+__global__ __launch_bounds__(256) void fr_ratio_rows_kernel(Fr *__restrict__ r, const Fr *__restrict__ num, const Fr *__restrict__ den_inv, size_t total,
+                                                            size_t seg_len, int chained) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t seg = g / seg_len, i = g - seg * seg_len;
+        const size_t dst = chained ? g + 1 : seg * (seg_len + 1) + i + 1;
+        r[dst] = fe_mul(num[g], den_inv[g]);
+        if (i == 0 && (!chained || seg == 0)) r[dst - 1] = Fr::one();
+    }
+}
+// dst.p[y][i] = src[y * src_stride + i], i < len: rows of a resident matrix out to separately allocated columns (32 per launch)
+struct RowPtrs {
+    Fr *p[32];
+};
+__global__ __launch_bounds__(256) void fr_scatter_rows_kernel(RowPtrs dst, const Fr *__restrict__ src, size_t src_stride, size_t len) {
+    Fr *__restrict__ d = dst.p[blockIdx.y];
+    const Fr *__restrict__ sp = src + (size_t)blockIdx.y * src_stride;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) d[i] = sp[i];
 }
 
 // ------------------------------------------------------------------ K7: eval_polynomial / kate_division
@@ -582,6 +639,104 @@ __global__ __launch_bounds__(256) void quotient_permutation_kernel(Fr *__restric
     }
 }
 
+// ---- the same identities for MANY columns / sets / lookups per launch (wide shapes: hundreds of columns of a few thousand rows): every
+// launch reads and writes the accumulator once and folds its jobs in order, acc = acc*y + term per job — the same values as one launch per
+// job, without a few-hundred-workgroup launch (and an accumulator round trip) per column.  Job tables travel as kernel arguments.
+constexpr uint32_t GATE_BATCH = 64, LOOKUP_BATCH = 32, PERM_BATCH = 12;
+struct GateBatchArgs {
+    const Fr *q[GATE_BATCH], *a[GATE_BATCH];
+    uint32_t count;
+    Fr y;
+};
+__global__ __launch_bounds__(256) void quotient_flex_gate_batch_kernel(Fr *__restrict__ acc, GateBatchArgs g, size_t n_ext, uint32_t rot_step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = n_ext - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ext; i += stride) {
+        const size_t i1 = (i + rot_step) & mask, i2 = (i + 2 * (size_t)rot_step) & mask, i3 = (i + 3 * (size_t)rot_step) & mask;
+        Fr v = acc[i];
+        for (uint32_t j = 0; j < g.count; ++j) {
+            const Fr *__restrict__ a = g.a[j];
+            Fr t = fe_mul(g.q[j][i], fe_sub(fe_add(a[i], fe_mul(a[i1], a[i2])), a[i3]));
+            v = fe_add(fe_mul(v, g.y), t);
+        }
+        acc[i] = v;
+    }
+}
+struct LookupJob {
+    const Fr *z, *a, *s, *ap, *sp;
+};
+struct LookupBatchArgs {
+    const Fr *l0, *l_last, *l_blind;
+    Fr beta, gamma, y;
+    uint32_t count;
+    LookupJob jobs[LOOKUP_BATCH];
+};
+__global__ __launch_bounds__(256) void quotient_lookup_batch_kernel(Fr *__restrict__ acc, LookupBatchArgs g, size_t ne, uint32_t step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = ne - 1;
+    const Fr one = Fr::one();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += stride) {
+        const size_t inext = (i + step) & mask, iprev = (i + ne - step) & mask;
+        const Fr l0 = g.l0[i], ll = g.l_last[i];
+        const Fr active = fe_sub(one, fe_add(ll, g.l_blind[i]));
+        Fr v = acc[i];
+        for (uint32_t j = 0; j < g.count; ++j) {
+            const LookupJob &q = g.jobs[j];
+            Fr z = q.z[i], a = q.a[i], sv = q.s[i], ap = q.ap[i], sp = q.sp[i];
+            v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(one, z)));
+            v = fe_add(fe_mul(v, g.y), fe_mul(ll, fe_sub(fe_sqr(z), z)));
+            Fr left = fe_mul(fe_mul(q.z[inext], fe_add(ap, g.beta)), fe_add(sp, g.gamma));
+            Fr right = fe_mul(fe_mul(z, fe_add(a, g.beta)), fe_add(sv, g.gamma));
+            v = fe_add(fe_mul(v, g.y), fe_mul(active, fe_sub(left, right)));
+            Fr d = fe_sub(ap, sp);
+            v = fe_add(fe_mul(v, g.y), fe_mul(l0, d));
+            v = fe_add(fe_mul(v, g.y), fe_mul(active, fe_mul(d, fe_sub(ap, q.ap[iprev]))));
+        }
+        acc[i] = v;
+    }
+}
+struct PermJob {
+    const Fr *z, *z_prev;
+    const Fr *cols[PERM_MAX_COLS], *sigmas[PERM_MAX_COLS];
+    Fr x0_delta;   // beta * zeta * delta^(first column index of the set)
+    uint32_t ncols, terms;
+};
+struct PermBatchArgs {
+    const Fr *l0, *l_last, *l_blind;
+    Fr beta, gamma, delta, y, ext_omega, xstep;
+    uint32_t last_rot_points, njobs;
+    PermJob jobs[PERM_BATCH];
+};
+__global__ __launch_bounds__(256) void quotient_permutation_batch_kernel(Fr *__restrict__ acc, PermBatchArgs g, size_t ne, uint32_t step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = ne - 1;
+    const Fr one = Fr::one();
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr wpow = fe_pow_u64(g.ext_omega, (uint64_t)i0);   // w_ext^i
+    for (size_t i = i0; i < ne; i += stride, wpow = fe_mul(wpow, g.xstep)) {
+        const size_t inext = (i + step) & mask;
+        const Fr l0 = g.l0[i], ll = g.l_last[i];
+        const Fr active = fe_sub(one, fe_add(ll, g.l_blind[i]));
+        Fr v = acc[i];
+        for (uint32_t jb = 0; jb < g.njobs; ++jb) {
+            const PermJob &q = g.jobs[jb];
+            const Fr z = q.z[i];
+            if (q.terms & H2HIP_PERM_FIRST) v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(one, z)));
+            if (q.terms & H2HIP_PERM_LAST) v = fe_add(fe_mul(v, g.y), fe_mul(ll, fe_sub(fe_sqr(z), z)));
+            if (q.terms & H2HIP_PERM_CHAIN) v = fe_add(fe_mul(v, g.y), fe_mul(l0, fe_sub(z, q.z_prev[(i + g.last_rot_points) & mask])));
+            if (q.terms & H2HIP_PERM_PRODUCT) {
+                Fr left = q.z[inext], right = z;
+                Fr xterm = fe_mul(q.x0_delta, wpow);
+                for (uint32_t j = 0; j < q.ncols; ++j) {
+                    Fr p = q.cols[j][i];
+                    left = fe_mul(left, fe_add(fe_add(p, fe_mul(g.beta, q.sigmas[j][i])), g.gamma));
+                    right = fe_mul(right, fe_add(fe_add(p, xterm), g.gamma));
+                    xterm = fe_mul(xterm, g.delta);
+                }
+                v = fe_add(fe_mul(v, g.y), fe_mul(active, fe_sub(left, right)));
+            }
+        }
+        acc[i] = v;
+    }
+}
+
 // HBM-counter calibration probes (profiles/r02_*_pmc_*.md): a random gather of aligned ENTRY-byte table entries — the access pattern
 // of msm_accum_kernel's base-table reads (one aligned 64-byte entry per mixed addition out of a table far larger than the 256 MiB
 // Infinity Cache) — with an exactly known useful byte count, and a coalesced stream of the same volume.
@@ -692,6 +847,36 @@ int h2hip_fr_scale_dev(h2hip_ctx *ctx, void *y, const void *s, size_t n) {
     return H2HIP_OK;
 }
 
+// out[i] = sum_j coeffs[j] * polys[j][i]
+int h2hip_fr_linear_combination_dev(h2hip_ctx *ctx, void *out, const void *const *polys, const void *coeffs, size_t count, size_t n) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && (n == 0 || out) && (count == 0 || (polys && coeffs)), "NULL argument");
+    if (!n) return H2HIP_OK;
+    for (size_t j = 0; j < count; ++j) H2_REQUIRE(polys[j], "NULL polynomial");
+    if (!count) {
+        H2_HIPCHK(hipMemsetAsync(out, 0, sizeof(Fr) * n, ctx->stream));
+        return H2HIP_OK;
+    }
+    const Fr *cs = (const Fr *)coeffs;
+    for (size_t j0 = 0; j0 < count; j0 += LINCOMB_MAX) {
+        LinCombArgs a;
+        a.count = (uint32_t)(count - j0 < LINCOMB_MAX ? count - j0 : LINCOMB_MAX);
+        a.accumulate = j0 ? 1u : 0u;
+        for (uint32_t t = 0; t < LINCOMB_MAX; ++t) {
+            const bool live = t < a.count;
+            Fr c;
+            if (live) memcpy(&c, cs + j0 + t, sizeof(Fr));
+            a.p[t] = live ? (const Fr *)polys[j0 + t] : nullptr;
+            a.c[t] = live ? fr29_from_sat(c) : Fr29::zero();
+        }
+        prof_begin(ctx, "fr_lincomb_kernel");
+        hipLaunchKernelGGL(fr_lincomb_kernel, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (Fr *)out, a, n);
+        prof_end(ctx);
+    }
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
 // ------------------------------------------------------------------ K4 / K5
 int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a, size_t n) {
     H2_DEVICE_GUARD(ctx);
@@ -715,19 +900,22 @@ int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a, size_t n) {
     return H2HIP_OK;
 }
 
-static int prefix_product_inplace(h2hip_ctx *ctx, const Fr *in, Fr *out, size_t n) {
+// inclusive prefix products of `segments` independent runs of n elements, `seg_stride` elements apart (in -> out, same layout)
+static int prefix_product_segments(h2hip_ctx *ctx, const Fr *in, Fr *out, size_t n, size_t segments, size_t seg_stride) {
     const uint32_t tile = 256 * SCAN_J;
     uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
+    H2_REQUIRE(segments >= 1 && segments <= 65535, "1..65535 segments");
     Fr *tp = nullptr;
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, sizeof(Fr) * (ntiles + 1), (void **)&tp));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, sizeof(Fr) * ((size_t)ntiles * segments + 1), (void **)&tp));
     prof_begin(ctx, "fr_prefix_prod_kernels");
-    hipLaunchKernelGGL(fr_prefix_prod_tile_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, in, out, tp, n);
-    hipLaunchKernelGGL(fr_prefix_prod_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, tp, ntiles);
-    hipLaunchKernelGGL(fr_prefix_prod_apply_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, out, (const Fr *)tp, n);
+    hipLaunchKernelGGL(fr_prefix_prod_tile_kernel, dim3(ntiles, (uint32_t)segments), dim3(256), 0, ctx->stream, in, out, tp, n, seg_stride);
+    hipLaunchKernelGGL(fr_prefix_prod_sums_kernel, dim3((uint32_t)segments), dim3(1024), 0, ctx->stream, tp, ntiles);
+    hipLaunchKernelGGL(fr_prefix_prod_apply_kernel, dim3(ntiles, (uint32_t)segments), dim3(256), 0, ctx->stream, out, (const Fr *)tp, n, seg_stride);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
 }
+static int prefix_product_inplace(h2hip_ctx *ctx, const Fr *in, Fr *out, size_t n) { return prefix_product_segments(ctx, in, out, n, 1, 0); }
 int h2hip_fr_prefix_product_dev(h2hip_ctx *ctx, void *out, const void *in, size_t n) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (n == 0 || (out && in)), "NULL argument");
@@ -747,6 +935,48 @@ int h2hip_fr_grand_product_dev(h2hip_ctx *ctx, void *z, const void *num, const v
     H2_CHK(h2hip_fr_batch_invert_dev(ctx, t, n));
     H2_CHK(binop(ctx, OP_MUL, t, t, num, n));
     return prefix_product_inplace(ctx, t, zz + 1, n);
+}
+
+// `segments` grand products of seg_len factors each in a handful of launches: num / den hold the factors of all segments back to back,
+// z[s] receives seg_len + 1 values.  chained != 0: z[s][0] = z[s-1][seg_len] (z[0][0] = 1) — the permutation argument's sets; otherwise every
+// z[s][0] = 1 — the lookup arguments.  0 denominators count as 0^-1 := 0.
+int h2hip_fr_grand_products_dev(h2hip_ctx *ctx, void *const *z, const void *num, const void *den, size_t segments, size_t seg_len, int chained) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && (segments == 0 || z) && (segments == 0 || seg_len == 0 || (num && den)), "NULL argument");
+    if (!segments) return H2HIP_OK;
+    for (size_t s2 = 0; s2 < segments; ++s2) H2_REQUIRE(z[s2], "NULL product column");
+    H2_REQUIRE(segments <= 65535 && seg_len < ((size_t)1 << 40), "too many segments");
+    const size_t total = segments * seg_len;
+    const size_t rlen = chained ? total + 1 : segments * (seg_len + 1);
+    Fr *t = nullptr, *r = nullptr;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(Fr) * (total + 2 * rlen), (void **)&t));
+    r = t + total;
+    Fr *e = r + rlen;
+    if (!total) {
+        for (size_t s2 = 0; s2 < segments; ++s2) hipLaunchKernelGGL(fr_set_one_kernel, dim3(1), dim3(64), 0, ctx->stream, (Fr *)z[s2]);
+        H2_HIPCHK(hipGetLastError());
+        return H2HIP_OK;
+    }
+    H2_HIPCHK(hipMemcpyAsync(t, den, sizeof(Fr) * total, hipMemcpyDeviceToDevice, ctx->stream));
+    H2_CHK(h2hip_fr_batch_invert_dev(ctx, t, total));
+    prof_begin(ctx, "fr_ratio_rows_kernel");
+    hipLaunchKernelGGL(fr_ratio_rows_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, r, (const Fr *)num, (const Fr *)t, total, seg_len,
+                       chained ? 1 : 0);
+    prof_end(ctx);
+    if (chained) H2_CHK(prefix_product_segments(ctx, r, e, rlen, 1, 0));
+    else H2_CHK(prefix_product_segments(ctx, r, e, seg_len + 1, segments, seg_len + 1));
+    prof_begin(ctx, "fr_scatter_rows_kernel");
+    for (size_t s0 = 0; s0 < segments; s0 += 32) {
+        const uint32_t g = (uint32_t)(segments - s0 < 32 ? segments - s0 : 32);
+        RowPtrs rows;
+        for (uint32_t j = 0; j < 32; ++j) rows.p[j] = (Fr *)z[s0 + (j < g ? j : 0)];
+        // chained: consecutive products share one element (the last value of one is the first of the next): rows seg_len apart, seg_len + 1 long
+        hipLaunchKernelGGL(fr_scatter_rows_kernel, dim3(grid_for(ctx, seg_len + 1), g), dim3(256), 0, ctx->stream, rows,
+                           (const Fr *)e + s0 * (chained ? seg_len : seg_len + 1), chained ? seg_len : seg_len + 1, seg_len + 1);
+    }
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
 }
 
 // ------------------------------------------------------------------ K7
@@ -985,6 +1215,13 @@ int h2hip_divide_by_vanishing_poly_dev(h2hip_ctx *ctx, void *a, uint32_t ext_k, 
     return H2HIP_OK;
 }
 
+// workgroups of the permutation-identity kernels: 8 points per lane from 2^21 extended points, 4 / 2 / 1 for 2^20 / 2^19 / smaller domains
+static uint32_t perm_grid(size_t ne) {
+    size_t per_lane = ne >> 18;
+    per_lane = per_lane < 1 ? 1 : per_lane > 8 ? 8 : per_lane;
+    const size_t g = (ne / per_lane + 255) / 256;
+    return g < 1 ? 1u : (uint32_t)g;
+}
 static Fr ld_fr(const void *p) {
     Fr r;
     memcpy(&r, p, sizeof(Fr));
@@ -1034,14 +1271,135 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z,
     g.last_rot_points = (uint32_t)(((uint64_t)rot * step) & (ne - 1));
     g.beta = ld_fr(beta); g.gamma = ld_fr(gamma); g.delta = ld_fr(delta); g.y = ld_fr(y); g.ext_omega = ld_fr(ext_omega);
     g.x0_delta = fe_mul(fe_mul(g.beta, ld_fr(zeta)), fe_pow_u64(g.delta, first_col_index));
-    // 8 extended points per lane: the per-lane start-up (ext_omega^i0, ~28 products) is amortised, the stride power is one
-    // host-side exponentiation
-    uint32_t pgrid = (uint32_t)((ne / 8 + 255) / 256);
-    if (pgrid < 1) pgrid = 1;
+    // 8 extended points per lane from 2^21 points (fewer below: small domains need the lanes): the per-lane start-up (ext_omega^i0,
+    // ~28 products) is amortised, the stride power is one host-side exponentiation
+    const uint32_t pgrid = perm_grid(ne);
     g.xstep = fe_pow_u64(g.ext_omega, (uint64_t)pgrid * 256);
     prof_begin(ctx, "quotient_permutation_kernel");
     hipLaunchKernelGGL(quotient_permutation_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
     prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+// ---- batched forms: all gate columns / all permutation sets / all lookups of a proof
+int h2hip_quotient_flex_gate_batch_dev(h2hip_ctx *ctx, void *acc, const void *const *q, const void *const *a, size_t count, uint32_t ext_k, uint32_t k,
+                                       const void *y) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && acc && y && (count == 0 || (q && a)), "NULL argument");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    const size_t n_ext = (size_t)1 << ext_k;
+    for (size_t j0 = 0; j0 < count; j0 += GATE_BATCH) {
+        GateBatchArgs g;
+        memset(&g, 0, sizeof(g));
+        g.count = (uint32_t)(count - j0 < GATE_BATCH ? count - j0 : GATE_BATCH);
+        g.y = ld_fr(y);
+        for (uint32_t j = 0; j < g.count; ++j) {
+            H2_REQUIRE(q[j0 + j] && a[j0 + j], "NULL column");
+            g.q[j] = (const Fr *)q[j0 + j];
+            g.a[j] = (const Fr *)a[j0 + j];
+        }
+        prof_begin(ctx, "quotient_flex_gate_batch_kernel");
+        hipLaunchKernelGGL(quotient_flex_gate_batch_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)acc, g, n_ext, 1u << (ext_k - k));
+        prof_end(ctx);
+    }
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+int h2hip_quotient_lookups_dev(h2hip_ctx *ctx, void *acc, const void *const *z, const void *const *a, const void *const *s, const void *const *a_perm,
+                               const void *const *s_perm, size_t count, const void *l0, const void *l_last, const void *l_blind, uint32_t ext_k, uint32_t k,
+                               const void *beta, const void *gamma, const void *y) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && acc && l0 && l_last && l_blind && beta && gamma && y && (count == 0 || (z && a && s && a_perm && s_perm)), "NULL argument");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    const size_t ne = (size_t)1 << ext_k;
+    for (size_t j0 = 0; j0 < count; j0 += LOOKUP_BATCH) {
+        LookupBatchArgs g;
+        memset(&g, 0, sizeof(g));
+        g.l0 = (const Fr *)l0; g.l_last = (const Fr *)l_last; g.l_blind = (const Fr *)l_blind;
+        g.beta = ld_fr(beta); g.gamma = ld_fr(gamma); g.y = ld_fr(y);
+        g.count = (uint32_t)(count - j0 < LOOKUP_BATCH ? count - j0 : LOOKUP_BATCH);
+        for (uint32_t j = 0; j < g.count; ++j) {
+            const size_t t = j0 + j;
+            H2_REQUIRE(z[t] && a[t] && s[t] && a_perm[t] && s_perm[t], "NULL column");
+            g.jobs[j].z = (const Fr *)z[t]; g.jobs[j].a = (const Fr *)a[t]; g.jobs[j].s = (const Fr *)s[t];
+            g.jobs[j].ap = (const Fr *)a_perm[t]; g.jobs[j].sp = (const Fr *)s_perm[t];
+        }
+        prof_begin(ctx, "quotient_lookup_batch_kernel");
+        hipLaunchKernelGGL(quotient_lookup_batch_kernel, dim3(grid_for(ctx, ne)), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, 1u << (ext_k - k));
+        prof_end(ctx);
+    }
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+// the whole permutation argument in evaluate_h's order: FIRST (set 0), LAST (last set), CHAIN (sets 1..), PRODUCT (all sets)
+int h2hip_quotient_permutation_sets_dev(h2hip_ctx *ctx, void *acc, const void *const *z, uint32_t num_sets, const void *const *cols, const void *const *sigmas,
+                                        uint32_t num_columns, uint32_t chunk_len, const void *l0, const void *l_last, const void *l_blind, uint32_t ext_k,
+                                        uint32_t k, int32_t last_rotation, const void *beta, const void *gamma, const void *delta, const void *zeta,
+                                        const void *ext_omega, const void *y) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && acc && l0 && l_last && l_blind && beta && gamma && delta && zeta && ext_omega && y, "NULL argument");
+    H2_REQUIRE(k <= ext_k && ext_k <= 28, "need k <= ext_k <= 28");
+    if (!num_sets) return H2HIP_OK;
+    H2_REQUIRE(z && cols && sigmas, "NULL argument");
+    H2_REQUIRE(chunk_len >= 1 && chunk_len <= PERM_MAX_COLS, "1..8 columns per permutation set");
+    H2_REQUIRE(num_columns > (uint64_t)(num_sets - 1) * chunk_len && num_columns <= (uint64_t)num_sets * chunk_len, "num_sets must be ceil(num_columns / chunk_len)");
+    for (uint32_t s2 = 0; s2 < num_sets; ++s2) H2_REQUIRE(z[s2], "NULL product column");
+    for (uint32_t c = 0; c < num_columns; ++c) H2_REQUIRE(cols[c] && sigmas[c], "NULL column");
+    const size_t ne = (size_t)1 << ext_k;
+    const uint32_t step = 1u << (ext_k - k);
+    PermBatchArgs g;
+    memset(&g, 0, sizeof(g));
+    g.l0 = (const Fr *)l0; g.l_last = (const Fr *)l_last; g.l_blind = (const Fr *)l_blind;
+    g.beta = ld_fr(beta); g.gamma = ld_fr(gamma); g.delta = ld_fr(delta); g.y = ld_fr(y); g.ext_omega = ld_fr(ext_omega);
+    const int64_t n = (int64_t)1 << k;
+    const int64_t rot = ((int64_t)last_rotation % n + n) % n;
+    g.last_rot_points = (uint32_t)(((uint64_t)rot * step) & (ne - 1));
+    const uint32_t pgrid = perm_grid(ne);
+    g.xstep = fe_pow_u64(g.ext_omega, (uint64_t)pgrid * 256);
+    const Fr beta_zeta = fe_mul(g.beta, ld_fr(zeta));
+    // the job list in upstream's order
+    struct Item {
+        uint32_t set, terms;
+    };
+    std::vector<Item> items;
+    if (num_sets == 1) {
+        items.push_back({0, H2HIP_PERM_FIRST | H2HIP_PERM_LAST | H2HIP_PERM_PRODUCT});
+    } else {
+        items.push_back({0, H2HIP_PERM_FIRST});
+        items.push_back({num_sets - 1, H2HIP_PERM_LAST});
+        for (uint32_t s2 = 1; s2 < num_sets; ++s2) items.push_back({s2, H2HIP_PERM_CHAIN});
+        for (uint32_t s2 = 0; s2 < num_sets; ++s2) items.push_back({s2, H2HIP_PERM_PRODUCT});
+    }
+    Fr dpow = Fr::one();   // delta^(first column of set s), kept per set
+    std::vector<Fr> set_x0(num_sets);
+    for (uint32_t s2 = 0; s2 < num_sets; ++s2) {
+        set_x0[s2] = fe_mul(beta_zeta, dpow);
+        for (uint32_t c = 0; c < chunk_len; ++c) dpow = fe_mul(dpow, g.delta);
+    }
+    for (size_t j0 = 0; j0 < items.size(); j0 += PERM_BATCH) {
+        g.njobs = (uint32_t)(items.size() - j0 < PERM_BATCH ? items.size() - j0 : PERM_BATCH);
+        for (uint32_t j = 0; j < g.njobs; ++j) {
+            const Item &it = items[j0 + j];
+            PermJob &q = g.jobs[j];
+            memset(&q, 0, sizeof(q));
+            q.z = (const Fr *)z[it.set];
+            q.z_prev = it.set ? (const Fr *)z[it.set - 1] : nullptr;
+            q.terms = it.terms;
+            q.x0_delta = set_x0[it.set];
+            if (it.terms & H2HIP_PERM_PRODUCT) {
+                const uint32_t c0 = it.set * chunk_len, c1 = c0 + chunk_len < num_columns ? c0 + chunk_len : num_columns;
+                q.ncols = c1 - c0;
+                for (uint32_t c = c0; c < c1; ++c) {
+                    q.cols[c - c0] = (const Fr *)cols[c];
+                    q.sigmas[c - c0] = (const Fr *)sigmas[c];
+                }
+            }
+        }
+        prof_begin(ctx, "quotient_permutation_batch_kernel");
+        hipLaunchKernelGGL(quotient_permutation_batch_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
+        prof_end(ctx);
+    }
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
 }

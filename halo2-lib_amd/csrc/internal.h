@@ -159,11 +159,13 @@ void prof_end(h2hip_ctx *ctx);
 // implemented in ntt.hip / msm.hip / fr_ops.hip, all on device pointers
 int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in_override, uint64_t in_len, const Fr *in_scale3,
             const Fr *out_scale3);
+int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, size_t ncols, uint32_t log_n, const Fr &omega, uint64_t in_len,
+                  const Fr *in_scale3, const Fr *out_scale3);   // the same transform over ncols equal-size columns, 32 columns per launch
 int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n);   // out[i] = sum_{j<i} in[j]; in != out
 int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_t n);
 int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *bases, bool precompute);
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
-constexpr uint32_t MSM_MAX_COLS = 8;   // columns one fused multi-column MSM handles
+constexpr uint32_t MSM_MAX_COLS = 32;   // columns one fused multi-column MSM handles
 // ext_buckets != nullptr: stop after the merge and leave the column's buckets ([sets][B], sets = window groups of msm_fold_windows; zeroed here) there for msm_reduce_cols
 enum { MSM_PHASE_SORT = 1u, MSM_PHASE_ACCUM = 2u, MSM_PHASE_MERGE = 4u, MSM_PHASE_REDUCE = 8u, MSM_PHASE_ALL = 15u };
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev,

@@ -52,12 +52,16 @@ constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t MAX_LDS_BUCKETS = 1u << 15;   // 128 KiB of u32 counters
 
 // ------------------------------------------------------------------ 1. digits
-__global__ __launch_bounds__(256) void msm_digits_kernel(const Fr *__restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                                                         uint32_t *__restrict__ digits) {
+// blockIdx.y = column of a fused multi-column MSM (column col's digits follow column col-1's: window col*W + w)
+struct DigitCols {
+    const Fr *scalars[MSM_MAX_COLS];
+};
+__global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_t n, uint32_t c, uint32_t W, uint32_t *__restrict__ digits) {
     H2_SORT_PRIORITY();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr s = fe_from_mont(scalars[i]);
+    digits += (size_t)blockIdx.y * W * n;
+    Fr s = fe_from_mont(cols.scalars[blockIdx.y][i]);
     const uint32_t B = 1u << (c - 1);
     const uint64_t mask = (1ull << c) - 1;
     uint32_t carry = 0;
@@ -834,7 +838,7 @@ int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t c, const 
 
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out, XYZZ29 *ext_buckets,
                  uint32_t phases) {
-    H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..8 columns per fused MSM");
+    H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..32 columns per fused MSM");
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
     H2_REQUIRE(n < (1u << 27), "n too large for 32-bit entry indices");
@@ -898,12 +902,13 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     H2_HIPCHK(hipMemsetAsync(offsets + nsort + 1, 0xff, sizeof(uint32_t) * ks, st));   // sentinel offsets[(nkeys + 1) * ks] read by the boundary walk
     H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
 
-    prof_begin(ctx, "msm_digits_kernel");
-    for (uint32_t col = 0; col < ncols; ++col) {
-        H2_REQUIRE(scalars[col], "NULL scalar column");
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, scalars[col], (uint32_t)n, c, Wcol,
-                           digits + (size_t)col * Wcol * n);
+    DigitCols dcols;
+    for (uint32_t col = 0; col < MSM_MAX_COLS; ++col) {
+        H2_REQUIRE(col >= ncols || scalars[col], "NULL scalar column");
+        dcols.scalars[col] = col < ncols ? scalars[col] : nullptr;
     }
+    prof_begin(ctx, "msm_digits_kernel");
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), ncols), dim3(256), 0, st, dcols, (uint32_t)n, c, Wcol, digits);
     prof_end(ctx);
     const uint32_t sort_threads = (uint32_t)ctx->msm_sort_threads;
     if (!ctx->msm_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once

@@ -68,11 +68,20 @@ __device__ __forceinline__ uint32_t bitrev_m(uint32_t x, uint32_t m) { return m 
 // bound grows by at most 2r per stage (<= 21 r after 10 stages) instead of doubling.  While a tile is being
 // transformed, the lane's share of the NEXT tile is already in flight from HBM into registers.
 constexpr uint32_t NTT_EPT = 4;   // elements per lane per tile (tile <= 1024 elements)
-__global__ __launch_bounds__(256) void ntt_pass_kernel(const Fr *__restrict__ x, Fr *__restrict__ y, uint32_t log_n, uint32_t m,
+// A launch transforms up to NTT_BATCH equal-size columns (blockIdx.y = column): a circuit with hundreds of 2^14-row columns gets its
+// transforms in a few full-chip launches instead of one 16-workgroup launch per column and pass.
+constexpr uint32_t NTT_BATCH = 32;
+struct NttCols {
+    const Fr *x[NTT_BATCH];
+    Fr *y[NTT_BATCH];
+};
+__global__ __launch_bounds__(256) void ntt_pass_kernel(NttCols cols, uint32_t log_n, uint32_t m,
                                                        uint32_t log_s, uint32_t cb, const Fr29L *__restrict__ t1,
                                                        const Fr29L *__restrict__ t2, uint32_t lo_bits, const Fr29L *__restrict__ tdirect,
                                                        uint64_t in_len, int in_mul, int out_mul, NttScale sc, int debug_skip, int wave_local) {
     HIP_DYNAMIC_SHARED(Fr29L, lds)
+    const Fr *__restrict__ x = cols.x[blockIdx.y];
+    Fr *__restrict__ y = cols.y[blockIdx.y];
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << m, C = 1u << cb;
     const uint32_t elems = R << cb;
@@ -290,15 +299,16 @@ static int get_direct_table(h2hip_ctx *ctx, TwiddleSet *tw, uint32_t log_s, cons
     return H2HIP_OK;   // all slots taken: fall back to the composed lookup
 }
 
-// a: N = 2^log_n device elements (result lands here).  in_override (optional): read the input from there
-// (in_len valid elements, implicit zeros beyond).  in_scale3 / out_scale3 (optional, host pointers to 3 Fr):
-// multiply input / output element i by scale[i mod 3].
-int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in_override, uint64_t in_len, const Fr *in_scale3,
-            const Fr *out_scale3) {
+// a[j]: N = 2^log_n device elements each (results land there), ncols equal-size columns transformed together.  in_override (optional):
+// column j reads its input from in_override[j] (in_len valid elements, implicit zeros beyond).  in_scale3 / out_scale3 (optional, host
+// pointers to 3 Fr): multiply input / output element i by scale[i mod 3].
+int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, size_t ncols, uint32_t log_n, const Fr &omega, uint64_t in_len,
+                  const Fr *in_scale3, const Fr *out_scale3) {
     H2_REQUIRE(log_n <= 28, "log_n exceeds the 2-adicity of F_r (28)");
     const uint64_t N = 1ull << log_n;
     if (!in_override) in_len = N;
     H2_REQUIRE(in_len <= N, "input longer than the transform");
+    if (!ncols) return H2HIP_OK;
     NttScale sc;
     for (int i = 0; i < 3; ++i) {
         sc.in3[i] = in_scale3 ? in_scale3[i] : Fr::one();
@@ -316,33 +326,50 @@ int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in
     }
     TwiddleSet *tw = nullptr;
     H2_CHK(get_twiddles(ctx, log_n, omega, &tw));
+    const size_t group = ncols < NTT_BATCH ? ncols : NTT_BATCH;
     Fr *scratch = nullptr;
-    if (P > 1) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_NTT, sizeof(Fr) * N, (void **)&scratch));
+    if (P > 1) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_NTT, sizeof(Fr) * N * group, (void **)&scratch));
 
-    const Fr *cur = in_override ? in_override : a;
-    uint32_t log_s = 0;
-    for (uint32_t i = 0; i < P; ++i) {
-        const uint32_t m = mlist[i];
-        Fr *dst = (i == P - 1) ? a : (cur == scratch ? a : scratch);
-        uint32_t cb = LT - m;
-        if (cb > log_n - m) cb = log_n - m;
-        if (i > 0 && cb > log_s) cb = log_s;
-        const uint32_t tiles = 1u << (log_n - m - cb);
-        const uint32_t grid = tiles < (uint32_t)ctx->num_cus * 3 ? tiles : (uint32_t)ctx->num_cus * 3;
-        const Fr29L *tdirect = nullptr;
-        if (i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
-        const int wave_local = (ctx->ntt_wave_local && cb >= 2 && m + cb == 10 && m >= 2) ? 1 : 0;
-        const size_t shmem = sizeof(Fr29L) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)) + 8 + (wave_local ? ((size_t)1 << cb) : 0));
-        const bool first = (i == 0), last = (i == P - 1);
-        prof_begin(ctx, "ntt_pass_kernel");
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid), dim3(256), shmem, ctx->stream, cur, dst, log_n, m, log_s, cb, (const Fr29L *)tw->t1, (const Fr29L *)tw->t2,
-                           tw->lo_bits, tdirect, first ? in_len : N, (first && in_scale3) ? 1 : 0, (last && out_scale3) ? 1 : 0, sc, ctx->ntt_debug_skip, wave_local);
-        prof_end(ctx);
-        H2_HIPCHK(hipGetLastError());
-        cur = dst;
-        log_s += m;
+    for (size_t c0 = 0; c0 < ncols; c0 += NTT_BATCH) {
+        const uint32_t gc = (uint32_t)(ncols - c0 < NTT_BATCH ? ncols - c0 : NTT_BATCH);
+        bool in_scratch = false;   // where the group's current data lives (same for every column: the pass structure is shared)
+        uint32_t log_s = 0;
+        for (uint32_t i = 0; i < P; ++i) {
+            const uint32_t m = mlist[i];
+            const bool first = (i == 0), last = (i == P - 1);
+            const bool to_scratch = !last && !in_scratch;
+            NttCols cols;
+            for (uint32_t j = 0; j < NTT_BATCH; ++j) {
+                const size_t col = c0 + (j < gc ? j : 0);
+                H2_REQUIRE(a[col] && (!in_override || in_override[col]), "NULL column");
+                cols.x[j] = first ? (in_override ? in_override[col] : a[col]) : (in_scratch ? scratch + N * j : a[col]);
+                cols.y[j] = to_scratch ? scratch + N * j : a[col];
+            }
+            uint32_t cb = LT - m;
+            if (cb > log_n - m) cb = log_n - m;
+            if (i > 0 && cb > log_s) cb = log_s;
+            const uint32_t tiles = 1u << (log_n - m - cb);
+            const uint32_t grid = tiles < (uint32_t)ctx->num_cus * 3 ? tiles : (uint32_t)ctx->num_cus * 3;
+            const Fr29L *tdirect = nullptr;
+            if (i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
+            const int wave_local = (ctx->ntt_wave_local && cb >= 2 && m + cb == 10 && m >= 2) ? 1 : 0;
+            const size_t shmem = sizeof(Fr29L) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)) + 8 + (wave_local ? ((size_t)1 << cb) : 0));
+            prof_begin(ctx, "ntt_pass_kernel");
+            hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid, gc), dim3(256), shmem, ctx->stream, cols, log_n, m, log_s, cb, (const Fr29L *)tw->t1,
+                               (const Fr29L *)tw->t2, tw->lo_bits, tdirect, first ? in_len : N, (first && in_scale3) ? 1 : 0,
+                               (last && out_scale3) ? 1 : 0, sc, ctx->ntt_debug_skip, wave_local);
+            prof_end(ctx);
+            H2_HIPCHK(hipGetLastError());
+            in_scratch = to_scratch;
+            log_s += m;
+        }
     }
     return H2HIP_OK;
+}
+
+int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in_override, uint64_t in_len, const Fr *in_scale3,
+            const Fr *out_scale3) {
+    return ntt_run_batch(ctx, &a, in_override ? &in_override : nullptr, 1, log_n, omega, in_len, in_scale3, out_scale3);
 }
 
 }  // namespace h2

@@ -733,50 +733,52 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     }
     const Fr beta = tr.squeeze_challenge();
     const Fr gamma = tr.squeeze_challenge();
-    // ---- grand products: permutation sets (chained through the last usable row), then the lookups
-    Fr *num = nullptr, *den = nullptr;
-    H2_CHK(sc.take(n, &num));
-    H2_CHK(sc.take(n, &den));
+    // ---- grand products: permutation sets (chained through the last usable row), then the lookups.  The factors of all sets (all lookups)
+    // are laid out back to back and go through one batched inversion and one prefix product: over the concatenated sets that prefix product
+    // IS the chain z_i(0) = z_{i-1}(last usable row), so neither a host round trip nor a rescaling pass is needed.
     auto column_values = [&](const ColumnRef &c) -> const Fr * {
         return c.kind == 0 ? pk->fixed_values[c.index] : c.kind == 1 ? adv[c.index] : inst_values[c.index];
     };
     std::vector<Fr *> perm_z(sh.num_perm_sets);
     {
-        // every set's product is first computed from 1; the chain z_i(0) = z_{i-1}(last usable row) is then a prefix product over the sets'
-        // last values on the host and one scaling launch per set — one synchronisation for the whole argument instead of one per set
-        std::vector<Fr> local_last(sh.num_perm_sets);
-        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
-            const uint32_t c0 = si * sh.chunk_len, c1 = std::min<uint32_t>(c0 + sh.chunk_len, (uint32_t)sh.perm_columns.size());
-            const void *cols[8], *sigs[8];
-            for (uint32_t c = c0; c < c1; ++c) {
-                cols[c - c0] = column_values(sh.perm_columns[c]);
-                sigs[c - c0] = pk->sigma_values[c];
+        const size_t segs = std::max<size_t>(sh.num_perm_sets, lks.size());
+        Fr *num = nullptr, *den = nullptr;
+        if (segs) {
+            H2_CHK(sc.take(segs * (size_t)u, &num));
+            H2_CHK(sc.take(segs * (size_t)u, &den));
+        }
+        if (sh.num_perm_sets) {
+            std::vector<const void *> pcols(sh.perm_columns.size()), psig(sh.perm_columns.size());
+            for (size_t c = 0; c < sh.perm_columns.size(); ++c) {
+                pcols[c] = column_values(sh.perm_columns[c]);
+                psig[c] = pk->sigma_values[c];
             }
-            H2_CHK(h2hip_permutation_product_terms_dev(ctx, num, den, cols, sigs, c1 - c0, c0, u, &beta, &gamma, &dom.delta, &dom.omega));
-            H2_CHK(sc.take(n, &perm_z[si]));
-            H2_CHK(h2hip_fr_grand_product_dev(ctx, perm_z[si], num, den, u));   // z[0] = 1 ... z[u]
-            if (si + 1 < sh.num_perm_sets) H2_HIPCHK(hipMemcpyAsync(&local_last[si], perm_z[si] + u, sizeof(Fr), hipMemcpyDeviceToHost, st));
+            H2_CHK(h2hip_permutation_product_terms_sets_dev(ctx, num, den, pcols.data(), psig.data(), (uint32_t)pcols.size(), sh.chunk_len, u, &beta, &gamma,
+                                                            &dom.delta, &dom.omega));
+        }
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(sc.take(n, &perm_z[si]));
+        if (sh.num_perm_sets) H2_CHK(h2hip_fr_grand_products_dev(ctx, (void *const *)perm_z.data(), num, den, sh.num_perm_sets, u, 1));
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
             const Fr *tail = draw(bf);
             H2_CHK(put(perm_z[si] + (n - bf), tail, bf));
             draw(1);   // blind
         }
-        if (sh.num_perm_sets > 1) {
-            H2_HIPCHK(hipStreamSynchronize(st));
-            Fr carry = Fr::one();
-            for (uint32_t si = 1; si < sh.num_perm_sets; ++si) {
-                carry = fe_mul(carry, local_last[si - 1]);   // = the true z_{si-1}(last usable row)
-                H2_CHK(h2hip_fr_scale_dev(ctx, perm_z[si], &carry, (size_t)u + 1));
-            }
-        }
+        std::vector<void *> lk_z(lks.size());
         for (size_t li = 0; li < lks.size(); ++li) {
             LookupState &s = lks[li];
-            H2_CHK(h2hip_lookup_product_terms_dev(ctx, num, den, s.inp, pk->fixed_values[sh.lookups[li].table_col], s.ap, s.sp, u, &beta, &gamma));
+            H2_CHK(h2hip_lookup_product_terms_dev(ctx, num + li * (size_t)u, den + li * (size_t)u, s.inp, pk->fixed_values[sh.lookups[li].table_col], s.ap, s.sp,
+                                                  u, &beta, &gamma));
             H2_CHK(sc.take(n, &s.z));
-            H2_CHK(h2hip_fr_grand_product_dev(ctx, s.z, num, den, u));
+            lk_z[li] = s.z;
+        }
+        if (!lks.empty()) H2_CHK(h2hip_fr_grand_products_dev(ctx, lk_z.data(), num, den, lks.size(), u, 0));
+        for (size_t li = 0; li < lks.size(); ++li) {
             const Fr *tail = draw(bf);
-            H2_CHK(put(s.z + (n - bf), tail, bf));
+            H2_CHK(put(lks[li].z + (n - bf), tail, bf));
             draw(1);   // blind
         }
+        if (num) sc.release(num);
+        if (den) sc.release(den);
         if (stage_ms) laps.lap(ST_PRODUCTS);
     }
     // ---- this round's commitments are the grand products AND the vanishing argument's random polynomial (nothing is squeezed between
@@ -784,34 +786,49 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // needs the Lagrange values of the first-round columns: their coefficient and extended forms — RNG, upload (own stream) and NTTs overlap.
     Fr *random_poly = nullptr;
     H2_CHK(sc.take(n, &random_poly));
-    auto to_coeff = [&](Fr *a) -> int { return h2hip_ifft_dev(ctx, a, &dom.omega_inv, k, &dom.ifft_divisor); };
-    auto to_ext = [&](const Fr *poly, Fr **out) -> int {
-        H2_CHK(sc.take(ne, out));
-        return h2hip_coeff_to_extended_dev(ctx, poly, k, *out, ek, &dom.ext_omega, &dom.zeta);
+    // all columns of a round go through the transforms together (32 per launch): a wide shape's 2^14-row columns are far too small to fill the chip alone
+    auto to_coeff = [&](const std::vector<Fr *> &cols) -> int {
+        return h2hip_ifft_batch_dev(ctx, (void *const *)cols.data(), cols.size(), &dom.omega_inv, k, &dom.ifft_divisor);
+    };
+    auto to_ext = [&](const std::vector<Fr *> &polys, const std::vector<Fr **> &outs) -> int {
+        std::vector<void *> o(outs.size());
+        for (size_t i = 0; i < outs.size(); ++i) {
+            H2_CHK(sc.take(ne, outs[i]));
+            o[i] = *outs[i];
+        }
+        return h2hip_coeff_to_extended_batch_dev(ctx, (const void *const *)polys.data(), k, o.data(), ek, polys.size(), &dom.ext_omega, &dom.zeta);
     };
     struct LookupCosets {
         Fr *z, *ap, *sp, *inp;
     };
     std::vector<Fr *> adv_cos(adv.size()), inst_cos(inst_values.size()), perm_cos(sh.num_perm_sets);
     std::vector<LookupCosets> lk_cos(lks.size());
-    for (Fr *a : adv) H2_CHK(to_coeff(a));
-    for (Fr *a : inst_values) H2_CHK(to_coeff(a));
-    for (LookupState &s : lks) {
-        if (s.own_inp) {
-            sc.release(s.inp);
-            s.inp = nullptr;
+    {
+        std::vector<Fr *> round1(adv.begin(), adv.end());
+        std::vector<Fr **> round1_cos;
+        for (size_t i = 0; i < adv.size(); ++i) round1_cos.push_back(&adv_cos[i]);
+        for (size_t i = 0; i < inst_values.size(); ++i) {
+            round1.push_back(inst_values[i]);
+            round1_cos.push_back(&inst_cos[i]);
         }
-        H2_CHK(to_coeff(s.ap));
-        H2_CHK(to_coeff(s.sp));
+        for (size_t li = 0; li < lks.size(); ++li) {
+            LookupState &s = lks[li];
+            if (s.own_inp) {
+                sc.release(s.inp);
+                s.inp = nullptr;
+            }
+            round1.push_back(s.ap);
+            round1_cos.push_back(&lk_cos[li].ap);
+            round1.push_back(s.sp);
+            round1_cos.push_back(&lk_cos[li].sp);
+        }
+        H2_CHK(to_coeff(round1));
+        H2_CHK(to_ext(round1, round1_cos));
     }
-    for (size_t i = 0; i < adv.size(); ++i) H2_CHK(to_ext(adv[i], &adv_cos[i]));
-    for (size_t i = 0; i < inst_values.size(); ++i) H2_CHK(to_ext(inst_values[i], &inst_cos[i]));
     for (size_t li = 0; li < lks.size(); ++li) {
         const Lookup &l = sh.lookups[li];
         LookupCosets &c = lk_cos[li];
         c.z = nullptr;
-        H2_CHK(to_ext(lks[li].ap, &c.ap));
-        H2_CHK(to_ext(lks[li].sp, &c.sp));
         c.inp = nullptr;
         if (l.q_col >= 0) {   // the product of the cosets is the coset of the product polynomial q_lookup(X) * a(X)
             H2_CHK(sc.take(ne, &c.inp));
@@ -841,48 +858,56 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     }
     H2_CHK(tr.write_point(random_commitment));
     const Fr y = tr.squeeze_challenge();
-    for (Fr *a : perm_z) H2_CHK(to_coeff(a));
-    for (LookupState &s : lks) H2_CHK(to_coeff(s.z));
-    if (stage_ms) laps.lap(ST_TO_COEFF);
-    for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(to_ext(perm_z[si], &perm_cos[si]));
-    for (size_t li = 0; li < lks.size(); ++li) H2_CHK(to_ext(lks[li].z, &lk_cos[li].z));
+    {
+        std::vector<Fr *> zs(perm_z.begin(), perm_z.end());
+        std::vector<Fr **> zs_cos;
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) zs_cos.push_back(&perm_cos[si]);
+        for (size_t li = 0; li < lks.size(); ++li) {
+            zs.push_back(lks[li].z);
+            zs_cos.push_back(&lk_cos[li].z);
+        }
+        H2_CHK(to_coeff(zs));
+        if (stage_ms) laps.lap(ST_TO_COEFF);
+        H2_CHK(to_ext(zs, zs_cos));
+    }
     Fr *acc = nullptr;
     H2_CHK(sc.take(ne, &acc));
     H2_HIPCHK(hipMemsetAsync(acc, 0, sizeof(Fr) * ne, st));
     if (stage_ms) laps.lap(ST_TO_EXT);
-    // ---- h(X) numerator on the extended domain: the pointwise identities, folded by y in evaluate_h's order
-    for (uint32_t a = 0; a < sh.p.num_advice; ++a)
-        H2_CHK(h2hip_quotient_flex_gate_dev(ctx, acc, pk->fixed_cosets[sh.first_q_enable_col + (int)a], adv_cos[a], ek, k, &y));
-    if (sh.num_perm_sets) {
-        const std::vector<Fr *> &zc = perm_cos;
-        auto column_coset = [&](const ColumnRef &c) -> const Fr * {
-            return c.kind == 0 ? pk->fixed_cosets[c.index] : c.kind == 1 ? adv_cos[c.index] : inst_cos[c.index];
-        };
-        auto perm_terms = [&](uint32_t si, uint32_t terms) -> int {
-            const uint32_t c0 = si * sh.chunk_len, c1 = std::min<uint32_t>(c0 + sh.chunk_len, (uint32_t)sh.perm_columns.size());
-            const void *cols[8], *sigs[8];
-            for (uint32_t c = c0; c < c1; ++c) {
-                cols[c - c0] = column_coset(sh.perm_columns[c]);
-                sigs[c - c0] = pk->sigma_cosets[c];
-            }
-            return h2hip_quotient_permutation_set_dev(ctx, acc, zc[si], si ? zc[si - 1] : nullptr, cols, sigs, c1 - c0, c0, pk->l0, pk->l_last, pk->l_blind,
-                                                      ek, k, terms, -(int32_t)(bf + 1), &beta, &gamma, &dom.delta, &dom.zeta, &dom.ext_omega, &y);
-        };
-        // evaluate_h's order: first set's l_0 term, last set's l_last term, the chaining terms, then every set's product identity
-        if (sh.num_perm_sets == 1) {   // the kernel folds a mask's terms in this same order: one pass over the extended domain
-            H2_CHK(perm_terms(0, H2HIP_PERM_FIRST | H2HIP_PERM_LAST | H2HIP_PERM_PRODUCT));
-        } else {
-            H2_CHK(perm_terms(0, H2HIP_PERM_FIRST));
-            H2_CHK(perm_terms(sh.num_perm_sets - 1, H2HIP_PERM_LAST));
-            for (uint32_t si = 1; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_CHAIN));
-            for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(perm_terms(si, H2HIP_PERM_PRODUCT));
+    // ---- h(X) numerator on the extended domain: the pointwise identities, folded by y in evaluate_h's order.  All gate columns, the whole
+    // permutation argument and all lookups go through batched launches (every launch reads and writes the accumulator once)
+    {
+        std::vector<const void *> gq(sh.p.num_advice), ga(sh.p.num_advice);
+        for (uint32_t a = 0; a < sh.p.num_advice; ++a) {
+            gq[a] = pk->fixed_cosets[sh.first_q_enable_col + (int)a];
+            ga[a] = adv_cos[a];
         }
+        H2_CHK(h2hip_quotient_flex_gate_batch_dev(ctx, acc, gq.data(), ga.data(), gq.size(), ek, k, &y));
     }
-    for (size_t li = 0; li < lks.size(); ++li) {
-        const Lookup &l = sh.lookups[li];
-        const LookupCosets &c = lk_cos[li];
-        H2_CHK(h2hip_quotient_lookup_dev(ctx, acc, c.z, c.inp ? c.inp : adv_cos[l.advice_col], pk->fixed_cosets[l.table_col], c.ap, c.sp, pk->l0, pk->l_last,
-                                         pk->l_blind, ek, k, &beta, &gamma, &y));
+    if (sh.num_perm_sets) {
+        std::vector<const void *> pcols(sh.perm_columns.size()), psig(sh.perm_columns.size()), pz(perm_cos.begin(), perm_cos.end());
+        for (size_t c = 0; c < sh.perm_columns.size(); ++c) {
+            const ColumnRef &r = sh.perm_columns[c];
+            pcols[c] = r.kind == 0 ? pk->fixed_cosets[r.index] : r.kind == 1 ? adv_cos[r.index] : inst_cos[r.index];
+            psig[c] = pk->sigma_cosets[c];
+        }
+        H2_CHK(h2hip_quotient_permutation_sets_dev(ctx, acc, pz.data(), sh.num_perm_sets, pcols.data(), psig.data(), (uint32_t)pcols.size(), sh.chunk_len,
+                                                   pk->l0, pk->l_last, pk->l_blind, ek, k, -(int32_t)(bf + 1), &beta, &gamma, &dom.delta, &dom.zeta,
+                                                   &dom.ext_omega, &y));
+    }
+    if (!lks.empty()) {
+        std::vector<const void *> lz(lks.size()), la(lks.size()), ls(lks.size()), lap(lks.size()), lsp(lks.size());
+        for (size_t li = 0; li < lks.size(); ++li) {
+            const Lookup &l = sh.lookups[li];
+            const LookupCosets &c = lk_cos[li];
+            lz[li] = c.z;
+            la[li] = c.inp ? c.inp : adv_cos[l.advice_col];
+            ls[li] = pk->fixed_cosets[l.table_col];
+            lap[li] = c.ap;
+            lsp[li] = c.sp;
+        }
+        H2_CHK(h2hip_quotient_lookups_dev(ctx, acc, lz.data(), la.data(), ls.data(), lap.data(), lsp.data(), lks.size(), pk->l0, pk->l_last, pk->l_blind, ek, k,
+                                          &beta, &gamma, &y));
     }
     laps.lap(ST_QUOTIENT);
     for (Fr *p : perm_cos) sc.release(p);
@@ -923,10 +948,16 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // vanishing.evaluate: h(X) = sum_i x^(n i) h_i(X) (its evaluation is not written to the proof; the multiopen needs it)
     Fr *h_poly = nullptr;
     H2_CHK(sc.take(n, &h_poly));
-    H2_HIPCHK(hipMemcpyAsync(h_poly, acc + (size_t)(sh.quotient_pieces - 1) * n, sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
     {
-        const Fr one = Fr::one();
-        for (int i = (int)sh.quotient_pieces - 2; i >= 0; --i) H2_CHK(h2hip_fr_axpby_dev(ctx, h_poly, &xn, &one, acc + (size_t)i * n, n));
+        std::vector<const void *> pieces(sh.quotient_pieces);
+        std::vector<Fr> xn_pows(sh.quotient_pieces);
+        Fr xp = Fr::one();
+        for (uint32_t i = 0; i < sh.quotient_pieces; ++i) {
+            pieces[i] = acc + (size_t)i * n;
+            xn_pows[i] = xp;
+            xp = fe_mul(xp, xn);
+        }
+        H2_CHK(h2hip_fr_linear_combination_dev(ctx, h_poly, pieces.data(), xn_pows.data(), pieces.size(), n));
     }
     const Fr x_next = rotate(1), x_last = rotate(-(int)(bf + 1)), x_inv = rotate(-1);
     std::vector<Query> evq;            // in the order the values are written: advice, fixed, random, sigma, permutation sets, lookups; then h
@@ -1024,15 +1055,16 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             Fr ypow = Fr::one();
             std::vector<Fr> pf_weights;
             const std::vector<std::vector<Fr>> basis = lagrange_basis(rs.points, pf_weights);
+            std::vector<const void *> terms(rs.polys.size());
+            std::vector<Fr> ypows(rs.polys.size());
             for (size_t j = 0; j < rs.polys.size(); ++j) {
-                if (j == 0)
-                    H2_HIPCHK(hipMemcpyAsync(S[i], polys[rs.polys[j]], sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
-                else
-                    H2_CHK(h2hip_fr_axpy_dev(ctx, S[i], &ypow, polys[rs.polys[j]], n));
+                terms[j] = polys[rs.polys[j]];
+                ypows[j] = ypow;
                 std::vector<Fr> r = lagrange_interpolate(basis, rs.evals[j]);
                 for (size_t t = 0; t < r.size(); ++t) low[i][t] = fe_add(low[i][t], fe_mul(ypow, r[t]));
                 ypow = fe_mul(ypow, yq);
             }
+            H2_CHK(h2hip_fr_linear_combination_dev(ctx, S[i], terms.data(), ypows.data(), terms.size(), n));   // every P_j read once
             // (S_i - r_i) / prod_j (X - point_j) = sum_j w_j (S_i(X) - S_i(point_j)) / (X - point_j) (partial fractions; r_i interpolates S_i
             // on the points by construction): all roots in ONE pass over S_i, no copy and no explicit subtraction of r_i
             H2_CHK(h2hip_fr_kate_division_multi_dev(ctx, buf_b, S[i], n, rs.points.data(), pf_weights.data(), (uint32_t)rs.points.size()));
@@ -1048,9 +1080,10 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         const Fr uq = tr.squeeze_challenge();
         // linearisation L(X) = sum_i v^i Z_{T\S_i}(u) (S_i(X) - r_i(u)) - Z_T(u) h(X), which vanishes at u
         Fr *l_x = buf_a;
-        H2_HIPCHK(hipMemsetAsync(l_x, 0, sizeof(Fr) * n, st));
         Fr const0 = Fr::zero(), z_diff_0 = Fr::one();
         vpow = Fr::one();
+        std::vector<const void *> lin_terms;
+        std::vector<Fr> lin_coeffs;
         for (size_t i = 0; i < sets.size(); ++i) {
             Fr z_i = Fr::one();
             for (const Fr &p : super_points) {
@@ -1060,15 +1093,17 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             }
             if (i == 0) z_diff_0 = z_i;
             const Fr c_i = fe_mul(vpow, z_i);
-            H2_CHK(h2hip_fr_axpy_dev(ctx, l_x, &c_i, S[i], n));
+            lin_terms.push_back(S[i]);
+            lin_coeffs.push_back(c_i);
             const0 = fe_add(const0, fe_mul(c_i, eval_small(low[i], uq)));
             vpow = fe_mul(vpow, v);
         }
-        H2_CHK(h2hip_fr_sub_low_dev(ctx, l_x, &const0, 1));
         Fr zt = Fr::one();
         for (const Fr &p : super_points) zt = fe_mul(zt, fe_sub(uq, p));
-        const Fr neg_zt = fe_neg(zt);
-        H2_CHK(h2hip_fr_axpy_dev(ctx, l_x, &neg_zt, h_x, n));
+        lin_terms.push_back(h_x);
+        lin_coeffs.push_back(fe_neg(zt));
+        H2_CHK(h2hip_fr_linear_combination_dev(ctx, l_x, lin_terms.data(), lin_coeffs.data(), lin_terms.size(), n));
+        H2_CHK(h2hip_fr_sub_low_dev(ctx, l_x, &const0, 1));
         H2_CHK(h2hip_fr_kate_division_dev(ctx, buf_b, l_x, n, &uq));
         const Fr inv0 = fe_inv(z_diff_0);
         H2_CHK(h2hip_fr_scale_dev(ctx, buf_b, &inv0, (size_t)n - 1));

@@ -37,6 +37,40 @@ __global__ __launch_bounds__(256) void perm_product_terms_kernel(Fr *__restrict_
     }
 }
 
+// The same factors for SEVERAL consecutive sets per launch (a wide shape has ~80 sets of three 2^14-row columns): set s of the launch owns
+// columns [s*chunk, (s+1)*chunk) of the launch's column table and rows [s*rows, (s+1)*rows) of num / den; omega^i is computed once per row.
+constexpr uint32_t PP_BATCH_COLS = 64;
+struct PermProductBatchArgs {
+    const Fr *cols[PP_BATCH_COLS], *sigmas[PP_BATCH_COLS];
+    uint32_t ncols, chunk;
+    Fr beta, gamma, delta;
+    Fr x0;      // beta * delta^(index of the launch's first column)
+    Fr omega, xstep;
+};
+__global__ __launch_bounds__(256) void perm_product_terms_batch_kernel(Fr *__restrict__ num, Fr *__restrict__ den, PermProductBatchArgs g, size_t rows) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= rows) return;
+    Fr xbase = fe_mul(g.x0, fe_pow_u64(g.omega, (uint64_t)i0));
+    for (size_t i = i0; i < rows; i += stride, xbase = fe_mul(xbase, g.xstep)) {
+        Fr xterm = xbase;
+        for (uint32_t c0 = 0, set = 0; c0 < g.ncols; c0 += g.chunk, ++set) {
+            const uint32_t c1 = c0 + g.chunk < g.ncols ? c0 + g.chunk : g.ncols;
+            Fr nu = Fr::one(), de = Fr::one();
+            for (uint32_t j = c0; j < c1; ++j) {
+                Fr v = g.cols[j][i];
+                Fr a = fe_add(fe_add(v, xterm), g.gamma);
+                Fr b = fe_add(fe_add(v, fe_mul(g.beta, g.sigmas[j][i])), g.gamma);
+                nu = j > c0 ? fe_mul(nu, a) : a;
+                de = j > c0 ? fe_mul(de, b) : b;
+                xterm = fe_mul(xterm, g.delta);
+            }
+            num[(size_t)set * rows + i] = nu;
+            den[(size_t)set * rows + i] = de;
+        }
+    }
+}
+
 // num[i] = (a[i] + beta)(s[i] + gamma),  den[i] = (a'[i] + beta)(s'[i] + gamma)
 __global__ __launch_bounds__(256) void lookup_product_terms_kernel(Fr *__restrict__ num, Fr *__restrict__ den, const Fr *__restrict__ a,
                                                                    const Fr *__restrict__ s, const Fr *__restrict__ ap, const Fr *__restrict__ sp,
@@ -95,6 +129,42 @@ int h2hip_permutation_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den
     prof_begin(ctx, "perm_product_terms_kernel");
     hipLaunchKernelGGL(perm_product_terms_kernel, dim3(grid), dim3(256), 0, ctx->stream, (Fr *)num_dev, (Fr *)den_dev, g, rows);
     prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+// every set of the permutation argument: set s owns columns [s*chunk_len, (s+1)*chunk_len) and rows [s*rows, (s+1)*rows) of num / den
+int h2hip_permutation_product_terms_sets_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
+                                             uint32_t num_columns, uint32_t chunk_len, size_t rows, const void *beta, const void *gamma,
+                                             const void *delta, const void *omega) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && beta && gamma && delta && omega && (num_columns == 0 || (cols_dev && sigmas_dev)) && (rows == 0 || num_columns == 0 || (num_dev && den_dev)),
+               "NULL argument");
+    H2_REQUIRE(chunk_len >= 1 && chunk_len <= PP_MAX_COLS, "1..8 columns per permutation set");
+    if (!rows || !num_columns) return H2HIP_OK;
+    for (uint32_t c = 0; c < num_columns; ++c) H2_REQUIRE(cols_dev[c] && sigmas_dev[c], "NULL column");
+    PermProductBatchArgs g;
+    memset(&g, 0, sizeof(g));
+    g.chunk = chunk_len;
+    g.beta = ld(beta); g.gamma = ld(gamma); g.delta = ld(delta); g.omega = ld(omega);
+    const uint32_t grid = grid_rows(ctx, rows, 1);
+    g.xstep = fe_pow_u64(g.omega, (uint64_t)grid * 256);
+    const uint32_t per_launch = PP_BATCH_COLS / chunk_len * chunk_len;   // whole sets
+    Fr x0 = g.beta;
+    for (uint32_t c0 = 0; c0 < num_columns; c0 += per_launch) {
+        g.ncols = num_columns - c0 < per_launch ? num_columns - c0 : per_launch;
+        g.x0 = x0;
+        for (uint32_t j = 0; j < g.ncols; ++j) {
+            g.cols[j] = (const Fr *)cols_dev[c0 + j];
+            g.sigmas[j] = (const Fr *)sigmas_dev[c0 + j];
+            x0 = fe_mul(x0, g.delta);
+        }
+        const size_t first_set = c0 / chunk_len;
+        prof_begin(ctx, "perm_product_terms_batch_kernel");
+        hipLaunchKernelGGL(perm_product_terms_batch_kernel, dim3(grid), dim3(256), 0, ctx->stream, (Fr *)num_dev + first_set * rows,
+                           (Fr *)den_dev + first_set * rows, g, rows);
+        prof_end(ctx);
+    }
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
 }

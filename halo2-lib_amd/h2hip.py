@@ -73,6 +73,7 @@ _PROTOS = {
     "h2hip_fr_batch_invert_dev": (_int, [_vp, _vp, _sz]),
     "h2hip_fr_prefix_product_dev": (_int, [_vp, _vp, _vp, _sz]),
     "h2hip_fr_grand_product_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
+    "h2hip_fr_grand_products_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _int]),
     "h2hip_fr_eval_polynomial_dev": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "h2hip_fr_eval_polynomial_batch_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, _vp]),
     "h2hip_fr_kate_division_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
@@ -84,6 +85,13 @@ _PROTOS = {
     "h2hip_fr_axpy_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "h2hip_fr_scale_dev": (_int, [_vp, _vp, _vp, _sz]),
     "h2hip_fr_axpby_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _sz]),
+    "h2hip_quotient_flex_gate_batch_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _u32, _vp]),
+    "h2hip_quotient_lookups_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "h2hip_quotient_permutation_sets_dev": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "h2hip_permutation_product_terms_sets_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
+    "h2hip_ifft_batch_dev": (_int, [_vp, _vp, _sz, _vp, _u32, _vp]),
+    "h2hip_coeff_to_extended_batch_dev": (_int, [_vp, _vp, _u32, _vp, _u32, _sz, _vp, _vp]),
+    "h2hip_fr_linear_combination_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz]),
     "h2hip_fr_sub_low_dev": (_int, [_vp, _vp, _vp, _u32]),
     "h2hip_assigned_resolve_dev": (_int, [_vp, _vp, _vp, _vp, _sz]),
     "h2hip_permutation_product_terms_dev": (_int, [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
@@ -404,6 +412,18 @@ class Context:
     def ifft_dev(self, dptr: int, omega_inv: np.ndarray, log_n: int, divisor: np.ndarray):
         self._chk(self.lib.h2hip_ifft_dev(self.handle, _vp(dptr), _ptr(_fe(omega_inv)), log_n, _ptr(_fe(divisor))))
 
+    def ifft_batch_dev(self, dptrs, omega_inv: np.ndarray, log_n: int, divisor: np.ndarray):
+        """ifft_dev over several resident columns at once (32 columns per launch)"""
+        arr = (_vp * max(len(dptrs), 1))(*[_vp(d) for d in dptrs])
+        self._chk(self.lib.h2hip_ifft_batch_dev(self.handle, arr, len(dptrs), _ptr(_fe(omega_inv)), log_n, _ptr(_fe(divisor))))
+
+    def coeff_to_extended_batch_dev(self, coeffs_dptrs, k: int, out_dptrs, ext_k: int, ext_omega: np.ndarray, zeta: np.ndarray):
+        """coeff_to_extended_dev over several resident columns at once"""
+        assert len(coeffs_dptrs) == len(out_dptrs)
+        a = (_vp * max(len(coeffs_dptrs), 1))(*[_vp(d) for d in coeffs_dptrs])
+        o = (_vp * max(len(out_dptrs), 1))(*[_vp(d) for d in out_dptrs])
+        self._chk(self.lib.h2hip_coeff_to_extended_batch_dev(self.handle, a, k, o, ext_k, len(coeffs_dptrs), _ptr(_fe(ext_omega)), _ptr(_fe(zeta))))
+
     def coeff_to_extended(self, coeffs: np.ndarray, k: int, ext_k: int, ext_omega: np.ndarray, zeta: np.ndarray) -> np.ndarray:
         a = _fe(coeffs)
         assert len(a) == 1 << k
@@ -517,6 +537,23 @@ class Context:
             for d in (dn, dd, z):
                 self.free(d)
 
+    def fr_grand_products(self, nums, dens, chained: bool):
+        """several grand products of equal length at once -> list of (len + 1, 4) arrays; chained: product s starts at the last value of s - 1"""
+        nums, dens = [_fe(a) for a in nums], [_fe(a) for a in dens]
+        seg = len(nums[0]) if nums else 0
+        if any(len(a) != seg for a in nums + dens) or len(nums) != len(dens):
+            raise ValueError("segments of equal length")
+        cat = lambda cols: np.concatenate(cols) if cols and seg else np.zeros((1, 4), dtype=np.uint64)
+        dn, dd = self.to_device(cat(nums)), self.to_device(cat(dens))
+        zs = [self.malloc(32 * (seg + 1)) for _ in nums]
+        try:
+            arr = (_vp * max(len(zs), 1))(*[_vp(z) for z in zs])
+            self._chk(self.lib.h2hip_fr_grand_products_dev(self.handle, arr, _vp(dn), _vp(dd), len(zs), seg, 1 if chained else 0))
+            return [self.download(z, (seg + 1, 4)) for z in zs]
+        finally:
+            for d in [dn, dd] + zs:
+                self.free(d)
+
     def fr_eval_polynomial(self, coeffs: np.ndarray, x: np.ndarray) -> np.ndarray:
         c = _fe(coeffs)
         d = self.to_device(c) if len(c) else self.malloc(32)
@@ -560,6 +597,23 @@ class Context:
         finally:
             self.free(dy)
             self.free(dx)
+
+    def fr_linear_combination(self, polys, coeffs: np.ndarray) -> np.ndarray:
+        """sum_j coeffs[j] * polys[j]  (columns of equal length)"""
+        cols = [_fe(p) for p in polys]
+        coeffs = _fe(coeffs)
+        if len(coeffs) != len(cols) or any(len(c) != len(cols[0]) for c in cols):
+            raise ValueError("one coefficient per polynomial, polynomials of equal length")
+        n = len(cols[0]) if cols else 0
+        dptrs = [self.to_device(c) for c in cols]
+        do = self.malloc(max(32 * n, 32))
+        try:
+            arr = (_vp * max(len(cols), 1))(*[_vp(d) for d in dptrs])
+            self._chk(self.lib.h2hip_fr_linear_combination_dev(self.handle, _vp(do), arr, _ptr(coeffs) if len(cols) else None, len(cols), n))
+            return self.download(do, (n, 4))
+        finally:
+            for d in dptrs + [do]:
+                self.free(d)
 
     def fr_sub_low(self, y: np.ndarray, low: np.ndarray) -> np.ndarray:
         y, low = _fe(y), _fe(low)
@@ -694,6 +748,68 @@ class Context:
             return self.download(d_acc, _fe(acc).shape)
         finally:
             for p in [d_acc, d_z] + ([d_zp] if d_zp else []) + d_cols + d_sig + d_l:
+                self.free(p)
+
+    def permutation_product_terms_sets(self, cols, sigmas, chunk_len, beta, gamma, delta, omega):
+        """(num, den) factor columns of every permutation set: two lists of (rows, 4) arrays"""
+        rows = len(_fe(cols[0]))
+        sets = (len(cols) + chunk_len - 1) // chunk_len
+        dc, pc = self._ptr_table(cols)
+        ds, ps = self._ptr_table(sigmas)
+        dn, dd = self.malloc(32 * rows * sets), self.malloc(32 * rows * sets)
+        try:
+            self._chk(self.lib.h2hip_permutation_product_terms_sets_dev(self.handle, _vp(dn), _vp(dd), pc, ps, len(dc), chunk_len, rows, _ptr(_fe(beta)),
+                                                                        _ptr(_fe(gamma)), _ptr(_fe(delta)), _ptr(_fe(omega))))
+            num, den = self.download(dn, (sets * rows, 4)), self.download(dd, (sets * rows, 4))
+            return [num[s * rows:(s + 1) * rows] for s in range(sets)], [den[s * rows:(s + 1) * rows] for s in range(sets)]
+        finally:
+            for p in dc + ds + [dn, dd]:
+                self.free(p)
+
+    def _ptr_table(self, cols):
+        d = [self.to_device(_fe(c)) for c in cols]
+        return d, (_vp * max(len(d), 1))(*[_vp(p) for p in d])
+
+    def quotient_flex_gate_batch(self, acc, qs, advs, ext_k, k, y) -> np.ndarray:
+        """acc folded with q_j*(a + b*c - d) for every (q_j, a_j) in order: one launch per 64 columns"""
+        d_acc = self.to_device(_fe(acc))
+        dq, pq = self._ptr_table(qs)
+        da, pa = self._ptr_table(advs)
+        try:
+            self._chk(self.lib.h2hip_quotient_flex_gate_batch_dev(self.handle, _vp(d_acc), pq, pa, len(dq), ext_k, k, _ptr(_fe(y))))
+            return self.download(d_acc, _fe(acc).shape)
+        finally:
+            for p in [d_acc] + dq + da:
+                self.free(p)
+
+    def quotient_lookups(self, acc, zs, a_s, s_s, aps, sps, l0, l_last, l_blind, ext_k, k, beta, gamma, y) -> np.ndarray:
+        """acc folded with the five identities of every lookup in order: one launch per 32 lookups"""
+        d_acc = self.to_device(_fe(acc))
+        tabs = [self._ptr_table(c) for c in (zs, a_s, s_s, aps, sps)]
+        d_l = [self.to_device(_fe(v)) for v in (l0, l_last, l_blind)]
+        try:
+            self._chk(self.lib.h2hip_quotient_lookups_dev(self.handle, _vp(d_acc), *[t[1] for t in tabs], len(zs), _vp(d_l[0]), _vp(d_l[1]), _vp(d_l[2]),
+                                                          ext_k, k, _ptr(_fe(beta)), _ptr(_fe(gamma)), _ptr(_fe(y))))
+            return self.download(d_acc, _fe(acc).shape)
+        finally:
+            for p in [d_acc] + d_l + [q for t in tabs for q in t[0]]:
+                self.free(p)
+
+    def quotient_permutation_sets(self, acc, zs, cols, sigmas, chunk_len, l0, l_last, l_blind, ext_k, k, last_rotation, beta, gamma, delta, zeta,
+                                  ext_omega, y) -> np.ndarray:
+        """the whole permutation argument (all sets, evaluate_h's order) folded into acc"""
+        d_acc = self.to_device(_fe(acc))
+        dz, pz = self._ptr_table(zs)
+        dc, pc = self._ptr_table(cols)
+        ds, ps = self._ptr_table(sigmas)
+        d_l = [self.to_device(_fe(v)) for v in (l0, l_last, l_blind)]
+        try:
+            self._chk(self.lib.h2hip_quotient_permutation_sets_dev(
+                self.handle, _vp(d_acc), pz, len(dz), pc, ps, len(dc), chunk_len, _vp(d_l[0]), _vp(d_l[1]), _vp(d_l[2]), ext_k, k, int(last_rotation),
+                _ptr(_fe(beta)), _ptr(_fe(gamma)), _ptr(_fe(delta)), _ptr(_fe(zeta)), _ptr(_fe(ext_omega)), _ptr(_fe(y))))
+            return self.download(d_acc, _fe(acc).shape)
+        finally:
+            for p in [d_acc] + dz + dc + ds + d_l:
                 self.free(p)
 
     def lookup_permute(self, a: np.ndarray, s: np.ndarray, usable_rows: int, presort_table: bool = False):

@@ -156,6 +156,13 @@ int h2hip_coeff_to_extended(h2hip_ctx *ctx, const void *coeffs_host, uint32_t k,
                             const void *zeta);
 int h2hip_coeff_to_extended_dev(h2hip_ctx *ctx, const void *coeffs_dev, uint32_t k, void *out_dev, uint32_t ext_k,
                                 const void *ext_omega, const void *zeta);
+/* ifft / coeff_to_extended over `count` equal-size columns at once (`cols_dev`, `coeffs_dev`, `outs_dev`: HOST arrays of device pointers):
+ * 32 columns per kernel launch.  What create_proof does with every advice / permuted / product column (upstream transforms them one by
+ * one on the CPU's thread pool, [UPSTREAM-RECALL plonk/prover.rs]); a wide halo2-base shape (bench_pairing.config: k = 14, 211 + 27 advice
+ * columns) has ~400 columns of 2^14 rows, each far too small to fill the chip alone. */
+int h2hip_ifft_batch_dev(h2hip_ctx *ctx, void *const *cols_dev, size_t count, const void *omega_inv, uint32_t log_n, const void *divisor);
+int h2hip_coeff_to_extended_batch_dev(h2hip_ctx *ctx, const void *const *coeffs_dev, uint32_t k, void *const *outs_dev, uint32_t ext_k, size_t count,
+                                      const void *ext_omega, const void *zeta);
 /* EvaluationDomain::extended_to_coeff (without the final truncation, which is a length change on the
  * caller's Vec): in-place iNTT with ext_omega_inv, times ext_divisor, times [1, zeta_inv, zeta_inv^2][i mod 3]
  * (zeta_inv = zeta^2 because zeta^3 = 1) */
@@ -176,6 +183,10 @@ int h2hip_fr_axpy_dev(h2hip_ctx *ctx, void *y_dev, const void *a, const void *x_
 int h2hip_fr_scale_dev(h2hip_ctx *ctx, void *y_dev, const void *s, size_t n);
 /* y[i] = s * y[i] + a * x[i]  (Horner steps over polynomial pieces, e.g. h(X) = sum_i x^(n i) h_i(X)) */
 int h2hip_fr_axpby_dev(h2hip_ctx *ctx, void *y_dev, const void *s, const void *a, const void *x_dev, size_t n);
+/* out[i] = sum_j coeffs[j] * polys[j][i]: `polys` a HOST array of `count` device columns, `coeffs` `count` host Fr; every operand is read
+ * once per 15 terms (the multiopen argument's sum_j y^j P_j(X) per rotation set and its linearisation
+ * [UPSTREAM-RECALL poly/kzg/multiopen/shplonk/prover.rs]; `out` may be one of the operands). count = 0 gives zeros. */
+int h2hip_fr_linear_combination_dev(h2hip_ctx *ctx, void *out_dev, const void *const *polys_dev, const void *coeffs_host, size_t count, size_t n);
 /* y[i] -= low[i] for i < m <= 8 (`low_host`: m elements): P(X) - r(X) for the low-degree interpolant r of an opening set */
 int h2hip_fr_sub_low_dev(h2hip_ctx *ctx, void *y_dev, const void *low_host, uint32_t m);
 
@@ -192,6 +203,12 @@ int h2hip_assigned_resolve_dev(h2hip_ctx *ctx, void *out_dev, const void *num_de
  *      z[0] = 1, z[i+1] = z[i]*num[i]/den[i] (z has n+1 elements) ---------------------------------------- */
 int h2hip_fr_prefix_product_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, size_t n);
 int h2hip_fr_grand_product_dev(h2hip_ctx *ctx, void *z_dev, const void *num_dev, const void *den_dev, size_t n);
+/* `segments` grand products of seg_len factors each in a handful of launches (one batched inversion, one segmented prefix product):
+ * num_dev / den_dev hold the factors of all segments back to back, z_dev (HOST array of device pointers) receives seg_len + 1 values per
+ * segment.  chained != 0: z[s][0] = z[s-1][seg_len], z[0][0] = 1 — the sets of the permutation argument, whose chain then needs neither a
+ * host round trip nor a rescaling pass; chained == 0: every z[s][0] = 1 — the lookup arguments of one proof. */
+int h2hip_fr_grand_products_dev(h2hip_ctx *ctx, void *const *z_dev, const void *num_dev, const void *den_dev, size_t segments, size_t seg_len,
+                                int chained);
 
 /* factors of ONE permutation set's grand product over rows [0, rows) (columns = the equality-enabled columns of
  * halo2-base's configs, flex_gate/mod.rs:69,124-128, range/mod.rs:104):  num[i] = prod_j (v_j[i] + beta*delta^(first_col_index+j)*omega^i
@@ -200,6 +217,11 @@ int h2hip_fr_grand_product_dev(h2hip_ctx *ctx, void *z_dev, const void *num_dev,
 int h2hip_permutation_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
                                         uint32_t ncols, uint32_t first_col_index, size_t rows, const void *beta, const void *gamma, const void *delta,
                                         const void *omega);
+/* every set of the permutation argument at once: set s owns columns [s*chunk_len, (s+1)*chunk_len) of cols_dev / sigmas_dev (HOST arrays of
+ * num_columns device pointers) and writes rows [s*rows, (s+1)*rows) of num_dev / den_dev — the layout h2hip_fr_grand_products_dev reads */
+int h2hip_permutation_product_terms_sets_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
+                                             uint32_t num_columns, uint32_t chunk_len, size_t rows, const void *beta, const void *gamma,
+                                             const void *delta, const void *omega);
 /* factors of a lookup's grand product: num[i] = (a[i]+beta)(s[i]+gamma), den[i] = (a'[i]+beta)(s'[i]+gamma) */
 int h2hip_lookup_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *a_dev, const void *s_dev, const void *a_perm_dev,
                                    const void *s_perm_dev, size_t rows, const void *beta, const void *gamma);
@@ -252,6 +274,21 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc_dev, const void
                                        const void *l_last_dev, const void *l_blind_dev, uint32_t ext_k, uint32_t k, uint32_t terms,
                                        int32_t last_rotation, const void *beta, const void *gamma, const void *delta, const void *zeta,
                                        const void *ext_omega, const void *y);
+/* The same identities for all gate columns / all lookups / the whole permutation argument of a proof: every launch folds up to 64 gate
+ * columns, 32 lookups or 12 (set, term) pairs into the accumulator in evaluate_h's order (acc = acc*y + term per identity, exactly the
+ * values of one call per column / lookup / (loop, set)), reading and writing the accumulator once.  A wide halo2-base shape
+ * (bench_pairing.config: k = 14, 211 gate columns, 80 permutation sets, 27 lookups) needs ~20 launches instead of ~400.
+ * q/a, z/a/s/a_perm/s_perm, z/cols/sigmas: HOST arrays of device pointers; permutation_sets: set i owns columns [i*chunk_len, (i+1)*chunk_len)
+ * of cols_dev / sigmas_dev (num_sets = ceil(num_columns / chunk_len), chunk_len <= 8), z_dev[i] is its grand product. */
+int h2hip_quotient_flex_gate_batch_dev(h2hip_ctx *ctx, void *acc_dev, const void *const *q_dev, const void *const *a_dev, size_t count, uint32_t ext_k,
+                                       uint32_t k, const void *y);
+int h2hip_quotient_lookups_dev(h2hip_ctx *ctx, void *acc_dev, const void *const *z_dev, const void *const *a_dev, const void *const *s_dev,
+                               const void *const *a_perm_dev, const void *const *s_perm_dev, size_t count, const void *l0_dev, const void *l_last_dev,
+                               const void *l_blind_dev, uint32_t ext_k, uint32_t k, const void *beta, const void *gamma, const void *y);
+int h2hip_quotient_permutation_sets_dev(h2hip_ctx *ctx, void *acc_dev, const void *const *z_dev, uint32_t num_sets, const void *const *cols_dev,
+                                        const void *const *sigmas_dev, uint32_t num_columns, uint32_t chunk_len, const void *l0_dev,
+                                        const void *l_last_dev, const void *l_blind_dev, uint32_t ext_k, uint32_t k, int32_t last_rotation,
+                                        const void *beta, const void *gamma, const void *delta, const void *zeta, const void *ext_omega, const void *y);
 
 /* permute_expression_pair of the lookup argument: a_perm = sort(a[..usable]); s_perm[i] = a_perm[i] on
  * run starts, the other rows take the unconsumed table elements (ascending) from the last repeated row backwards.

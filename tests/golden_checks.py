@@ -93,7 +93,7 @@ def check_c_oracle_against_golden():
 def check_prover_steps(ctx, n, seed=5):
     """the device steps of create_proof that sit between the big kernels, against big-int arithmetic: Assigned::Rational resolution
     (zero denominators included, reference halo2-base/src/gates/flex_gate/mod.rs:677-681), the factors of the permutation and lookup grand
-    products, the Horner step over h's pieces, P(X) - r(X), and the batched evaluation round"""
+    products, the Horner step over h's pieces, P(X) - r(X), the one-pass linear combinations and the batched evaluation round"""
     from tests.util import rand_fr
 
     g = np.random.default_rng(seed)
@@ -122,6 +122,15 @@ def check_prover_steps(ctx, n, seed=5):
         wd.append(b)
         wpow = wpow * omega % R
     assert to_i(gn) == wn and to_i(gd) == wd
+    # all sets at once (chunks of 3 and 2 columns, a ragged last set; 70 columns cross the 64-column launch boundary)
+    many_c = [rand_fr(n, seed + 300 + j) for j in range(70 if n <= 64 else 7)]
+    many_s = [rand_fr(n, seed + 400 + j) for j in range(len(many_c))]
+    for chunk in (3, 2):
+        nums, dens = ctx.permutation_product_terms_sets(many_c, many_s, chunk, fr([beta]), fr([gamma]), fr([O.DELTA]), fr([omega]))
+        for si in range(len(nums)):
+            c0, c1 = si * chunk, min((si + 1) * chunk, len(many_c))
+            wn1, wd1 = ctx.permutation_product_terms(many_c[c0:c1], many_s[c0:c1], c0, fr([beta]), fr([gamma]), fr([O.DELTA]), fr([omega]))
+            assert np.array_equal(nums[si], wn1) and np.array_equal(dens[si], wd1), (chunk, si)
     # lookup factors
     a_, s_, ap, sp = (rand_fr(n, seed + 30 + j) for j in range(4))
     gn, gd = ctx.lookup_product_terms(a_, s_, ap, sp, fr([beta]), fr([gamma]))
@@ -137,6 +146,33 @@ def check_prover_steps(ctx, n, seed=5):
     for i, v in enumerate(to_i(low)):
         want[i] = (want[i] - v) % R
     assert to_i(ctx.fr_sub_low(a_, low)) == want
+    # several grand products at once (zero denominators count as 0): independent (lookups) and chained (permutation sets), 1 / 3 / 34 segments
+    for segs in (1, 3, 34):
+        seg = max(1, n // segs)
+        nums = [rand_fr(seg, seed + 60 + j) for j in range(segs)]
+        dens = [rand_fr(seg, seed + 160 + j) for j in range(segs)]
+        if seg > 3:
+            dens[0][2] = 0
+        single = [to_i(ctx.fr_grand_product(a, b)) for a, b in zip(nums, dens)]
+        assert single[0][0] == 1 and (seg <= 3 or single[0][-1] == 0)
+        got = [to_i(z) for z in ctx.fr_grand_products(nums, dens, chained=False)]
+        assert got == single, segs
+        got = [to_i(z) for z in ctx.fr_grand_products(nums, dens, chained=True)]
+        carry = 1
+        for j in range(segs):
+            assert got[j] == [v * carry % R for v in single[j]], (segs, j)
+            carry = got[j][-1]
+    # sum_j c_j P_j in one pass: 1, 5, 6, 15, 16 and 33 terms (five products per reduction, 15 terms per launch), extreme coefficients and values
+    pool = [a_, s_, ap, sp] + [rand_fr(n, seed + 50 + j) for j in range(3)]
+    pool[4][: max(1, n // 2)] = fr([R - 1])[0]
+    for count in (1, 5, 6, 15, 16, 33):
+        cs = [int(v) for v in g.integers(0, 1 << 62, size=count)]
+        if count >= 5:
+            cs[0], cs[1], cs[4] = R - 1, 0, 1
+        ps = [pool[j % len(pool)] for j in range(count)]
+        pi = [to_i(p_) for p_ in ps]
+        want = [sum(c * p_[i] for c, p_ in zip(cs, pi)) % R for i in range(n)]
+        assert to_i(ctx.fr_linear_combination(ps, fr(cs))) == want, count
     # batched evaluations: different polynomials / lengths / points, repeated points (the kernel shares their power tables)
     polys = [a_, s_, ap[: max(1, n // 3)], sp[:1], a_]
     pts = [int(v) for v in g.integers(1, 1 << 62, size=3)]
@@ -170,3 +206,87 @@ def check_prover_steps(ctx, n, seed=5):
             assert got == want
             if m > 1:                                # ... and it IS the quotient by the product of the roots: top m-1 coefficients vanish
                 assert got[len(got) - (m - 1):] == [0] * (m - 1)
+
+
+def check_ntt_batches(ctx, ks=(3, 11), ncols=35):
+    """h2hip_ifft_batch_dev / h2hip_coeff_to_extended_batch_dev (32 columns per launch: 35 columns cross a group boundary, k = 11 -> 13 runs
+    the multi-pass path with per-column scratch) against the one-column entries, which the other tests pin to the oracle"""
+    from tests.util import rand_fr
+
+    for k in ks:
+        ek, n = k + 2, 1 << k
+        omega, ext_omega = O.omega_for(k), O.omega_for(ek)
+        om_inv, div = fr([O.inv_mod(omega, R)]), fr([O.inv_mod(n, R)])
+        cols = [rand_fr(n, 900 + 37 * k + j) for j in range(ncols)]
+        cols[1][:] = 0
+        want_coeff = [ctx.ifft(c, om_inv, k, div) for c in cols]
+        want_ext = [ctx.coeff_to_extended(c, k, ek, fr([ext_omega]), fr([O.ZETA])) for c in want_coeff]
+        d = [ctx.to_device(c) for c in cols]
+        e = [ctx.malloc(32 << ek) for _ in cols]
+        try:
+            ctx.ifft_batch_dev(d, om_inv, k, div)
+            for j in range(ncols):
+                assert np.array_equal(ctx.download(d[j], (n, 4)), want_coeff[j]), (k, j)
+            ctx.coeff_to_extended_batch_dev(d, k, e, ek, fr([ext_omega]), fr([O.ZETA]))
+            for j in range(ncols):
+                assert np.array_equal(ctx.download(e[j], (1 << ek, 4)), want_ext[j]), (k, j)
+                assert np.array_equal(ctx.download(d[j], (n, 4)), want_coeff[j]), (k, j, "input preserved")
+            ctx.ifft_batch_dev([], om_inv, k, div)   # empty batch: nothing to do
+        finally:
+            for p_ in d + e:
+                ctx.free(p_)
+
+
+def check_quotient_batches(ctx, k=3, gate_cols=67, lookups=34, perm_cols=40, chunk_len=3):
+    """the batched quotient entries (64 gate columns / 32 lookups / 12 (set, term) jobs per launch: the counts cross every group boundary,
+    the last permutation set is ragged) against the one-identity-per-call entries the other tests pin to the big-int formulae, folded in
+    evaluate_h's order"""
+    from tests.util import rand_fr
+
+    ek = k + 2
+    ne = 1 << ek
+    y, beta, gamma = fr([0x1234567]), fr([0x89ABCDEF]), fr([0x13579B])
+    col = lambda j: rand_fr(ne, 7000 + j)
+    acc0 = col(0)
+    l0, l_last, l_blind = col(1), col(2), col(3)
+    # gate
+    qs, advs = [col(10 + j) for j in range(gate_cols)], [col(200 + j) for j in range(gate_cols)]
+    want = acc0
+    for q, a in zip(qs, advs):
+        want = ctx.quotient_flex_gate(want, q, a, ek, k, y)
+    assert np.array_equal(ctx.quotient_flex_gate_batch(acc0, qs, advs, ek, k, y), want)
+    assert np.array_equal(ctx.quotient_flex_gate_batch(acc0, [], [], ek, k, y), acc0)
+    # lookups
+    cols5 = [[col(400 + 40 * t + j) for j in range(lookups)] for t in range(5)]
+    want = acc0
+    for j in range(lookups):
+        want = ctx.quotient_lookup(want, *[cols5[t][j] for t in range(5)], l0, l_last, l_blind, ek, k, beta, gamma, y)
+    assert np.array_equal(ctx.quotient_lookups(acc0, *cols5, l0, l_last, l_blind, ek, k, beta, gamma, y), want)
+    # permutation argument
+    from halo2_lib_amd.h2hip import PERM_CHAIN, PERM_FIRST, PERM_LAST, PERM_PRODUCT
+
+    ext_omega = fr([O.omega_for(ek)])
+    delta, zeta = fr([O.DELTA]), fr([O.ZETA])
+    for ncols in (perm_cols, 2):
+        sets = (ncols + chunk_len - 1) // chunk_len
+        zs = [col(800 + j) for j in range(sets)]
+        pc, ps = [col(900 + j) for j in range(ncols)], [col(1000 + j) for j in range(ncols)]
+        last_rot = -3
+
+        def one(acc, si, terms):
+            c0, c1 = si * chunk_len, min((si + 1) * chunk_len, ncols)
+            return ctx.quotient_permutation_set(acc, zs[si], zs[si - 1] if si else None, pc[c0:c1], ps[c0:c1], c0, l0, l_last, l_blind, ek, k, terms,
+                                                last_rot, beta, gamma, delta, zeta, ext_omega, y)
+
+        want = acc0
+        if sets == 1:
+            want = one(want, 0, PERM_FIRST | PERM_LAST | PERM_PRODUCT)
+        else:
+            want = one(want, 0, PERM_FIRST)
+            want = one(want, sets - 1, PERM_LAST)
+            for si in range(1, sets):
+                want = one(want, si, PERM_CHAIN)
+            for si in range(sets):
+                want = one(want, si, PERM_PRODUCT)
+        got = ctx.quotient_permutation_sets(acc0, zs, pc, ps, chunk_len, l0, l_last, l_blind, ek, k, last_rot, beta, gamma, delta, zeta, ext_omega, y)
+        assert np.array_equal(got, want), ncols

@@ -250,7 +250,7 @@ def test_msm_batch_pipelined(ctx):
 
     bp = ctx.bases_upload(bases, BASES_PRECOMPUTE)
     many = dptrs + dptrs[:4]                       # 9 columns: groups of 5 + 4 at the default, 3 x 3 at fuse = 3
-    for fuse in (8, 3, 1):
+    for fuse in (16, 8, 3, 1):                     # 16: all nine columns in one fused MSM
         ctx.set_param("msm_fuse_cols", fuse)
         gotf = ctx.msm_batch_dev(bp, many, n, H.POINT_AFFINE)
         for j in range(len(many)):
@@ -425,6 +425,18 @@ def test_prover_steps_emulated(ctx, n):
     from tests.golden_checks import check_prover_steps
 
     check_prover_steps(ctx, n)
+
+
+def test_quotient_batches_emulated(ctx):
+    from tests.golden_checks import check_quotient_batches
+
+    check_quotient_batches(ctx)
+
+
+def test_ntt_batches_emulated(ctx):
+    from tests.golden_checks import check_ntt_batches
+
+    check_ntt_batches(ctx)
 
 
 def _g2_msm_checks(ctx, sizes):

@@ -310,6 +310,20 @@ def test_msm_randomized_shapes(ctx):
 
 
 @pytest.mark.gpu
+def test_quotient_batches(ctx):
+    from tests.golden_checks import check_quotient_batches
+
+    check_quotient_batches(ctx, k=9, gate_cols=130)
+
+
+@pytest.mark.gpu
+def test_ntt_batches(ctx):
+    from tests.golden_checks import check_ntt_batches
+
+    check_ntt_batches(ctx, ks=(3, 11, 14), ncols=70)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 37, 2500, 70001])
 def test_prover_steps(ctx, n):
     from tests.golden_checks import check_prover_steps

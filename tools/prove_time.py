@@ -63,6 +63,8 @@ if "--register" in sys.argv:   # page-lock the advice columns (a prover keeps th
         ctx.host_register(c)
 for rep in range(reps):
     tm = {}
+    if rep == reps - 1:
+        ctx.bench_modmul(1, 1)   # a kernel the prover never launches: tools/rocprof_proof.py takes what follows the last one as the proof
     t = time.time()
     proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(vals), tm if rep == reps - 1 else None)
     dt = time.time() - t
