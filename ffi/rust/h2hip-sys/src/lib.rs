@@ -150,6 +150,9 @@ extern "C" {
                                                l0_dev: *const c_void, l_last_dev: *const c_void, l_blind_dev: *const c_void, ext_k: u32, k: u32,
                                                last_rotation: i32, beta: *const c_void, gamma: *const c_void, delta: *const c_void,
                                                zeta: *const c_void, ext_omega: *const c_void, y: *const c_void) -> c_int;
+    pub fn h2hip_lookup_permute_presorted_batch_dev(ctx: *mut h2hip_ctx, a_dev: *const *const c_void, sorted_table_dev: *const c_void,
+                                                    usable_rows: usize, a_perm_dev: *const *mut c_void, s_perm_dev: *const *mut c_void,
+                                                    count: usize) -> c_int;
     pub fn h2hip_lookup_permute_dev(ctx: *mut h2hip_ctx, a_dev: *const c_void, s_dev: *const c_void, usable_rows: usize, a_perm_dev: *mut c_void,
                                     s_perm_dev: *mut c_void) -> c_int;
     // prover steps between the big kernels

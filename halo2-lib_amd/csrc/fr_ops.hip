@@ -916,6 +916,24 @@ static int prefix_product_segments(h2hip_ctx *ctx, const Fr *in, Fr *out, size_t
     return H2HIP_OK;
 }
 static int prefix_product_inplace(h2hip_ctx *ctx, const Fr *in, Fr *out, size_t n) { return prefix_product_segments(ctx, in, out, n, 1, 0); }
+}  // extern "C"
+namespace h2 {
+// dst[j][i] = src[j * src_stride + i], i < len, for `count` separately allocated destinations (32 per launch)
+int fr_scatter_rows(h2hip_ctx *ctx, Fr *const *dst, size_t count, const Fr *src, size_t src_stride, size_t len) {
+    if (!count || !len) return H2HIP_OK;
+    prof_begin(ctx, "fr_scatter_rows_kernel");
+    for (size_t s0 = 0; s0 < count; s0 += 32) {
+        const uint32_t g = (uint32_t)(count - s0 < 32 ? count - s0 : 32);
+        RowPtrs rows;
+        for (uint32_t j = 0; j < 32; ++j) rows.p[j] = dst[s0 + (j < g ? j : 0)];
+        hipLaunchKernelGGL(fr_scatter_rows_kernel, dim3(grid_for(ctx, len), g), dim3(256), 0, ctx->stream, rows, src + s0 * src_stride, src_stride, len);
+    }
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+}  // namespace h2
+extern "C" {
 int h2hip_fr_prefix_product_dev(h2hip_ctx *ctx, void *out, const void *in, size_t n) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (n == 0 || (out && in)), "NULL argument");
@@ -965,18 +983,8 @@ int h2hip_fr_grand_products_dev(h2hip_ctx *ctx, void *const *z, const void *num,
     prof_end(ctx);
     if (chained) H2_CHK(prefix_product_segments(ctx, r, e, rlen, 1, 0));
     else H2_CHK(prefix_product_segments(ctx, r, e, seg_len + 1, segments, seg_len + 1));
-    prof_begin(ctx, "fr_scatter_rows_kernel");
-    for (size_t s0 = 0; s0 < segments; s0 += 32) {
-        const uint32_t g = (uint32_t)(segments - s0 < 32 ? segments - s0 : 32);
-        RowPtrs rows;
-        for (uint32_t j = 0; j < 32; ++j) rows.p[j] = (Fr *)z[s0 + (j < g ? j : 0)];
-        // chained: consecutive products share one element (the last value of one is the first of the next): rows seg_len apart, seg_len + 1 long
-        hipLaunchKernelGGL(fr_scatter_rows_kernel, dim3(grid_for(ctx, seg_len + 1), g), dim3(256), 0, ctx->stream, rows,
-                           (const Fr *)e + s0 * (chained ? seg_len : seg_len + 1), chained ? seg_len : seg_len + 1, seg_len + 1);
-    }
-    prof_end(ctx);
-    H2_HIPCHK(hipGetLastError());
-    return H2HIP_OK;
+    // chained: consecutive products share one element (the last value of one is the first of the next): rows seg_len apart, seg_len + 1 long
+    return fr_scatter_rows(ctx, (Fr *const *)z, segments, e, chained ? seg_len : seg_len + 1, seg_len + 1);
 }
 
 // ------------------------------------------------------------------ K7

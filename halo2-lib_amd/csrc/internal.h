@@ -161,6 +161,9 @@ int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in
             const Fr *out_scale3);
 int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, size_t ncols, uint32_t log_n, const Fr &omega, uint64_t in_len,
                   const Fr *in_scale3, const Fr *out_scale3);   // the same transform over ncols equal-size columns, 32 columns per launch
+int fr_scatter_rows(h2hip_ctx *ctx, Fr *const *dst, size_t count, const Fr *src, size_t src_stride, size_t len);   // dst[j][i] = src[j*src_stride + i]
+int exclusive_scan_u32_segments(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t segments, size_t in_stride,
+                                size_t out_stride);   // `segments` independent scans of n elements, in_stride / out_stride elements apart
 int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n);   // out[i] = sum_{j<i} in[j]; in != out
 int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_t n);
 int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *bases, bool precompute);

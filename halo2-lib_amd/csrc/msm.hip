@@ -145,10 +145,14 @@ __global__ __launch_bounds__(256) void msm_hist_scan_kernel(uint32_t *__restrict
 
 // exclusive scan of u32 (3 kernels)
 constexpr uint32_t SCAN_TILE = 1024;   // 256 lanes x 4
+// (blockIdx.y = segment: independent scans of n elements each, in_stride / out_stride elements apart)
 __global__ __launch_bounds__(256) void scan_tile_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                        uint32_t *__restrict__ tile_sums, uint32_t n) {
+                                                        uint32_t *__restrict__ tile_sums, uint32_t n, size_t in_stride, size_t out_stride) {
     H2_SORT_PRIORITY();
     __shared__ uint32_t sh[256];
+    in += (size_t)blockIdx.y * in_stride;
+    out += (size_t)blockIdx.y * out_stride;
+    tile_sums += (size_t)blockIdx.y * gridDim.x;
     uint32_t tid = threadIdx.x, base = blockIdx.x * SCAN_TILE + tid * 4;
     uint32_t v[4], sum = 0;
 #pragma unroll
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(256) void scan_tile_kernel(const uint32_t *__restri
 __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ tile_sums, uint32_t ntiles) {
     H2_SORT_PRIORITY();
     __shared__ uint32_t sh[1024];
+    tile_sums += (size_t)blockIdx.x * ntiles;   // one workgroup per segment
     uint32_t tid = threadIdx.x;
     uint32_t per = (ntiles + 1023) / 1024, lo = tid * per, hi = lo + per < ntiles ? lo + per : ntiles;
     uint32_t sum = 0;
@@ -194,25 +199,29 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t *__restrict__ 
         excl += t;
     }
 }
-__global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ out, const uint32_t *__restrict__ tile_sums, uint32_t n) {
+__global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ out, const uint32_t *__restrict__ tile_sums, uint32_t n, size_t out_stride) {
     H2_SORT_PRIORITY();
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 4, add = tile_sums[blockIdx.x];
+    out += (size_t)blockIdx.y * out_stride;
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 4, add = tile_sums[(size_t)blockIdx.y * gridDim.x + blockIdx.x];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (base + k < n) out[base + k] += add;
 }
-int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n) {
+int exclusive_scan_u32_segments(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t segments, size_t in_stride, size_t out_stride) {
+    if (!n || !segments) return H2HIP_OK;
+    H2_REQUIRE(segments <= 65535, "too many scan segments");
     uint32_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     uint32_t *sums = nullptr;
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SCAN, sizeof(uint32_t) * (ntiles + 1), (void **)&sums));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SCAN, sizeof(uint32_t) * ((size_t)ntiles * segments + 1), (void **)&sums));
     prof_begin(ctx, "scan_kernels");
-    hipLaunchKernelGGL(scan_tile_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, in, out, sums, n);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums, ntiles);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, out, (const uint32_t *)sums, n);
+    hipLaunchKernelGGL(scan_tile_kernel, dim3(ntiles, segments), dim3(256), 0, ctx->stream, in, out, sums, n, in_stride, out_stride);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(segments), dim3(1024), 0, ctx->stream, sums, ntiles);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(ntiles, segments), dim3(256), 0, ctx->stream, out, (const uint32_t *)sums, n, out_stride);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
 }
+int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n) { return exclusive_scan_u32_segments(ctx, in, out, n, 1, 0, 0); }
 
 // ------------------------------------------------------------------ 4. scatter with LDS cursors
 // Each workgroup scatters the entries of chunk g of window w whose bucket lies in sub-range h of S: all workgroups of

@@ -608,6 +608,41 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         if (cnt) H2_HIPCHK(hipMemcpyAsync(dst, src, sizeof(Fr) * cnt, hipMemcpyHostToDevice, st));
         return H2HIP_OK;
     };
+    // Blinding rows of MANY columns: drawn back to back they sit `stride` apart in the staging buffer, so one upload and one scatter launch per
+    // 32 columns replace a small copy per column (a wide shape has hundreds).  reserve() makes room for the whole run first (it may
+    // synchronise and rewind the buffer); runs longer than the buffer fall back to one copy per column.
+    struct TailRun {
+        std::vector<Fr *> dst;
+        const Fr *first = nullptr;
+        size_t stride = 0, len = 0;
+        bool batched = false;
+    };
+    auto tails_reserve = [&](TailRun &t, size_t columns, size_t stride, size_t len) {
+        t.stride = stride;
+        t.len = len;
+        t.batched = columns >= 4 && columns * stride <= pk->host_stage_elems;
+        if (t.batched && stage_off + columns * stride > pk->host_stage_elems) {
+            hipStreamSynchronize(st);
+            stage_off = 0;
+        }
+    };
+    auto tails_add = [&](TailRun &t, Fr *dst, const Fr *src) -> int {   // src: the draw holding this column's `len` rows
+        if (!t.batched) return put(dst, src, t.len);
+        if (t.dst.empty()) t.first = src;
+        t.dst.push_back(dst);
+        return H2HIP_OK;
+    };
+    auto tails_flush = [&](TailRun &t) -> int {
+        if (!t.batched || t.dst.empty() || !t.len) return H2HIP_OK;
+        const size_t span = (t.dst.size() - 1) * t.stride + t.len;
+        Fr *tmp = nullptr;
+        H2_CHK(sc.take(span, &tmp));
+        H2_HIPCHK(hipMemcpyAsync(tmp, t.first, sizeof(Fr) * span, hipMemcpyHostToDevice, st));
+        H2_CHK(fr_scatter_rows(ctx, t.dst.data(), t.dst.size(), tmp, t.stride, t.len));
+        // (the few KiB stay with this proof's scope: a buffer handed back now could be picked up by the copy stream's upload while the scatter still reads it)
+        t.dst.clear();
+        return H2HIP_OK;
+    };
     // `bases_per_col`: empty = all columns over `bases`
     auto commit_points_multi = [&](const h2hip_bases *bases, const std::vector<const h2hip_bases *> &bases_per_col, const std::vector<const void *> &cols,
                                    size_t len, std::vector<G1Affine> &pts) -> int {
@@ -682,12 +717,17 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_HIPCHK(hipStreamSynchronize(st));
     }
     // ---- advice columns: witness rows from the caller, blinding rows from the RNG
-    for (uint32_t c = 0; c < sh.num_advice_total; ++c) {
-        H2_REQUIRE(advice[c], "NULL advice column");
-        H2_CHK(sc.take(n, &adv[c]));
-        H2_HIPCHK(hipMemcpyAsync(adv[c], advice[c], sizeof(Fr) * u, advice_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        const Fr *tail = draw(n - u);
-        H2_CHK(put(adv[c] + u, tail, n - u));
+    {
+        TailRun tails;
+        tails_reserve(tails, sh.num_advice_total, n - u, n - u);
+        for (uint32_t c = 0; c < sh.num_advice_total; ++c) {
+            H2_REQUIRE(advice[c], "NULL advice column");
+            H2_CHK(sc.take(n, &adv[c]));
+            H2_HIPCHK(hipMemcpyAsync(adv[c], advice[c], sizeof(Fr) * u, advice_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+            const Fr *tail = draw(n - u);
+            H2_CHK(tails_add(tails, adv[c] + u, tail));
+        }
+        H2_CHK(tails_flush(tails));
     }
     draw(sh.num_advice_total);   // Blind(Fr::random) per column: drawn, unused by KZG
     laps.lap(ST_UPLOAD);
@@ -713,14 +753,33 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             }
             H2_CHK(sc.take(n, &s.ap));
             H2_CHK(sc.take(n, &s.sp));
-            H2_CHK(h2hip_lookup_permute_presorted_dev(ctx, s.inp, pk->table_sorted, u, s.ap, s.sp));
-            const Fr *t1 = draw(bf + 1);
-            H2_CHK(put(s.ap + u, t1, bf + 1));
-            const Fr *t2 = draw(bf + 1);
-            H2_CHK(put(s.sp + u, t2, bf + 1));
-            draw(2);   // the two commitment blinds
-            cols.push_back(s.ap);
-            cols.push_back(s.sp);
+        }
+        {   // all lookups read the one table column: their multiset checks come back in one host synchronisation
+            std::vector<const void *> ins(lks.size());
+            std::vector<void *> aps(lks.size()), sps(lks.size());
+            for (size_t li = 0; li < lks.size(); ++li) {
+                ins[li] = lks[li].inp;
+                aps[li] = lks[li].ap;
+                sps[li] = lks[li].sp;
+            }
+            if (!lks.empty()) H2_CHK(h2hip_lookup_permute_presorted_batch_dev(ctx, ins.data(), pk->table_sorted, u, aps.data(), sps.data(), lks.size()));
+        }
+        {
+            TailRun ta, ts;   // per lookup the staging holds [a' rows][s' rows][2 blinds]
+            tails_reserve(ta, lks.size(), 2 * ((size_t)bf + 1) + 2, bf + 1);
+            ts = ta;
+            for (size_t li = 0; li < sh.lookups.size(); ++li) {
+                LookupState &s = lks[li];
+                const Fr *t1 = draw(bf + 1);
+                H2_CHK(tails_add(ta, s.ap + u, t1));
+                const Fr *t2 = draw(bf + 1);
+                H2_CHK(tails_add(ts, s.sp + u, t2));
+                draw(2);   // the two commitment blinds
+                cols.push_back(s.ap);
+                cols.push_back(s.sp);
+            }
+            H2_CHK(tails_flush(ta));
+            H2_CHK(tails_flush(ts));
         }
         laps.lap(ST_LOOKUP_PERMUTE);
         std::vector<G1Affine> pts;
@@ -758,10 +817,15 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         }
         for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(sc.take(n, &perm_z[si]));
         if (sh.num_perm_sets) H2_CHK(h2hip_fr_grand_products_dev(ctx, (void *const *)perm_z.data(), num, den, sh.num_perm_sets, u, 1));
-        for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
-            const Fr *tail = draw(bf);
-            H2_CHK(put(perm_z[si] + (n - bf), tail, bf));
-            draw(1);   // blind
+        {
+            TailRun tz;
+            tails_reserve(tz, sh.num_perm_sets, (size_t)bf + 1, bf);
+            for (uint32_t si = 0; si < sh.num_perm_sets; ++si) {
+                const Fr *tail = draw(bf);
+                H2_CHK(tails_add(tz, perm_z[si] + (n - bf), tail));
+                draw(1);   // blind
+            }
+            H2_CHK(tails_flush(tz));
         }
         std::vector<void *> lk_z(lks.size());
         for (size_t li = 0; li < lks.size(); ++li) {
@@ -772,10 +836,15 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             lk_z[li] = s.z;
         }
         if (!lks.empty()) H2_CHK(h2hip_fr_grand_products_dev(ctx, lk_z.data(), num, den, lks.size(), u, 0));
-        for (size_t li = 0; li < lks.size(); ++li) {
-            const Fr *tail = draw(bf);
-            H2_CHK(put(lks[li].z + (n - bf), tail, bf));
-            draw(1);   // blind
+        {
+            TailRun tz;
+            tails_reserve(tz, lks.size(), (size_t)bf + 1, bf);
+            for (size_t li = 0; li < lks.size(); ++li) {
+                const Fr *tail = draw(bf);
+                H2_CHK(tails_add(tz, lks[li].z + (n - bf), tail));
+                draw(1);   // blind
+            }
+            H2_CHK(tails_flush(tz));
         }
         if (num) sc.release(num);
         if (den) sc.release(den);

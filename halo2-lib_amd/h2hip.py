@@ -89,6 +89,7 @@ _PROTOS = {
     "h2hip_quotient_lookups_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "h2hip_quotient_permutation_sets_dev": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2hip_permutation_product_terms_sets_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
+    "h2hip_lookup_permute_presorted_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _sz]),
     "h2hip_ifft_batch_dev": (_int, [_vp, _vp, _sz, _vp, _u32, _vp]),
     "h2hip_coeff_to_extended_batch_dev": (_int, [_vp, _vp, _u32, _vp, _u32, _sz, _vp, _vp]),
     "h2hip_fr_linear_combination_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz]),
@@ -764,6 +765,25 @@ class Context:
             return [num[s * rows:(s + 1) * rows] for s in range(sets)], [den[s * rows:(s + 1) * rows] for s in range(sets)]
         finally:
             for p in dc + ds + [dn, dd]:
+                self.free(p)
+
+    def lookup_permute_batch(self, inputs, table: np.ndarray, usable_rows: int):
+        """[(a_perm, s_perm)] for several input columns against one table (sorted once): h2hip_lookup_permute_presorted_batch_dev"""
+        table = _fe(table)
+        da, pa = self._ptr_table(inputs)
+        dt = self.to_device(table)
+        dsorted = self.malloc(max(self.lib.h2hip_lookup_sorted_table_bytes(usable_rows), 32))
+        outs = [self.malloc(max(table.nbytes, 32)) for _ in range(2 * len(da))]
+        try:
+            if usable_rows:
+                self._chk(self.lib.h2hip_lookup_table_sort_dev(self.handle, _vp(dt), usable_rows, _vp(dsorted)))
+            pap = (_vp * max(len(da), 1))(*[_vp(p) for p in outs[0::2]])
+            psp = (_vp * max(len(da), 1))(*[_vp(p) for p in outs[1::2]])
+            self._chk(self.lib.h2hip_lookup_permute_presorted_batch_dev(self.handle, pa, _vp(dsorted), usable_rows, pap, psp, len(da)))
+            return [(self.download(outs[2 * j], table.shape)[:usable_rows], self.download(outs[2 * j + 1], table.shape)[:usable_rows])
+                    for j in range(len(da))]
+        finally:
+            for p in da + [dt, dsorted] + outs:
                 self.free(p)
 
     def _ptr_table(self, cols):

@@ -301,6 +301,11 @@ size_t h2hip_lookup_sorted_table_bytes(size_t usable_rows);
 int h2hip_lookup_table_sort_dev(h2hip_ctx *ctx, const void *s_dev, size_t usable_rows, void *sorted_out_dev);
 int h2hip_lookup_permute_presorted_dev(h2hip_ctx *ctx, const void *a_dev, const void *sorted_table_dev, size_t usable_rows, void *a_perm_dev,
                                        void *s_perm_dev);
+/* `count` input columns against ONE presorted table (all range lookups of a halo2-base circuit read the same table column,
+ * halo2-base/src/gates/range/mod.rs:131-150): the multiset checks of the whole batch come back in one host synchronisation.
+ * a_dev / a_perm_dev / s_perm_dev: HOST arrays of `count` device pointers. */
+int h2hip_lookup_permute_presorted_batch_dev(h2hip_ctx *ctx, const void *const *a_dev, const void *sorted_table_dev, size_t usable_rows,
+                                             void *const *a_perm_dev, void *const *s_perm_dev, size_t count);
 
 /* ---- K8: Poseidon permutation batches (halo2-base PoseidonState::permutation, reference
  *      halo2-base/src/poseidon/hasher/state.rs:35-83,124-160).  The caller supplies the spec its

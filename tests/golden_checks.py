@@ -290,3 +290,31 @@ def check_quotient_batches(ctx, k=3, gate_cols=67, lookups=34, perm_cols=40, chu
                 want = one(want, si, PERM_PRODUCT)
         got = ctx.quotient_permutation_sets(acc0, zs, pc, ps, chunk_len, l0, l_last, l_blind, ek, k, last_rot, beta, gamma, delta, zeta, ext_omega, y)
         assert np.array_equal(got, want), ncols
+
+
+def check_lookup_permute_batch(ctx, u=700, bits=6, count=5):
+    """several input columns against one range table in one call (one host synchronisation): the same columns as one call per input;
+    an input value missing from the table in ANY column fails the whole batch"""
+    import halo2_lib_amd as H
+
+    g = np.random.default_rng(u + count)
+    table = np.concatenate([fr(list(range(1 << bits)) + [0] * (u - (1 << bits))), fr([7] * 5)])   # padded like a halo2-base table column
+    inputs = []
+    for j in range(count):
+        vals = [int(v) for v in g.integers(0, 1 << bits, size=u)]
+        if j == 1:
+            vals = [0] * u
+        inputs.append(np.concatenate([fr(vals), fr([9] * 5)]))
+    got = ctx.lookup_permute_batch(inputs, table, u)
+    for j in range(count):
+        a1, s1 = ctx.lookup_permute(inputs[j], table, u, presort_table=True)
+        assert np.array_equal(got[j][0], a1) and np.array_equal(got[j][1], s1), j
+    assert ctx.lookup_permute_batch([], table, u) == []
+    bad = [c.copy() for c in inputs]
+    bad[count - 1][3] = fr([(1 << bits) + 5])[0]
+    try:
+        ctx.lookup_permute_batch(bad, table, u)
+    except H.H2HipError:
+        pass
+    else:
+        raise AssertionError("a value outside the table went unnoticed")

@@ -373,6 +373,12 @@ def test_lookup_permute_expression_pair(ctx):
         ctx.set_param("lookup_big_tile_bits", 19)
 
 
+def test_lookup_permute_batch_emulated(ctx):
+    from tests.golden_checks import check_lookup_permute_batch
+
+    check_lookup_permute_batch(ctx)
+
+
 def test_emulated_kernels_match_committed_golden_fixtures(ctx):
     from tests.golden_checks import check_backend_against_golden
 

@@ -310,6 +310,13 @@ def test_msm_randomized_shapes(ctx):
 
 
 @pytest.mark.gpu
+def test_lookup_permute_batch(ctx):
+    from tests.golden_checks import check_lookup_permute_batch
+
+    check_lookup_permute_batch(ctx, u=70000, bits=13, count=9)
+
+
+@pytest.mark.gpu
 def test_quotient_batches(ctx):
     from tests.golden_checks import check_quotient_batches
 

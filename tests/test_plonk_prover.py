@@ -124,7 +124,8 @@ def _tamper_checks(sh, params, vk, inst, proof, circ, gpk, forge=True):
     assert not PL.verify_proof(gpk, circ.instances, proof[:-32]) and not PL.verify_proof(gpk, circ.instances, proof + bytes(32))
 
 
-SMALL_SHAPES = [(6, 1, 1, 1, 0, 4), (7, 2, 1, 1, 1, 5), (6, 1, 0, 1, 0, None), (6, 2, 2, 2, 1, 3)]
+SMALL_SHAPES = [(6, 1, 1, 1, 0, 4), (7, 2, 1, 1, 1, 5), (6, 1, 0, 1, 0, None), (6, 2, 2, 2, 1, 3),
+                (5, 6, 4, 1, 1, 3)]   # the last: enough columns / lookups / permutation sets for every batched path (>= 4 of each)
 
 
 @pytest.mark.parametrize("shape", SMALL_SHAPES)

@@ -56,7 +56,7 @@ pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
 print("keygen %.2fs" % (time.time() - t), flush=True)
 n = 1 << k
 g = np.random.default_rng(1)
-vals = g.integers(0, 2**63, size=(n + 4096, 4), dtype=np.uint64)
+vals = g.integers(0, 2**63, size=(n + 4096 + 64 * (na + 4 * nl + 64), 4), dtype=np.uint64)   # blinding rows of every column + the random polynomial
 vals[:, 3] &= np.uint64((1 << 60) - 1)
 if "--register" in sys.argv:   # page-lock the advice columns (a prover keeps them across proofs)
     for c in circ.advice:
