@@ -1024,14 +1024,26 @@ int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs
     if (!count) return H2HIP_OK;
     H2_REQUIRE(count <= 4096, "too many evaluations in one batch");
     std::vector<EvalJob> jobs(count);
+    std::vector<size_t> distinct;   // jobs holding the first table of each point
     size_t nmax = 0;
     for (size_t j = 0; j < count; ++j) {
         H2_REQUIRE(lens[j] == 0 || coeffs_dev[j], "NULL polynomial");
         jobs[j].coeffs = (const Fr *)coeffs_dev[j];
         jobs[j].n = lens[j];
         memcpy(&jobs[j].x, (const char *)points + sizeof(Fr) * j, sizeof(Fr));
-        if (j && jobs[j].x == jobs[j - 1].x) jobs[j].pw = jobs[j - 1].pw;   // queries arrive grouped by point
-        else pow_table(jobs[j].x, EVAL_J, jobs[j].pw);
+        // a proof asks for hundreds of evaluations at a handful of points (x and its rotations): one power table per distinct point
+        size_t seen = j;
+        for (size_t t = 0; t < distinct.size(); ++t)
+            if (jobs[distinct[t]].x == jobs[j].x) {
+                seen = distinct[t];
+                break;
+            }
+        if (seen != j) {
+            jobs[j].pw = jobs[seen].pw;
+        } else {
+            pow_table(jobs[j].x, EVAL_J, jobs[j].pw);
+            if (distinct.size() < 16) distinct.push_back(j);
+        }
         if (lens[j] > nmax) nmax = lens[j];
     }
     const uint32_t tile = 256 * EVAL_J;

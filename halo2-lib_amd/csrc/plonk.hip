@@ -462,7 +462,10 @@ static void construct_intermediate_sets(const std::vector<Query> &queries, std::
     // polynomial -> its point set, polynomials in order of first appearance
     std::vector<int> order;
     std::map<int, std::vector<Fr>> pset;
-    for (const Query &q : queries) {
+    std::map<int, std::vector<size_t>> asked;   // polynomial -> its queries (a wide shape asks ~1000 queries: no scan over all of them per point)
+    for (size_t qi = 0; qi < queries.size(); ++qi) {
+        const Query &q = queries[qi];
+        asked[q.poly].push_back(qi);
         auto it = pset.find(q.poly);
         if (it == pset.end()) {
             order.push_back(q.poly);
@@ -494,9 +497,9 @@ static void construct_intermediate_sets(const std::vector<Query> &queries, std::
         rs->polys.push_back(poly);
         std::vector<Fr> ev;
         for (const Fr &p : ps)
-            for (const Query &q : queries)
-                if (q.poly == poly && fr_cmp(q.point, p) == 0) {
-                    ev.push_back(q.eval);
+            for (size_t qi : asked[poly])
+                if (fr_cmp(queries[qi].point, p) == 0) {
+                    ev.push_back(queries[qi].eval);
                     break;
                 }
         rs->evals.push_back(ev);
@@ -1008,10 +1011,12 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         return fe_mul(x, fe_pow_u64(dom.omega, (uint64_t)r));
     };
     std::vector<const Fr *> polys;     // SHPLONK's polynomial list; Query.poly indexes it
+    std::map<const Fr *, int> poly_index;
     auto poly_id = [&](const Fr *p) -> int {
-        for (size_t i = 0; i < polys.size(); ++i)
-            if (polys[i] == p) return (int)i;
+        auto it = poly_index.find(p);
+        if (it != poly_index.end()) return it->second;
         polys.push_back(p);
+        poly_index[p] = (int)polys.size() - 1;
         return (int)polys.size() - 1;
     };
     // vanishing.evaluate: h(X) = sum_i x^(n i) h_i(X) (its evaluation is not written to the proof; the multiopen needs it)
