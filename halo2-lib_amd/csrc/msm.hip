@@ -690,8 +690,12 @@ static uint32_t pick_window(size_t n, bool precomp = false) {
     double best_cost = 1e300;
     for (uint32_t c = 4; c <= 16; ++c) {
         double W = (double)((255 + c - 1) / c);
-        double cost = precomp ? W * 10.0 * (double)n + 150.0 * (double)(1u << (c - 1))
-                              : W * (10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + 400.0 * c);
+        // precomputed tables: W*n mixed additions; every (window, bucket) pair costs a full addition in the per-index presum plus its share of
+        // the run boundaries, zero fill and merge (~34 products' worth, fitted on proofs of 2^14..2^17-row shapes: tools/prove_time.py
+        // --param=msm_window_bits=..); the running sums over one bucket set per column come last
+        const double B = (double)(1u << (c - 1));
+        double cost = precomp ? W * 10.0 * (double)n + W * B * 34.0 + 60.0 * B
+                              : W * (10.0 * (double)n + 28.0 * B + 400.0 * c);
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
