@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--param", action="append", default=[], help="name=value tuning knob passed to h2hip_set_param (repeatable)")
     ap.add_argument("--lanes", type=int, default=0, help="override msm_lanes (streams used by the batch API)")
     ap.add_argument("--no-replay", action="store_true", help="skip the k=19 create_proof, NTT and K8 blocks (extra fields)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip create_proof over the reference's 18 benchmark shapes (an extra field, ~25 s)")
     ap.add_argument("--precompute", type=int, default=1, help="1: bases carry precomputed 2^(c*w) window tables (fixed-base SRS, H2HIP_BASES_PRECOMPUTE)")
     ap.add_argument("--batch", type=int, default=4, help="MSMs issued per h2hip_msm_g1_batch_dev call (a prover commits several columns per round); 1 = synchronous")
     args = ap.parse_args()
@@ -359,6 +360,11 @@ def main():
                                                                                 "(halo2-ecc/configs/bn254/bench_pairing.config:8), 14 MSMs of 2^21, extended_k 23")
             except Exception as e:
                 out["create_proof_k21_pairing_shape"] = {"error": repr(e)}
+            if not args.no_sweep:
+                try:
+                    out["create_proof_config_sweep"] = create_proof_config_sweep(ctx)
+                except Exception as e:
+                    out["create_proof_config_sweep"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx.bases_download(bases), scal_h, adds_per_msm)
     if world > 1 and args.sharded_proof:   # every rank takes part: the k=19 create_proof with point-range-sharded commitments
@@ -516,6 +522,31 @@ def create_proof_shape(ctx, k, na, nl, nf, ni, lb, reps, what):
     return {"what": what, "seconds": seconds, "reps": reps, "proof_bytes": len(proof), "constraints": cells, "constraints_per_sec": cells / seconds,
             "msm_count": sh.num_commitments, "msm_size": 1 << k, "extended_k": sh.extended_k, "stage_ms": {k_: round(v, 3) for k_, v in stages.items()},
             "verified_by_h2hip_plonk_verify_proof": bool(ok)}
+
+
+# the reference's two benchmark sweeps: (degree, num_advice, num_lookup_advice, num_fixed, lookup_bits) of every line of
+# halo2-ecc/configs/bn254/bench_pairing.config and halo2-ecc/configs/secp256k1/bench_ecdsa.config
+PAIRING_SHAPES = [(14, 211, 27, 1, 13), (15, 105, 14, 1, 14), (16, 50, 6, 1, 15), (17, 25, 3, 1, 16), (18, 13, 2, 1, 17), (19, 6, 1, 1, 18),
+                  (20, 3, 1, 1, 19), (21, 2, 1, 1, 20), (22, 1, 1, 1, 21)]
+ECDSA_SHAPES = [(19, 1, 1, 1, 18), (18, 2, 1, 1, 17), (17, 4, 1, 1, 16), (16, 8, 2, 1, 15), (15, 17, 3, 1, 14), (14, 34, 6, 1, 13),
+                (13, 68, 12, 1, 12), (12, 139, 24, 2, 11), (11, 291, 53, 4, 10)]
+
+
+def create_proof_config_sweep(ctx, reps: int = 3):
+    """create_proof over synthetic halo2-base circuits of all 18 shapes the reference benchmarks (the same cell budget laid out from 1 column of
+    2^22 rows to 291 + 53 columns of 2^11): ms per proof, each proof checked by libh2hip's verifier"""
+    out = {}
+    for name, shapes in (("bench_ecdsa.config", ECDSA_SHAPES), ("bench_pairing.config", PAIRING_SHAPES)):
+        rows = []
+        for k, na, nl, nf, lb in shapes:
+            try:
+                r = create_proof_shape(ctx, k, na, nl, nf, 0, lb, reps, "")
+                rows.append({"k": k, "num_advice": na, "num_lookup_advice": nl, "num_fixed": nf, "lookup_bits": lb, "ms": round(r["seconds"] * 1e3, 2),
+                             "proof_bytes": r["proof_bytes"], "verified": r["verified_by_h2hip_plonk_verify_proof"]})
+            except Exception as e:
+                rows.append({"k": k, "num_advice": na, "error": repr(e)})
+        out[name] = rows
+    return out
 
 
 def create_proof_k19_sharded(ctx, dist, device, reps: int = 5):

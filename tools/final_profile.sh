@@ -20,6 +20,13 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ptrace -o t -- python $REPO
 cd $REPO
 python tools/rocprof_proof.py $(find $OUT/ptrace -name "*.db" | head -1) > $OUT/create_proof_kernels.md 2>&1
 rm -rf $OUT/ptrace
+# the reference's 18 benchmark shapes (halo2-ecc/configs/{bn254/bench_pairing,secp256k1/bench_ecdsa}.config) and the kernel account of the widest one
+timeout 600 python tools/config_sweep.py all 5 > $OUT/config_sweep.md 2> $OUT/config_sweep.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/wtrace -o t -- python $REPO/tools/prove_time.py 14 211 27 1 0 13 3 > $OUT/prove_time_k14_wide.log 2>&1
+cd $REPO
+python tools/rocprof_proof.py $(find $OUT/wtrace -name "*.db" | head -1) > $OUT/create_proof_k14_wide_kernels.md 2>&1
+rm -rf $OUT/wtrace
 python tools/rocprof_summary.py $(ls $OUT/trace/*.db | head -1) > $OUT/kernel_trace.md 2>&1
 python tools/rocprof_pmc.py $(ls $OUT/pmc_fetch/*.db | head -1) $(ls $OUT/pmc_write/*.db | head -1) $OUT/pmc_hbm.md $OUT/pmc_hbm.json > /dev/null 2>&1
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
