@@ -255,6 +255,30 @@ pub fn kate_division<'b>(be: &'b Backend, f: &DeviceVec<'b>, b: Fr) -> Result<De
 pub fn axpy(be: &Backend, y: &mut DeviceVec, a: Fr, x: &DeviceVec) -> Result<(), HipError> {
     check(unsafe { h2hip_fr_axpy_dev(be.ctx, y.ptr, fr_ptr(&a), x.ptr, x.len.min(y.len)) })
 }
+/// `EvaluationDomain::lagrange_to_coeff` over many columns at once (32 per kernel launch)
+pub fn lagrange_to_coeff_many(be: &Backend, columns: &mut [&mut DeviceVec], omega_inv: Fr, k: u32, ifft_divisor: Fr) -> Result<(), HipError> {
+    let p: Vec<*mut c_void> = columns.iter().map(|v| v.ptr).collect();
+    check(unsafe { h2hip_ifft_batch_dev(be.ctx, p.as_ptr(), p.len(), fr_ptr(&omega_inv), k, fr_ptr(&ifft_divisor)) })
+}
+/// `EvaluationDomain::coeff_to_extended` over many columns at once
+pub fn coeff_to_extended_many<'b>(be: &'b Backend, coeffs: &[&DeviceVec<'b>], k: u32, extended_k: u32, extended_omega: Fr, zeta: Fr)
+                                  -> Result<Vec<DeviceVec<'b>>, HipError> {
+    let outs = coeffs.iter().map(|_| DeviceVec::zeroed(be, 1usize << extended_k)).collect::<Result<Vec<_>, _>>()?;
+    let pi: Vec<*const c_void> = coeffs.iter().map(|v| v.ptr as *const c_void).collect();
+    let po: Vec<*mut c_void> = outs.iter().map(|v| v.ptr).collect();
+    check(unsafe { h2hip_coeff_to_extended_batch_dev(be.ctx, pi.as_ptr(), k, po.as_ptr(), extended_k, pi.len(), fr_ptr(&extended_omega), fr_ptr(&zeta)) })?;
+    Ok(outs)
+}
+/// all grand products of one argument: `num` / `den` hold the factors of `segments` products back to back; chained = the permutation
+/// argument's sets (z_i(0) = z_{i-1}(last usable row)), unchained = the lookup arguments
+pub fn grand_products<'b>(be: &'b Backend, num: &DeviceVec<'b>, den: &DeviceVec<'b>, segments: usize, chained: bool) -> Result<Vec<DeviceVec<'b>>, HipError> {
+    assert!(segments > 0 && num.len == den.len && num.len % segments == 0);
+    let seg = num.len / segments;
+    let zs = (0..segments).map(|_| DeviceVec::zeroed(be, seg + 1)).collect::<Result<Vec<_>, _>>()?;
+    let pz: Vec<*mut c_void> = zs.iter().map(|v| v.ptr).collect();
+    check(unsafe { h2hip_fr_grand_products_dev(be.ctx, pz.as_ptr(), num.ptr, den.ptr, segments, seg, chained as c_int) })?;
+    Ok(zs)
+}
 /// sum_j coeffs[j] * polys[j]: a rotation set's sum_j y^j P_j(X) of the multiopen argument in one pass
 pub fn linear_combination<'b>(be: &'b Backend, polys: &[&DeviceVec<'b>], coeffs: &[Fr]) -> Result<DeviceVec<'b>, HipError> {
     assert_eq!(polys.len(), coeffs.len());
