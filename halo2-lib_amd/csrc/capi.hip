@@ -80,14 +80,6 @@ static void prof_collect(h2hip_ctx *ctx) {
     ctx->pending.clear();
 }
 
-// one workgroup per result slot
-__global__ void point_finish_batch_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff) {
-    if (threadIdx.x == 0) {
-        XYZZ p = in[blockIdx.x];
-        if (jac) jac[blockIdx.x] = xyzz_to_jacobian(p);
-        if (aff) aff[blockIdx.x] = xyzz_to_affine(p);
-    }
-}
 __global__ void point_finish_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         XYZZ p = in[0];
@@ -588,20 +580,20 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         r0 = r1;
     }
     (void)mixed;
-    const bool deferred = precomp && fuse == 1 && ctx->msm_defer_reduce && count >= 2 && count <= 64 && n > 0;
-    XYZZ29 *all_buckets = nullptr;
+    // deferred bucket reduction: every column (or fused group of columns) stops after its merge and leaves its buckets in one array; the
+    // latency-bound reduction then runs once per 64 columns for the whole batch instead of once per MSM / group
     size_t keys_per_col = 0;
-    if (deferred) {
+    if (precomp) {
         const uint32_t cw = bases->window_bits;
         const uint32_t wcol = (255 + cw - 1) / cw;
-        uint32_t sets = wcol;   // bucket sets per column: one per group of msm_fold_windows windows (msm.hip, sort_key)
-        if (ctx->msm_fold_windows > 1) {
-            const uint32_t fg = (uint32_t)ctx->msm_fold_windows < wcol ? (uint32_t)ctx->msm_fold_windows : wcol;
-            sets = (wcol + fg - 1) / fg;
-        }
+        uint32_t sets = wcol;
+        if (ctx->msm_fold_windows > 1) sets = (wcol + std::min<uint32_t>((uint32_t)ctx->msm_fold_windows, wcol) - 1) / std::min<uint32_t>((uint32_t)ctx->msm_fold_windows, wcol);
         keys_per_col = (size_t)sets << (cw - 1);
-        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH_BUCKETS, sizeof(XYZZ29) * keys_per_col * count, (void **)&all_buckets));
     }
+    const bool deferred = precomp && ctx->msm_defer_reduce && count >= 2 && n > 0 && (fuse == 1 ? count <= 64 : true) &&
+                          sizeof(XYZZ29) * keys_per_col * count <= ((size_t)2 << 30);
+    XYZZ29 *all_buckets = nullptr;
+    if (deferred) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH_BUCKETS, sizeof(XYZZ29) * keys_per_col * count, (void **)&all_buckets));
     // host columns: one staging area for all of them; column j is copied on its lane's stream right before its kernels are
     // queued, so the (host-blocking, pageable) copy of column j+1 overlaps the GPU work of column j
     std::vector<const void *> staged(count, nullptr);
@@ -696,13 +688,16 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));
         H2_HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
     }
-    if (deferred) {   // one bucket reduction for all columns, on the caller's stream
+    if (deferred) {   // one bucket reduction per 64 columns, on the caller's stream
         XYZZ *sums = nullptr;
-        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, sizeof(XYZZ) * 64, (void **)&sums));
-        H2_CHK(msm_reduce_cols(ctx, bases, bases->window_bits, all_buckets, (uint32_t)count, sums));
+        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, sizeof(XYZZ) * count, (void **)&sums));
+        for (size_t c0 = 0; c0 < count; c0 += 64) {
+            const uint32_t cc = (uint32_t)(count - c0 < 64 ? count - c0 : 64);
+            H2_CHK(msm_reduce_cols(ctx, bases, bases->window_bits, all_buckets + keys_per_col * c0, cc, sums + c0));
+        }
         prof_begin(ctx, "point_finish_kernel");
-        hipLaunchKernelGGL(point_finish_batch_kernel, dim3((uint32_t)count), dim3(64), 0, ctx->stream, (const XYZZ *)sums,
-                           affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr);
+        hipLaunchKernelGGL(point_finish_slot_kernel, dim3((uint32_t)count), dim3(64), 0, ctx->stream, (const XYZZ *)sums,
+                           affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr, 0u);
         prof_end(ctx);
         H2_HIPCHK(hipGetLastError());
     }
