@@ -184,10 +184,38 @@ static void destroy_split_streams(h2hip_ctx *ctx) {
     if (ctx->split_aux) hipStreamDestroy(ctx->split_aux);
     ctx->split_acc = ctx->split_aux = nullptr;
 }
+}  // extern "C"
+namespace h2 {
+// Small host tables (job descriptors) -> device without a synchronisation: the bytes are copied into a pinned ring first, so the caller's
+// buffer may go away at once and the asynchronous copy has a stable source.  The ring only wraps after a stream synchronisation.
+constexpr size_t JOB_RING_BYTES = (size_t)1 << 20;
+int upload_jobs(h2hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (!bytes) return H2HIP_OK;
+    if (bytes > JOB_RING_BYTES / 4) {   // large tables: plain (staged, host-synchronous) copy
+        H2_HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+        return H2HIP_OK;
+    }
+    if (!ctx->job_ring) H2_HIPCHK(hipHostMalloc((void **)&ctx->job_ring, JOB_RING_BYTES, 0));
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (ctx->job_ring_off + need > JOB_RING_BYTES) {
+        H2_HIPCHK(hipStreamSynchronize(ctx->stream));   // everything staged so far has been consumed
+        ctx->job_ring_off = 0;
+    }
+    char *slot = ctx->job_ring + ctx->job_ring_off;
+    memcpy(slot, src_host, bytes);
+    ctx->job_ring_off += need;
+    H2_HIPCHK(hipMemcpyAsync(dst_dev, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return H2HIP_OK;
+}
+}  // namespace h2
+extern "C" {
+
 void h2hip_destroy(h2hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->job_ring) hipHostFree(ctx->job_ring);
     for (auto &b : ctx->ws)
         if (b.p) hipFree(b.p);
     for (auto &t : ctx->twiddles) {

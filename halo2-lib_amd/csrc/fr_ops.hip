@@ -1105,7 +1105,7 @@ int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, jobs_bytes + sizeof(Fr) * 2 * (size_t)m * (ntiles + 1), (void **)&buf));
     KateJob *djobs = (KateJob *)buf;
     Fr *heads = (Fr *)(buf + jobs_bytes), *carry = heads + (size_t)m * (ntiles + 1);
-    H2_HIPCHK(hipMemcpyAsync(djobs, jobs.data(), sizeof(KateJob) * m, hipMemcpyHostToDevice, ctx->stream));
+    H2_CHK(upload_jobs(ctx, djobs, jobs.data(), sizeof(KateJob) * m));   // through the pinned ring: no synchronisation per call
     prof_begin(ctx, "fr_kate_kernels");
     hipLaunchKernelGGL(fr_kate_heads_multi_kernel, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, ntiles, heads);
     hipLaunchKernelGGL(fr_kate_carry_multi_kernel, dim3(m), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles, (const KateJob *)djobs);
@@ -1113,7 +1113,6 @@ int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs
                        (const Fr *)carry, (Fr *)q);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    H2_HIPCHK(hipStreamSynchronize(ctx->stream));   // `jobs` is uploaded from pageable memory
     return H2HIP_OK;
 }
 

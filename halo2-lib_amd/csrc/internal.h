@@ -109,6 +109,10 @@ struct h2hip_ctx {
                                  // higher-priority one (MSM i+1 sorted and MSM i-1 merged while MSM i accumulates).  Measured SLOWER (tools/batch_ab.py, same run:
                                  // 2^19 1.00 vs 0.95 ms per MSM in batches of 4, 2^20 1.75-1.82 vs 1.69): kernels that share the chip with an accumulation
                                  // stretch more than the overlap hides, and stretch the accumulation.  Off by default.
+    // pinned ring for small job tables (kernel argument tables too large for the kernarg segment): staged there, they are uploaded
+    // asynchronously without a stream synchronisation per call (upload_jobs in capi.hip)
+    char *job_ring = nullptr;
+    size_t job_ring_off = 0;
     hipStream_t split_acc = nullptr, split_aux = nullptr;
     std::vector<hipEvent_t> split_ev;
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
@@ -162,6 +166,7 @@ int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in
 int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, size_t ncols, uint32_t log_n, const Fr &omega, uint64_t in_len,
                   const Fr *in_scale3, const Fr *out_scale3);   // the same transform over ncols equal-size columns, 32 columns per launch
 int fr_scatter_rows(h2hip_ctx *ctx, Fr *const *dst, size_t count, const Fr *src, size_t src_stride, size_t len);   // dst[j][i] = src[j*src_stride + i]
+int upload_jobs(h2hip_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   // async H2D of a small table through the context's pinned ring
 int exclusive_scan_u32_segments(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t segments, size_t in_stride,
                                 size_t out_stride);   // `segments` independent scans of n elements, in_stride / out_stride elements apart
 int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n);   // out[i] = sum_{j<i} in[j]; in != out
