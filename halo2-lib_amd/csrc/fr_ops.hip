@@ -461,9 +461,15 @@ __global__ __launch_bounds__(256) void fr_kate_carry_multi_kernel(const Fr *__re
         }
     }
 }
+// All M points of the set advance TOGETHER: their Horner chains, their suffix scans (one pair of barriers per doubling step for all points)
+// and their quotient chains are independent, so a lane always has M products in flight — the kernel is a dependent chain of ~35 products per
+// tile instead of ~50 per point (it runs one wave per SIMD at the sizes of a proof, i.e. latency-bound).  The tile's incoming carry sits in
+// an extra scan slot (index 256), which the scan multiplies by the right power of b^J on its own.  Points beyond m (padding up to the
+// compiled M) carry weight 0.
+template <int M>
 __global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__restrict__ c, size_t n, const KateJob *__restrict__ jobs, uint32_t m,
-                                                                  uint32_t ntiles, const Fr *__restrict__ carry, Fr *__restrict__ q) {
-    __shared__ Fr sh[256];
+                                                                  uint32_t ntiles, const Fr *__restrict__ carry, Fr *__restrict__ q, int accumulate) {
+    __shared__ Fr sh[M][257];
     const uint32_t tid = threadIdx.x;
     const size_t lo = (size_t)blockIdx.x * KATE_TILE, base = lo + (size_t)tid * KATE_J;
     Fr cv[KATE_J], acc[KATE_J];
@@ -472,34 +478,52 @@ __global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__re
         cv[k] = base + k < n ? c[base + k] : Fr::zero();
         acc[k] = Fr::zero();
     }
-    for (uint32_t j = 0; j < m; ++j) {
-        const Fr b = jobs[j].b, w = jobs[j].w;
-        const PowTable &pw = jobs[j].pw;
-        Fr h = Fr::zero();
+    Fr b[M], h[M];
 #pragma unroll
-        for (int k = KATE_J - 1; k >= 0; --k) h = fe_add(fe_mul(h, b), cv[k]);   // coefficients past n are zero
-        __syncthreads();   // the previous point's scan has been read
-        sh[tid] = h;
+    for (int j = 0; j < M; ++j) {
+        b[j] = (uint32_t)j < m ? jobs[j].b : Fr::zero();
+        h[j] = Fr::zero();
+    }
+#pragma unroll
+    for (int k = KATE_J - 1; k >= 0; --k) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) h[j] = fe_add(fe_mul(h[j], b[j]), cv[k]);   // coefficients past n are zero
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        sh[j][tid] = h[j];
+        if (tid == 0) sh[j][256] = (uint32_t)j < m ? carry[(size_t)j * (ntiles + 1) + blockIdx.x] : Fr::zero();
+    }
+    __syncthreads();
+    for (uint32_t d = 1, l = 0; d <= 256; d <<= 1, ++l) {   // inclusive suffix scan over 257 slots: I_t = h_t + b^J * I_{t+1}, I_256 = carry
+        Fr o[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) o[j] = tid + d <= 256 ? sh[j][tid + d] : Fr::zero();
         __syncthreads();
-        for (uint32_t d = 1, l = 0; d < 256; d <<= 1, ++l) {   // inclusive suffix scan: I_t = h_t + b^J * I_{t+1}
-            Fr o = Fr::zero();
-            if (tid + d < 256) o = sh[tid + d];
-            __syncthreads();
-            if (tid + d < 256) sh[tid] = fe_add(sh[tid], fe_mul(o, pw.p[l]));
-            __syncthreads();
-        }
-        Fr car = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
-        car = fe_add(car, fe_mul(fe_pow_u64(pw.p[0], 255 - tid), carry[(size_t)j * (ntiles + 1) + blockIdx.x]));
-        Fr tmp = car;
+        if (tid + d <= 256) {
 #pragma unroll
-        for (int k = KATE_J - 1; k >= 0; --k) {
-            tmp = fe_add(cv[k], fe_mul(tmp, b));             // = quotient coefficient of index base + k - 1
-            acc[k] = fe_add(acc[k], fe_mul(w, tmp));
+            for (int j = 0; j < M; ++j)
+                if ((uint32_t)j < m) sh[j][tid] = fe_add(sh[j][tid], fe_mul(o[j], jobs[j].pw.p[l]));
+        }
+        __syncthreads();
+    }
+    Fr tmp[M], w[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        tmp[j] = sh[j][tid + 1];
+        w[j] = (uint32_t)j < m ? jobs[j].w : Fr::zero();
+    }
+#pragma unroll
+    for (int k = KATE_J - 1; k >= 0; --k) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            tmp[j] = fe_add(cv[k], fe_mul(tmp[j], b[j]));             // = quotient coefficient of index base + k - 1 for point j
+            acc[k] = fe_add(acc[k], fe_mul(w[j], tmp[j]));
         }
     }
 #pragma unroll
     for (uint32_t k = 0; k < KATE_J; ++k)
-        if (base + k < n && base + k >= 1) q[base + k - 1] = acc[k];
+        if (base + k < n && base + k >= 1) q[base + k - 1] = accumulate ? fe_add(q[base + k - 1], acc[k]) : acc[k];
 }
 
 // ------------------------------------------------------------------ K8: Poseidon permutation batches
@@ -1109,8 +1133,18 @@ int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs
     prof_begin(ctx, "fr_kate_kernels");
     hipLaunchKernelGGL(fr_kate_heads_multi_kernel, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, ntiles, heads);
     hipLaunchKernelGGL(fr_kate_carry_multi_kernel, dim3(m), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles, (const KateJob *)djobs);
-    hipLaunchKernelGGL(fr_kate_apply_multi_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, m, ntiles,
-                       (const Fr *)carry, (Fr *)q);
+    for (uint32_t j0 = 0; j0 < m; j0 += 4) {   // four points per pass (the scans of a pass share the workgroup's LDS); halo2-base's sets stop at 4
+        const uint32_t mm = m - j0 < 4 ? m - j0 : 4;
+        const KateJob *jb = djobs + j0;
+        const Fr *cr = carry + (size_t)j0 * (ntiles + 1);
+        const int accumulate = j0 ? 1 : 0;
+        if (mm == 1)
+            hipLaunchKernelGGL(fr_kate_apply_multi_kernel<1>, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
+        else if (mm == 2)
+            hipLaunchKernelGGL(fr_kate_apply_multi_kernel<2>, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
+        else
+            hipLaunchKernelGGL(fr_kate_apply_multi_kernel<4>, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
+    }
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;

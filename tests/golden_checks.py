@@ -189,7 +189,7 @@ def check_prover_steps(ctx, n, seed=5):
     # multi-point division: (f - r) / prod (X - b_j) via the weighted sum of kate divisions, against sequential exact divisions
     if n >= 6:
         f = to_i(a_)
-        for m in (1, 2, 4):
+        for m in (1, 2, 3, 4, 5, 8):   # 3: padded to four points; 5, 8: two passes of four with accumulation
             bs = [int(v) for v in g.integers(2, 1 << 62, size=m)]
             ws = []
             for j in range(m):
