@@ -462,17 +462,17 @@ def create_proof_k19(ctx, with_cpu_baseline: bool, reps: int = 10):
     pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
     keygen_s = time.perf_counter() - t0
     draws = synthetic_scalars(n + 4096, 4242)
-    PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))            # warm-up (allocates the key's buffer pool)
+    PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))            # warm-up (allocates the key's buffer pool)
     ctx.sync()
     each = []
     t0 = time.perf_counter()
     for _ in range(reps):
         t1 = time.perf_counter()
-        proof = PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))   # returns after the proof bytes are on the host
+        proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))   # returns after the proof bytes are on the host
         each.append(time.perf_counter() - t1)
     seconds = (time.perf_counter() - t0) / reps
     stages = {}
-    PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws), stages)    # per-stage laps (adds a stream sync per stage)
+    PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws), stages)    # per-stage laps (adds a stream sync per stage)
     t0 = time.perf_counter()
     verified = PL.verify_proof(pk, circ.instances, proof)     # libh2hip's own verifier (host code): the reference's check_proof
     verify_s = time.perf_counter() - t0
@@ -510,14 +510,14 @@ def create_proof_shape(ctx, k, na, nl, nf, ni, lb, reps, what):
     circ = T.build_circuit(_ShapeView(bp, sh), k, Backend)
     pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
     draws = synthetic_scalars((1 << k) + 65536, 4243)
-    PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))
+    PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))
     ctx.sync()
     t0 = time.perf_counter()
     for _ in range(reps):
-        proof = PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))
+        proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))
     seconds = (time.perf_counter() - t0) / reps
     stages = {}
-    PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws), stages)
+    PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws), stages)
     ok = PL.verify_proof(pk, circ.instances, proof)
     cells = 4 * (sh.usable_rows // 4) * na
     pk.free()
@@ -591,11 +591,11 @@ def create_proof_k19_sharded(ctx, dist, device, reps: int = 5):
     if any(o is not None for o in oks):
         raise RuntimeError("sharded create_proof set-up failed on some rank: %r" % (oks,))
     sk = shard_proving_key(pk, g_pts, gl_pts, device=device, precompute=True)
-    proof = PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))
+    proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
-        proof = PL.create_proof(pk, circ.advice, circ.instances, _PreDrawnRng(draws))
+        proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))
     dist.barrier()
     sec = (time.perf_counter() - t0) / reps
     te = torch.tensor([sec], dtype=torch.float64, device=device if device is not None else "cpu")

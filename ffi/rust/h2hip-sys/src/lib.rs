@@ -28,6 +28,15 @@ pub struct h2hip_base_circuit_params {
     pub num_instance: u32,
     pub lookup_bits: i32,
 }
+/// state of libh2hip's ready-made array RNG (`h2hip_array_rng_fill` as the `h2hip_rng_fill_fn`)
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct h2hip_array_rng {
+    pub values: *const c_void,
+    pub count: usize,
+    pub pos: usize,
+    pub exhausted: c_int,
+}
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct h2hip_plonk_shape {
@@ -185,6 +194,7 @@ extern "C" {
     pub fn h2hip_plonk_pk_set_transcript_repr(pk: *mut h2hip_plonk_pk, fr: *const c_void) -> c_int;
     pub fn h2hip_plonk_pk_set_msm_sharding(pk: *mut h2hip_plonk_pk, g_shard: *const h2hip_bases, g_lagrange_shard: *const h2hip_bases, offset: usize,
                                            len: usize, world: u32, allgather: h2hip_allgather_fn, user: *mut c_void) -> c_int;
+    pub fn h2hip_array_rng_fill(user: *mut c_void, out_fr: *mut c_void, n: usize);
     pub fn h2hip_plonk_stage_name(stage: c_int) -> *const c_char;
     pub fn h2hip_plonk_create_proof(ctx: *mut h2hip_ctx, pk: *mut h2hip_plonk_pk, advice: *const *const c_void, advice_on_device: c_int,
                                     instances_host: *const *const c_void, instance_lens: *const usize, rng: h2hip_rng_fill_fn, rng_user: *mut c_void,

@@ -453,56 +453,60 @@ struct RotationSet {
 };
 // poly/kzg/multiopen/shplonk.rs::construct_intermediate_sets [UPSTREAM-RECALL]
 static void construct_intermediate_sets(const std::vector<Query> &queries, std::vector<RotationSet> &sets, std::vector<Fr> &super_points) {
-    std::vector<Fr> pts;
-    for (const Query &q : queries) pts.push_back(q.point);
-    std::sort(pts.begin(), pts.end(), FrLess());
-    super_points.clear();
-    for (const Fr &p : pts)
-        if (super_points.empty() || fr_cmp(super_points.back(), p) != 0) super_points.push_back(p);
-    // polynomial -> its point set, polynomials in order of first appearance
-    std::vector<int> order;
-    std::map<int, std::vector<Fr>> pset;
-    std::map<int, std::vector<size_t>> asked;   // polynomial -> its queries (a wide shape asks ~1000 queries: no scan over all of them per point)
+    // A proof asks ~1000 queries at a handful of points (x and its rotations): every point gets a small index first, every polynomial a bit
+    // mask of the points it is opened at — sets are then found by comparing masks, without a container per polynomial.
+    std::vector<Fr> distinct;                  // in order of first appearance
+    std::vector<uint32_t> point_of(queries.size());
+    int max_poly = -1;
     for (size_t qi = 0; qi < queries.size(); ++qi) {
-        const Query &q = queries[qi];
-        asked[q.poly].push_back(qi);
-        auto it = pset.find(q.poly);
-        if (it == pset.end()) {
-            order.push_back(q.poly);
-            pset[q.poly] = {q.point};
-        } else {
-            bool have = false;
-            for (const Fr &p : it->second) have |= fr_cmp(p, q.point) == 0;
-            if (!have) it->second.push_back(q.point);
-        }
+        uint32_t pi = 0;
+        while (pi < distinct.size() && fr_cmp(distinct[pi], queries[qi].point) != 0) ++pi;
+        if (pi == distinct.size()) distinct.push_back(queries[qi].point);
+        point_of[qi] = pi;
+        if (queries[qi].poly > max_poly) max_poly = queries[qi].poly;
     }
-    for (auto &kv : pset) std::sort(kv.second.begin(), kv.second.end(), FrLess());
-    auto same = [](const std::vector<Fr> &a, const std::vector<Fr> &b) {
-        if (a.size() != b.size()) return false;
-        for (size_t i = 0; i < a.size(); ++i)
-            if (fr_cmp(a[i], b[i]) != 0) return false;
-        return true;
-    };
-    sets.clear();
-    for (int poly : order) {
-        const std::vector<Fr> &ps = pset[poly];
-        RotationSet *rs = nullptr;
-        for (RotationSet &s : sets)
-            if (same(s.points, ps)) rs = &s;
-        if (!rs) {
-            sets.push_back(RotationSet());
-            rs = &sets.back();
-            rs->points = ps;
+    const size_t np = distinct.size();
+    std::vector<uint32_t> by_value(np);        // point indices in ascending order of the field element
+    for (uint32_t i = 0; i < np; ++i) by_value[i] = i;
+    std::sort(by_value.begin(), by_value.end(), [&](uint32_t a, uint32_t b) { return fr_cmp(distinct[a], distinct[b]) < 0; });
+    super_points.clear();
+    for (uint32_t i : by_value) super_points.push_back(distinct[i]);
+    if (np > 64) {   // cannot happen for halo2-base's constraint system (rotations -1..3 and the last row); keep the masks honest
+        sets.clear();
+        return;
+    }
+    const size_t P = (size_t)max_poly + 1;
+    std::vector<uint64_t> mask(P, 0);
+    std::vector<int> first_query(P, -1), order;
+    std::vector<size_t> eval_at(P * np, (size_t)-1);   // [poly][point] -> first query asking it
+    for (size_t qi = 0; qi < queries.size(); ++qi) {
+        const int poly = queries[qi].poly;
+        if (first_query[poly] < 0) {
+            first_query[poly] = (int)qi;
+            order.push_back(poly);
         }
-        rs->polys.push_back(poly);
-        std::vector<Fr> ev;
-        for (const Fr &p : ps)
-            for (size_t qi : asked[poly])
-                if (fr_cmp(queries[qi].point, p) == 0) {
-                    ev.push_back(queries[qi].eval);
-                    break;
-                }
-        rs->evals.push_back(ev);
+        mask[poly] |= 1ull << point_of[qi];
+        size_t &slot = eval_at[(size_t)poly * np + point_of[qi]];
+        if (slot == (size_t)-1) slot = qi;
+    }
+    sets.clear();
+    std::vector<uint64_t> set_mask;
+    for (int poly : order) {
+        size_t si = 0;
+        while (si < set_mask.size() && set_mask[si] != mask[poly]) ++si;
+        if (si == set_mask.size()) {
+            set_mask.push_back(mask[poly]);
+            sets.push_back(RotationSet());
+            for (uint32_t i : by_value)
+                if (mask[poly] >> i & 1) sets.back().points.push_back(distinct[i]);
+        }
+        RotationSet &rs = sets[si];
+        rs.polys.push_back(poly);
+        rs.evals.emplace_back();
+        std::vector<Fr> &ev = rs.evals.back();
+        ev.reserve(rs.points.size());
+        for (uint32_t i : by_value)
+            if (mask[poly] >> i & 1) ev.push_back(queries[eval_at[(size_t)poly * np + i]].eval);
     }
 }
 // Lagrange basis of a point set: basis[j] = coefficients (low to high) of L_j(X) = prod_{i != j} (X - x_i) / (x_j - x_i).  Computed once
@@ -1111,6 +1115,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         std::vector<RotationSet> sets;
         std::vector<Fr> super_points;
         construct_intermediate_sets(queries, sets, super_points);
+        H2_REQUIRE(!sets.empty(), "more than 64 distinct opening points");
         const Fr v = tr.squeeze_challenge();
         // S_i(X) = sum_j y^j P_ij(X) (kept for the linearisation), r_i(X) = sum_j y^j * interpolant of P_ij on the set's points
         std::vector<Fr *> S(sets.size());
@@ -1139,6 +1144,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                 ypow = fe_mul(ypow, yq);
             }
             H2_CHK(h2hip_fr_linear_combination_dev(ctx, S[i], terms.data(), ypows.data(), terms.size(), n));   // every P_j read once
+
             // (S_i - r_i) / prod_j (X - point_j) = sum_j w_j (S_i(X) - S_i(point_j)) / (X - point_j) (partial fractions; r_i interpolates S_i
             // on the points by construction): all roots in ONE pass over S_i, no copy and no explicit subtraction of r_i
             H2_CHK(h2hip_fr_kate_division_multi_dev(ctx, buf_b, S[i], n, rs.points.data(), pf_weights.data(), (uint32_t)rs.points.size()));
@@ -1288,6 +1294,18 @@ int h2hip_plonk_pk_set_msm_sharding(h2hip_plonk_pk *pk, const h2hip_bases *g_sha
     pk->allgather = allgather;
     pk->allgather_user = user;
     return H2HIP_OK;
+}
+
+void h2hip_array_rng_fill(void *user, void *out_fr, size_t n) {
+    h2hip_array_rng *r = (h2hip_array_rng *)user;
+    if (!r || !out_fr) return;
+    const size_t have = r->pos < r->count ? r->count - r->pos : 0, take = n < have ? n : have;
+    if (take) memcpy(out_fr, (const char *)r->values + sizeof(Fr) * r->pos, sizeof(Fr) * take);
+    if (take < n) {
+        memset((char *)out_fr + sizeof(Fr) * take, 0, sizeof(Fr) * (n - take));
+        r->exhausted = 1;
+    }
+    r->pos += take;
 }
 
 const char *h2hip_plonk_stage_name(int stage) { return stage >= 0 && stage < H2HIP_PLONK_STAGES ? STAGE_NAMES[stage] : ""; }

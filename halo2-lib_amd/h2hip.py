@@ -90,6 +90,7 @@ _PROTOS = {
     "h2hip_quotient_permutation_sets_dev": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2hip_permutation_product_terms_sets_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
     "h2hip_lookup_permute_presorted_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _sz]),
+    "h2hip_array_rng_fill": (None, [_vp, _vp, _sz]),
     "h2hip_ifft_batch_dev": (_int, [_vp, _vp, _sz, _vp, _u32, _vp]),
     "h2hip_coeff_to_extended_batch_dev": (_int, [_vp, _vp, _u32, _vp, _u32, _sz, _vp, _vp]),
     "h2hip_fr_linear_combination_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz]),

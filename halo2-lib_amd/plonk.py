@@ -72,6 +72,10 @@ def transcript_repr(params: BaseCircuitParams, fixed_commitments: np.ndarray, pe
 _RNG_FN = C.CFUNCTYPE(None, _vp, _vp, C.c_size_t)
 
 
+class _ArrayRngState(C.Structure):   # h2hip_array_rng
+    _fields_ = [("values", _vp), ("count", C.c_size_t), ("pos", C.c_size_t), ("exhausted", C.c_int)]
+
+
 class ArrayRng:
     """`Fr::random(rng)` stream served from a pre-drawn (m, 4) Montgomery array (the RNG itself stays with the caller: upstream draws
     from the `StdRng` the reference seeds at halo2-base/src/utils/testing.rs:38)."""
@@ -184,12 +188,21 @@ def create_proof(pk: ProvingKey, advice: Sequence, instances: Sequence[np.ndarra
             err.append(e)
             C.memset(out, 0, 32 * count)
 
-    cb = _RNG_FN(_fill)
     proof = np.zeros(pk.proof_size(), dtype=np.uint8)
     plen = C.c_size_t(0)
     stage = (C.c_double * PLONK_STAGES)() if timings is not None else None
-    rc = ctx.lib.h2hip_plonk_create_proof(ctx.handle, pk.handle, adv, 1 if advice_on_device else 0, ip, il, C.cast(cb, _vp), None, _ptr(proof),
-                                          proof.nbytes, C.byref(plen), stage)
+    if isinstance(rng, ArrayRng):   # libh2hip's own array RNG: no Python frame per draw (a wide shape draws several hundred blinding tails)
+        st = _ArrayRngState(rng.values.ctypes.data + 32 * rng.pos, len(rng.values) - rng.pos, 0, 0)
+        rc = ctx.lib.h2hip_plonk_create_proof(ctx.handle, pk.handle, adv, 1 if advice_on_device else 0, ip, il,
+                                              C.cast(ctx.lib.h2hip_array_rng_fill, _vp), C.cast(C.pointer(st), _vp), _ptr(proof), proof.nbytes,
+                                              C.byref(plen), stage)
+        rng.pos += st.pos
+        if st.exhausted:
+            raise RuntimeError("ArrayRng exhausted")
+    else:
+        cb = _RNG_FN(_fill)
+        rc = ctx.lib.h2hip_plonk_create_proof(ctx.handle, pk.handle, adv, 1 if advice_on_device else 0, ip, il, C.cast(cb, _vp), None, _ptr(proof),
+                                              proof.nbytes, C.byref(plen), stage)
     if err:
         raise err[0]
     ctx._chk(rc)

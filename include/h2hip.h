@@ -372,6 +372,15 @@ int h2hip_plonk_pk_set_msm_sharding(h2hip_plonk_pk *pk, const h2hip_bases *g_sha
 
 /* `Fr::random(rng)` x n into out (Montgomery limbs); called in upstream's draw order */
 typedef void (*h2hip_rng_fill_fn)(void *user, void *out_fr, size_t n);
+/* a ready-made h2hip_rng_fill_fn for callers that pre-draw their randomness (tests, deterministic replays, a host RNG running ahead of the
+ * prover): serves `count` Montgomery Fr from `values` in order; past the end it writes zeros and sets `exhausted`, which the caller checks
+ * after create_proof.  `user` = pointer to the h2hip_array_rng. */
+typedef struct {
+    const void *values;
+    size_t count, pos;
+    int exhausted;
+} h2hip_array_rng;
+void h2hip_array_rng_fill(void *user, void *out_fr, size_t n);
 #define H2HIP_PLONK_STAGES 12
 const char *h2hip_plonk_stage_name(int stage);
 /* advice: num_advice_total columns of 2^k Montgomery Fr (host pointers, or device pointers when advice_on_device != 0); rows >=

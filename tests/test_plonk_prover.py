@@ -80,6 +80,12 @@ def _check(ctx, k, na, nl, nf, ni, lb, seed=3, threads=4, oracle_prover=True, pr
             vk = _vk_from_gpu(sh, gpk)
         assert P.verify_proof(params, vk, inst, got), "the oracle verifier rejects the HIP proof"
         assert PL.verify_proof(gpk, circ.instances, got), "libh2hip's own verifier rejects the proof"
+        # libh2hip's own array RNG (h2hip_array_rng_fill, no Python frame per draw) serves the same stream: same bytes, position advanced alike
+        ref_rng, arr_rng = PreDrawnRng(budget, 1000 + seed), None
+        arr_rng = PL.ArrayRng(ref_rng.values)
+        assert PL.create_proof(gpk, circ.advice, circ.instances, arr_rng) == got
+        PL.create_proof(gpk, circ.advice, circ.instances, ref_rng)
+        assert arr_rng.pos == ref_rng.pos > 0
         # a second proof from the same key (pooled buffers reused) with another RNG stream: different bytes, still valid
         if second_proof:
             again = PL.create_proof(gpk, circ.advice, circ.instances, PreDrawnRng(budget, 2000 + seed))
@@ -154,6 +160,8 @@ def test_create_proof_argument_errors_emulated():
             PL.create_proof(gpk, [], [], PreDrawnRng(8, 1))
         with pytest.raises(RuntimeError):      # the RNG runs dry: reported, nothing hangs
             PL.create_proof(gpk, circ.advice, [], PreDrawnRng(8, 1))
+        with pytest.raises(RuntimeError):      # the same through the library's array RNG
+            PL.create_proof(gpk, circ.advice, [], PL.ArrayRng(PreDrawnRng(8, 1).values))
         bad_copy = np.array([[0, sh.usable_rows, 1, 0]], dtype=np.uint32)   # a copy constraint in the blinding rows
         with pytest.raises(H.H2HipError):
             PL.keygen(kzg, PL.BaseCircuitParams.new(6, 1, 1, 1, 0, 4), circ.fixed, bad_copy)
