@@ -99,7 +99,9 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
 /* `count` independent MSMs over the same bases (all advice columns of a phase, the pieces of h(X), ...).
  * scalars_dev: host array of `count` device pointers, n scalars each; out_host: `count` points.  The MSMs are
  * pipelined over the context's lanes ("msm_lanes" internal streams; default: chosen by size) so that one MSM's sort and latency-bound tail
- * overlap another one's accumulation. */
+ * overlap another one's accumulation.  With precomputed tables, columns of up to 2^17 scalars are FUSED into multi-column MSMs of about
+ * 2^19 scalars (up to 16 columns share every launch), and the latency-bound bucket reduction is deferred: it runs once per 64 columns of
+ * the batch after the lanes have joined. */
 int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count,
                            int point_format, void *out_host);
 /* the same with a base set PER COLUMN: the commitments of one prover round that live over different SRS columns (Lagrange-basis and
