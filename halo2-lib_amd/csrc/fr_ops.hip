@@ -1005,6 +1005,7 @@ int h2hip_fr_grand_products_dev(h2hip_ctx *ctx, void *const *z, const void *num,
     hipLaunchKernelGGL(fr_ratio_rows_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, r, (const Fr *)num, (const Fr *)t, total, seg_len,
                        chained ? 1 : 0);
     prof_end(ctx);
+    if (segments == 1) return prefix_product_segments(ctx, r, (Fr *)z[0], rlen, 1, 0);   // one product: straight into its column
     if (chained) H2_CHK(prefix_product_segments(ctx, r, e, rlen, 1, 0));
     else H2_CHK(prefix_product_segments(ctx, r, e, seg_len + 1, segments, seg_len + 1));
     // chained: consecutive products share one element (the last value of one is the first of the next): rows seg_len apart, seg_len + 1 long
@@ -1399,6 +1400,9 @@ int h2hip_quotient_permutation_sets_dev(h2hip_ctx *ctx, void *acc, const void *c
     H2_REQUIRE(num_columns > (uint64_t)(num_sets - 1) * chunk_len && num_columns <= (uint64_t)num_sets * chunk_len, "num_sets must be ceil(num_columns / chunk_len)");
     for (uint32_t s2 = 0; s2 < num_sets; ++s2) H2_REQUIRE(z[s2], "NULL product column");
     for (uint32_t c = 0; c < num_columns; ++c) H2_REQUIRE(cols[c] && sigmas[c], "NULL column");
+    if (num_sets == 1)   // one set: the dedicated kernel (no job loop, the X term without the per-job product)
+        return h2hip_quotient_permutation_set_dev(ctx, acc, z[0], nullptr, cols, sigmas, num_columns, 0, l0, l_last, l_blind, ext_k, k,
+                                                  H2HIP_PERM_FIRST | H2HIP_PERM_LAST | H2HIP_PERM_PRODUCT, last_rotation, beta, gamma, delta, zeta, ext_omega, y);
     const size_t ne = (size_t)1 << ext_k;
     const uint32_t step = 1u << (ext_k - k);
     PermBatchArgs g;

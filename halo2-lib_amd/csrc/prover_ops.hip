@@ -147,7 +147,7 @@ int h2hip_permutation_product_terms_sets_dev(h2hip_ctx *ctx, void *num_dev, void
     memset(&g, 0, sizeof(g));
     g.chunk = chunk_len;
     g.beta = ld(beta); g.gamma = ld(gamma); g.delta = ld(delta); g.omega = ld(omega);
-    const uint32_t grid = grid_rows(ctx, rows, 1);
+    const uint32_t grid = grid_rows(ctx, rows, rows >= ((size_t)1 << 16) ? 4 : 1);   // long columns: four rows per lane amortise the omega^i start-up
     g.xstep = fe_pow_u64(g.omega, (uint64_t)grid * 256);
     const uint32_t per_launch = PP_BATCH_COLS / chunk_len * chunk_len;   // whole sets
     Fr x0 = g.beta;
