@@ -335,13 +335,14 @@ __global__ __launch_bounds__(256) void fr_eval_final_batch_kernel(const EvalJob 
 // workgroup's head H = sum_{j in tile} c_j b^(j-lo); stage 2 turns heads into carries
 // carry[blk] = sum_{blk'>blk} H[blk'] * (b^TILE)^(blk'-blk-1); stage 3 replays the tile with its carry.
 constexpr uint32_t KATE_J = 8, KATE_TILE = 256 * KATE_J;
+template <uint32_t J>
 __device__ __forceinline__ Fr kate_tile_scan(const Fr *__restrict__ c, size_t n, size_t lo, Fr b, const PowTable &pw, Fr *sh, Fr carry_in,
                                              Fr *__restrict__ q) {
-    // returns the tile head; when q != nullptr also writes the quotient coefficients of this tile
+    // returns the tile head; when q != nullptr also writes the quotient coefficients of this tile (256 * J coefficients, J per lane)
     const uint32_t tid = threadIdx.x;
-    const size_t base = lo + (size_t)tid * KATE_J;
+    const size_t base = lo + (size_t)tid * J;
     Fr h = Fr::zero();
-    for (int k = KATE_J - 1; k >= 0; --k) {
+    for (int k = (int)J - 1; k >= 0; --k) {
         h = fe_mul(h, b);
         if (base + k < n) h = fe_add(h, c[base + k]);
     }
@@ -361,7 +362,7 @@ __device__ __forceinline__ Fr kate_tile_scan(const Fr *__restrict__ c, size_t n,
         Fr car = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
         car = fe_add(car, fe_mul(fe_pow_u64(pw.p[0], 255 - tid), carry_in));
         Fr tmp = car;
-        for (int k = KATE_J - 1; k >= 0; --k) {
+        for (int k = (int)J - 1; k >= 0; --k) {
             if (base + k < n) {
                 tmp = fe_add(c[base + k], fe_mul(tmp, b));
                 if (base + k >= 1) q[base + k - 1] = tmp;
@@ -372,7 +373,7 @@ __device__ __forceinline__ Fr kate_tile_scan(const Fr *__restrict__ c, size_t n,
 }
 __global__ __launch_bounds__(256) void fr_kate_heads_kernel(const Fr *__restrict__ c, size_t n, Fr b, PowTable pw, Fr *__restrict__ heads) {
     __shared__ Fr sh[256];
-    Fr h = kate_tile_scan(c, n, (size_t)blockIdx.x * KATE_TILE, b, pw, sh, Fr::zero(), nullptr);
+    Fr h = kate_tile_scan<KATE_J>(c, n, (size_t)blockIdx.x * KATE_TILE, b, pw, sh, Fr::zero(), nullptr);
     if (threadIdx.x == 0) heads[blockIdx.x] = h;
 }
 // carry[blk] = sum_{blk'>blk} H[blk'] * B^(blk'-blk-1), B = b^TILE = pw.p[8]: one workgroup, lane-serial runs of
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) void fr_kate_carry_kernel(const Fr *__restrict
 __global__ __launch_bounds__(256) void fr_kate_apply_kernel(const Fr *__restrict__ c, size_t n, Fr b, PowTable pw, const Fr *__restrict__ carry,
                                                             Fr *__restrict__ q) {
     __shared__ Fr sh[256];
-    kate_tile_scan(c, n, (size_t)blockIdx.x * KATE_TILE, b, pw, sh, carry[blockIdx.x], q);
+    kate_tile_scan<KATE_J>(c, n, (size_t)blockIdx.x * KATE_TILE, b, pw, sh, carry[blockIdx.x], q);
 }
 
 // Division by the vanishing polynomial of SEVERAL points in one pass (ProverSHPLONK's per-rotation-set quotient): by partial fractions,
@@ -421,11 +422,14 @@ struct KateJob {
     Fr b, w;
     PowTable pw;
 };
+// (J = coefficients per lane: a tile is 256 * J coefficients.  The multi-point kernels pick J by the polynomial's length — when there are fewer
+// waves than SIMDs, a wave's instruction count IS the kernel's time, and short tiles spread a short polynomial over more waves)
+template <uint32_t J>
 __global__ __launch_bounds__(256) void fr_kate_heads_multi_kernel(const Fr *__restrict__ c, size_t n, const KateJob *__restrict__ jobs, uint32_t ntiles,
                                                                   Fr *__restrict__ heads) {
     __shared__ Fr sh[256];
     const KateJob &job = jobs[blockIdx.y];
-    Fr h = kate_tile_scan(c, n, (size_t)blockIdx.x * KATE_TILE, job.b, job.pw, sh, Fr::zero(), nullptr);
+    Fr h = kate_tile_scan<J>(c, n, (size_t)blockIdx.x * (256 * J), job.b, job.pw, sh, Fr::zero(), nullptr);
     if (threadIdx.x == 0) heads[(size_t)blockIdx.y * (ntiles + 1) + blockIdx.x] = h;
 }
 __global__ __launch_bounds__(256) void fr_kate_carry_multi_kernel(const Fr *__restrict__ heads, Fr *__restrict__ carry, uint32_t ntiles,
@@ -461,20 +465,18 @@ __global__ __launch_bounds__(256) void fr_kate_carry_multi_kernel(const Fr *__re
         }
     }
 }
-// All M points of the set advance TOGETHER: their Horner chains, their suffix scans (one pair of barriers per doubling step for all points)
-// and their quotient chains are independent, so a lane always has M products in flight — the kernel is a dependent chain of ~35 products per
-// tile instead of ~50 per point (it runs one wave per SIMD at the sizes of a proof, i.e. latency-bound).  The tile's incoming carry sits in
-// an extra scan slot (index 256), which the scan multiplies by the right power of b^J on its own.  Points beyond m (padding up to the
-// compiled M) carry weight 0.
-template <int M>
+// All M points of the set advance together through one pass over the tile: their Horner values, their suffix scans (one pair of barriers
+// per doubling step for all points) and their quotient chains; the tile's incoming carry sits in an extra scan slot (index 256), which the scan
+// multiplies by the right power of b^J on its own.  Points beyond m (padding up to the compiled M) carry weight 0.
+template <int M, uint32_t J>
 __global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__restrict__ c, size_t n, const KateJob *__restrict__ jobs, uint32_t m,
                                                                   uint32_t ntiles, const Fr *__restrict__ carry, Fr *__restrict__ q, int accumulate) {
     __shared__ Fr sh[M][257];
     const uint32_t tid = threadIdx.x;
-    const size_t lo = (size_t)blockIdx.x * KATE_TILE, base = lo + (size_t)tid * KATE_J;
-    Fr cv[KATE_J], acc[KATE_J];
+    const size_t lo = (size_t)blockIdx.x * (256 * J), base = lo + (size_t)tid * J;
+    Fr cv[J], acc[J];
 #pragma unroll
-    for (uint32_t k = 0; k < KATE_J; ++k) {
+    for (uint32_t k = 0; k < J; ++k) {
         cv[k] = base + k < n ? c[base + k] : Fr::zero();
         acc[k] = Fr::zero();
     }
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__re
         h[j] = Fr::zero();
     }
 #pragma unroll
-    for (int k = KATE_J - 1; k >= 0; --k) {
+    for (int k = (int)J - 1; k >= 0; --k) {
 #pragma unroll
         for (int j = 0; j < M; ++j) h[j] = fe_add(fe_mul(h[j], b[j]), cv[k]);   // coefficients past n are zero
     }
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__re
         w[j] = (uint32_t)j < m ? jobs[j].w : Fr::zero();
     }
 #pragma unroll
-    for (int k = KATE_J - 1; k >= 0; --k) {
+    for (int k = (int)J - 1; k >= 0; --k) {
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             tmp[j] = fe_add(cv[k], fe_mul(tmp[j], b[j]));             // = quotient coefficient of index base + k - 1 for point j
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__re
         }
     }
 #pragma unroll
-    for (uint32_t k = 0; k < KATE_J; ++k)
+    for (uint32_t k = 0; k < J; ++k)
         if (base + k < n && base + k >= 1) q[base + k - 1] = accumulate ? fe_add(q[base + k - 1], acc[k]) : acc[k];
 }
 
@@ -1112,18 +1114,17 @@ int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size
     return H2HIP_OK;
 }
 
+}  // extern "C"
 // q[0..n-1) = sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j]),  m <= 8 points; q_dev must not alias coeffs_dev
-int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m) {
-    H2_DEVICE_GUARD(ctx);
-    H2_REQUIRE(ctx && points && weights && n >= 1 && coeffs && (n == 1 || q) && m >= 1 && m <= 8, "bad argument (1..8 points)");
-    H2_REQUIRE(q != coeffs, "q must not alias coeffs");
-    if (n == 1) return H2HIP_OK;
-    const uint32_t ntiles = (uint32_t)((n + KATE_TILE - 1) / KATE_TILE);
+template <uint32_t J>
+static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m) {
+    const uint32_t tile = 256 * J;
+    const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
     std::vector<KateJob> jobs(m);
     for (uint32_t j = 0; j < m; ++j) {
         memcpy(&jobs[j].b, (const char *)points + sizeof(Fr) * j, sizeof(Fr));
         memcpy(&jobs[j].w, (const char *)weights + sizeof(Fr) * j, sizeof(Fr));
-        pow_table(jobs[j].b, KATE_J, jobs[j].pw);
+        pow_table(jobs[j].b, J, jobs[j].pw);   // p[l] = b^(J * 2^l): p[8] = b^tile
     }
     char *buf = nullptr;
     const size_t jobs_bytes = (sizeof(KateJob) * m + 255) / 256 * 256;
@@ -1132,7 +1133,7 @@ int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs
     Fr *heads = (Fr *)(buf + jobs_bytes), *carry = heads + (size_t)m * (ntiles + 1);
     H2_CHK(upload_jobs(ctx, djobs, jobs.data(), sizeof(KateJob) * m));   // through the pinned ring: no synchronisation per call
     prof_begin(ctx, "fr_kate_kernels");
-    hipLaunchKernelGGL(fr_kate_heads_multi_kernel, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, ntiles, heads);
+    hipLaunchKernelGGL(fr_kate_heads_multi_kernel<J>, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, ntiles, heads);
     hipLaunchKernelGGL(fr_kate_carry_multi_kernel, dim3(m), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles, (const KateJob *)djobs);
     for (uint32_t j0 = 0; j0 < m; j0 += 4) {   // four points per pass (the scans of a pass share the workgroup's LDS); halo2-base's sets stop at 4
         const uint32_t mm = m - j0 < 4 ? m - j0 : 4;
@@ -1140,15 +1141,27 @@ int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs
         const Fr *cr = carry + (size_t)j0 * (ntiles + 1);
         const int accumulate = j0 ? 1 : 0;
         if (mm == 1)
-            hipLaunchKernelGGL(fr_kate_apply_multi_kernel<1>, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
+            hipLaunchKernelGGL((fr_kate_apply_multi_kernel<1, J>), dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
         else if (mm == 2)
-            hipLaunchKernelGGL(fr_kate_apply_multi_kernel<2>, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
+            hipLaunchKernelGGL((fr_kate_apply_multi_kernel<2, J>), dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
         else
-            hipLaunchKernelGGL(fr_kate_apply_multi_kernel<4>, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
+            hipLaunchKernelGGL((fr_kate_apply_multi_kernel<4, J>), dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
     }
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
+}
+extern "C" {
+int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && points && weights && n >= 1 && coeffs && (n == 1 || q) && m >= 1 && m <= 8, "bad argument (1..8 points)");
+    H2_REQUIRE(q != coeffs, "q must not alias coeffs");
+    if (n == 1) return H2HIP_OK;
+    // coefficients per lane: about one wave per SIMD or more (2^19 coefficients: 8 per lane -> 256 tiles of 4 waves)
+    if (n >= ((size_t)1 << 19)) return kate_division_multi_run<8>(ctx, q, coeffs, n, points, weights, m);
+    if (n >= ((size_t)1 << 18)) return kate_division_multi_run<4>(ctx, q, coeffs, n, points, weights, m);
+    if (n >= ((size_t)1 << 17)) return kate_division_multi_run<2>(ctx, q, coeffs, n, points, weights, m);
+    return kate_division_multi_run<1>(ctx, q, coeffs, n, points, weights, m);
 }
 
 // ------------------------------------------------------------------ K8 Poseidon

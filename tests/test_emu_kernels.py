@@ -91,7 +91,7 @@ def test_msm_parameter_sweep(ctx, c, k1, seg):
         for s in (rand_fr(n, c), circuit_like_fr(n, c)):
             assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=4))
     finally:
-        for name, v in (("msm_window_bits", 0), ("msm_chunk", 0), ("msm_seg", 8)):
+        for name, v in (("msm_window_bits", 0), ("msm_chunk", 0), ("msm_seg", 4)):
             ctx.set_param(name, v)
         b.free()
 

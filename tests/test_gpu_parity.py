@@ -310,6 +310,18 @@ def test_msm_randomized_shapes(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [(1 << 17) + 3, 1 << 18, (1 << 19) - 1, 1 << 20])
+def test_kate_division_multi_tile_lengths(ctx, n):
+    """the multi-point division picks its tile (1 / 2 / 4 / 8 coefficients per lane) by the polynomial's length: every variant against the
+    weighted sum of single-point divisions (pinned to big-int arithmetic by test_prover_steps), 3 and 5 points (one and two passes)"""
+    f = rand_fr(n, 31)
+    for m in (3, 5):
+        pts, ws = rand_fr(m, 32 + m), rand_fr(m, 40 + m)
+        want = ctx.fr_linear_combination([ctx.fr_kate_division(f, pts[j:j + 1]) for j in range(m)], ws)
+        assert np.array_equal(ctx.fr_kate_division_multi(f, pts, ws), want), (n, m)
+
+
+@pytest.mark.gpu
 def test_lookup_permute_batch(ctx):
     from tests.golden_checks import check_lookup_permute_batch
 

@@ -28,7 +28,7 @@ for log_n in (19, 20):
     for seg in (4, 8, 16, 32, 64, 128):
         ctx.set_param("msm_seg", seg)
         both("seg=%d" % seg)
-    ctx.set_param("msm_seg", int(os.environ.get("H2_SEG_DEFAULT", "8")))
+    ctx.set_param("msm_seg", int(os.environ.get("H2_SEG_DEFAULT", "4")))
     for chunk in (0, 24, 32, 43, 48, 64, 86, 128):
         ctx.set_param("msm_chunk", chunk)
         both("chunk=%d" % chunk)
