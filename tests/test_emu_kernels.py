@@ -515,6 +515,15 @@ def test_msm_batch_split_streams_and_mixed_bases(ctx):
     finally:
         ctx.set_param("msm_fuse_cols", 0)
         ctx.set_param("msm_split_streams", 0)
+    # automatic fusing: runs of columns over the same set become fused multi-column MSMs (a group never spans two sets), reduced together
+    many = [ba] * 7 + [bb] * 2 + [ba] * 3
+    mptrs = [dptrs[j % 5] for j in range(len(many))]
+    for defer in (1, 0):
+        ctx.set_param("msm_defer_reduce", defer)
+        got = ctx.msm_multi_dev(many, mptrs, n, H.POINT_AFFINE)
+        for j, s2 in enumerate(many):
+            assert np.array_equal(got[j:j + 1], (want_a if s2 is ba else want_b)[j % 5]), (defer, j)
+    ctx.set_param("msm_defer_reduce", 1)
     for d in dptrs:
         ctx.free(d)
     ba.free()

@@ -310,6 +310,31 @@ def test_msm_randomized_shapes(ctx):
 
 
 @pytest.mark.gpu
+def test_msm_batch_many_small_columns(ctx):
+    """a wide shape's commitment round: 70 columns of 3000 scalars over two base sets — fused groups of up to 16 columns that never span two
+    sets, the deferred bucket reduction in chunks of 64 columns — against the oracle, column by column"""
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    n = 3000
+    bases_a = CO.known_dlog_bases(n, fr([77]), fr([3]))
+    bases_b = CO.known_dlog_bases(n, fr([1234567]), fr([11]))
+    ba, bb = ctx.bases_upload(bases_a, BASES_PRECOMPUTE), ctx.bases_upload(bases_b, BASES_PRECOMPUTE)
+    cols = [rand_fr(n, 500 + j) if j % 3 else circuit_like_fr(n, 500 + j) for j in range(70)]
+    which = [ba] * 50 + [bb] * 3 + [ba] * 17          # runs of 50, 3 and 17 columns
+    dptrs = [ctx.to_device(c) for c in cols]
+    try:
+        got = ctx.msm_multi_dev(which, dptrs, n, H.POINT_AFFINE)
+        for j in range(70):
+            want = CO.best_multiexp(cols[j], bases_a if which[j] is ba else bases_b, threads=8)
+            assert np.array_equal(got[j:j + 1], want), j
+    finally:
+        for d in dptrs:
+            ctx.free(d)
+        ba.free()
+        bb.free()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [(1 << 17) + 3, 1 << 18, (1 << 19) - 1, 1 << 20])
 def test_kate_division_multi_tile_lengths(ctx, n):
     """the multi-point division picks its tile (1 / 2 / 4 / 8 coefficients per lane) by the polynomial's length: every variant against the
