@@ -548,9 +548,9 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     const size_t psz = affine ? sizeof(G1Affine) : sizeof(G1Jac);
     // lanes: the kernels of one MSM are issue-bound or latency-bound, so lanes that overlap whole MSMs mostly contend (measured,
     // tools/batch_ab.py, batches of 4 with the deferred reduction: 2^20 1.71 / 1.75 / 1.80 / 1.84 ms per MSM on 1 / 2 / 3 / 4 lanes, 2^19
-    // 0.99 / 0.95 / 0.98 / 1.00) — auto picks 1 lane from 2^20 points, 2 below, 3 for the fused small sizes
+    // 0.99 / 0.95 / 0.98 / 1.00) — auto picks 1 lane from 2^20 points, 3 below
     int NL = ctx->msm_lanes;
-    if (NL <= 0) NL = n >= ((size_t)1 << 20) ? 1 : n > ((size_t)1 << 17) ? 2 : 3;
+    if (NL <= 0) NL = n >= ((size_t)1 << 20) ? 1 : 3;   // (2^18 / 2^19 were on 2 lanes until the window model moved them to c = 15: 3 lanes now win by 2 %, k = 18 / 19 proofs)
     if (NL > 4) NL = 4;
     if (NL < 2 && ctx->msm_split_streams && !scalars_on_host && count >= 2 && n > ((size_t)1 << 17)) NL = 2;   // the split-stream schedule alternates two scratch sets
     for (int l = 0; l < NL; ++l) {
