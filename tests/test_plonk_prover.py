@@ -192,6 +192,21 @@ def test_create_proof_gpu(shape):
 
 
 @pytest.mark.gpu
+def test_create_proof_gpu_very_wide_shape():
+    """a shape past every batching boundary at once — 70 gate columns (> 64 per quotient launch, > 32 per NTT launch), 34 lookups (> 32 per
+    launch), 36 permutation sets (> 12 (set, term) jobs per launch), > 64 commitments in one round (deferred reduction in chunks) — like the
+    reference's low-k configurations (bench_ecdsa.config: k = 11, 291 + 53 columns).  Byte equality with the oracle prover."""
+    ctx = H.Context()
+    try:
+        sh, params, vk, inst, proof, circ, gpk, kzg = _check(ctx, 8, 70, 34, 2, 1, 5, threads=16, precompute=True, second_proof=False)
+        assert sh.num_perm_sets > 24 and len(sh.lookups) == 34
+        gpk.free()
+        kzg.free()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_create_proof_gpu_k16_bytes_equal():
     ctx = H.Context()
     try:
