@@ -1,7 +1,7 @@
 //! Raw bindings to `include/h2hip.h` (one declaration per exported symbol) + the safe layer in `safe.rs`.
 //! NOT COMPILED in this repository's environment (no Rust toolchain) — see ffi/rust/README.md.
 #![allow(non_camel_case_types)]
-use std::os::raw::{c_char, c_int, c_void};
+use std::os::raw::{c_char, c_int, c_uint, c_void};
 
 pub mod safe;
 
@@ -207,6 +207,8 @@ extern "C" {
                                     transcript_repr: *const c_void, g1: *const c_void, g2: *const c_void, s_g2: *const c_void,
                                     instances_host: *const *const c_void, instance_lens: *const usize, proof: *const u8, proof_len: usize,
                                     accepted: *mut c_int) -> c_int;
+    pub fn h2hip_pairing_check(g1_points: *const c_void, g2_points: *const c_void, n: usize, is_one: *mut c_int) -> c_int;
+    pub fn h2hip_blake2b(personal16: *const c_void, digest_len: c_uint, msg: *const c_void, len: usize, out: *mut c_void) -> c_int;
     // timing / diagnostics
     pub fn h2hip_profile_enable(ctx: *mut h2hip_ctx, on: c_int) -> c_int;
     pub fn h2hip_profile_reset(ctx: *mut h2hip_ctx) -> c_int;

@@ -9,26 +9,20 @@ namespace h2 {
 class Blake2b {
   public:
     // digest_len <= 64, unkeyed; `personal`: up to 16 bytes (zero padded)
-    explicit Blake2b(unsigned digest_len = 64, const char *personal = nullptr) : outlen_(digest_len) {
-        static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
-                                       0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
-        uint8_t param[64];
-        memset(param, 0, sizeof(param));
-        param[0] = (uint8_t)digest_len;   // digest length
-        param[2] = 1;                     // fanout
-        param[3] = 1;                     // depth
+    explicit Blake2b(unsigned digest_len = 64, const char *personal = nullptr) {
+        uint8_t pers[16];
+        memset(pers, 0, sizeof(pers));
         if (personal) {
             size_t l = strlen(personal);
-            memcpy(param + 48, personal, l > 16 ? 16 : l);
+            memcpy(pers, personal, l > 16 ? 16 : l);
         }
-        for (int i = 0; i < 8; ++i) {
-            uint64_t w;
-            memcpy(&w, param + 8 * i, 8);
-            h_[i] = IV[i] ^ w;
-        }
-        t_[0] = t_[1] = 0;
-        buflen_ = 0;
-        memset(buf_, 0, sizeof(buf_));
+        init(digest_len, pers);
+    }
+    // the 16 personalisation bytes given raw (may contain zero bytes)
+    static Blake2b with_personal16(unsigned digest_len, const uint8_t personal[16]) {
+        Blake2b b;
+        b.init(digest_len, personal);
+        return b;
     }
     void update(const void *data, size_t len) {
         const uint8_t *in = (const uint8_t *)data;
@@ -58,6 +52,25 @@ class Blake2b {
     }
 
   private:
+    void init(unsigned digest_len, const uint8_t personal[16]) {
+        static const uint64_t IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                       0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+        outlen_ = digest_len;
+        uint8_t param[64];
+        memset(param, 0, sizeof(param));
+        param[0] = (uint8_t)digest_len;   // digest length
+        param[2] = 1;                     // fanout
+        param[3] = 1;                     // depth
+        memcpy(param + 48, personal, 16);
+        for (int i = 0; i < 8; ++i) {
+            uint64_t w;
+            memcpy(&w, param + 8 * i, 8);
+            h_[i] = IV[i] ^ w;
+        }
+        t_[0] = t_[1] = 0;
+        buflen_ = 0;
+        memset(buf_, 0, sizeof(buf_));
+    }
     static uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
     void add_counter(uint64_t n) {
         t_[0] += n;

@@ -175,6 +175,9 @@ static XYZZ g1_scalar_mul(const G1Affine &p, const Fr &k_mont) {
     }
     return acc;
 }
+static bool g1_on_curve_host(const G1Affine &p) {   // y^2 == x^3 + 3
+    return fe_mul(p.y, p.y) == fe_add(fe_mul(fe_mul(p.x, p.x), p.x), fq_small(3));
+}
 static G1Affine g1_neg(const G1Affine &p) {
     G1Affine r = p;
     if (!p.is_identity()) r.y = fe_neg(p.y);
@@ -639,6 +642,40 @@ int h2hip_plonk_verify_proof(const h2hip_base_circuit_params *params, const void
     const G1Affine right = g1_neg(xyzz_to_affine(outer));
     F12 f = f12_mul(miller_loop(h2, SQ2), miller_loop(right, Q2));
     *accepted = f12_is_one(final_exponentiation(f)) ? 1 : 0;
+    return H2HIP_OK;
+}
+
+// e(P_0, Q_0) * ... * e(P_{n-1}, Q_{n-1}) == 1 — the "final CPU-side pairing" of the north star as an entry of its own (the verifier above ends in
+// the two-pair instance of it).  g1: n x 64 B Montgomery G1Affine (identity = all-zero), g2: n x 128 B RawBytes (x.c0, x.c1, y.c0, y.c1), identity = all-zero.
+int h2hip_pairing_check(const void *g1_points, const void *g2_points, size_t n, int *is_one) {
+    H2_REQUIRE(is_one && (n == 0 || (g1_points && g2_points)), "null argument");
+    *is_one = 0;
+    F12 f = f12_one();
+    for (size_t i = 0; i < n; ++i) {
+        G1Affine P;
+        memcpy(&P, (const uint8_t *)g1_points + 64 * i, 64);
+        const uint8_t *q = (const uint8_t *)g2_points + 128 * i;
+        G2A Q = {load_f2(q), load_f2(q + 64), false};
+        Q.inf = f2_is_zero(Q.x) && f2_is_zero(Q.y);
+        H2_REQUIRE(canonical(P.x) && canonical(P.y) && (P.is_identity() || g1_on_curve_host(P)), "a G1 point is not on the curve");
+        H2_REQUIRE(g2_on_curve(Q), "a G2 point is not on the twist");
+        f = f12_mul(f, miller_loop(P, Q));
+    }
+    *is_one = f12_is_one(final_exponentiation(f)) ? 1 : 0;
+    return H2HIP_OK;
+}
+
+// BLAKE2b (RFC 7693), unkeyed, with an optional 16-byte personalisation: the transcript's hash (blake2b.h) as an entry of its own, so that it can
+// be pinned against the RFC's vectors and an independent implementation.  personal16: 16 bytes or NULL.
+int h2hip_blake2b(const void *personal16, unsigned digest_len, const void *msg, size_t len, void *out) {
+    H2_REQUIRE(out && digest_len >= 1 && digest_len <= 64 && (len == 0 || msg), "bad argument");
+    uint8_t pers[16] = {0};
+    if (personal16) memcpy(pers, personal16, 16);
+    h2::Blake2b h = h2::Blake2b::with_personal16(digest_len, pers);
+    h.update(msg, len);
+    uint8_t d[64];
+    h.digest(d);
+    memcpy(out, d, digest_len);
     return H2HIP_OK;
 }
 

@@ -115,6 +115,8 @@ _PROTOS = {
     "h2hip_poseidon_set_spec": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
     "h2hip_poseidon_permute_batch_dev": (_int, [_vp, _vp, _vp, _u32, _sz]),
     "h2hip_plonk_verify_proof": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, C.POINTER(_int)]),
+    "h2hip_pairing_check": (_int, [_vp, _vp, _sz, C.POINTER(_int)]),
+    "h2hip_blake2b": (_int, [_vp, C.c_uint, _vp, _sz, _vp]),
     "h2hip_bench_gather": (_int, [_vp, _u32, _sz, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "h2hip_bench_modmul29": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "h2hip_bench_modmul": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -402,6 +402,15 @@ int h2hip_plonk_verify_proof(const h2hip_base_circuit_params *params, const void
                              const void *transcript_repr, const void *g1, const void *g2, const void *s_g2, const void *const *instances_host,
                              const size_t *instance_lens, const uint8_t *proof, size_t proof_len, int *accepted);
 
+/* The final CPU-side pairing check of the north star as an entry of its own: *is_one = 1 iff prod_i e(P_i, Q_i) == 1 in Fq12 (what
+ * DualMSM::check / halo2curves' multi_miller_loop + final_exponentiation decide for KZG's two pairs).  g1_points: n x 64 B G1Affine
+ * (Montgomery, identity all-zero); g2_points: n x 128 B G2Affine in SerdeFormat::RawBytes order (x.c0, x.c1, y.c0, y.c1; identity all-zero).
+ * Host code.  Points off the curve / twist are H2HIP_ERR_INVALID.  Pinned by an EIP-197 vector (tests/test_external_vectors.py). */
+int h2hip_pairing_check(const void *g1_points, const void *g2_points, size_t n, int *is_one);
+/* BLAKE2b (RFC 7693), unkeyed, digest_len 1..64, optional 16-byte personalisation (NULL = none): the hash of the Blake2bWrite / Blake2bRead
+ * transcripts (personalisation "Halo2-Transcript"), exported so that it is pinned by the RFC's vectors, not only by proofs. */
+int h2hip_blake2b(const void *personal16, unsigned digest_len, const void *msg, size_t len, void *out);
+
 /* ---- diagnostics: 254-bit Montgomery multiplier throughput (the integer roofline bench.py quotes) ------ */
 int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);
 /* HBM-counter calibration probes: kind 0 = coalesced stream of table_bytes, kind 64 / 128 = lanes * per_lane random gathers of aligned

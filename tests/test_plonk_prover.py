@@ -219,11 +219,11 @@ def test_create_proof_gpu_k16_bytes_equal():
 
 @pytest.mark.gpu
 def test_create_proof_gpu_k19_ecdsa_shape():
-    """BASELINE.json configs[3]: the k = 19 secp256k1-ECDSA configuration (halo2-ecc/configs/secp256k1/bench_ecdsa.config:1).  The HIP
-    proof is checked by the oracle verifier; bench.py compares the bytes with the oracle prover's at this size (its cpu_baseline leg)."""
+    """BASELINE.json configs[3]: the k = 19 secp256k1-ECDSA configuration (halo2-ecc/configs/secp256k1/bench_ecdsa.config:1).  Proof BYTES
+    equal to the oracle prover's (its C kernels on the host cores: a few seconds), then the oracle's and libh2hip's verifiers."""
     ctx = H.Context()
     try:
-        sh, params, vk, inst, proof, circ, gpk, kzg = _check(ctx, 19, 1, 1, 1, 0, 18, threads=16, oracle_prover=False, precompute=True)
+        sh, params, vk, inst, proof, circ, gpk, kzg = _check(ctx, 19, 1, 1, 1, 0, 18, threads=32, oracle_prover=True, precompute=True)
         assert (sh.degree, sh.extended_k, gpk.shape.num_commitments) == (5, 21, 12)
         gpk.free()
         kzg.free()
@@ -256,11 +256,11 @@ def test_create_proof_repeatable_with_interleaved_keys():
 @pytest.mark.gpu
 def test_create_proof_gpu_k21_pairing_shape():
     """BASELINE.json configs[4] on one GPU: the k = 21 BN254-pairing configuration (halo2-ecc/configs/bn254/bench_pairing.config:8: 2 gate advice
-    columns, 1 lookup-advice column, 1 constants column, lookup_bits 20 -> degree 4, extended_k 23, 14 commitments of 2^21 points): the proof is
-    checked by the oracle verifier and by libh2hip's own"""
+    columns, 1 lookup-advice column, 1 constants column, lookup_bits 20 -> degree 4, extended_k 23, 14 commitments of 2^21 points): proof BYTES
+    equal to the oracle prover's (about half a minute of C kernels on the host cores), then the oracle's and libh2hip's verifiers"""
     ctx = H.Context()
     try:
-        sh, params, vk, inst, proof, circ, gpk, kzg = _check(ctx, 21, 2, 1, 1, 0, 20, threads=16, oracle_prover=False, precompute=True, second_proof=False)
+        sh, params, vk, inst, proof, circ, gpk, kzg = _check(ctx, 21, 2, 1, 1, 0, 20, threads=32, oracle_prover=True, precompute=True, second_proof=False)
         assert (sh.degree, sh.extended_k, gpk.shape.num_commitments) == (4, 23, 14)
         gpk.free()
         kzg.free()
