@@ -2,23 +2,22 @@
 """
 bench.py — headline benchmark of the MI355X prover backend (contract: see the task statement).
 
-Workload (BASELINE.json configs[1]): one step = one 2^20-point BN254 G1 Pippenger MSM
-(`h2hip_msm_g1_dev`: scalars and bases already resident in HBM, the Jacobian result is returned to the
-host like arithmetic::best_multiexp returns C::Curve).  Synthetic data: uniformly random scalars (a distinct
-column per MSM of a batch); bases are 2^20 DISTINCT points P_i = (k0 + i*d)*G built on the GPU, whose known discrete
-logs give the closed form (sum_i s_i*(k0+i*d))*G against which the last timed batch is verified in-run.
+One step = ONE `create_proof` for the configuration BASELINE.json's metric is quoted on: the k = 19 secp256k1-ECDSA shape of
+halo2-ecc/configs/secp256k1/bench_ecdsa.config:1 (`h2hip_plonk_create_proof`: Blake2b transcript, 12 MSMs of 2^19 points, the lookup sort, grand
+products, h(X) over the 2^21-point extended domain, evaluations, SHPLONK; proof bytes out).  Inputs are resident where the reference holds them: SRS
+tables and proving key in HBM, the advice column in host memory like the Vec the Rust prover fills (its 16 MiB upload is inside the timed call).
 
-  value      = G1-adds/s over the whole job, with the add count defined by SURVEY.md §8d:
-               adds(n) = n*W + 2*W*2^(c-1) for the window the kernel actually used (c, W reported).
-  roofline   = dominant kernel (msm_accum_kernel<affine>) — algorithmic bytes 96 B/pair x n per launch
-               over its mean duration, measured with HIP events on the context's stream inside the timed
-               region; `roofline_int` adds the binding roof: Montgomery multiplies/s vs. the chip's measured
-               254-bit multiplier peak (h2hip_bench_modmul on the same GPU, same run).
-  cpu_baseline = oracle/ restatement of best_multiexp ("port") on the box's own host cores, rank 0, N=1 only.
+  value        = constraints/s = assigned advice cells of the circuit / seconds per proof
+  roofline     = the proof's dominant kernel, msm_accum_kernel: algorithmic 96 B x 2^19 per launch over its mean duration inside the timed
+                 region (HIP events on the launch streams); `roofline_int`: the same launch against the binding roof, the 254-bit
+                 multiplier peak measured in the same run; `roofline_proof`: the whole proof's algorithmic products / bytes over its wall time
+  cpu_baseline = the oracle's restatement of the same prover ("port": identical step list, C kernels) on the box's host cores, one full
+                 proof, whose BYTES are compared with the GPU proof's
+  msm_2_20     = the other half of the metric (BASELINE configs[1]): G1-adds/s of 2^20-point MSMs with its own roofline and CPU line;
+  ntt_2_22, k8_witness_batches, create_proof_k21_pairing_shape, create_proof_config_sweep: further blocks, outside the timed region.
 
-Multi-GPU (`--gpus N` under torch.distributed.run): point-range sharding — every rank owns a
-2^20-point slice of an N*2^20-point MSM (weak scaling), computes its partial on its own GPU, partials are
-all-gathered over RCCL (96 B each) and summed on every rank's GPU (RCCL has no group-law reduction).
+Multi-GPU (`--gpus N` under torch.distributed.run): `--scaling strong` (default) = ONE k = 19 proof per step with its work sharded over the N
+GPUs, every rank emitting the same proof bytes; `--scaling weak` = an independent proof per GPU.
 """
 from __future__ import annotations
 
@@ -137,32 +136,59 @@ def window_for(ctx, n):
     return c, (255 + c - 1) // c
 
 
+def kernel_account(ctx, proofs):
+    """{kernel: {"ms": per proof, "launches": per proof, "busy_ms": per proof}} from the library's HIP-event profile (h2hip_profile_dump)"""
+    acc = {}
+    for name, (ms, cnt, busy) in sorted(ctx.profile_dump().items(), key=lambda kv: -kv[1][0]):
+        acc[name] = {"ms": round(ms / proofs, 4), "launches": round(cnt / proofs, 2), "busy_ms": round(busy / proofs, 4)}
+    return acc
+
+
+def proof_algorithmic_work(ctx, bp, sh):
+    """the algorithmic work of one create_proof for a BaseCircuitParams shape (SURVEY.md §8d's formulas, summed over the proof's MSMs and
+    transforms): 254-bit products = 10*n*W per MSM (XYZZ mixed addition, window of the implementation) + (m/2)*log2(m) per transform of m
+    points; bytes = 96 B per (scalar, base) pair + 64 B per transformed element"""
+    k, n = bp.k, 1 << bp.k
+    c, W = window_for(ctx, n)
+    msms = sh.num_commitments
+    A, L, P = sh.num_advice_total, sh.num_lookups, sh.num_perm_sets
+    cols = A + 3 * L + P                       # columns that go Lagrange -> coefficients -> extended coset
+    ext = sh.extended_k
+    intt, cntt, cintt = cols * (n // 2) * k, cols * ((1 << ext) // 2) * ext, ((1 << ext) // 2) * ext
+    return {"msm_count": msms, "msm_window_bits": c, "msm_windows": W, "msm_products": 10.0 * n * W * msms,
+            "transforms": {"lagrange_to_coeff": cols, "coeff_to_extended": cols, "extended_to_coeff": 1},
+            "ntt_products": float(intt + cntt + cintt), "products": 10.0 * n * W * msms + intt + cntt + cintt,
+            "bytes": 96.0 * n * msms + 64.0 * (cols * n + cols * (1 << ext) + (1 << ext))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512, help="timed MSMs (default: a timed region of about one second)")
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20, help="timed create_proof calls (one step = one k=19 proof)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--k", type=int, default=19, help="the metric's configuration is k=19 (bench_ecdsa.config:1); other k: the same 1+1+1 column shape")
+    ap.add_argument("--log-n", type=int, default=20, help="size of the MSM block (BASELINE configs[1])")
+    ap.add_argument("--msm-steps", type=int, default=128, help="timed MSMs of the MSM block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sharded-proof", action="store_true",
-                    help="N > 1: also time the k=19 create_proof with point-range-sharded commitments (extra block `create_proof_k19_sharded`; opt-in so that "
-                         "the contract line of a multi-GPU run never depends on it)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = every rank owns a 2^log_n-point slice of an N*2^log_n-point MSM (default); strong = ONE 2^log_n-point MSM "
-                         "split into N point ranges (2^log_n / N points per GPU)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1, top-level line: strong = ONE k=19 proof per step, sharded over the N GPUs (north star; default); weak = every rank "
+                         "proves its own circuit (independent replicas, no exchange).  The MSM block follows the same choice.")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (exchange staged through the host; testing)")
     ap.add_argument("--share-device", action="store_true", help="testing on a 1-GPU box: every rank uses GPU 0 (requires --dist-backend gloo)")
     ap.add_argument("--param", action="append", default=[], help="name=value tuning knob passed to h2hip_set_param (repeatable)")
     ap.add_argument("--lanes", type=int, default=0, help="override msm_lanes (streams used by the batch API)")
-    ap.add_argument("--no-replay", action="store_true", help="skip the k=19 create_proof, NTT and K8 blocks (extra fields)")
+    ap.add_argument("--no-replay", action="store_true", help="skip the MSM 2^20, NTT 2^22, K8 and k=21 blocks (extra fields)")
     ap.add_argument("--no-sweep", action="store_true", help="skip create_proof over the reference's 18 benchmark shapes (an extra field, ~25 s)")
     ap.add_argument("--precompute", type=int, default=1, help="1: bases carry precomputed 2^(c*w) window tables (fixed-base SRS, H2HIP_BASES_PRECOMPUTE)")
-    ap.add_argument("--batch", type=int, default=4, help="MSMs issued per h2hip_msm_g1_batch_dev call (a prover commits several columns per round); 1 = synchronous")
+    ap.add_argument("--batch", type=int, default=4, help="MSM block: MSMs issued per h2hip_msm_g1_batch_dev call (a prover commits several columns per round); 1 = synchronous")
     args = ap.parse_args()
 
     import torch
 
     import halo2_lib_amd as H
+    from halo2_lib_amd import halo2_proofs as HP
+    from halo2_lib_amd import plonk as PL
+    from halo2_lib_amd import testing as T
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -184,9 +210,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     xdev = dev if args.dist_backend == "nccl" else None   # where the all-gather tensors live
-
-    n_total = 1 << args.log_n
-    n = n_total // world if args.scaling == "strong" else n_total   # points per rank
     # a non-default torch stream: the legacy null stream adds implicit synchronisation to every launch
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
@@ -196,6 +219,208 @@ def main():
     for kv in args.param:
         name, val = kv.split("=")
         ctx.set_param(name, int(val))
+
+    # ------------------------------------------------------------------ the metric's configuration: create_proof, k = 19 ECDSA shape
+    k = args.k
+    n = 1 << k
+    s_toxic = 0x1D0C0FFEE1234567890ABCDEF
+    sharded = world > 1 and args.scaling == "strong"
+    bp = PL.BaseCircuitParams.new(k, 1, 1, 1, 0, k - 1)
+    sh = PL.shape_of(ctx, bp)
+
+    class Backend:   # the synthetic witness is computed through the K8 batch kernels
+        mul = staticmethod(ctx.fr_mul)
+        add = staticmethod(ctx.fr_add)
+
+    # set-up without collectives; the ranks then agree that all of them got through it before the first sharded proof
+    err = None
+    try:
+        kzg = HP.ParamsKZG.setup(ctx, k, s_toxic, precompute=not sharded)   # sharded: only the rank's slice gets window tables
+        circ = T.build_circuit(_ShapeView(bp, sh), 19 + (0 if sharded else rank), Backend)
+        t0 = time.perf_counter()
+        pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
+        keygen_s = time.perf_counter() - t0
+        draws = synthetic_scalars(n + 4096, 4242)
+    except Exception as e:
+        if world == 1:
+            raise
+        err = repr(e)
+    sk = None
+    if world > 1:
+        oks = [None] * world
+        dist.all_gather_object(oks, err)
+        if any(o is not None for o in oks):
+            raise SystemExit("bench.py: set-up failed on some rank: %r" % (oks,))
+        if sharded:
+            from halo2_lib_amd.multi_gpu import shard_proving_key
+
+            sk = shard_proving_key(pk, ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange), device=xdev, precompute=True)
+
+    prove = lambda stages=None: PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws), stages)
+    t0 = time.perf_counter()
+    first = prove()                      # the cold first proof after keygen (allocates the key's buffer pool, builds twiddle tables)
+    cold_s = time.perf_counter() - t0
+    for _ in range(max(0, args.warmup - 1)):
+        prove()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = prove()                  # returns after the proof bytes are on the host
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    seconds = elapsed / args.steps
+    if proof != first:
+        raise SystemExit("bench.py: create_proof is not repeatable for a fixed RNG stream — refusing to report a number")
+    if not PL.verify_proof(pk, circ.instances, proof):
+        raise SystemExit("bench.py: the timed proof does not verify — refusing to report a number")
+    if world > 1:
+        import hashlib
+
+        digests = [None] * world
+        dist.all_gather_object(digests, hashlib.sha256(proof).hexdigest())
+        if sharded and len(set(digests)) != 1:
+            raise SystemExit("bench.py: the ranks of a sharded proof emitted different bytes")
+
+    out = None
+    if rank == 0:
+        account = kernel_account(ctx, args.steps)
+        k_ms, k_cnt = ctx.profile_get("msm_accum_kernel")
+        k_busy_ms = ctx.profile_get_busy("msm_accum_kernel")
+        k_avg_s = k_ms / max(k_cnt, 1) * 1e-3
+        busy_all_ms = ctx.profile_get_busy("")
+        # the same call without the profile's events, then with per-stage laps (a stream synchronisation per stage)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            prove()
+        unprofiled_s = (time.perf_counter() - t0) / 5
+        stages = {}
+        prove(stages)
+        mm_ms, mm_n = ctx.bench_modmul(16384, 256, 2)
+        modmul_peak_sat = mm_n / (mm_ms * 1e-3)
+        mm_ms, mm_n = ctx.bench_modmul(16384, 256, 2, unsaturated=True)
+        modmul_peak = mm_n / (mm_ms * 1e-3)
+        work = proof_algorithmic_work(ctx, bp, sh)
+        msm_n = n // world if sharded else n
+        c19, W19 = window_for(ctx, msm_n)
+        cells = 4 * (sh.usable_rows // 4)    # assigned advice cells: `constraints` of SURVEY.md §8d (total_advice of the circuit)
+        proofs_per_step = 1 if (world == 1 or sharded) else world
+        alg_bytes = 96.0 * msm_n
+        traffic_prof = None
+        pmc_path = os.path.join(ROOT, "profiles", "r03_create_proof_k19_pmc_hbm.json")
+        if os.path.exists(pmc_path) and k == 19 and world == 1:
+            traffic_prof = {"source": os.path.relpath(pmc_path, ROOT), **json.load(open(pmc_path))}
+        out = {
+            "metric": "create_proof constraints/sec (k=%d ECDSA configuration, halo2-ecc/configs/secp256k1/bench_ecdsa.config:1); MSM G1-adds/sec in `msm_2_%d`" % (k, args.log_n),
+            "value": proofs_per_step * cells / seconds,
+            "unit": "constraints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": seconds * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8 (254-bit Montgomery integers; point and butterfly arithmetic on 9x29-bit limbs)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: h2hip_plonk_create_proof for the k=%d secp256k1-ECDSA configuration (bench_ecdsa.config:1: 1 advice column with the "
+                                   "lookup behind q_lookup, 1 constants column, lookup_bits %d, no instances), synthetic circuit-like witness (halo2_lib_amd/testing.py: "
+                                   "every gate satisfied, 0/1 / small / full-width cells, range-checked cells, copy constraints); one step = one proof: host wall clock "
+                                   "around the C call, incl. host->device staging of the advice column and the RNG-drawn scalars (16 MiB each) and the proof bytes "
+                                   "coming back; witness generation (CPU gadgets, Rust) excluded" % (k, k - 1),
+                       "constraints_per_proof": cells, "constraints_definition": "assigned advice cells (SURVEY.md §8d)", "msm_count": sh.num_commitments, "msm_size": n,
+                       "extended_k": sh.extended_k, "degree": sh.degree, "proof_bytes": len(proof),
+                       "sharding": ("ONE proof per step over %d GPUs: commitments point-range sharded (2^%d / %d points per GPU), see DESIGN.md §6" % (world, k, world)) if sharded else
+                                   ("none (1 GPU)" if world == 1 else "%d independent proofs per step, one per GPU (replicas, no exchange)" % world)},
+            "seconds_per_proof": seconds, "seconds_per_proof_unprofiled": unprofiled_s, "cold_first_proof_seconds": cold_s, "keygen_seconds": keygen_s,
+            "proof_verified_by_h2hip_plonk_verify_proof": True, "proof_repeatable": True,
+            "stage_ms": {k_: round(v, 3) for k_, v in stages.items()}, "stage_ms_sum": round(sum(stages.values()), 3),
+            "kernel_ms_per_proof": account, "gpu_busy_ms_per_proof": busy_all_ms / args.steps,
+            "roofline": {"bound": "hbm", "kernel": "msm_accum_kernel (2^%d points per launch, %d launches per proof)" % (int(np.log2(msm_n)), round(k_cnt / args.steps)),
+                         "achieved": alg_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                         "frac": alg_bytes / k_avg_s / 8e12 if k_avg_s > 0 else 0.0, "traffic": None,
+                         "traffic_note": "not measured in this run (PMC counters need rocprofv3); the separately collected figure is under `traffic_from_profiles`",
+                         "traffic_from_profiles": traffic_prof,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg_s * 1e3, "launches": int(k_cnt),
+                         "busy_ms_per_launch": k_busy_ms / max(k_cnt, 1),
+                         "note": "algorithmic bytes = 96 B per (scalar, base) pair (SURVEY.md §8d); avg_launch_ms = mean duration of the kernel's launches inside the "
+                                 "timed region, HIP events on the launch streams (h2hip_profile_*); the binding roof of this kernel is the integer multiplier: `roofline_int`"},
+            "roofline_int": {"bound": "integer multiplier (v_mad_u64_u32, 4 cycles per wave64)", "kernel": "msm_accum_kernel",
+                             "achieved": 10.0 * msm_n * W19 / k_avg_s if k_avg_s > 0 else 0.0, "peak": modmul_peak, "unit": "modmul/s",
+                             "frac": (10.0 * msm_n * W19 / k_avg_s / modmul_peak) if k_avg_s > 0 else 0.0,
+                             "algorithmic_products_per_launch": 10.0 * msm_n * W19, "window_bits": c19, "windows": W19,
+                             "peak_saturated_8x32": modmul_peak_sat, "silicon_issue_peak": 256 * 4 * 16 * 2.4e9 / 171.0,
+                             "note": "peak = the chip's best 254-bit Montgomery multiplier known to us, measured in this run (h2hip_bench_modmul29: the unsaturated 9x29-limb form "
+                                     "the kernel itself uses); algorithmic products = 10*n*W (XYZZ mixed addition 8M+2S per signed digit)"},
+            "roofline_proof": {"algorithmic": work,
+                               "int": {"achieved": work["products"] / seconds, "peak": modmul_peak, "unit": "modmul/s", "frac": work["products"] / seconds / modmul_peak,
+                                       "ideal_ms": work["products"] / modmul_peak * 1e3},
+                               "hbm": {"achieved": work["bytes"] / seconds / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": work["bytes"] / seconds / 8e12},
+                               "note": "whole proof: (sum of the algorithmic products of its MSMs and transforms) / seconds_per_proof against the multiplier peak measured in "
+                                       "this run; recompute from `algorithmic`, `seconds_per_proof` and `roofline_int.peak`"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb = cpu_baseline_create_proof(ctx, kzg, pk, circ, draws, proof, k, s_toxic)
+                out["cpu_baseline"] = {"value": cells / cb["seconds"], "unit": "constraints/s", "cores": cb["cores"], "kind": "port", "sample": cb["sample"], **{
+                    k_: v for k_, v in cb.items() if k_ not in ("cores", "kind", "sample")}}
+                out["speedup_vs_cpu_port"] = cb["seconds"] / seconds
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+        out["reference_published"] = {"total_proof_time_s": 7.6, "source": "/root/reference/README.md:242 (32 vCPU r6a / M2 Max, end to end incl. witness generation; other hardware)"}
+    if sk is not None:
+        sk.free()
+    pk.free()
+    kzg.free()
+
+    # ------------------------------------------------------------------ extra blocks (never part of the timed region above)
+    if not args.no_replay:
+        try:
+            blk = msm_block(ctx, args, torch, dev, world, rank, dist, xdev)
+        except Exception as e:
+            blk = {"error": repr(e)}
+        if rank == 0:
+            out["msm_2_%d" % args.log_n] = blk
+    if rank == 0 and world == 1 and not args.no_replay:
+        for name, fn in (("ntt_2_22", lambda: ntt_config3(ctx, torch, dev, modmul_peak)),
+                         ("k8_witness_batches", lambda: k8_batches(ctx, torch, dev, modmul_peak_sat, modmul_peak)),
+                         ("create_proof_k21_pairing_shape", lambda: create_proof_shape(
+                             ctx, 21, 2, 1, 1, 0, 20, reps=3, what="BASELINE configs[4] on ONE GPU: the k=21 BN254-pairing configuration "
+                                                                   "(halo2-ecc/configs/bn254/bench_pairing.config:8), 14 MSMs of 2^21, extended_k 23"))):
+            try:
+                out[name] = fn()
+            except Exception as e:   # never let an extra block break the contract line
+                out[name] = {"error": repr(e)}
+        if not args.no_sweep:
+            try:
+                out["create_proof_config_sweep"] = create_proof_config_sweep(ctx)
+            except Exception as e:
+                out["create_proof_config_sweep"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def msm_block(ctx, args, torch, dev, world, rank, dist, xdev):
+    """BASELINE configs[1]: 2^log_n-point G1 MSMs on resident scalars and bases (the other half of the metric: G1-adds/s), verified in-run against
+    the closed form of known-dlog bases.  N > 1: point-range sharding — weak (every rank a 2^log_n slice of an N*2^log_n-point MSM) or strong."""
+    from halo2_lib_amd.multi_gpu import sharded_msm, sharded_msm_batch
+
+    steps, warmup = args.msm_steps, 8
+    n_total = 1 << args.log_n
+    n = n_total // world if args.scaling == "strong" else n_total   # points per rank
     # each rank owns its own slice of the (world * n)-point MSM: n DISTINCT known-dlog bases built on the GPU, and --batch
     # distinct uniformly random scalar columns (a prover round commits different columns; identical columns would share
     # cache lines between the concurrent lanes)
@@ -207,18 +432,15 @@ def main():
     scal_cols_d = [torch.from_numpy(c.view(np.int64)).to(dev) for c in scal_cols_h]
     scal_h, scal_d = scal_cols_h[0], scal_cols_d[0]
     torch.cuda.synchronize()
-
-    from halo2_lib_amd.multi_gpu import sharded_msm, sharded_msm_batch
-
     last = {}
 
-    def run_steps(k):
-        """k steps = k MSMs over this rank's slice, issued in batches of --batch (pipelined over the context's lanes);
+    def run_steps(cnt):
+        """cnt MSMs over this rank's slice, issued in batches of --batch (pipelined over the context's lanes);
         N>1: one RCCL all-gather of the 96 B partials per batch + on-GPU sums."""
         done = 0
         res = None
-        while done < k:
-            b = min(args.batch, k - done)
+        while done < cnt:
+            b = min(args.batch, cnt - done)
             if b == 1:
                 res = sharded_msm(ctx, bases, scal_d.data_ptr(), n, device=xdev if world > 1 else None)
             else:
@@ -227,15 +449,14 @@ def main():
             done += b
         return res
 
-    run_steps(args.warmup)
-    ctx.profile_reset()
+    run_steps(warmup)
     ctx.profile_reset()
     ctx.profile_enable(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    result = run_steps(args.steps)
+    result = run_steps(steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -245,7 +466,6 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-
     # ---- verify the LAST timed batch against the closed form (sum_i s_i * dlog_i) * G — no MSM implementation involved
     mine = [closed_form_dlog(scal_cols_h[j], K0, D, first_index=rank * n) for j in range(last["cols"])]
     if world > 1:
@@ -254,28 +474,21 @@ def main():
         mine = [sum(v[j] for v in allv) % R for j in range(last["cols"])]
     verified = all(jac_to_affine(result[j]) == _g1_mul(mine[j]) for j in range(last["cols"]))
     if not verified:
-        raise SystemExit("bench.py: the timed MSM results do not match the closed form — refusing to report a number")
-
+        raise RuntimeError("the timed MSM results do not match the closed form")
+    blk = None
     if rank == 0:
         c, W = window_for(ctx, n)
         # G1 additions actually performed (SURVEY.md §8d's definition, specialised to the kernel's structure): one mixed addition per
         # (scalar, window) pair, plus the running-sum reduction of ONE bucket set with precomputed 2^(c*w) tables (all windows share
         # it) or of W bucket sets with plain bases
         adds_per_msm = n * W + 2 * (1 if args.precompute else W) * (1 << (c - 1))
-        units = world * args.steps * adds_per_msm   # strong scaling: N ranks x their n/N-point share = the adds of the one MSM (+ N bucket sets)
-        ms_per_step = elapsed / args.steps * 1e3
-        # dominant kernel, timed with HIP events on the launch stream inside the timed region
+        units = world * steps * adds_per_msm
+        ms_per_msm = elapsed / steps * 1e3
         k_ms, k_cnt = ctx.profile_get("msm_accum_kernel")
         k_avg_s = (k_ms / max(k_cnt, 1)) * 1e-3
         k_busy_s = ctx.profile_get_busy("msm_accum_kernel") / max(k_cnt, 1) * 1e-3   # union of the launch spans / launches
         alg_bytes = 96.0 * n
-        achieved_gbs = alg_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
-        breakdown = {}
-        for name in ("msm_digits", "msm_hist_kernel", "msm_hist_scan", "scan_kernels", "msm_scatter", "msm_accum_kernel", "msm_merge",
-                     "msm_presum", "msm_seg", "msm_winsum", "msm_fold", "point_finish"):
-            ms, cnt = ctx.profile_get(name)
-            if cnt:
-                breakdown[name] = round(ms / args.steps, 4)
+        breakdown = {name: round(v[0] / steps, 4) for name, v in ctx.profile_dump().items()}
         # single synchronous MSM (no pipelining): latency, and the dominant kernel's duration without overlap
         ctx.profile_reset()
         ctx.timer_start()
@@ -288,99 +501,27 @@ def main():
         iso_ms, iso_cnt = ctx.profile_get("msm_accum_kernel")
         ctx.profile_enable(False)
         iso_avg_s = iso_ms / max(iso_cnt, 1) * 1e-3
-        traffic, traffic_src = None, None
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_msm20_pmc_hbm.json", "r01_msm20_pmc_hbm.json")) if os.path.exists(q)), "")
-        if os.path.exists(pmc_path) and args.log_n == 20 and args.precompute:
-            pmc = json.load(open(pmc_path))
-            for kname, v in pmc.items():
-                if kname.startswith("msm_accum_kernel"):
-                    traffic, traffic_src = v["traffic_bytes_per_launch"], os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2)"
-        mm_ms, mm_n = ctx.bench_modmul(16384, 256, 2)
-        modmul_peak_sat = mm_n / (mm_ms * 1e-3)
         mm_ms, mm_n = ctx.bench_modmul(16384, 256, 2, unsaturated=True)
         modmul_peak = mm_n / (mm_ms * 1e-3)
         alg_modmul = 10.0 * n * W   # XYZZ mixed add = 8M + 2S per (scalar, window) pair
-        out = {
-            "metric": "MSM G1-adds/sec (2^%d-point BN254 G1 Pippenger MSM; create_proof's dominant kernel, k=19 ECDSA shape = 12 such MSMs of 2^19)" % args.log_n,
-            "value": units / elapsed,
-            "unit": "G1-adds/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": args.scaling,
-            "vs_baseline": None,
-            "dtype": "u32x8 (254-bit Montgomery integers)",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 2^%d-point BN254 G1 MSM, uniform random scalars (distinct column per MSM of a batch), 2^%d distinct random-looking bases (known-dlog multiples of G built on the GPU) resident in HBM" % (args.log_n, args.log_n),
-                       "points_per_gpu": n, "bases": "precomputed 2^(c*w) tables" if args.precompute else "plain", "window_bits": c, "windows": W, "adds_per_msm": adds_per_msm,
-                       "sharding": ("point-range, one 2^%d slice per GPU (weak scaling), all-gather of 96 B partials" % args.log_n) if args.scaling == "weak" else
-                                   ("point-range, ONE 2^%d-point MSM split into %d ranges of %d points (strong scaling), all-gather of 96 B partials" % (args.log_n, world, n))},
-            "pairs_per_sec": world * args.steps * n / elapsed, "batch": args.batch, "result_verified": "last timed batch == (sum_i s_i*dlog_i)*G for every column (closed form, known-dlog bases)", "sync_ms_per_msm": sync_ms,
-            "kernel_ms_per_msm": breakdown,
-            "roofline": {"bound": "hbm", "kernel": "msm_accum_kernel", "achieved": (alg_bytes / k_busy_s / 1e9) if k_busy_s > 0 else achieved_gbs, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (alg_bytes / k_busy_s / 8e12) if k_busy_s > 0 else achieved_gbs / 8000.0, "duration_used": "busy_ms_per_launch",
-                         "frac_per_dispatch": achieved_gbs / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg_s * 1e3, "launches": int(k_cnt),
-                         "avg_launch_ms_isolated": iso_avg_s * 1e3, "busy_ms_per_launch": k_busy_s * 1e3,
-                         "frac_busy": (alg_bytes / k_busy_s / 8e12) if k_busy_s > 0 else 0.0,
-                         "note": "achieved/frac use busy_ms_per_launch (launches of concurrent lanes overlap, so the per-dispatch mean exceeds ms_per_step and is not a per-launch cost); avg_launch_ms = mean per-dispatch duration inside the timed region (what rocprofv3 reports): launches of up to three "
-                                 "pipelined MSMs run concurrently there, each at a fraction of the chip; busy_ms_per_launch = (time during which at least "
-                                 "one launch was executing) / launches = what one launch effectively costs; _isolated = the same kernel in a synchronous MSM"},
-            "roofline_int": {"bound": "integer multiplier (v_mad_u64_u32, 4 cycles per wave64)", "kernel": "msm_accum_kernel",
-                             "achieved": alg_modmul / k_busy_s if k_busy_s > 0 else 0.0, "peak": modmul_peak, "unit": "modmul/s",
-                             "frac": (alg_modmul / k_busy_s / modmul_peak) if k_busy_s > 0 else 0.0,
-                             "frac_per_dispatch": (alg_modmul / k_avg_s / modmul_peak) if k_avg_s > 0 else 0.0,
-                             "frac_whole_msm": alg_modmul / (ms_per_step * 1e-3) / modmul_peak,
-                             "silicon_issue_peak": 256 * 4 * 16 * 2.4e9 / 171.0,
-                             "frac_isolated": (alg_modmul / iso_avg_s / modmul_peak) if iso_avg_s > 0 else 0.0,
-                             "frac_busy": (alg_modmul / k_busy_s / modmul_peak) if k_busy_s > 0 else 0.0,
-                             "peak_saturated_8x32": modmul_peak_sat,
-                             "note": "peak = the chip's best 254-bit Montgomery multiplier known to us, the unsaturated 9x29-limb form the kernel "
-                                     "itself uses (h2hip_bench_modmul29, measured in this run; the saturated 8x32 form is also reported); "
-                                     "algorithmic modmuls = 10*n*W (XYZZ mixed addition 8M+2S per signed digit)"},
-        }
-        if world == 1 and not args.no_replay:
-            try:
-                out["ntt_2_22"] = ntt_config3(ctx, torch, dev, modmul_peak)
-            except Exception as e:
-                out["ntt_2_22"] = {"error": repr(e)}
-            try:
-                out["k8_witness_batches"] = k8_batches(ctx, torch, dev, modmul_peak_sat, modmul_peak)
-            except Exception as e:
-                out["k8_witness_batches"] = {"error": repr(e)}
-            try:
-                out["create_proof_k19"] = create_proof_k19(ctx, with_cpu_baseline=not args.no_cpu_baseline)
-            except Exception as e:   # never let the second half of the metric break the contract line
-                out["create_proof_k19"] = {"error": repr(e)}
-            try:
-                out["create_proof_k21_pairing_shape"] = create_proof_shape(ctx, 21, 2, 1, 1, 0, 20, reps=3,
-                                                                           what="BASELINE configs[4] on ONE GPU: the k=21 BN254-pairing configuration "
-                                                                                "(halo2-ecc/configs/bn254/bench_pairing.config:8), 14 MSMs of 2^21, extended_k 23")
-            except Exception as e:
-                out["create_proof_k21_pairing_shape"] = {"error": repr(e)}
-            if not args.no_sweep:
-                try:
-                    out["create_proof_config_sweep"] = create_proof_config_sweep(ctx)
-                except Exception as e:
-                    out["create_proof_config_sweep"] = {"error": repr(e)}
+        blk = {"workload": "BASELINE configs[1]: 2^%d-point BN254 G1 MSM, uniform random scalars (distinct column per MSM of a batch), 2^%d distinct random-looking bases "
+                           "(known-dlog multiples of G built on the GPU) resident in HBM, Jacobian result returned to the host" % (args.log_n, args.log_n),
+               "value": units / elapsed, "unit": "G1-adds/s", "ms_per_msm": ms_per_msm, "steps": steps, "batch": args.batch, "pairs_per_sec": world * steps * n / elapsed,
+               "points_per_gpu": n, "bases": "precomputed 2^(c*w) tables" if args.precompute else "plain", "window_bits": c, "windows": W, "adds_per_msm": adds_per_msm,
+               "scaling": args.scaling if world > 1 else None,
+               "result_verified": "last timed batch == (sum_i s_i*dlog_i)*G for every column (closed form, known-dlog bases)", "sync_ms_per_msm": sync_ms,
+               "kernel_ms_per_msm": breakdown,
+               "roofline": {"bound": "hbm", "kernel": "msm_accum_kernel", "achieved": alg_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                            "frac": alg_bytes / k_avg_s / 8e12 if k_avg_s > 0 else 0.0, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg_s * 1e3,
+                            "launches": int(k_cnt), "avg_launch_ms_isolated": iso_avg_s * 1e3, "busy_ms_per_launch": k_busy_s * 1e3},
+               "roofline_int": {"kernel": "msm_accum_kernel", "achieved": alg_modmul / k_avg_s if k_avg_s > 0 else 0.0, "peak": modmul_peak, "unit": "modmul/s",
+                                "frac": (alg_modmul / k_avg_s / modmul_peak) if k_avg_s > 0 else 0.0,
+                                "frac_whole_msm": alg_modmul / (ms_per_msm * 1e-3) / modmul_peak,
+                                "frac_isolated": (alg_modmul / iso_avg_s / modmul_peak) if iso_avg_s > 0 else 0.0}}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ctx.bases_download(bases), scal_h, adds_per_msm)
-    if world > 1 and args.sharded_proof:   # every rank takes part: the k=19 create_proof with point-range-sharded commitments
-        try:
-            sharded = create_proof_k19_sharded(ctx, dist, xdev)
-        except Exception as e:
-            sharded = {"error": repr(e)}
-        if rank == 0:
-            out["create_proof_k19_sharded"] = sharded
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+            blk["cpu_baseline"] = cpu_baseline(ctx.bases_download(bases), scal_h, adds_per_msm)
     bases.free()
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
-
+    return blk
 
 
 def _fr_from_ints(vals):

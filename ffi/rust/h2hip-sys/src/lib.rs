@@ -214,6 +214,7 @@ extern "C" {
     pub fn h2hip_profile_reset(ctx: *mut h2hip_ctx) -> c_int;
     pub fn h2hip_profile_get_busy(ctx: *mut h2hip_ctx, prefix: *const c_char, busy_ms: *mut f64) -> c_int;
     pub fn h2hip_profile_get(ctx: *mut h2hip_ctx, prefix: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
+    pub fn h2hip_profile_dump(ctx: *mut h2hip_ctx, out: *mut c_char, cap: usize, needed: *mut usize) -> c_int;
     pub fn h2hip_timer_start(ctx: *mut h2hip_ctx) -> c_int;
     pub fn h2hip_timer_stop(ctx: *mut h2hip_ctx, elapsed_ms: *mut f64) -> c_int;
     pub fn h2hip_bench_modmul(ctx: *mut h2hip_ctx, blocks: u32, iters: u32, chains: u32, elapsed_ms: *mut f64, modmuls: *mut f64) -> c_int;

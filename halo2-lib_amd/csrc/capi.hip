@@ -56,27 +56,34 @@ void prof_begin(h2hip_ctx *ctx, const char *name) {
     hipEvent_t a = get_event(ctx), b = get_event(ctx);
     if (!a || !b) return;
     hipEventRecord(a, ctx->stream);
-    ctx->pending.push_back({name, {a, b}});
+    ctx->pending.push_back({name, a, b, false});
 }
+// closes the innermost open bracket (brackets nest: the lookup permutation's bracket contains the scan's)
 void prof_end(h2hip_ctx *ctx) {
-    if (!ctx->profiling || ctx->pending.empty()) return;
-    hipEventRecord(ctx->pending.back().second.second, ctx->stream);
+    if (!ctx->profiling) return;
+    for (size_t i = ctx->pending.size(); i-- > 0;)
+        if (!ctx->pending[i].ended) {
+            hipEventRecord(ctx->pending[i].end, ctx->stream);
+            ctx->pending[i].ended = true;
+            return;
+        }
 }
 static void prof_collect(h2hip_ctx *ctx) {
     if (ctx->pending.empty()) return;
     hipStreamSynchronize(ctx->stream);
     for (auto &p : ctx->pending) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
-            KernelStat &s = ctx->stats[p.first];
+        if (p.ended && hipEventElapsedTime(&ms, p.begin, p.end) == hipSuccess) {
+            KernelStat &s = ctx->stats[p.name];
             s.total_ms += ms;
             s.launches += 1;
             float t0 = 0;
-            if (ctx->prof_ref && hipEventElapsedTime(&t0, ctx->prof_ref, p.second.first) == hipSuccess) s.spans.push_back({t0, t0 + ms});
+            if (ctx->prof_ref && hipEventElapsedTime(&t0, ctx->prof_ref, p.begin) == hipSuccess) s.spans.push_back({t0, t0 + ms});
         }
-        ctx->event_pool.push_back(p.second.first);
-        ctx->event_pool.push_back(p.second.second);
+        ctx->event_pool.push_back(p.begin);
+        ctx->event_pool.push_back(p.end);
     }
+    (void)hipGetLastError();   // a failed elapsed-time query must not surface as the next launch's error
     ctx->pending.clear();
 }
 
@@ -225,8 +232,8 @@ void h2hip_destroy(h2hip_ctx *ctx) {
             if (t.direct[k]) hipFree(t.direct[k]);
     }
     for (auto &p : ctx->pending) {
-        hipEventDestroy(p.second.first);
-        hipEventDestroy(p.second.second);
+        hipEventDestroy(p.begin);
+        hipEventDestroy(p.end);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->prof_ref && ctx->own_prof_ref) hipEventDestroy(ctx->prof_ref);
@@ -416,6 +423,39 @@ int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint
         }
     if (total_ms) *total_ms = ms;
     if (launches) *launches = cnt;
+    return H2HIP_OK;
+}
+// every kernel name with launches since the last reset, as "name total_ms launches busy_ms\n" lines (NUL-terminated; truncated at cap)
+int h2hip_profile_dump(h2hip_ctx *ctx, char *out, size_t cap, size_t *needed) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && (out || cap == 0), "NULL argument");
+    prof_collect(ctx);
+    std::string text;
+    for (auto &kv : ctx->stats) {
+        std::vector<std::pair<float, float>> all(kv.second.spans.begin(), kv.second.spans.end());
+        std::sort(all.begin(), all.end());
+        double busy = 0;
+        float cur0 = 0, cur1 = -1;
+        for (auto &sp : all) {
+            if (cur1 < cur0 || sp.first > cur1) {
+                if (cur1 >= cur0) busy += cur1 - cur0;
+                cur0 = sp.first;
+                cur1 = sp.second;
+            } else if (sp.second > cur1) {
+                cur1 = sp.second;
+            }
+        }
+        if (cur1 >= cur0) busy += cur1 - cur0;
+        char line[256];
+        snprintf(line, sizeof(line), "%s %.6f %llu %.6f\n", kv.first.c_str(), kv.second.total_ms, (unsigned long long)kv.second.launches, busy);
+        text += line;
+    }
+    if (needed) *needed = text.size() + 1;
+    if (cap) {
+        size_t m = text.size() < cap - 1 ? text.size() : cap - 1;
+        memcpy(out, text.data(), m);
+        out[m] = 0;
+    }
     return H2HIP_OK;
 }
 int h2hip_timer_start(h2hip_ctx *ctx) {

@@ -98,7 +98,12 @@ struct h2hip_ctx {
     // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled
     bool profiling = false;
     std::map<std::string, h2::KernelStat> stats;
-    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    struct PendingLaunch {
+        std::string name;
+        hipEvent_t begin, end;
+        bool ended;   // prof_end ran (a bracket left open by an early return is dropped, not timed)
+    };
+    std::vector<PendingLaunch> pending;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t prof_ref = nullptr;       // reference event (recorded at h2hip_profile_reset) the launch spans are measured from
     bool own_prof_ref = false;           // lanes borrow the parent's reference

@@ -38,6 +38,7 @@ _PROTOS = {
     "h2hip_profile_reset": (_int, [_vp]),
     "h2hip_profile_get_busy": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "h2hip_profile_get": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "h2hip_profile_dump": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "h2hip_timer_start": (_int, [_vp]),
     "h2hip_timer_stop": (_int, [_vp, C.POINTER(C.c_double)]),
     "h2hip_bases_upload": (_int, [_vp, _vp, _sz, _u32, C.POINTER(_vp)]),
@@ -296,6 +297,18 @@ class Context:
         ms, cnt = C.c_double(), C.c_uint64()
         self._chk(self.lib.h2hip_profile_get(self.handle, prefix.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def profile_dump(self) -> dict:
+        """{kernel name: (total_ms, launches, busy_ms)} since the last profile_reset"""
+        need = _sz(0)
+        self._chk(self.lib.h2hip_profile_dump(self.handle, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value + 16)
+        self._chk(self.lib.h2hip_profile_dump(self.handle, buf, len(buf), None))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, cnt, busy = line.split()
+            out[name] = (float(ms), int(cnt), float(busy))
+        return out
 
     def timer_start(self):
         self._chk(self.lib.h2hip_timer_start(self.handle))

@@ -79,6 +79,9 @@ int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint
 /* milliseconds (since the last h2hip_profile_reset) during which at least one launch of the matching kernels was executing:
  * the union of the launch spans — with pipelined MSMs several launches of one kernel overlap */
 int h2hip_profile_get_busy(h2hip_ctx *ctx, const char *prefix, double *busy_ms);
+/* the whole account since the last reset as text, one "name total_ms launches busy_ms" line per kernel name (NUL-terminated, truncated at
+ * cap; *needed = bytes for all of it) — what bench.py turns into the per-kernel table of a create_proof */
+int h2hip_profile_dump(h2hip_ctx *ctx, char *out, size_t cap, size_t *needed);
 /* bracket an arbitrary region with events on the context's stream (bench.py's timed region) */
 int h2hip_timer_start(h2hip_ctx *ctx);
 int h2hip_timer_stop(h2hip_ctx *ctx, double *elapsed_ms);

@@ -177,6 +177,30 @@ def test_create_proof_argument_errors_emulated():
         ctx.close()
 
 
+def test_create_proof_with_kernel_profile_emulated():
+    """bench.py times proofs with the library's HIP-event profile enabled: brackets nest (the lookup permutation's contains the scan's), an
+    open bracket must never poison the next launch, and the account names the prover's kernels"""
+    from tests.emu_util import emu_context
+
+    ctx = emu_context()
+    try:
+        sh, kzg, params, circ, gpk = _setup(ctx, 6, 2, 1, 1, 0, 4, 1, 1, False)
+        plain = PL.create_proof(gpk, circ.advice, circ.instances, PreDrawnRng(_rng_budget(sh), 1))
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(2):
+            assert PL.create_proof(gpk, circ.advice, circ.instances, PreDrawnRng(_rng_budget(sh), 1)) == plain
+        ctx.profile_enable(False)
+        acc = ctx.profile_dump()
+        assert {"msm_accum_kernel", "ntt_pass_kernel", "lookup_permute_kernels", "scan_kernels"} <= set(acc), sorted(acc)
+        assert all(cnt > 0 and ms >= 0 and busy >= 0 for ms, cnt, busy in acc.values())
+        assert acc["msm_accum_kernel"][1] % 2 == 0
+        gpk.free()
+        kzg.free()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(9, 1, 1, 1, 0, 8), (12, 1, 1, 1, 1, 11), (12, 2, 1, 1, 1, 11), (13, 4, 2, 2, 2, 10), (10, 1, 0, 1, 0, None),
                                    (11, 20, 4, 2, 1, 10), (9, 1, 1, 0, 0, 7), (9, 2, 0, 0, 1, None), (10, 1, 2, 1, 0, 8)])   # (11, 20, 4, ...): a wide shape like the reference's low-k configurations (13 chained permutation sets); then: no constants column, no range chip with an instance column, one advice column with num_lookup_advice > 1
