@@ -212,6 +212,7 @@ extern "C" {
     // timing / diagnostics
     pub fn h2hip_profile_enable(ctx: *mut h2hip_ctx, on: c_int) -> c_int;
     pub fn h2hip_profile_reset(ctx: *mut h2hip_ctx) -> c_int;
+    pub fn h2hip_profile_filter(ctx: *mut h2hip_ctx, prefix: *const c_char) -> c_int;
     pub fn h2hip_profile_get_busy(ctx: *mut h2hip_ctx, prefix: *const c_char, busy_ms: *mut f64) -> c_int;
     pub fn h2hip_profile_get(ctx: *mut h2hip_ctx, prefix: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
     pub fn h2hip_profile_dump(ctx: *mut h2hip_ctx, out: *mut c_char, cap: usize, needed: *mut usize) -> c_int;

@@ -53,6 +53,7 @@ static hipEvent_t get_event(h2hip_ctx *ctx) {
 
 void prof_begin(h2hip_ctx *ctx, const char *name) {
     if (!ctx->profiling) return;
+    if (!ctx->prof_filter.empty() && strncmp(name, ctx->prof_filter.c_str(), ctx->prof_filter.size()) != 0) return;
     hipEvent_t a = get_event(ctx), b = get_event(ctx);
     if (!a || !b) return;
     hipEventRecord(a, ctx->stream);
@@ -60,7 +61,14 @@ void prof_begin(h2hip_ctx *ctx, const char *name) {
 }
 // closes the innermost open bracket (brackets nest: the lookup permutation's bracket contains the scan's)
 void prof_end(h2hip_ctx *ctx) {
-    if (!ctx->profiling) return;
+    if (!ctx->profiling || !ctx->prof_filter.empty()) {
+        // with a filter the brackets kept are leaf brackets of one name: close the open one of that name, if any
+        if (ctx->profiling && !ctx->pending.empty() && !ctx->pending.back().ended) {
+            hipEventRecord(ctx->pending.back().end, ctx->stream);
+            ctx->pending.back().ended = true;
+        }
+        return;
+    }
     for (size_t i = ctx->pending.size(); i-- > 0;)
         if (!ctx->pending[i].ended) {
             hipEventRecord(ctx->pending[i].end, ctx->stream);
@@ -296,7 +304,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_sort_threads) H2_REQUIRE(value == 256 || value == 512 || value == 1024, "msm_sort_threads must be 256, 512 or 1024");
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
     if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 0 && value <= 4, "msm_lanes must be 0 (auto) or 1..4");
-    if (p == &ctx->msm_accum_variant) H2_REQUIRE(value >= 2 && value <= 4, "msm_accum_variant must be 2, 3 or 4");
+    if (p == &ctx->msm_accum_variant) H2_REQUIRE(value >= 2 && value <= 5, "msm_accum_variant must be 2, 3, 4 or 5");
     if (p == &ctx->ntt_min_col_bits) H2_REQUIRE(value >= 0 && value <= 5, "ntt_min_col_bits must be 0..5");
     if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
     *p = value;
@@ -366,6 +374,13 @@ int h2hip_profile_enable(h2hip_ctx *ctx, int on) {
     H2_REQUIRE(ctx, "ctx is NULL");
     prof_collect(ctx);
     ctx->profiling = on != 0;
+    return H2HIP_OK;
+}
+int h2hip_profile_filter(h2hip_ctx *ctx, const char *prefix) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx, "ctx is NULL");
+    prof_collect(ctx);
+    ctx->prof_filter = prefix ? prefix : "";
     return H2HIP_OK;
 }
 int h2hip_profile_reset(h2hip_ctx *ctx) {
@@ -613,6 +628,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         c->msm_quad_seg_max = ctx->msm_quad_seg_max;
         c->msm_window_bits = ctx->msm_window_bits;
         c->profiling = ctx->profiling;
+        c->prof_filter = ctx->prof_filter;
         c->prof_ref = ctx->prof_ref;   // launch spans of all lanes share the parent's time origin
     }
     if (!ctx->fork_ev) H2_HIPCHK(hipEventCreate(&ctx->fork_ev));

@@ -82,11 +82,25 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_
     }
 }
 
-// workgroup -> (window, chunk): window w lives on XCD (w mod 8) (blocks are dealt round-robin to XCDs)
-__device__ __forceinline__ void block_to_window_chunk(uint32_t L, uint32_t G, uint32_t &w, uint32_t &g) {
-    uint32_t x = L & 7u, q = L >> 3;
-    w = x + 8u * (q / G);
-    g = q % G;
+// workgroup -> (window, chunk).  Workgroups are dealt round-robin to the 8 XCDs, each XCD works through its own sequence in order: the first
+// 8 * floor(total / 8) windows are pinned — window w lives on XCD (w mod 8), its G chunk workgroups run together there, one window after the
+// other — so that a window's slice of the sorted array stays in ONE 4 MiB L2 while it is written.  The total % 8 windows left over (17 windows:
+// one) are dealt chunk by chunk over all XCDs: pinned too, the 17th window was a third round on XCD 0 alone with seven XCDs idle (2.1 rounds of
+// work in the time of 3); its 4-byte writes now combine per XCD only (1/17 of the entries).
+H2_HD uint32_t sort_grid_size(uint32_t total, uint32_t G) {
+    const uint32_t full = total / 8u, rem = total - 8u * full;
+    return 8u * (full * G + (rem * G + 7u) / 8u);
+}
+__device__ __forceinline__ void block_to_window_chunk(uint32_t L, uint32_t G, uint32_t total, uint32_t &w, uint32_t &g) {
+    const uint32_t x = L & 7u, q = L >> 3, full = total / 8u;
+    if (q < full * G) {
+        w = x + 8u * (q / G);
+        g = q % G;
+        return;
+    }
+    const uint32_t p = (q - full * G) * 8u + x;   // pair index among the leftover windows' (window, chunk) pairs
+    w = 8u * full + p / G;                        // >= total when p runs past the last pair: the caller returns
+    g = p % G;
 }
 
 // ------------------------------------------------------------------ 2. per-(window, chunk) LDS histogram
@@ -95,15 +109,21 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t *__restri
     H2_SORT_PRIORITY();
     HIP_DYNAMIC_SHARED(uint32_t, hist)   // B counters
     uint32_t w, g;
-    block_to_window_chunk(blockIdx.x, G, w, g);
+    block_to_window_chunk(blockIdx.x, G, W, w, g);
     if (w >= W) return;
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t *dw = digits + (size_t)w * n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint32_t d = dw[i] & 0x7fffffffu;
-        if (d) atomicAdd(&hist[d - 1], 1u);
+    // eight independent loads in flight per lane, then the LDS atomics: one load -> one atomic per iteration left the kernel latency-bound
+    const uint32_t T = blockDim.x;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 8 * T) {
+        uint32_t d[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) d[k] = i + k * T < hi ? dw[i + k * T] & 0x7fffffffu : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            if (d[k]) atomicAdd(&hist[d[k] - 1], 1u);
     }
     __syncthreads();
     uint32_t *out = bhist + ((size_t)w * G + g) * B;
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     H2_SORT_PRIORITY();
     HIP_DYNAMIC_SHARED(uint32_t, cursor)   // B / S cursors
     uint32_t seg, g;
-    block_to_window_chunk(blockIdx.x, G, seg, g);
+    block_to_window_chunk(blockIdx.x, G, W * S, seg, g);
     if (seg >= W * S) return;
     const uint32_t w = seg / S, h = seg - w * S;
     const uint32_t Bs = B / S, b0 = h * Bs;   // this workgroup's bucket range [b0, b0 + Bs)
@@ -245,13 +265,21 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t *dw = digits + (size_t)w * n;
     const uint32_t idx_base = (w % Wcol) * table_stride;   // precomputed bases: window w of a column reads table level w
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint32_t dv = dw[i], d = dv & 0x7fffffffu;
-        if (!d) continue;
-        uint32_t b = d - 1 - b0;
-        if (b >= Bs) continue;   // another sub-range's entry
-        uint32_t pos = atomicAdd(&cursor[b], 1u);
-        sval[pos] = (idx_base + i) | (dv & 0x80000000u);
+    // eight entries per lane and round: the loads, then the returning LDS atomics, then the stores — each group independent, so the
+    // latencies of a group overlap instead of adding up per entry
+    const uint32_t T = blockDim.x;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 8 * T) {
+        uint32_t dv[8], pos[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) dv[k] = i + k * T < hi ? dw[i + k * T] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t d = dv[k] & 0x7fffffffu, b = d - 1 - b0;   // d == 0 wraps to a huge b: skipped like another sub-range's entry
+            pos[k] = (d && b < Bs) ? atomicAdd(&cursor[b], 1u) : KEY_INVALID;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            if (pos[k] != KEY_INVALID) sval[pos[k]] = (idx_base + i + k * T) | (dv[k] & 0x80000000u);
     }
 }
 
@@ -291,31 +319,61 @@ __device__ __forceinline__ G1Affine load_table_entry(const G1Affine *__restrict_
 #endif
 }
 
+// a lane's XYZZ29 from lane `src` of its wave (36 ds_bpermute; no LDS allocation)
+__device__ __forceinline__ XYZZ29 xyzz29_shfl(const XYZZ29 &v, uint32_t src) {
+    XYZZ29 r;
+#ifdef H2_HIPEMU
+    hipemu_shfl_words<9>(r.x.l, v.x.l, src);
+    hipemu_shfl_words<9>(r.y.l, v.y.l, src);
+    hipemu_shfl_words<9>(r.zz.l, v.zz.l, src);
+    hipemu_shfl_words<9>(r.zzz.l, v.zzz.l, src);
+#else
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        r.x.l[i] = __shfl(v.x.l[i], (int)src);
+        r.y.l[i] = __shfl(v.y.l[i], (int)src);
+        r.zz.l[i] = __shfl(v.zz.l[i], (int)src);
+        r.zzz.l[i] = __shfl(v.zzz.l[i], (int)src);
+    }
+#endif
+    return r;
+}
+
+// Every lane owns K consecutive entries [start, end) of the sorted list.  Runs (= buckets) that lie inside the lane go straight to their
+// bucket.  The runs a lane shares with its neighbours — its first run L when that began in an earlier lane, its last run R when that goes
+// on in a later one — are closed INSIDE THE WAVE before anything is written: a segmented scan over the lanes' R sums (shuffles, no LDS; it
+// stops as soon as no lane has anything left to pull, which for uniform scalars is after one or two steps) gives every lane the sum of its
+// run up to its own end, the lane in which a run ends adds its L and writes the bucket.  Only the (at most two) runs that cross the WAVE's
+// boundaries leave as (key, XYZZ) partials — slot 2*wave (left) and 2*wave + 1 (right) of a sorted, hole-free list that msm_merge_kernel
+// finishes: 2 slots per 64 lanes instead of 2 per lane (r02: 0.5 M partials of 144 B per 2^19-point MSM through HBM and a first merge level
+// of 2048 workgroups).  No lane leaves early: lanes without entries take part in the shuffles with empty sums.
 template <bool NT>
 __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
                                                const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t ks, uint32_t K,
                                                XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals,
                                                uint32_t nthreads) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nthreads) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, wave = t >> 6;
     const uint32_t total = offsets[(size_t)nkeys * ks];
-    uint64_t start64 = (uint64_t)t * K;
-    if (start64 >= total) {
-        out_keys[2 * (size_t)t] = KEY_INVALID;
-        out_keys[2 * (size_t)t + 1] = KEY_INVALID;
-        return;
-    }
-    uint32_t start = (uint32_t)start64, end = (start64 + K > total) ? total : start + K;
-    uint32_t cur = find_key(offsets, ks, 0, nkeys, start);
-    uint32_t next = offsets[(size_t)(cur + 1) * ks];
-    uint32_t hk = KEY_INVALID;
+    const uint64_t start64 = (uint64_t)t * K;
+    const bool valid = t < nthreads && start64 < total;
+    uint32_t start = 0, end = 0, cur = 0, next = 0, hk = KEY_INVALID;
     bool first = true;
     XYZZ29 acc = XYZZ29::identity();
+    __shared__ XYZZ29 lsave[256];   // the lane's first-run sum waits here (not in 36 registers) while the lane walks the rest of its entries
+    if (valid) {
+        start = (uint32_t)start64;
+        end = (start64 + K > total) ? total : start + K;
+        cur = find_key(offsets, ks, 0, nkeys, start);
+        next = offsets[(size_t)(cur + 1) * ks];
+    }
+    const uint32_t first_key = valid ? cur : KEY_INVALID;   // key of the lane's first entry
+    bool l_open = false;                                     // the lane's first run began before `start`
+    if (valid) l_open = offsets[(size_t)cur * ks] < start;
     uint4 sv4 = {0u, 0u, 0u, 0u};
     for (uint32_t e = start; e < end; ++e) {
         if (e >= next) {   // bucket boundary: close the run
             if (first) {
-                out_vals[2 * (size_t)t] = acc;
+                lsave[threadIdx.x] = acc;
                 hk = cur;
                 first = false;
             } else {
@@ -336,16 +394,80 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
         G1Affine p = load_table_entry<NT>(bases + (v & 0x7fffffffu));   // packed R'-domain point, one aligned 64-byte gather
         if (!p.is_identity()) xyzz29_add_affine(acc, f29_split<Q29P>(p.x), f29_split<Q29P>(p.y), (v >> 31) != 0);
     }
-    // the list handed to msm_merge is sorted and hole-free: a single-run chunk emits (key, sum), (key, identity)
-    if (first) {
-        out_vals[2 * (size_t)t] = acc;
-        out_vals[2 * (size_t)t + 1] = XYZZ29::identity();
-        out_keys[2 * (size_t)t] = cur;
-    } else {
-        out_vals[2 * (size_t)t + 1] = acc;
-        out_keys[2 * (size_t)t] = hk;
+    // ---- close the shared runs inside the wave
+    const bool multi = valid && !first;               // the lane crossed at least one run boundary: L = (hk, lsave[lane]), R = (cur, acc)
+    const bool r_open = valid && next > end;          // R goes on in the next lane
+    bool head = !(valid && first && l_open);          // R's run starts inside this lane (lanes without entries: an empty, closed run)
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const bool need = !head && lane >= d;
+        if (!(__any(need ? 1 : 0) != 0)) break;                // lanes still open after step d sit below lane d: nothing left to pull
+        const XYZZ29 other = xyzz29_shfl(acc, lane >= d ? lane - d : lane);
+        const uint32_t oh = __shfl(head ? 1u : 0u, (int)(lane >= d ? lane - d : lane));
+        if (need) {
+            xyzz29_add(acc, other);
+            head = oh != 0;
+        }
     }
-    out_keys[2 * (size_t)t + 1] = cur;
+    // acc = the sum of R's run from its start (head) or from the wave's left edge (!head) to this lane's end
+    const uint32_t src1 = lane ? lane - 1 : 0;
+    const uint32_t prev_head = __shfl(head ? 1u : 0u, (int)src1);
+    const bool pull = multi && l_open && lane > 0;
+    XYZZ29 lval = XYZZ29::identity();
+    if (multi) lval = lsave[threadIdx.x];
+    if (multi && !l_open) {                           // L began exactly at `start` and ended inside the lane: a complete run
+        buckets[hk] = lval;
+        lval = XYZZ29::identity();
+    }
+    if ((__any(pull ? 1 : 0) != 0)) {                          // the run that ends in this lane: L + (what the lanes before it summed)
+        const XYZZ29 prev = xyzz29_shfl(acc, src1);
+        if (pull) xyzz29_add(lval, prev);
+    }
+    bool left_mine = false, right_mine = false;
+    uint32_t pkey = KEY_INVALID;
+    XYZZ29 pv = XYZZ29::identity();
+    if (multi && l_open) {
+        if (lane > 0 && prev_head) {
+            if (!lval.is_identity()) buckets[hk] = lval;
+        } else {                                      // the chain reaches the wave's left edge
+            left_mine = true;
+            pkey = hk;
+            pv = lval;
+        }
+    }
+    const uint32_t next_valid = __shfl(valid ? 1u : 0u, (int)(lane < 63 ? lane + 1 : lane));
+    const bool last_valid = valid && (lane == 63 || !next_valid);
+    if (valid) {
+        if (r_open && last_valid) {                   // crosses the wave's right edge (with !head: the whole wave lies inside one run)
+            right_mine = true;
+        } else if (!r_open) {                         // R ends with this lane
+            if (head) {
+                if (!acc.is_identity()) buckets[cur] = acc;
+            } else {
+                left_mine = true;
+                pkey = cur;
+                pv = acc;
+            }
+        }
+    }
+    // the wave's two slots: a partial, or an identity filler that keeps the list sorted and hole-free
+    const bool any_left = (__any(left_mine ? 1 : 0) != 0);
+    if (left_mine) {
+        out_keys[2 * (size_t)wave] = pkey;
+        out_vals[2 * (size_t)wave] = pv;
+    } else if (lane == 0 && !any_left) {
+        out_keys[2 * (size_t)wave] = first_key;
+        if (first_key != KEY_INVALID) out_vals[2 * (size_t)wave] = XYZZ29::identity();
+    }
+    const bool any_valid = (__any(valid ? 1 : 0) != 0);
+    if (right_mine) {
+        out_keys[2 * (size_t)wave + 1] = cur;
+        out_vals[2 * (size_t)wave + 1] = acc;
+    } else if (last_valid) {
+        out_keys[2 * (size_t)wave + 1] = cur;
+        out_vals[2 * (size_t)wave + 1] = XYZZ29::identity();
+    } else if (lane == 0 && !any_valid) {
+        out_keys[2 * (size_t)wave + 1] = KEY_INVALID;
+    }
 }
 
 template <int MINW, bool NT>
@@ -880,16 +1002,22 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     const uint64_t emax = (uint64_t)n * W;
     H2_REQUIRE(emax < 0xFFFFFFF0ull, "n*W overflows 32 bits");
     uint32_t K1 = (uint32_t)ctx->msm_chunk;
-    if (K1 == 0) {   // auto: as long as possible (fewer partials to merge) while the grid still fills 4 waves per SIMD
+    if (K1 == 0) {   // auto: as long as possible (fewer shared runs to merge) while the grid is still several waves per SIMD
+        // Measured at 2^19 / 17 windows (tools/msm_r03.py): 34 entries per lane = 4096 waves 0.72 ms; 32 = 4352 waves 0.81 ms; 64 = 2176 waves
+        // 0.98 ms; ONE exact round of two waves per SIMD (68 entries = 2048 waves) 0.72 ms although its wave-level merge is a single
+        // addition per lane — with one round the kernel ends with its slowest wave, shorter lanes in several rounds balance themselves.
         uint64_t k = emax / 262144;
         K1 = k < 8 ? 8u : k > 64 ? 64u : (uint32_t)k;
     }
-    // chunking of the counting sort: about 32 chunks per window, 4Ki..64Ki scalars each
+    // chunking of the counting sort: about 32 chunks per window, 4Ki..64Ki scalars each.  32 = the CUs of an XCD: the (window, chunk)
+    // workgroups of one window run together on the window's XCD, one per CU (tried: chunks sized for ONE round over the whole chip,
+    // W * G <= CUs — 2^19: scatter 0.081 -> 0.145 ms, 2^20: 0.154 -> 0.242 ms: half of every XCD's CUs idle and three windows' slices
+    // competing for one 4 MiB L2).
     uint32_t chunk = (uint32_t)((n + 31) / 32);
     if (chunk < 4096) chunk = 4096;
     if (chunk > 65536) chunk = 65536;
     const uint32_t G = (uint32_t)((n + chunk - 1) / chunk);
-    const uint32_t sort_grid = 8 * G * ((W + 7) / 8);
+    const uint32_t sort_grid = sort_grid_size(W, G);
 
     uint32_t *digits, *bhist, *counts, *offsets, *sval, *pkey[2];
     XYZZ29 *buckets, *pval[2];
@@ -901,7 +1029,8 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     if (ext_buckets) buckets = ext_buckets;
     else H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(XYZZ29) * nkeys, (void **)&buckets));
     const uint32_t T1 = (uint32_t)((emax + K1 - 1) / K1);
-    const uint32_t len1 = 2 * T1, blocks1 = (len1 + 255) / 256;
+    const uint32_t accum_blocks = (T1 + 255) / 256;
+    const uint32_t len1 = 8 * accum_blocks, blocks1 = (len1 + 255) / 256;   // the accumulation leaves two partial slots per wave (4 waves per workgroup)
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY0, sizeof(uint32_t) * (size_t)len1, (void **)&pkey[0]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL0, sizeof(XYZZ29) * (size_t)len1, (void **)&pval[0]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY1, sizeof(uint32_t) * 2 * (size_t)blocks1, (void **)&pkey[1]));
@@ -944,7 +1073,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         while (S < 4 && S * 2 <= B && ((uint64_t)n * 4) / S > (2u << 20)) S *= 2;
     }
     if (S > B) S = B;
-    const uint32_t scatter_grid = 8 * G * ((W * S + 7) / 8);
+    const uint32_t scatter_grid = sort_grid_size(W * S, G);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(sort_threads), sizeof(uint32_t) * MAX_LDS_BUCKETS, st,   // full 128 KiB: one workgroup per CU keeps a segment's writes on one XCD
                        (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S,
                        precomp ? (uint32_t)bases->n : 0u, Wcol, fold_w, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
@@ -954,7 +1083,10 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 
     if (phases & MSM_PHASE_ACCUM) {
     prof_begin(ctx, "msm_accum_kernel");
-    if (ctx->msm_accum_variant == 2)
+    if (ctx->msm_accum_variant == 5)   // two waves per SIMD by launch bounds (256 registers: the wave-level merge's epilogue then spills nothing)
+        hipLaunchKernelGGL((msm_accum_kernel<2, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
+    else if (ctx->msm_accum_variant == 2)
         hipLaunchKernelGGL(msm_accum_w2_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
                            (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     else if (ctx->msm_accum_variant == 4)

@@ -38,6 +38,7 @@ _PROTOS = {
     "h2hip_profile_reset": (_int, [_vp]),
     "h2hip_profile_get_busy": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "h2hip_profile_get": (_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "h2hip_profile_filter": (_int, [_vp, C.c_char_p]),
     "h2hip_profile_dump": (_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "h2hip_timer_start": (_int, [_vp]),
     "h2hip_timer_stop": (_int, [_vp, C.POINTER(C.c_double)]),
@@ -283,6 +284,9 @@ class Context:
     # -- profiling / timing
     def profile_enable(self, on: bool = True):
         self._chk(self.lib.h2hip_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_filter(self, prefix: str = ""):
+        self._chk(self.lib.h2hip_profile_filter(self.handle, prefix.encode()))
 
     def profile_reset(self):
         self._chk(self.lib.h2hip_profile_reset(self.handle))

@@ -74,6 +74,9 @@ int h2hip_host_unregister(h2hip_ctx *ctx, void *host_ptr);
 /* ---- per-kernel timing (HIP events on the context's stream around every launch) ------------------- */
 int h2hip_profile_enable(h2hip_ctx *ctx, int on);
 int h2hip_profile_reset(h2hip_ctx *ctx);
+/* restrict the event brackets to kernels whose name starts with `prefix` (NULL or "" = all): a timed region can then carry the dominant
+ * kernel's events only (two events per launch cost ~1 us each; a k = 19 proof has ~200 launches) */
+int h2hip_profile_filter(h2hip_ctx *ctx, const char *prefix);
 /* total milliseconds and launch count accumulated for kernels whose name starts with `prefix` */
 int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);
 /* milliseconds (since the last h2hip_profile_reset) during which at least one launch of the matching kernels was executing:
