@@ -294,28 +294,54 @@ pub fn linear_combination<'b>(be: &'b Backend, polys: &[&DeviceVec<'b>], coeffs:
 // for `ConcreteCircuit = BaseCircuitBuilder<Fr>` (the reference's only circuit type, halo2-base/src/utils/testing.rs:32-50): synthesis, the
 // RNG and the transcript's verifying-key hash stay in Rust, everything else is one FFI call.
 
-pub struct ProvingKeyHip<'b> {
+/// The C key stores the raw `h2hip_bases*` of `g` and `g_lagrange` and reads them on every commitment (include/h2hip.h: "the bases must
+/// outlive the key"): the key therefore BORROWS both base sets for its whole life (`'g`), so that safe code cannot drop a `ResidentBases`
+/// (whose `Drop` frees the tables) while a key that points into it is alive.
+pub struct ProvingKeyHip<'b, 'g> {
     be: &'b Backend,
     pk: *mut h2hip_plonk_pk,
+    pub params: h2hip_base_circuit_params,
     pub shape: h2hip_plonk_shape,
+    _g: &'g ResidentBases<'b>,
+    _g_lagrange: &'g ResidentBases<'b>,
 }
-impl<'b> ProvingKeyHip<'b> {
+fn invalid(message: String) -> HipError {
+    HipError { code: H2HIP_ERR_INVALID, message }
+}
+impl<'b, 'g> ProvingKeyHip<'b, 'g> {
     /// `keygen_vk` + `keygen_pk`: `fixed` = the fixed columns after synthesis (table, constants, selector columns), `copies` = the copy
     /// constraints as (permutation column, row, permutation column, row) in emission order.
-    pub fn keygen(be: &'b Backend, params: h2hip_base_circuit_params, g: &ResidentBases<'b>, g_lagrange: &ResidentBases<'b>, fixed: &[Vec<Fr>],
-                  copies: &[[u32; 4]], transcript_repr: impl FnOnce(&[G1Affine], &[G1Affine]) -> Fr) -> Result<Self, HipError> {
+    /// `phases` = `BaseCircuitParams::num_advice_per_phase.len()`: libh2hip proves first-phase circuits only (include/h2hip.h, LIMITS).
+    pub fn keygen(be: &'b Backend, params: h2hip_base_circuit_params, phases: usize, g: &'g ResidentBases<'b>, g_lagrange: &'g ResidentBases<'b>,
+                  fixed: &[Vec<Fr>], copies: &[[u32; 4]], transcript_repr: impl FnOnce(&[G1Affine], &[G1Affine]) -> Fr) -> Result<Self, HipError> {
+        if phases > 1 {
+            return Err(invalid(format!("libh2hip proves first-phase circuits only; the circuit uses {phases} challenge phases")));
+        }
         let mut shape = h2hip_plonk_shape::default();
         check(unsafe { h2hip_plonk_shape_of(&params, &mut shape) })?;
-        assert_eq!(fixed.len(), shape.num_fixed_total as usize);
+        // the C side reads num_fixed_total pointers and 2^k elements behind each: check the shapes here, in safe code
+        let n = 1usize << params.k;
+        if fixed.len() != shape.num_fixed_total as usize {
+            return Err(invalid(format!("keygen: {} fixed columns, the shape has {}", fixed.len(), shape.num_fixed_total)));
+        }
+        if let Some(c) = fixed.iter().position(|c| c.len() != n) {
+            return Err(invalid(format!("keygen: fixed column {c} has {} rows, expected 2^k = {n}", fixed[c].len())));
+        }
+        if g.len() < n || g_lagrange.len() < n {
+            return Err(invalid(format!("keygen: the SRS holds fewer than 2^k = {n} bases")));
+        }
         let cols: Vec<*const c_void> = fixed.iter().map(|c| c.as_ptr().cast()).collect();
         let mut pk = ptr::null_mut();
         check(unsafe { h2hip_plonk_keygen(be.ctx, &params, g.h, g_lagrange.h, cols.as_ptr(), copies.as_ptr().cast(), copies.len(), &mut pk) })?;
+        // from here on `key`'s Drop frees the handle on every early return and on a panic inside the caller's `transcript_repr`
+        let key = Self { be, pk, params, shape, _g: g, _g_lagrange: g_lagrange };
         let mut fc = vec![G1Affine::default(); shape.num_fixed_total as usize];
-        let mut pc = vec![G1Affine::default(); shape.num_perm_columns as usize];
-        check(unsafe { h2hip_plonk_pk_commitments(pk, fc.as_mut_ptr().cast(), pc.as_mut_ptr().cast()) })?;
+        let mut pc = vec![G1Affine::default(); (shape.num_perm_columns as usize).max(1)];
+        check(unsafe { h2hip_plonk_pk_commitments(key.pk, fc.as_mut_ptr().cast(), pc.as_mut_ptr().cast()) })?;
+        pc.truncate(shape.num_perm_columns as usize);
         let repr = transcript_repr(&fc, &pc);   // VerifyingKey::transcript_repr, computed by the Rust side from the pinned key
-        check(unsafe { h2hip_plonk_pk_set_transcript_repr(pk, fr_ptr(&repr)) })?;
-        Ok(Self { be, pk, shape })
+        check(unsafe { h2hip_plonk_pk_set_transcript_repr(key.pk, fr_ptr(&repr)) })?;
+        Ok(key)
     }
     /// `create_proof(params, pk, &[circuit], &[instances], rng, &mut transcript)` after synthesis: returns what
     /// `transcript.finalize()` would.  `rng_fill` is called for every batch of `Fr::random(rng)` draws, in upstream's order.
@@ -323,6 +349,19 @@ impl<'b> ProvingKeyHip<'b> {
         unsafe extern "C" fn trampoline<R: FnMut(&mut [Fr])>(user: *mut c_void, out: *mut c_void, n: usize) {
             let f = &mut *(user as *mut R);
             f(std::slice::from_raw_parts_mut(out as *mut Fr, n));
+        }
+        // the C side reads num_advice_total column pointers with usable_rows elements each and num_instance instance arrays
+        if advice.len() != self.shape.num_advice_total as usize {
+            return Err(invalid(format!("create_proof: {} advice columns, the shape has {}", advice.len(), self.shape.num_advice_total)));
+        }
+        if let Some(c) = advice.iter().position(|c| c.len() < self.shape.usable_rows as usize) {
+            return Err(invalid(format!("create_proof: advice column {c} has {} rows, fewer than the {} usable rows", advice[c].len(), self.shape.usable_rows)));
+        }
+        if instances.len() != self.params.num_instance as usize {
+            return Err(invalid(format!("create_proof: {} instance columns, the circuit has {}", instances.len(), self.params.num_instance)));
+        }
+        if let Some(c) = instances.iter().position(|c| c.len() > self.shape.usable_rows as usize) {
+            return Err(invalid(format!("create_proof: instance column {c} is longer than the usable rows")));
         }
         let adv: Vec<*const c_void> = advice.iter().map(|c| c.as_ptr().cast()).collect();
         let ins: Vec<*const c_void> = instances.iter().map(|c| c.as_ptr().cast()).collect();
@@ -341,6 +380,16 @@ impl<'b> ProvingKeyHip<'b> {
 /// halo2-base/src/utils/testing.rs:64-88): `g1` = params.get_g()[0], `g2` / `s_g2` = the verifier half of the SRS in RawBytes form.
 pub fn verify_proof(params: h2hip_base_circuit_params, fixed_commitments: &[G1Affine], permutation_commitments: &[G1Affine], transcript_repr: Fr,
                     g1: G1Affine, g2: &[u8; 128], s_g2: &[u8; 128], instances: &[&[Fr]], proof: &[u8]) -> Result<bool, HipError> {
+    // the C side reads num_fixed_total / num_perm_columns commitments and num_instance instance arrays: check the slices first
+    let mut shape = h2hip_plonk_shape::default();
+    check(unsafe { h2hip_plonk_shape_of(&params, &mut shape) })?;
+    if fixed_commitments.len() != shape.num_fixed_total as usize || permutation_commitments.len() != shape.num_perm_columns as usize {
+        return Err(invalid(format!("verify_proof: {} fixed / {} permutation commitments, the shape has {} / {}", fixed_commitments.len(),
+                                   permutation_commitments.len(), shape.num_fixed_total, shape.num_perm_columns)));
+    }
+    if instances.len() != params.num_instance as usize {
+        return Err(invalid(format!("verify_proof: {} instance columns, the circuit has {}", instances.len(), params.num_instance)));
+    }
     let ins: Vec<*const c_void> = instances.iter().map(|c| c.as_ptr().cast()).collect();
     let lens: Vec<usize> = instances.iter().map(|c| c.len()).collect();
     let mut ok: c_int = 0;
@@ -352,7 +401,7 @@ pub fn verify_proof(params: h2hip_base_circuit_params, fixed_commitments: &[G1Af
     Ok(ok != 0)
 }
 
-impl Drop for ProvingKeyHip<'_> {
+impl Drop for ProvingKeyHip<'_, '_> {
     fn drop(&mut self) {
         unsafe { h2hip_plonk_pk_free(self.be.ctx, self.pk) }
     }

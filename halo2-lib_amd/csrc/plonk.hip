@@ -130,7 +130,8 @@ struct Shape {
         while (((uint64_t)1 << extended_k) < (uint64_t)n * quotient_pieces) ++extended_k;
         H2_REQUIRE(extended_k <= 28, "extended domain exceeds the 2-adicity of F_r");
         num_perm_sets = (uint32_t)((perm_columns.size() + chunk_len - 1) / chunk_len);
-        if (bp.lookup_bits >= 0 && with_range) H2_REQUIRE(((uint64_t)1 << bp.lookup_bits) <= usable_rows, "lookup table is too large for the circuit degree plus blinding factors");
+        // range/mod.rs:117-121: the table must fit gate.max_rows = 2^k - meta.minimum_rows() = n - (blinding_factors + 3)
+        if (bp.lookup_bits >= 0 && with_range) H2_REQUIRE(((uint64_t)1 << bp.lookup_bits) <= n - (blinding_factors + 3), "lookup table is too large for the circuit degree plus blinding factors");
         return H2HIP_OK;
     }
     uint32_t num_commitments() const {
@@ -1223,6 +1224,40 @@ int h2hip_plonk_shape_of(const h2hip_base_circuit_params *params, h2hip_plonk_sh
     return H2HIP_OK;
 }
 
+// Shape::init gives every gate column's q_enable selector a fixed column of its own.  Upstream's compress_selectors [UPSTREAM-RECALL] would
+// instead COMBINE simple selectors that are never enabled on a common row (as far as the degree bound allows) — e.g. a gate column that the
+// circuit left empty — which changes the number of fixed columns, the verifying key and the proof size.  Such circuits are rejected here
+// rather than proven against a key halo2 would not derive: every pair of q_enable columns must share an enabled row.
+static int check_selectors_stay_apart(const Shape &sh, const void *const *fixed_host) {
+    const uint32_t na = sh.p.num_advice;
+    if (na < 2) return H2HIP_OK;
+    const size_t words = (sh.n + 63) / 64;
+    std::vector<uint64_t> bits((size_t)na * words, 0);
+    for (uint32_t a = 0; a < na; ++a) {
+        const Fr *col = (const Fr *)fixed_host[sh.first_q_enable_col + (int)a];
+        H2_REQUIRE(col, "NULL fixed column");
+        for (size_t r = 0; r < sh.usable_rows; ++r)
+            if (!col[r].is_zero()) bits[a * words + (r >> 6)] |= 1ull << (r & 63);
+    }
+    // a row enabled in EVERY column settles all pairs at once (the usual case: gates start at row 0 of every column)
+    for (size_t w = 0; w < words; ++w) {
+        uint64_t all = ~0ull;
+        for (uint32_t a = 0; a < na && all; ++a) all &= bits[a * words + w];
+        if (all) return H2HIP_OK;
+    }
+    for (uint32_t a = 0; a < na; ++a)
+        for (uint32_t b = a + 1; b < na; ++b) {
+            bool share = false;
+            for (size_t w = 0; w < words && !share; ++w) share = (bits[a * words + w] & bits[b * words + w]) != 0;
+            if (!share) {
+                set_error("h2hip_plonk_keygen: the selectors of gate columns %u and %u are never enabled on a common row (an empty gate column?): "
+                          "halo2's selector compression would merge them into one fixed column, which this backend's fixed-column layout does not model", a, b);
+                return H2HIP_ERR_INVALID;
+            }
+        }
+    return H2HIP_OK;
+}
+
 int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, const h2hip_bases *g, const h2hip_bases *g_lagrange,
                        const void *const *fixed_host, const uint32_t *copies, size_t ncopies, h2hip_plonk_pk **out) {
     H2_DEVICE_GUARD(ctx);
@@ -1233,6 +1268,7 @@ int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, 
         set_error("h2hip_plonk_keygen: the SRS holds fewer than 2^k bases");
         rc = H2HIP_ERR_INVALID;
     }
+    if (rc == H2HIP_OK) rc = check_selectors_stay_apart(pk->sh, fixed_host);
     if (rc == H2HIP_OK) {
         pk->ctx = ctx;
         pk->g = g;

@@ -317,6 +317,17 @@ class ParamsKZG {
     G1 commit_lagrange(const std::vector<Fr> &values) const { return msm(g_lagrange_, values); }
     const Bases &get_g() const { return g_; }
     const Bases &get_g_lagrange() const { return g_lagrange_; }
+    // the verifier half: g2 = the G2 generator, s_g2 = s * g2 (SerdeFormat::RawBytes: x.c0, x.c1, y.c0, y.c1 as Montgomery limbs) for the
+    // toxic waste the caller's RNG drew in setup()
+    static void g2_pair(Backend &b, const Fr &s, uint8_t g2[128], uint8_t s_g2[128]) {
+        static const uint64_t G2_GEN[16] = {   // alt_bn128 / EIP-197 generator of G2, Montgomery form (tests/test_external_vectors.py pins it)
+            0x8e83b5d102bc2026ULL, 0xdceb1935497b0172ULL, 0xfbb8264797811adfULL, 0x19573841af96503bULL,
+            0xafb4737da84c6140ULL, 0x6043dd5a5802d8c4ULL, 0x09e950fc52a02f86ULL, 0x14fef0833aea7b6bULL,
+            0x619dfa9d886be9f6ULL, 0xfe7fd297f59e9b78ULL, 0xff9e1a62231b7dfeULL, 0x28fd7eebae9e4206ULL,
+            0x64095b56c71856eeULL, 0xdc57f922327d3cbbULL, 0x55f935be33351076ULL, 0x0da4a0e693fd6482ULL};
+        memcpy(g2, G2_GEN, 128);
+        check(h2hip_msm_g2(b.raw(), g2, &s, 1, s_g2));
+    }
 
   private:
     ParamsKZG(Backend &b, uint32_t k, Bases g, Bases gl) : be_(&b), k_(k), g_(std::move(g)), g_lagrange_(std::move(gl)) {}
@@ -332,6 +343,92 @@ class ParamsKZG {
 };
 }  // namespace kzg
 }  // namespace poly
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The physical layout of halo2-base's virtual cells, restating
+//   halo2-base/src/gates/flex_gate/threads/single_phase.rs:193-263  assign_with_constraints (keygen: break points, selector rows, break-cell copies)
+//   halo2-base/src/gates/flex_gate/threads/single_phase.rs:273-312  assign_witnesses        (proving: the same columns from the break points alone)
+// for one phase of gate columns.  A thread is one Context's cell stream: advice values + the selector bit of each cell.  (The Python twin,
+// halo2-lib_amd/virtual_region.py, also restates the lookup, constants and instance managers; tests/test_virtual_region.py.)
+namespace virtual_region {
+constexpr size_t ROTATIONS = 4;   // the vertical gate q * (a + b * c - d) spans four rows
+struct Thread {
+    std::vector<Fr> advice;
+    std::vector<uint8_t> selector;   // same length as advice (keygen stage)
+};
+struct RawCell {
+    uint32_t column, row;   // gate column index, row
+    bool operator==(const RawCell &o) const { return column == o.column && row == o.row; }
+};
+struct Layout {
+    std::vector<std::vector<Fr>> columns;                 // gate columns, 2^k rows, zero where nothing is assigned
+    std::vector<std::vector<uint32_t>> q_enable_rows;     // per gate column: rows whose selector is enabled
+    std::vector<std::pair<RawCell, RawCell>> break_copies;   // (cell at row 0 of the next column, cell at the break) — raw_constrain_equal(ncell, cell)
+    std::vector<size_t> break_points;
+    std::vector<std::vector<RawCell>> cell_of;            // per thread: the FIRST raw cell of every virtual cell (copy_manager.assigned_advices)
+};
+inline Layout assign_with_constraints(const std::vector<Thread> &threads, size_t num_gate_columns, uint32_t k, size_t max_rows) {
+    const Fr zero = {{0, 0, 0, 0}};
+    Layout out;
+    out.columns.assign(num_gate_columns, std::vector<Fr>((size_t)1 << k, zero));
+    out.q_enable_rows.assign(num_gate_columns, {});
+    out.cell_of.resize(threads.size());
+    size_t gate_index = 0, row_offset = 0;
+    auto need_column = [&]() {
+        if (gate_index >= num_gate_columns) throw Error(H2HIP_ERR_INVALID, "NOT ENOUGH ADVICE COLUMNS. Perhaps blinding factors were not taken into account.");
+    };
+    for (size_t t = 0; t < threads.size(); ++t) {
+        const Thread &ctx = threads[t];
+        if (ctx.advice.empty()) continue;
+        need_column();
+        if (ctx.selector.size() != ctx.advice.size()) throw Error(H2HIP_ERR_INVALID, "selector / advice length mismatch");
+        for (size_t i = 0; i < ctx.advice.size(); ++i) {
+            const bool q = ctx.selector[i] != 0;
+            out.columns[gate_index][row_offset] = ctx.advice[i];
+            const RawCell cell = {(uint32_t)gate_index, (uint32_t)row_offset};
+            out.cell_of[t].push_back(cell);
+            if ((q && row_offset + ROTATIONS > max_rows) || row_offset >= max_rows - 1) {
+                out.break_points.push_back(row_offset);
+                row_offset = 0;
+                ++gate_index;
+                if (ROTATIONS > 1 && i + 2 >= ROTATIONS)
+                    for (size_t delta = 1; delta < ROTATIONS - 1; ++delta)
+                        if (ctx.selector[i - delta]) throw Error(H2HIP_ERR_INVALID, "We do not support overlaps with delta < ROTATIONS - 1");
+                need_column();
+                out.columns[gate_index][0] = ctx.advice[i];
+                out.break_copies.push_back({RawCell{(uint32_t)gate_index, 0u}, cell});
+            }
+            if (q) out.q_enable_rows[gate_index].push_back((uint32_t)row_offset);
+            ++row_offset;
+        }
+    }
+    return out;
+}
+inline std::vector<std::vector<Fr>> assign_witnesses(const std::vector<Thread> &threads, size_t num_gate_columns, uint32_t k,
+                                                     const std::vector<size_t> &break_points) {
+    const Fr zero = {{0, 0, 0, 0}};
+    std::vector<std::vector<Fr>> columns(num_gate_columns, std::vector<Fr>((size_t)1 << k, zero));
+    if (!num_gate_columns) {
+        for (auto &t : threads)
+            if (!t.advice.empty()) throw Error(H2HIP_ERR_INVALID, "Trying to assign threads in a phase with no columns");
+        return columns;
+    }
+    size_t bp = 0, gate_index = 0, row_offset = 0;
+    for (const Thread &ctx : threads)
+        for (const Fr &advice : ctx.advice) {
+            columns[gate_index][row_offset] = advice;
+            if (bp < break_points.size() && break_points[bp] == row_offset) {
+                ++bp;
+                row_offset = 0;
+                ++gate_index;
+                if (gate_index >= num_gate_columns) throw Error(H2HIP_ERR_INVALID, "break points do not fit the gate columns");
+                columns[gate_index][0] = advice;
+            }
+            ++row_offset;
+        }
+    return columns;
+}
+}  // namespace virtual_region
 
 namespace plonk {
 // keygen_vk + keygen_pk and create_proof for BaseConfig circuits (reference halo2-base/src/utils/testing.rs:224-227, :32-50): the whole

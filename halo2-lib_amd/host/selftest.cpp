@@ -76,6 +76,66 @@ static std::vector<uint8_t> prove_small_circuit(Backend &be, uint32_t k, uint64_
     return plonk::create_proof(be, pk, advice, {}, rng);
 }
 
+// SURVEY.md §8 row a5 in C++: threads of chained gates (running-sum cells shared by consecutive gates) laid out over two gate columns by
+// virtual_region::assign_with_constraints, proven from the columns virtual_region::assign_witnesses rebuilds out of the break points, and
+// checked by libh2hip's verifier; a witness whose duplicated break cell differs from the original must be rejected.
+static void layout_selftest(Backend &be) {
+    const uint32_t k = 8;
+    h2hip_base_circuit_params bp = {k, 2, 0, 1, 0, -1};   // two gate columns, no range chip, one constants column
+    h2hip_plonk_shape sh;
+    check(h2hip_plonk_shape_of(&bp, &sh));
+    const size_t n = (size_t)1 << k;
+    const Fr zero = {{0, 0, 0, 0}}, one = host_fr::R1;
+    uint64_t s = 2024;
+    std::vector<virtual_region::Thread> threads(2);
+    size_t budget = sh.usable_rows + sh.usable_rows / 2;   // more cells than one column holds
+    for (size_t t = 0; t < 2; ++t) {
+        virtual_region::Thread &th = threads[t];
+        Fr sum = zero;
+        th.advice.push_back(sum);                      // | 0 | a0 | b0 | s1 | a1 | b1 | s2 | ...  (inner_product_simple's layout)
+        th.selector.push_back(1);
+        for (size_t j = 0; th.advice.size() + 3 <= budget / 2; ++j) {
+            Fr a = draw_fr(s), b = draw_fr(s);
+            sum = host_fr::add(sum, host_fr::mul(a, b));
+            th.advice.insert(th.advice.end(), {a, b, sum});
+            th.selector.insert(th.selector.end(), {0, 0, 1});
+        }
+        th.selector.back() = 0;                        // the last running sum starts no gate
+    }
+    virtual_region::Layout lay = virtual_region::assign_with_constraints(threads, 2, k, sh.usable_rows);
+    if (lay.break_points.size() != 1 || lay.break_copies.size() != 1) throw Error(-1, "layout: expected exactly one break");
+    if (!(lay.break_copies[0].first == virtual_region::RawCell{1, 0})) throw Error(-1, "layout: the break cell's duplicate is not at row 0 of the next column");
+    if (!(lay.columns[1][0] == lay.columns[0][lay.break_points[0]])) throw Error(-1, "layout: duplicate value");
+    std::vector<std::vector<Fr>> advice = virtual_region::assign_witnesses(threads, 2, k, lay.break_points);
+    if (!(advice == lay.columns)) throw Error(-1, "layout: assign_witnesses differs from assign_with_constraints");
+    std::vector<std::vector<Fr>> fixed(sh.num_fixed_total, std::vector<Fr>(n, zero));
+    for (size_t c = 0; c < 2; ++c)
+        for (uint32_t r : lay.q_enable_rows[c]) {
+            fixed[sh.first_q_enable_col + c][r] = one;
+            if (!(host_fr::add(advice[c][r], host_fr::mul(advice[c][r + 1], advice[c][r + 2])) == advice[c][r + 3])) throw Error(-1, "layout: a gate row does not hold");
+        }
+    // permutation columns: 0 = constants, 1.. = advice (gate columns first); the break copy, and each thread's leading 0 tied to the constant 0
+    std::vector<uint32_t> copies;
+    for (auto &bc : lay.break_copies) copies.insert(copies.end(), {1 + bc.first.column, bc.first.row, 1 + bc.second.column, bc.second.row});
+    for (size_t t = 0; t < 2; ++t) copies.insert(copies.end(), {0u, 0u, 1 + lay.cell_of[t][0].column, lay.cell_of[t][0].row});
+    Fr toxic = host_fr::from_u64(0xabcdef12345ULL);
+    poly::kzg::ParamsKZG params = poly::kzg::ParamsKZG::setup(be, k, toxic, false);
+    plonk::ProvingKey pk(be, bp, params, fixed, copies);
+    const Fr repr = host_fr::from_u64(77);
+    pk.set_transcript_repr(repr);
+    StreamRng rng{5};
+    std::vector<uint8_t> proof = plonk::create_proof(be, pk, advice, {}, rng);
+    std::vector<G1Affine> g = params.get_g().download();
+    uint8_t g2[128], s_g2[128];
+    poly::kzg::ParamsKZG::g2_pair(be, toxic, g2, s_g2);
+    if (!plonk::verify_proof(pk, bp, repr, g[0], g2, s_g2, {}, proof)) throw Error(-1, "layout: the proof of the laid-out circuit does not verify");
+    advice[1][0] = host_fr::add(advice[1][0], one);   // the duplicate no longer equals the break cell (its own gate row is re-satisfied below)
+    advice[1][3] = host_fr::add(advice[1][0], host_fr::mul(advice[1][1], advice[1][2]));
+    StreamRng rng2{6};
+    std::vector<uint8_t> forged = plonk::create_proof(be, pk, advice, {}, rng2);
+    if (plonk::verify_proof(pk, bp, repr, g[0], g2, s_g2, {}, forged)) throw Error(-1, "layout: a broken break-cell copy was accepted");
+}
+
 int main(int argc, char **argv) {
     uint32_t k = argc > 1 ? (uint32_t)atoi(argv[1]) : 10;
     try {
@@ -173,6 +233,7 @@ int main(int argc, char **argv) {
             threw = true;
         }
         if (!threw) throw Error(-1, "length assertion missing");
+        layout_selftest(be);
         printf("selftest OK (k=%u)\n", k);
         return 0;
     } catch (const Error &e) {

@@ -334,6 +334,14 @@ int h2hip_poseidon_permute_batch_dev(h2hip_ctx *ctx, void *states_dev, const voi
  * prover draws, in upstream's order), the verifying key's transcript representation, and the proof bytes.
  * Everything between — 12 MSMs, ~11 NTTs, the lookup sort, grand products, h(X), evaluations, SHPLONK — runs on the device with
  * every polynomial resident in HBM; the host part is the Blake2b transcript and the O(#openings) bookkeeping of the multiopen. */
+/* LIMITS, stated once: (1) ONE challenge phase.  The reference's params are per-phase vectors with MAX_PHASE = 3
+ * (num_advice_per_phase / num_lookup_advice_per_phase, halo2-base/src/gates/flex_gate/mod.rs:28,100,132-137, gates/range/mod.rs:87-108); this
+ * struct carries phase 0 only, so a circuit that uses SecondPhase / ThirdPhase columns (none of halo2-ecc's benchmark circuits does) cannot
+ * be expressed and must stay on the CPU prover — the Rust shim checks `params.num_advice_per_phase.len() == 1` (ffi/rust/h2hip-sys/src/safe.rs)
+ * and returns an error otherwise.  (2) Every gate column's q_enable keeps a fixed column of its own: h2hip_plonk_keygen returns
+ * H2HIP_ERR_INVALID for selector activations that upstream's compress_selectors would merge (two gate columns never enabled on a common
+ * row, e.g. an empty gate column).  (3) lookup_bits: the table 0..2^lookup_bits must fit 2^k - (blinding_factors + 3) rows, as in
+ * RangeConfig::configure (gates/range/mod.rs:117-121). */
 typedef struct {
     uint32_t k;                 /* BaseCircuitParams (gates/circuit/mod.rs:25-45), first phase */
     uint32_t num_advice;        /* num_advice_per_phase[0] */
