@@ -708,63 +708,6 @@ def create_proof_config_sweep(ctx, reps: int = 5):
     return out
 
 
-def create_proof_k19_sharded(ctx, dist, device, reps: int = 5):
-    """N > 1: the same k = 19 create_proof on every rank with its commitments sharded by point range (h2hip_plonk_pk_set_msm_sharding): each of
-    the five MSM rounds is a partial MSM over 2^19 / N points of the rank's SRS slice + one all-gather of 96-byte partials; the NTT / quotient
-    work is replicated (strong scaling of the MSM share only).  seconds = max over ranks."""
-    import hashlib
-
-    import torch
-
-    from halo2_lib_amd import halo2_proofs as HP
-    from halo2_lib_amd import plonk as PL
-    from halo2_lib_amd import testing as T
-    from halo2_lib_amd.multi_gpu import shard_proving_key
-
-    k = 19
-    kzg = HP.ParamsKZG.setup(ctx, k, 0x1D0C0FFEE1234567890ABCDEF, precompute=False)   # only the rank's slice gets window tables
-    bp = PL.BaseCircuitParams.new(k, 1, 1, 1, 0, 18)
-    sh = PL.shape_of(ctx, bp)
-
-    class Backend:
-        mul = staticmethod(ctx.fr_mul)
-        add = staticmethod(ctx.fr_add)
-
-    # set-up without collectives; the ranks then agree that all of them got through it before the first sharded proof (a rank that failed
-    # here would leave the others waiting in the proof's all-gathers)
-    err = None
-    try:
-        circ = T.build_circuit(_ShapeView(bp, sh), 19, Backend)
-        pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
-        g_pts, gl_pts = ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange)
-        draws = synthetic_scalars((1 << k) + 4096, 4242)
-    except Exception as e:
-        err = repr(e)
-    oks = [None] * dist.get_world_size()
-    dist.all_gather_object(oks, err)
-    if any(o is not None for o in oks):
-        raise RuntimeError("sharded create_proof set-up failed on some rank: %r" % (oks,))
-    sk = shard_proving_key(pk, g_pts, gl_pts, device=device, precompute=True)
-    proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        proof = PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))
-    dist.barrier()
-    sec = (time.perf_counter() - t0) / reps
-    te = torch.tensor([sec], dtype=torch.float64, device=device if device is not None else "cpu")
-    dist.all_reduce(te, op=dist.ReduceOp.MAX)
-    digests = [None] * dist.get_world_size()
-    dist.all_gather_object(digests, hashlib.sha256(proof).hexdigest())
-    sk.free()
-    pk.free()
-    kzg.free()
-    return {"seconds": float(te.item()), "reps": reps, "ranks": dist.get_world_size(), "proof_bytes": len(proof),
-            "all_ranks_emit_the_same_proof": len(set(digests)) == 1, "proof_sha256": digests[0],
-            "what": "k=19 ECDSA-configuration create_proof, commitments point-range sharded over the ranks (one all-gather of 96 B partials per "
-                    "MSM round), NTT / quotient work replicated"}
-
-
 def _cpu_threads():
     hw = os.cpu_count() or 1
     cores = min(hw, len(os.sched_getaffinity(0)))

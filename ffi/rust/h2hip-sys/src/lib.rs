@@ -61,6 +61,13 @@ pub type h2hip_rng_fill_fn = Option<unsafe extern "C" fn(user: *mut c_void, out_
 pub type h2hip_allgather_fn = Option<unsafe extern "C" fn(user: *mut c_void, local: *const c_void, bytes: usize, all: *mut c_void) -> c_int>;
 pub const H2HIP_PLONK_STAGES: usize = 12;
 
+#[repr(C)]
+pub struct h2hip_comm {
+    _private: [u8; 0],
+}
+pub const H2HIP_SHARD_QUOTIENT: u32 = 1;
+pub const H2HIP_SHARD_FORCE: u32 = 2;
+pub const H2HIP_ERR_PEER: c_int = -5;
 pub const H2HIP_OK: c_int = 0;
 pub const H2HIP_ERR_INVALID: c_int = -1;
 pub const H2HIP_ERR_HIP: c_int = -2;
@@ -192,8 +199,20 @@ extern "C" {
     pub fn h2hip_plonk_pk_free(ctx: *mut h2hip_ctx, pk: *mut h2hip_plonk_pk);
     pub fn h2hip_plonk_pk_commitments(pk: *const h2hip_plonk_pk, fixed_out: *mut c_void, permutation_out: *mut c_void) -> c_int;
     pub fn h2hip_plonk_pk_set_transcript_repr(pk: *mut h2hip_plonk_pk, fr: *const c_void) -> c_int;
-    pub fn h2hip_plonk_pk_set_msm_sharding(pk: *mut h2hip_plonk_pk, g_shard: *const h2hip_bases, g_lagrange_shard: *const h2hip_bases, offset: usize,
-                                           len: usize, world: u32, allgather: h2hip_allgather_fn, user: *mut c_void) -> c_int;
+    pub fn h2hip_plonk_pk_set_sharding(pk: *mut h2hip_plonk_pk, comm: *mut h2hip_comm, g_shard: *const h2hip_bases, g_lagrange_shard: *const h2hip_bases,
+                                       offset: usize, len: usize, flags: u32) -> c_int;
+    pub fn h2hip_comm_rccl_unique_id(out128: *mut c_void) -> c_int;
+    pub fn h2hip_comm_init_rccl(ctx: *mut h2hip_ctx, unique_id128: *const c_void, world: c_int, rank: c_int, out: *mut *mut h2hip_comm) -> c_int;
+    pub fn h2hip_comm_init_callback(world: c_int, rank: c_int, allgather: h2hip_allgather_fn, user: *mut c_void, out: *mut *mut h2hip_comm) -> c_int;
+    pub fn h2hip_comm_info(comm: *const h2hip_comm, world: *mut c_int, rank: *mut c_int, is_rccl: *mut c_int) -> c_int;
+    pub fn h2hip_comm_destroy(comm: *mut h2hip_comm);
+    pub fn h2hip_comm_allgather_dev(comm: *mut h2hip_comm, ctx: *mut h2hip_ctx, send_dev: *const c_void, bytes: usize, recv_dev: *mut c_void) -> c_int;
+    pub fn h2hip_comm_allgather_host(comm: *mut h2hip_comm, ctx: *mut h2hip_ctx, send_host: *const c_void, bytes: usize, recv_host: *mut c_void) -> c_int;
+    pub fn h2hip_fr_coset_scale_batch_dev(ctx: *mut h2hip_ctx, outs_dev: *const *mut c_void, ins_dev: *const *const c_void, count: usize, n: usize,
+                                          s: *const c_void) -> c_int;
+    pub fn h2hip_fr_coset_gather_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, in_dev: *const c_void, cosets: *const u32, count: u32, log_cosets: u32,
+                                     n: usize) -> c_int;
+    pub fn h2hip_fr_coset_interleave_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, in_dev: *const c_void, slots: *const u32, log_cosets: u32, n: usize) -> c_int;
     pub fn h2hip_array_rng_fill(user: *mut c_void, out_fr: *mut c_void, n: usize);
     pub fn h2hip_plonk_stage_name(stage: c_int) -> *const c_char;
     pub fn h2hip_plonk_create_proof(ctx: *mut h2hip_ctx, pk: *mut h2hip_plonk_pk, advice: *const *const c_void, advice_on_device: c_int,

@@ -231,12 +231,21 @@ struct h2hip_plonk_pk {
     bool have_repr = false;
     BufPool pool;
     std::vector<void *> owned;
-    // multi-GPU: point-range sharding of every commitment (h2hip_plonk_pk_set_msm_sharding)
+    // multi-GPU (h2hip_plonk_pk_set_sharding): point-range sharding of every commitment, coset sharding of h(X)'s numerator
     const h2hip_bases *g_shard = nullptr, *g_lagrange_shard = nullptr;
     size_t shard_offset = 0, shard_len = 0;
-    uint32_t shard_world = 1;
-    h2hip_allgather_fn allgather = nullptr;
-    void *allgather_user = nullptr;
+    uint32_t shard_world = 1, shard_rank = 0;
+    h2hip_comm *comm = nullptr;
+    bool shard_quotient = false;
+    std::vector<uint32_t> my_cosets;          // cosets of the extended domain (rows = coset mod 2^(ek-k)) this rank evaluates h(X) on
+    uint32_t max_cosets = 1;                  // cosets of the busiest rank (the all-gather's uniform slot count)
+    std::vector<Fr *> fixed_cosets_sh, sigma_cosets_sh;   // [my_cosets][n] slices of the key's extended-domain arrays
+    Fr *l0_sh = nullptr, *l_last_sh = nullptr, *l_blind_sh = nullptr;
+    std::vector<void *> shard_owned;
+    // exchanges of the running sharded proof: every host exchange carries a status word, so that a rank that fails between two
+    // exchanges can tell its peers (it takes part in the NEXT exchange with an error status and a zero payload of the scheduled size)
+    std::vector<size_t> exch_sizes;
+    size_t exch_next = 0;
     hipStream_t copy_stream = nullptr;   // the RNG-drawn random polynomial is uploaded on its own stream, next to the NTTs
     hipEvent_t copy_ev = nullptr;
     Fr *host_stage = nullptr;   // pinned staging for the RNG-drawn scalars (the n coefficients of the random polynomial, the blinding rows)
@@ -651,11 +660,31 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         t.dst.clear();
         return H2HIP_OK;
     };
+    // ---- multi-GPU exchanges.  Host payloads travel as [8-byte status][payload] per rank; a non-zero status of any rank aborts the proof on
+    // every rank at the same exchange (H2HIP_ERR_PEER), so nobody is left waiting in the next collective.
+    const bool sharded_any = pk->comm != nullptr;   // (set only for world > 1, or for a forced single-rank run of the sharded path)
+    auto exchange_host = [&](const void *payload, size_t bytes, std::vector<uint8_t> &all) -> int {
+        H2_REQUIRE(pk->exch_next < pk->exch_sizes.size() && pk->exch_sizes[pk->exch_next] == bytes, "internal: exchange out of schedule");
+        std::vector<uint8_t> send(8 + bytes, 0);
+        if (bytes) memcpy(send.data() + 8, payload, bytes);
+        all.assign((8 + bytes) * (size_t)pk->shard_world, 0);
+        H2_CHK(h2hip_comm_allgather_host(pk->comm, ctx, send.data(), send.size(), all.data()));
+        pk->exch_next++;
+        for (uint32_t r = 0; r < pk->shard_world; ++r) {
+            uint64_t status;
+            memcpy(&status, all.data() + (size_t)r * (8 + bytes), 8);
+            if (status) {
+                set_error("create_proof: rank %u of the sharded proof reported an error; all ranks abort", r);
+                return H2HIP_ERR_PEER;
+            }
+        }
+        return H2HIP_OK;
+    };
     // `bases_per_col`: empty = all columns over `bases`
     auto commit_points_multi = [&](const h2hip_bases *bases, const std::vector<const h2hip_bases *> &bases_per_col, const std::vector<const void *> &cols,
                                    size_t len, std::vector<G1Affine> &pts) -> int {
         std::vector<G1Jac> jac(cols.size());
-        const bool sharded = pk->shard_world > 1;
+        const bool sharded = sharded_any;
         std::vector<const h2hip_bases *> bpc(cols.size());
         for (size_t i = 0; i < cols.size(); ++i) {
             const h2hip_bases *b = bases_per_col.empty() ? bases : bases_per_col[i];
@@ -673,15 +702,14 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             H2_CHK(h2hip_msm_g1_multi_dev(ctx, bpc.data(), local.data(), hi - lo, cols.size(), H2HIP_POINT_JACOBIAN, jac.data()));
         pts.resize(cols.size());
         if (sharded) {
-            std::vector<G1Jac> all(cols.size() * pk->shard_world);
-            if (pk->allgather(pk->allgather_user, jac.data(), sizeof(G1Jac) * cols.size(), all.data()) != 0) {
-                set_error("create_proof: the all-gather callback failed");
-                return H2HIP_ERR_INVALID;
-            }
+            std::vector<uint8_t> all;
+            H2_CHK(exchange_host(jac.data(), sizeof(G1Jac) * cols.size(), all));
+            const size_t slot = 8 + sizeof(G1Jac) * cols.size();
             for (size_t i = 0; i < cols.size(); ++i) {
                 XYZZ acc = XYZZ::identity();
                 for (uint32_t r = 0; r < pk->shard_world; ++r) {
-                    const G1Jac &p = all[(size_t)r * cols.size() + i];
+                    G1Jac p;
+                    memcpy(&p, all.data() + (size_t)r * slot + 8 + sizeof(G1Jac) * i, sizeof(G1Jac));
                     if (p.z.is_zero()) continue;
                     XYZZ q;
                     q.x = p.x;
@@ -709,6 +737,19 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         return H2HIP_OK;
     };
 
+    const bool qshard = sharded_any && pk->shard_quotient;
+    const size_t ncm = qshard ? pk->my_cosets.size() : 0;                 // cosets of the extended domain evaluated here
+    const size_t ne_loc = qshard ? std::max<size_t>(ncm * (size_t)n, 1) : ne;   // extended-domain evaluations of a column held by this rank
+    pk->exch_sizes.clear();
+    pk->exch_next = 0;
+    if (sharded_any) {   // the proof's host exchanges in order (payload bytes): hello, the five commitment rounds, the quotient's go-ahead
+        const size_t P = sizeof(G1Jac);
+        pk->exch_sizes = {9 * sizeof(uint64_t), P * (sh.num_advice_total + 2 * sh.lookups.size()), P * (sh.num_perm_sets + sh.lookups.size() + 1)};
+        if (qshard) pk->exch_sizes.push_back(0);
+        pk->exch_sizes.push_back(P * sh.quotient_pieces);
+        pk->exch_sizes.push_back(P);
+        pk->exch_sizes.push_back(P);
+    }
     tr.common_scalar(pk->transcript_repr);   // vk.hash_into(transcript)
     // ---- instance columns: values are hashed, not committed (KZG: QUERY_INSTANCE = false)
     std::vector<Fr *> inst_values(sh.p.num_instance), adv(sh.num_advice_total);
@@ -738,6 +779,50 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(tails_flush(tails));
     }
     draw(sh.num_advice_total);   // Blind(Fr::random) per column: drawn, unused by KZG
+    if (sharded_any) {
+        // every rank must run the same proof: same shape, same RNG stream (a digest of the first column's blinding rows), and point ranges
+        // that tile [0, n) — otherwise the ranks would emit a proof that fails to verify without any of them noticing
+        struct Hello {
+            uint64_t offset, len, rank, k, ncols, digest[4];
+        } me;
+        me.offset = pk->shard_offset;
+        me.len = pk->shard_len;
+        me.rank = pk->shard_rank;
+        me.k = k;
+        me.ncols = sh.num_advice_total;
+        {
+            Blake2b h(32, "h2hip-shard-rng");
+            h.update(pk->host_stage, sizeof(Fr) * (size_t)(n - u));   // the first draw of this proof sits at the start of the staging buffer
+            uint8_t d[32];
+            h.digest(d);
+            memcpy(me.digest, d, 32);
+        }
+        std::vector<uint8_t> all;
+        H2_CHK(exchange_host(&me, sizeof(me), all));
+        std::vector<std::pair<uint64_t, uint64_t>> ranges;
+        for (uint32_t r = 0; r < pk->shard_world; ++r) {
+            Hello o;
+            memcpy(&o, all.data() + (size_t)r * (8 + sizeof(Hello)) + 8, sizeof(Hello));
+            if (o.k != me.k || o.ncols != me.ncols || memcmp(o.digest, me.digest, 32) != 0 || o.rank != r) {
+                set_error("create_proof: rank %u of the sharded proof runs a different proof (shape, rank order or RNG stream differ)", r);
+                return H2HIP_ERR_INVALID;
+            }
+            ranges.push_back({o.offset, o.len});
+        }
+        std::sort(ranges.begin(), ranges.end());
+        uint64_t pos = 0;
+        for (auto &rg : ranges) {
+            if (rg.first != pos) {
+                set_error("create_proof: the ranks' point ranges do not tile [0, 2^k)");
+                return H2HIP_ERR_INVALID;
+            }
+            pos += rg.second;
+        }
+        if (pos != n) {
+            set_error("create_proof: the ranks' point ranges do not tile [0, 2^k)");
+            return H2HIP_ERR_INVALID;
+        }
+    }
     laps.lap(ST_UPLOAD);
     // ---- lookups: permuted input / table columns.  Every lookup of halo2-base compresses a single (input, table) expression pair, so
     // theta does not enter the values: the permuted columns are computed before the advice commitments are out, and all of this round's
@@ -867,14 +952,28 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     auto to_coeff = [&](const std::vector<Fr *> &cols) -> int {
         return h2hip_ifft_batch_dev(ctx, (void *const *)cols.data(), cols.size(), &dom.omega_inv, k, &dom.ifft_divisor);
     };
+    // the shift of coset c of the extended domain: s_c = zeta * omega_e^c (rows i = (j << (ek - k)) + c are the points s_c * omega^j)
+    auto coset_shift = [&](uint32_t c) -> Fr { return fe_mul(dom.zeta, fe_pow_u64(dom.ext_omega, c)); };
     auto to_ext = [&](const std::vector<Fr *> &polys, const std::vector<Fr **> &outs) -> int {
         std::vector<void *> o(outs.size());
         for (size_t i = 0; i < outs.size(); ++i) {
-            H2_CHK(sc.take(ne, outs[i]));
+            H2_CHK(sc.take(ne_loc, outs[i]));
             o[i] = *outs[i];
         }
-        return h2hip_coeff_to_extended_batch_dev(ctx, (const void *const *)polys.data(), k, o.data(), ek, polys.size(), &dom.ext_omega, &dom.zeta);
+        if (!qshard) return h2hip_coeff_to_extended_batch_dev(ctx, (const void *const *)polys.data(), k, o.data(), ek, polys.size(), &dom.ext_omega, &dom.zeta);
+        // sharded: only this rank's cosets, each a 2^k-point transform of f(s_c X) — [coset][n] per column
+        for (size_t m = 0; m < ncm; ++m) {
+            std::vector<void *> om(outs.size());
+            for (size_t i = 0; i < outs.size(); ++i) om[i] = (Fr *)o[i] + m * (size_t)n;
+            const Fr s_c = coset_shift(pk->my_cosets[m]);
+            H2_CHK(h2hip_fr_coset_scale_batch_dev(ctx, om.data(), (const void *const *)polys.data(), polys.size(), n, &s_c));
+            H2_CHK(ntt_run_batch(ctx, (Fr *const *)om.data(), nullptr, om.size(), k, dom.omega, 0, nullptr, nullptr));
+        }
+        return H2HIP_OK;
     };
+    // the proving key's extended-domain arrays as this rank holds them
+    auto fixed_cos = [&](int col) -> const Fr * { return qshard ? pk->fixed_cosets_sh[col] : pk->fixed_cosets[col]; };
+    auto sigma_cos = [&](size_t col) -> const Fr * { return qshard ? pk->sigma_cosets_sh[col] : pk->sigma_cosets[col]; };
     struct LookupCosets {
         Fr *z, *ap, *sp, *inp;
     };
@@ -908,8 +1007,8 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         c.z = nullptr;
         c.inp = nullptr;
         if (l.q_col >= 0) {   // the product of the cosets is the coset of the product polynomial q_lookup(X) * a(X)
-            H2_CHK(sc.take(ne, &c.inp));
-            H2_CHK(h2hip_fr_mul_batch_dev(ctx, c.inp, pk->fixed_cosets[l.q_col], adv_cos[l.advice_col], ne));
+            H2_CHK(sc.take(ne_loc, &c.inp));
+            H2_CHK(h2hip_fr_mul_batch_dev(ctx, c.inp, fixed_cos(l.q_col), adv_cos[l.advice_col], qshard ? ncm * (size_t)n : ne));
         }
     }
     G1Affine random_commitment;
@@ -949,42 +1048,73 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     }
     Fr *acc = nullptr;
     H2_CHK(sc.take(ne, &acc));
-    H2_HIPCHK(hipMemsetAsync(acc, 0, sizeof(Fr) * ne, st));
+    Fr *acc_loc = acc;   // sharded: [coset][n] numerators of this rank's cosets (max_cosets slots: the all-gather's send buffer)
+    if (qshard) H2_CHK(sc.take((size_t)pk->max_cosets * n, &acc_loc));
+    H2_HIPCHK(hipMemsetAsync(acc_loc, 0, sizeof(Fr) * (qshard ? (size_t)pk->max_cosets * n : ne), st));
     if (stage_ms) laps.lap(ST_TO_EXT);
     // ---- h(X) numerator on the extended domain: the pointwise identities, folded by y in evaluate_h's order.  All gate columns, the whole
-    // permutation argument and all lookups go through batched launches (every launch reads and writes the accumulator once)
-    {
-        std::vector<const void *> gq(sh.p.num_advice), ga(sh.p.num_advice);
-        for (uint32_t a = 0; a < sh.p.num_advice; ++a) {
-            gq[a] = pk->fixed_cosets[sh.first_q_enable_col + (int)a];
-            ga[a] = adv_cos[a];
+    // permutation argument and all lookups go through batched launches (every launch reads and writes the accumulator once).
+    // One pass covers the whole extended domain (single GPU) or one coset of it (sharded: the same kernels on a 2^k-point domain with
+    // shift s_c and generator omega; `off` = the coset's offset in the [coset][n] arrays), followed by the division by X^n - 1.
+    auto quotient_pass = [&](size_t off, uint32_t ek_, const Fr &zeta_, const Fr &w_) -> int {
+        {
+            std::vector<const void *> gq(sh.p.num_advice), ga(sh.p.num_advice);
+            for (uint32_t a = 0; a < sh.p.num_advice; ++a) {
+                gq[a] = fixed_cos(sh.first_q_enable_col + (int)a) + off;
+                ga[a] = adv_cos[a] + off;
+            }
+            H2_CHK(h2hip_quotient_flex_gate_batch_dev(ctx, acc_loc + off, gq.data(), ga.data(), gq.size(), ek_, k, &y));
         }
-        H2_CHK(h2hip_quotient_flex_gate_batch_dev(ctx, acc, gq.data(), ga.data(), gq.size(), ek, k, &y));
-    }
-    if (sh.num_perm_sets) {
-        std::vector<const void *> pcols(sh.perm_columns.size()), psig(sh.perm_columns.size()), pz(perm_cos.begin(), perm_cos.end());
-        for (size_t c = 0; c < sh.perm_columns.size(); ++c) {
-            const ColumnRef &r = sh.perm_columns[c];
-            pcols[c] = r.kind == 0 ? pk->fixed_cosets[r.index] : r.kind == 1 ? adv_cos[r.index] : inst_cos[r.index];
-            psig[c] = pk->sigma_cosets[c];
+        const Fr *l0 = (qshard ? pk->l0_sh : pk->l0) + off, *l_last = (qshard ? pk->l_last_sh : pk->l_last) + off,
+                 *l_blind = (qshard ? pk->l_blind_sh : pk->l_blind) + off;
+        if (sh.num_perm_sets) {
+            std::vector<const void *> pcols(sh.perm_columns.size()), psig(sh.perm_columns.size()), pz(perm_cos.size());
+            for (size_t i = 0; i < perm_cos.size(); ++i) pz[i] = perm_cos[i] + off;
+            for (size_t c = 0; c < sh.perm_columns.size(); ++c) {
+                const ColumnRef &r = sh.perm_columns[c];
+                pcols[c] = (r.kind == 0 ? fixed_cos(r.index) : r.kind == 1 ? adv_cos[r.index] : inst_cos[r.index]) + off;
+                psig[c] = sigma_cos(c) + off;
+            }
+            H2_CHK(h2hip_quotient_permutation_sets_dev(ctx, acc_loc + off, pz.data(), sh.num_perm_sets, pcols.data(), psig.data(), (uint32_t)pcols.size(),
+                                                       sh.chunk_len, l0, l_last, l_blind, ek_, k, -(int32_t)(bf + 1), &beta, &gamma, &dom.delta, &zeta_, &w_, &y));
         }
-        H2_CHK(h2hip_quotient_permutation_sets_dev(ctx, acc, pz.data(), sh.num_perm_sets, pcols.data(), psig.data(), (uint32_t)pcols.size(), sh.chunk_len,
-                                                   pk->l0, pk->l_last, pk->l_blind, ek, k, -(int32_t)(bf + 1), &beta, &gamma, &dom.delta, &dom.zeta,
-                                                   &dom.ext_omega, &y));
-    }
-    if (!lks.empty()) {
-        std::vector<const void *> lz(lks.size()), la(lks.size()), ls(lks.size()), lap(lks.size()), lsp(lks.size());
-        for (size_t li = 0; li < lks.size(); ++li) {
-            const Lookup &l = sh.lookups[li];
-            const LookupCosets &c = lk_cos[li];
-            lz[li] = c.z;
-            la[li] = c.inp ? c.inp : adv_cos[l.advice_col];
-            ls[li] = pk->fixed_cosets[l.table_col];
-            lap[li] = c.ap;
-            lsp[li] = c.sp;
+        if (!lks.empty()) {
+            std::vector<const void *> lz(lks.size()), la(lks.size()), ls(lks.size()), lap(lks.size()), lsp(lks.size());
+            for (size_t li = 0; li < lks.size(); ++li) {
+                const Lookup &l = sh.lookups[li];
+                const LookupCosets &c = lk_cos[li];
+                lz[li] = c.z + off;
+                la[li] = (c.inp ? c.inp : adv_cos[l.advice_col]) + off;
+                ls[li] = fixed_cos(l.table_col) + off;
+                lap[li] = c.ap + off;
+                lsp[li] = c.sp + off;
+            }
+            H2_CHK(h2hip_quotient_lookups_dev(ctx, acc_loc + off, lz.data(), la.data(), ls.data(), lap.data(), lsp.data(), lks.size(), l0, l_last, l_blind, ek_,
+                                              k, &beta, &gamma, &y));
         }
-        H2_CHK(h2hip_quotient_lookups_dev(ctx, acc, lz.data(), la.data(), ls.data(), lap.data(), lsp.data(), lks.size(), pk->l0, pk->l_last, pk->l_blind, ek, k,
-                                          &beta, &gamma, &y));
+        return h2hip_divide_by_vanishing_poly_dev(ctx, acc_loc + off, ek_, k, &w_, &zeta_);   // vanishing.construct: numerator / (X^n - 1)
+    };
+    if (!qshard) {
+        H2_CHK(quotient_pass(0, ek, dom.zeta, dom.ext_omega));
+    } else {
+        for (size_t m = 0; m < ncm; ++m) {
+            const Fr s_c = coset_shift(pk->my_cosets[m]);
+            H2_CHK(quotient_pass(m * (size_t)n, k, s_c, dom.omega));
+        }
+        // every rank needs all of h's coefficients (its slices of the pieces are committed next, its evaluations opened later): one go-ahead
+        // exchange (status only), then ONE all-gather of the cosets, device to device, and the interleave into extended-domain order
+        std::vector<uint8_t> all;
+        H2_CHK(exchange_host(nullptr, 0, all));
+        Fr *gathered = nullptr;
+        const size_t slot_elems = (size_t)pk->max_cosets * n;
+        H2_CHK(sc.take(slot_elems * pk->shard_world, &gathered));
+        H2_CHK(h2hip_comm_allgather_dev(pk->comm, ctx, acc_loc, sizeof(Fr) * slot_elems, gathered));
+        const uint32_t log_c = ek - k;
+        uint32_t slots[16] = {0};
+        for (uint32_t c = 0; c < (1u << log_c); ++c) slots[c] = (c % pk->shard_world) * pk->max_cosets + c / pk->shard_world;
+        H2_CHK(h2hip_fr_coset_interleave_dev(ctx, acc, gathered, slots, log_c, n));
+        sc.release(gathered);
+        sc.release(acc_loc);
     }
     laps.lap(ST_QUOTIENT);
     for (Fr *p : perm_cos) sc.release(p);
@@ -996,8 +1126,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     }
     for (Fr *p : adv_cos) sc.release(p);
     for (Fr *p : inst_cos) sc.release(p);
-    // ---- vanishing.construct: h = numerator / (X^n - 1), back to coefficients, split into pieces, commit
-    H2_CHK(h2hip_divide_by_vanishing_poly_dev(ctx, acc, ek, k, &dom.ext_omega, &dom.zeta));
+    // ---- back to coefficients, split into pieces, commit
     H2_CHK(h2hip_extended_to_coeff_dev(ctx, acc, ek, &dom.ext_omega_inv, &dom.ext_ifft_divisor, &dom.zeta_inv));
     laps.lap(ST_H_COEFF);
     draw(sh.quotient_pieces);   // h_blinds
@@ -1289,6 +1418,7 @@ void h2hip_plonk_pk_free(h2hip_ctx *ctx, h2hip_plonk_pk *pk) {
     if (!pk) return;
     if (ctx) hipStreamSynchronize(ctx->stream);
     for (void *p : pk->owned) hipFree(p);
+    for (void *p : pk->shard_owned) hipFree(p);
     if (pk->host_stage) hipHostFree(pk->host_stage);
     if (pk->copy_ev) hipEventDestroy(pk->copy_ev);
     if (pk->copy_stream) hipStreamDestroy(pk->copy_stream);
@@ -1311,25 +1441,67 @@ int h2hip_plonk_pk_set_transcript_repr(h2hip_plonk_pk *pk, const void *fr) {
     return H2HIP_OK;
 }
 
-int h2hip_plonk_pk_set_msm_sharding(h2hip_plonk_pk *pk, const h2hip_bases *g_shard, const h2hip_bases *g_lagrange_shard, size_t offset, size_t len,
-                                    uint32_t world, h2hip_allgather_fn allgather, void *user) {
+static void shard_release(h2hip_plonk_pk *pk) {
+    if (pk->ctx) hipStreamSynchronize(pk->ctx->stream);
+    for (void *q : pk->shard_owned) hipFree(q);
+    pk->shard_owned.clear();
+    pk->fixed_cosets_sh.clear();
+    pk->sigma_cosets_sh.clear();
+    pk->l0_sh = pk->l_last_sh = pk->l_blind_sh = nullptr;
+    pk->my_cosets.clear();
+    pk->shard_world = 1;
+    pk->shard_rank = 0;
+    pk->g_shard = pk->g_lagrange_shard = nullptr;
+    pk->comm = nullptr;
+    pk->shard_quotient = false;
+}
+
+int h2hip_plonk_pk_set_sharding(h2hip_plonk_pk *pk, h2hip_comm *comm, const h2hip_bases *g_shard, const h2hip_bases *g_lagrange_shard, size_t offset,
+                                size_t len, uint32_t flags) {
     H2_REQUIRE(pk, "NULL argument");
-    if (world <= 1) {
-        pk->shard_world = 1;
-        pk->g_shard = pk->g_lagrange_shard = nullptr;
-        pk->allgather = nullptr;
-        return H2HIP_OK;
-    }
-    H2_REQUIRE(g_shard && g_lagrange_shard && allgather, "NULL argument");
+    H2_DEVICE_GUARD(pk->ctx);
+    shard_release(pk);
+    int world = 1, rank = 0;
+    if (comm) H2_CHK(h2hip_comm_info(comm, &world, &rank, nullptr));
+    if (!comm || (world <= 1 && !(flags & H2HIP_SHARD_FORCE))) return H2HIP_OK;
+    H2_REQUIRE(g_shard && g_lagrange_shard, "NULL argument");
     H2_REQUIRE(offset + len <= pk->sh.n && g_shard->n >= len && g_lagrange_shard->n >= len, "shard range outside the SRS / shard base sets too small");
     pk->g_shard = g_shard;
     pk->g_lagrange_shard = g_lagrange_shard;
     pk->shard_offset = offset;
     pk->shard_len = len;
-    pk->shard_world = world;
-    pk->allgather = allgather;
-    pk->allgather_user = user;
-    return H2HIP_OK;
+    pk->shard_world = (uint32_t)world;
+    pk->shard_rank = (uint32_t)rank;
+    pk->comm = comm;
+    pk->shard_quotient = (flags & H2HIP_SHARD_QUOTIENT) != 0;
+    if (!pk->shard_quotient) return H2HIP_OK;
+    // this rank's cosets of the extended domain: c = rank, rank + world, ... < 2^(ek - k), and the [coset][n] slices of the key's arrays
+    const uint32_t log_c = pk->sh.extended_k - pk->sh.k, ncos = 1u << log_c, n = pk->sh.n;
+    H2_REQUIRE(log_c <= 4, "more than 16 cosets");
+    for (uint32_t c = (uint32_t)rank; c < ncos; c += (uint32_t)world) pk->my_cosets.push_back(c);
+    pk->max_cosets = (ncos + (uint32_t)world - 1) / (uint32_t)world;
+    const size_t cnt = pk->my_cosets.size(), elems = std::max<size_t>(cnt * (size_t)n, 1);
+    auto slice = [&](const Fr *full, Fr **out) -> int {
+        void *d = nullptr;
+        if (hipMalloc(&d, sizeof(Fr) * elems) != hipSuccess) {
+            set_error("hipMalloc for the sharded proving key failed");
+            return H2HIP_ERR_NOMEM;
+        }
+        pk->shard_owned.push_back(d);
+        *out = (Fr *)d;
+        return h2hip_fr_coset_gather_dev(pk->ctx, d, full, pk->my_cosets.data(), (uint32_t)cnt, log_c, n);
+    };
+    int rc = H2HIP_OK;
+    pk->fixed_cosets_sh.assign(pk->fixed_cosets.size(), nullptr);
+    pk->sigma_cosets_sh.assign(pk->sigma_cosets.size(), nullptr);
+    for (size_t i = 0; rc == H2HIP_OK && i < pk->fixed_cosets.size(); ++i) rc = slice(pk->fixed_cosets[i], &pk->fixed_cosets_sh[i]);
+    for (size_t i = 0; rc == H2HIP_OK && i < pk->sigma_cosets.size(); ++i) rc = slice(pk->sigma_cosets[i], &pk->sigma_cosets_sh[i]);
+    if (rc == H2HIP_OK) rc = slice(pk->l0, &pk->l0_sh);
+    if (rc == H2HIP_OK) rc = slice(pk->l_last, &pk->l_last_sh);
+    if (rc == H2HIP_OK) rc = slice(pk->l_blind, &pk->l_blind_sh);
+    if (rc == H2HIP_OK && hipStreamSynchronize(pk->ctx->stream) != hipSuccess) rc = H2HIP_ERR_HIP;
+    if (rc != H2HIP_OK) shard_release(pk);
+    return rc;
 }
 
 void h2hip_array_rng_fill(void *user, void *out_fr, size_t n) {
@@ -1361,6 +1533,18 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     if (rc != H2HIP_OK) {
         if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
         hipStreamSynchronize(ctx->stream);   // nothing of the failed proof may still run on buffers that go back to the pool
+        if (rc != H2HIP_ERR_PEER && pk->comm && pk->exch_next < pk->exch_sizes.size()) {
+            // a sharded proof failed HERE (a lookup value missing from the table, an identity commitment, an allocation ...): the other
+            // ranks are on their way into the next exchange — take part in it with an error status so that all of them return too
+            const std::string msg = h2hip_last_error();
+            const size_t bytes = 8 + pk->exch_sizes[pk->exch_next];
+            std::vector<uint8_t> send(bytes, 0), all(bytes * (size_t)pk->shard_world);
+            const uint64_t status = 1;
+            memcpy(send.data(), &status, 8);
+            h2hip_comm_allgather_host(pk->comm, ctx, send.data(), bytes, all.data());
+            pk->exch_next = pk->exch_sizes.size();
+            set_error("%s", msg.c_str());
+        }
         return rc;
     }
     if (proof.size() != need) {

@@ -105,6 +105,50 @@ static Fr ld(const void *p) {
 
 using namespace h2;
 
+// ---------------------------------------------------------------------------------------------- cosets of the extended domain (multi-GPU)
+// The extended domain zeta * <omega_e> of size 2^ek splits into 2^(ek-k) cosets of the ORIGINAL domain: rows i = (j << (ek-k)) + c hold the
+// evaluations at s_c * omega^j with s_c = zeta * omega_e^c.  Every identity of h(X) is pointwise up to rotations by omega, which stay inside
+// a coset — so a rank of the sharded prover evaluates whole cosets with the ordinary 2^k-point kernels (ek := k, zeta := s_c, omega_e := omega).
+constexpr uint32_t COSET_BATCH = 32;
+struct CosetScaleArgs {
+    const Fr *in[COSET_BATCH];
+    Fr *out[COSET_BATCH];
+    Fr sblock;   // s^(elements per lane)
+};
+// out[col][t] = in[col][t] * s^t: the coefficients of f(s X).  Four consecutive coefficients per lane; s^(4 i0) by square-and-multiply.
+__global__ __launch_bounds__(256) void coset_scale_kernel(CosetScaleArgs g, Fr s, size_t n) {
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    const Fr *in = g.in[blockIdx.y];
+    Fr *out = g.out[blockIdx.y];
+    Fr p = fe_pow_u64(s, (uint64_t)i0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j < n) out[i0 + j] = fe_mul(in[i0 + j], p);
+        p = fe_mul(p, s);
+    }
+}
+// out[m * n + j] = in[(j << log_c) + cosets[m]]   (the rank's cosets of a 2^ek-point array, each contiguous)
+struct CosetList {
+    uint32_t c[16];
+    uint32_t count;
+};
+__global__ __launch_bounds__(256) void coset_gather_kernel(Fr *__restrict__ out, const Fr *__restrict__ in, CosetList cl, uint32_t log_c, size_t n) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    for (uint32_t m = 0; m < cl.count; ++m) out[(size_t)m * n + j] = in[(j << log_c) + cl.c[m]];
+}
+// out[(j << log_c) + c] = in[slot(c) * n + j] for every coset c < 2^log_c; slot(c) = position of coset c in the all-gathered buffer
+struct CosetSlots {
+    uint32_t slot[16];
+};
+__global__ __launch_bounds__(256) void coset_interleave_kernel(Fr *__restrict__ out, const Fr *__restrict__ in, CosetSlots sl, uint32_t log_c, size_t n) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t nc = 1u << log_c;
+    for (uint32_t c = 0; c < nc; ++c) out[(j << log_c) + c] = in[(size_t)sl.slot[c] * n + j];
+}
+
 extern "C" {
 
 int h2hip_permutation_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
@@ -206,6 +250,60 @@ int h2hip_assigned_resolve_dev(h2hip_ctx *ctx, void *out_dev, const void *num_de
     if (out_dev != den_dev) H2_HIPCHK(hipMemcpyAsync(out_dev, den_dev, sizeof(Fr) * n, hipMemcpyDeviceToDevice, ctx->stream));
     H2_CHK(h2hip_fr_batch_invert_dev(ctx, out_dev, n));
     return h2hip_fr_mul_batch_dev(ctx, out_dev, out_dev, num_dev, n);
+}
+
+// f(X) -> f(s X) in coefficient form for `count` columns of n coefficients (out may alias in): the first half of a coset evaluation
+int h2hip_fr_coset_scale_batch_dev(h2hip_ctx *ctx, void *const *outs_dev, const void *const *ins_dev, size_t count, size_t n, const void *s) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && s && (count == 0 || (outs_dev && ins_dev)), "NULL argument");
+    if (!n) return H2HIP_OK;
+    Fr sv;
+    memcpy(&sv, s, sizeof(Fr));
+    for (size_t c0 = 0; c0 < count; c0 += COSET_BATCH) {
+        const uint32_t cc = (uint32_t)(count - c0 < COSET_BATCH ? count - c0 : COSET_BATCH);
+        CosetScaleArgs g;
+        for (uint32_t j = 0; j < COSET_BATCH; ++j) {
+            g.in[j] = j < cc ? (const Fr *)ins_dev[c0 + j] : nullptr;
+            g.out[j] = j < cc ? (Fr *)outs_dev[c0 + j] : nullptr;
+            H2_REQUIRE(j >= cc || (g.in[j] && g.out[j]), "NULL column");
+        }
+        g.sblock = Fr::one();
+        prof_begin(ctx, "coset_scale_kernel");
+        hipLaunchKernelGGL(coset_scale_kernel, dim3((uint32_t)(((n + 3) / 4 + 255) / 256), cc), dim3(256), 0, ctx->stream, g, sv, n);
+        prof_end(ctx);
+    }
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+// the listed cosets (count <= 16, each < 2^log_cosets) of a (n << log_cosets)-point array, one after the other in out (count * n elements)
+int h2hip_fr_coset_gather_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, const uint32_t *cosets, uint32_t count, uint32_t log_cosets, size_t n) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && (count == 0 || (out_dev && in_dev && cosets)) && count <= 16 && log_cosets <= 4, "bad argument");
+    if (!count || !n) return H2HIP_OK;
+    CosetList cl;
+    cl.count = count;
+    for (uint32_t m = 0; m < 16; ++m) {
+        cl.c[m] = m < count ? cosets[m] : 0;
+        H2_REQUIRE(cl.c[m] < (1u << log_cosets), "coset index out of range");
+    }
+    prof_begin(ctx, "coset_gather_kernel");
+    hipLaunchKernelGGL(coset_gather_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr *)out_dev, (const Fr *)in_dev, cl, log_cosets, n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+// the inverse: coset c of the (n << log_cosets)-point array out comes from in[slots[c] * n ...]
+int h2hip_fr_coset_interleave_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, const uint32_t *slots, uint32_t log_cosets, size_t n) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && out_dev && in_dev && slots && log_cosets <= 4, "bad argument");
+    if (!n) return H2HIP_OK;
+    CosetSlots sl;
+    for (uint32_t c = 0; c < 16; ++c) sl.slot[c] = c < (1u << log_cosets) ? slots[c] : 0;
+    prof_begin(ctx, "coset_interleave_kernel");
+    hipLaunchKernelGGL(coset_interleave_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr *)out_dev, (const Fr *)in_dev, sl, log_cosets, n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
 }
 
 }  // extern "C"

@@ -105,7 +105,17 @@ _PROTOS = {
     "h2hip_plonk_pk_free": (None, [_vp, _vp]),
     "h2hip_plonk_pk_commitments": (_int, [_vp, _vp, _vp]),
     "h2hip_plonk_pk_set_transcript_repr": (_int, [_vp, _vp]),
-    "h2hip_plonk_pk_set_msm_sharding": (_int, [_vp, _vp, _vp, _sz, _sz, _u32, _vp, _vp]),
+    "h2hip_plonk_pk_set_sharding": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _u32]),
+    "h2hip_comm_rccl_unique_id": (_int, [_vp]),
+    "h2hip_comm_init_rccl": (_int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
+    "h2hip_comm_init_callback": (_int, [_int, _int, _vp, _vp, C.POINTER(_vp)]),
+    "h2hip_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
+    "h2hip_comm_destroy": (None, [_vp]),
+    "h2hip_comm_allgather_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "h2hip_comm_allgather_host": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "h2hip_fr_coset_scale_batch_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _sz, _sz, _vp]),
+    "h2hip_fr_coset_gather_dev": (_int, [_vp, _vp, _vp, C.POINTER(_u32), _u32, _u32, _sz]),
+    "h2hip_fr_coset_interleave_dev": (_int, [_vp, _vp, _vp, C.POINTER(_u32), _u32, _sz]),
     "h2hip_plonk_stage_name": (C.c_char_p, [_int]),
     "h2hip_plonk_create_proof": (_int, [_vp, _vp, C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_sz), _vp, _vp, _vp, _sz, C.POINTER(_sz),
                                         C.POINTER(C.c_double)]),

@@ -8,8 +8,9 @@ over xGMI on ROCm; "gloo" in CPU tests).
 * NTT — independent columns are dealt round-robin to ranks (`columns_for_rank`); `sharded_ntt_columns` runs each rank's transforms
   on its own GPU and leaves the results there (where the matching commitments / quotient terms are computed), or, on request,
   all-gathers them so that every rank holds every transformed column.
-* create_proof — `shard_proving_key` switches a proving key's commitments to point-range sharding (h2hip_plonk_pk_set_msm_sharding):
-  all ranks run the same create_proof call; each MSM round costs one all-gather of 96-byte partials.
+* create_proof — `shard_proving_key` (h2hip_plonk_pk_set_sharding): all ranks run the same create_proof call; commitments are point-range
+  sharded (one all-gather of 96-byte partials per round), h(X)'s numerator is evaluated by cosets of the extended domain (one
+  device-to-device all-gather); the exchange is libh2hip's own (`Comm`: RCCL via dlopen, or a torch.distributed callback).
 """
 from __future__ import annotations
 
@@ -142,25 +143,79 @@ def sharded_ntt_columns(ctx: Context, columns, transform, group=None, gather: bo
     return out
 
 
-class ShardedKey:
-    """keeps the shard base sets and the all-gather callback of a sharded proving key alive"""
+class Comm:
+    """h2hip_comm: the exchange step of the sharded prover inside libh2hip.  `rccl=True`: an RCCL communicator of the library's own
+    (librccl is dlopen'ed by libh2hip; the 128-byte id travels from rank 0 over torch.distributed's object broadcast) — device-to-device
+    all-gathers over xGMI on the context's stream.  Otherwise a callback transport over torch.distributed's all_gather on host tensors
+    (gloo: the CPU tests; also usable with any backend)."""
 
-    def __init__(self, pk, g_shard, g_lagrange_shard, callback):
-        self.pk, self.g_shard, self.g_lagrange_shard, self.callback = pk, g_shard, g_lagrange_shard, callback
+    def __init__(self, ctx: Context, group=None, rccl: bool = False, device=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        self.ctx, self.handle, self._cb = ctx, C.c_void_p(), None
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        self.world, self.rank = world, rank
+        if rccl:
+            uid = (C.c_uint8 * 128)()
+            if rank == 0:
+                ctx._chk(ctx.lib.h2hip_comm_rccl_unique_id(uid))
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group, device=device)
+            ctx._chk(ctx.lib.h2hip_comm_init_rccl(ctx.handle, box[0], world, rank, C.byref(self.handle)))
+            return
+
+        def _allgather(_user, local, nbytes, out):
+            try:
+                buf = (C.c_uint8 * nbytes).from_address(local)
+                t = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+                if device is not None:
+                    t = t.to(device)
+                gathered = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(gathered, t, group=group)
+                flat = torch.cat(gathered).cpu().numpy()
+                C.memmove(out, flat.ctypes.data, nbytes * world)
+                return 0
+            except BaseException:   # never unwind through the C frames
+                return 1
+
+        self._cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)(_allgather)
+        ctx._chk(ctx.lib.h2hip_comm_init_callback(world, rank, C.cast(self._cb, C.c_void_p), None, C.byref(self.handle)))
+
+    def allgather_dev(self, send_dptr: int, nbytes: int, recv_dptr: int):
+        self.ctx._chk(self.ctx.lib.h2hip_comm_allgather_dev(self.handle, self.ctx.handle, send_dptr, nbytes, recv_dptr))
+
+    def destroy(self):
+        if self.handle:
+            self.ctx.lib.h2hip_comm_destroy(self.handle)
+            self.handle = None
+
+
+SHARD_QUOTIENT = 1
+
+
+class ShardedKey:
+    """keeps the shard base sets and the communicator of a sharded proving key alive"""
+
+    def __init__(self, pk, g_shard, g_lagrange_shard, comm):
+        self.pk, self.g_shard, self.g_lagrange_shard, self.comm = pk, g_shard, g_lagrange_shard, comm
 
     def free(self):
-        self.pk.ctx._chk(self.pk.ctx.lib.h2hip_plonk_pk_set_msm_sharding(self.pk.handle, None, None, 0, 0, 1, None, None))
+        self.pk.ctx._chk(self.pk.ctx.lib.h2hip_plonk_pk_set_sharding(self.pk.handle, None, None, None, 0, 0, 0))
         self.g_shard.free()
         self.g_lagrange_shard.free()
+        self.comm.destroy()
 
 
-def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, group=None, device=None, precompute: bool = True) -> ShardedKey:
-    """Point-range sharding of a proving key's commitments over the process group: this rank uploads ONLY its slice of the SRS
-    (g_points / g_lagrange_points: the full (n, 8) affine arrays or anything sliceable that yields them) as base sets with their own window
-    tables, and installs an all-gather over torch.distributed ("nccl" = RCCL with `device`, "gloo" on the CPU) as the exchange step."""
-    import ctypes as C
-
-    import torch
+def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, group=None, device=None, precompute: bool = True,
+                      rccl: bool = None, shard_quotient: bool = True) -> ShardedKey:
+    """Shards a proving key's create_proof over the process group (h2hip_plonk_pk_set_sharding): this rank uploads ONLY its point range of
+    the SRS (g_points / g_lagrange_points: the full (n, 8) affine arrays or anything sliceable that yields them) as base sets with their own
+    window tables; h(X)'s numerator is evaluated by cosets of the extended domain (shard_quotient).  The exchange runs inside libh2hip:
+    over its own RCCL communicator when the process group's backend is nccl (rccl=None: decided from the backend), else over a
+    torch.distributed callback (gloo on the CPU)."""
     import torch.distributed as dist
 
     from .h2hip import BASES_PLAIN, BASES_PRECOMPUTE
@@ -170,24 +225,11 @@ def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, g
     n = 1 << pk.params.k
     lo, hi = shard_range(n, rank, world)
     ctx = pk.ctx
+    if rccl is None:
+        rccl = dist.get_backend(group) == "nccl"
+    comm = Comm(ctx, group=group, rccl=rccl, device=device)
     flags = BASES_PRECOMPUTE if precompute else BASES_PLAIN
     gs = ctx.bases_upload(np.ascontiguousarray(g_points[lo:hi]), flags)
     gls = ctx.bases_upload(np.ascontiguousarray(g_lagrange_points[lo:hi]), flags)
-
-    def _allgather(_user, local, nbytes, out):
-        try:
-            buf = (C.c_uint8 * nbytes).from_address(local)
-            t = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
-            if device is not None:
-                t = t.to(device)
-            gathered = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(gathered, t, group=group)
-            flat = torch.cat(gathered).cpu().numpy()
-            C.memmove(out, flat.ctypes.data, nbytes * world)
-            return 0
-        except BaseException:   # never unwind through the C frames
-            return 1
-
-    cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)(_allgather)
-    ctx._chk(ctx.lib.h2hip_plonk_pk_set_msm_sharding(pk.handle, gs.handle, gls.handle, lo, hi - lo, world, C.cast(cb, C.c_void_p), None))
-    return ShardedKey(pk, gs, gls, cb)
+    ctx._chk(ctx.lib.h2hip_plonk_pk_set_sharding(pk.handle, comm.handle, gs.handle, gls.handle, lo, hi - lo, SHARD_QUOTIENT if shard_quotient else 0))
+    return ShardedKey(pk, gs, gls, comm)

@@ -37,6 +37,7 @@ extern "C" {
 #define H2HIP_ERR_HIP (-2)       /* HIP runtime / kernel launch failure */
 #define H2HIP_ERR_NOMEM (-3)
 #define H2HIP_ERR_NO_DEVICE (-4)
+#define H2HIP_ERR_PEER (-5)      /* another rank of a sharded (multi-GPU) call reported an error: every rank returns */
 
 #define H2HIP_POINT_JACOBIAN 0   /* 96 B, what best_multiexp returns (C::Curve) */
 #define H2HIP_POINT_AFFINE 1     /* 64 B, normalised on the device (one field inversion) */
@@ -376,15 +377,49 @@ int h2hip_plonk_pk_commitments(const h2hip_plonk_pk *pk, void *fixed_out, void *
 /* vk.transcript_repr — upstream hashes the Debug rendering of the pinned key; it is computed by the Rust side and handed over */
 int h2hip_plonk_pk_set_transcript_repr(h2hip_plonk_pk *pk, const void *fr);
 
-/* Multi-GPU (one process per GPU): every commitment of create_proof becomes a partial MSM over this rank's point range
- * [offset, offset + len) of the SRS — g_shard / g_lagrange_shard hold just that slice (1/N of the table memory) — followed by ONE
- * all-gather of the 96-byte Jacobian partials per commitment round and an N-term sum on the host (RCCL has no group-law reduction).
- * allgather(user, local, bytes, all): gather `bytes` from every rank into all[rank * bytes ...], return 0; the host library above
- * implements it with its collective of choice (torch.distributed / RCCL over xGMI).  All ranks run the same create_proof call on the
- * same inputs and emit identical proof bytes.  world <= 1 switches sharding off. */
+/* ---- multi-GPU: one process per GPU (north star: "MSM ranges and independent transforms shard across the 8 GPUs of one node
+ * with RCCL over xGMI").  h2hip_comm is the exchange step, inside the library so that the Rust host needs no collective library of its own:
+ *   - RCCL transport: librccl.so is dlopen'ed on first use (libh2hip does not link it); rank 0 obtains a 128-byte id with
+ *     h2hip_comm_rccl_unique_id and hands it to the other ranks over any channel the host has; h2hip_comm_init_rccl is collective.
+ *     ncclAllGather then runs on the context's stream over device buffers (xGMI peer-to-peer, no host staging);
+ *   - callback transport: allgather(user, local, bytes, all) gathers `bytes` of host memory from every rank into all[rank * bytes ...] and
+ *     returns 0 — torch.distributed / gloo in the CPU tests, MPI, ...; device payloads are staged through pinned memory.
+ * The reference has no counterpart (single process, rayon threads). */
+typedef struct h2hip_comm h2hip_comm;
 typedef int (*h2hip_allgather_fn)(void *user, const void *local, size_t bytes, void *all);
-int h2hip_plonk_pk_set_msm_sharding(h2hip_plonk_pk *pk, const h2hip_bases *g_shard, const h2hip_bases *g_lagrange_shard, size_t offset, size_t len,
-                                    uint32_t world, h2hip_allgather_fn allgather, void *user);
+int h2hip_comm_rccl_unique_id(void *out128);
+int h2hip_comm_init_rccl(h2hip_ctx *ctx, const void *unique_id128, int world, int rank, h2hip_comm **out);
+int h2hip_comm_init_callback(int world, int rank, h2hip_allgather_fn allgather, void *user, h2hip_comm **out);
+int h2hip_comm_info(const h2hip_comm *comm, int *world, int *rank, int *is_rccl);
+void h2hip_comm_destroy(h2hip_comm *comm);
+/* recv[r * bytes ...] = rank r's send[0 .. bytes): device buffers, ordered on the context's stream (RCCL: queued there, returns at once) /
+ * host buffers (the 96-byte commitment partials of a round; RCCL: staged through device memory) */
+int h2hip_comm_allgather_dev(h2hip_comm *comm, h2hip_ctx *ctx, const void *send_dev, size_t bytes, void *recv_dev);
+int h2hip_comm_allgather_host(h2hip_comm *comm, h2hip_ctx *ctx, const void *send_host, size_t bytes, void *recv_host);
+
+/* Sharded create_proof: all ranks run the same h2hip_plonk_create_proof call on the same inputs (same circuit, same RNG stream) and emit
+ * identical proof bytes.
+ *   - every commitment is a partial MSM over this rank's point range [offset, offset + len) of the SRS — g_shard / g_lagrange_shard hold
+ *     just that slice (1/N of the table memory) — followed by ONE all-gather of the 96-byte Jacobian partials per commitment round and
+ *     an N-term sum (RCCL has no group-law reduction);
+ *   - with H2HIP_SHARD_QUOTIENT, h(X)'s numerator is evaluated by cosets: the extended domain of 2^(ek-k) cosets of the original domain is
+ *     dealt round-robin to the ranks (coset c to rank c mod N), each rank runs coeff_to_extended and the quotient identities for its
+ *     cosets only (identities are pointwise up to rotations, which stay inside a coset), ONE device-to-device all-gather (2^ek x 32 B in
+ *     total) precedes extended_to_coeff.  Ranks >= 2^(ek-k) take no part in this stage.
+ *   - replicated on every rank: uploads, lookup permutation, grand products, lagrange_to_coeff, evaluations, SHPLONK's pointwise work.
+ * Safety: at its first exchange a proof checks that all ranks agree on the shape and the RNG stream and that the point ranges tile
+ * [0, 2^k) (H2HIP_ERR_INVALID otherwise); every host exchange carries a status word, and a rank that fails takes part in the next
+ * exchange with an error status, so that all ranks return (H2HIP_ERR_PEER on the others) instead of waiting in a collective.
+ * comm == NULL or world 1 switches sharding off.  The bases and the communicator must outlive the key (or the next set_sharding call). */
+#define H2HIP_SHARD_QUOTIENT 1u
+#define H2HIP_SHARD_FORCE 2u /* run the sharded code path even with a one-rank communicator (tests: a 1-GPU box exercises RCCL and the coset kernels) */
+int h2hip_plonk_pk_set_sharding(h2hip_plonk_pk *pk, h2hip_comm *comm, const h2hip_bases *g_shard, const h2hip_bases *g_lagrange_shard, size_t offset,
+                                size_t len, uint32_t flags);
+/* coefficient / extended-domain helpers of the sharded prover: f(X) -> f(s X) for `count` columns of n coefficients; the listed cosets
+ * (count <= 16) of an (n << log_cosets)-point array one after the other; and the inverse with slots[c] = position of coset c in `in` */
+int h2hip_fr_coset_scale_batch_dev(h2hip_ctx *ctx, void *const *outs_dev, const void *const *ins_dev, size_t count, size_t n, const void *s);
+int h2hip_fr_coset_gather_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, const uint32_t *cosets, uint32_t count, uint32_t log_cosets, size_t n);
+int h2hip_fr_coset_interleave_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, const uint32_t *slots, uint32_t log_cosets, size_t n);
 
 /* `Fr::random(rng)` x n into out (Montgomery limbs); called in upstream's draw order */
 typedef void (*h2hip_rng_fill_fn)(void *user, void *out_fr, size_t n);

@@ -144,3 +144,90 @@ def test_sharded_create_proof_and_ntt_columns_world2():
         assert p.exitcode == 0
     assert all(r[1] and r[2] and r[3] for r in res), res
     assert res[0][4] == res[1][4]   # both ranks emit the same proof
+
+
+def _worker_scenarios(rank, world, port, q):
+    """sharded create_proof beyond the plain case: uneven coset / point-range splits (world 3: four cosets dealt 2 + 1 + 1), the single-column
+    q_lookup shape (degree 5: the product coset q_lookup * a), MSM-only sharding, and the failure protocol — a rank whose witness misses
+    the lookup table, or whose RNG stream differs, makes EVERY rank return an error instead of leaving the others in a collective"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import halo2_lib_amd as H
+        from halo2_lib_amd import halo2_proofs as HP
+        from halo2_lib_amd import plonk as PL
+        from halo2_lib_amd import testing as T
+        from halo2_lib_amd.multi_gpu import shard_proving_key
+        from oracle import bn254 as O
+        from oracle import plonk as P
+        from tests.emu_util import emu_context
+        from tests.test_plonk_prover import _OracleBackend, _rng_budget
+        from tests.util import PreDrawnRng
+
+        ctx = emu_context()
+        out = {}
+        for name, shape in (("multi", (6, 2, 1, 1, 1, 4)), ("single", (6, 1, 1, 1, 0, 4))):
+            sh = P.Shape(*shape)
+            kzg = HP.ParamsKZG.setup(ctx, shape[0], 0xABCDEF0123, precompute=False)
+            circ = T.build_circuit(sh, 4, _OracleBackend)
+            pk = PL.keygen(kzg, PL.BaseCircuitParams.new(*shape), circ.fixed, circ.copies)
+            budget = _rng_budget(sh)
+            single = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9))
+            g, gl = ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange)
+            sk = shard_proving_key(pk, g, gl, precompute=False)
+            out[name] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
+            if name == "multi":
+                # a witness outside the lookup table on ONE rank: that rank reports the cause, the others H2HIP_ERR_PEER; nobody hangs
+                adv = [np.array(c) for c in circ.advice]
+                if rank == world - 1:
+                    adv[sh.lookup_advice[0]][0] = O.ints_to_limbs([(1 << 4) + 3], O.R_MOD)[0]
+                try:
+                    PL.create_proof(pk, adv, circ.instances, PreDrawnRng(budget, 9))
+                    out["fail"] = "no error"
+                except H.H2HipError as e:
+                    out["fail"] = e.code
+                # the key still proves afterwards
+                out["after_fail"] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
+                # ranks on different RNG streams: caught at the first exchange on every rank
+                try:
+                    PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9 + (rank == 0)))
+                    out["rng"] = "no error"
+                except H.H2HipError as e:
+                    out["rng"] = e.code
+                out["after_rng"] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
+            sk.free()
+            if name == "multi":   # commitments only (h(X) replicated)
+                sk = shard_proving_key(pk, g, gl, precompute=False, shard_quotient=False)
+                out["msm_only"] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
+                sk.free()
+            out[name + "_unsharded_again"] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
+            pk.free()
+            kzg.free()
+        q.put((rank, out))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_create_proof_scenarios(world):
+    from tests.emu_util import emu_context
+
+    emu_context().close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker_scenarios, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        o = res[r]
+        assert o["multi"] and o["single"] and o["msm_only"] and o["multi_unsharded_again"] and o["single_unsharded_again"], (r, o)
+        assert o["after_fail"] and o["after_rng"], (r, o)
+        assert o["fail"] == (-1 if r == world - 1 else -5), (r, o)     # H2HIP_ERR_INVALID where the witness is wrong, H2HIP_ERR_PEER elsewhere
+        assert o["rng"] == -1, (r, o)                                   # every rank sees the mismatch in the hello exchange
