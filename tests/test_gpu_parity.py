@@ -426,3 +426,24 @@ def test_msm_g2(ctx):
     from tests.test_emu_kernels import _g2_msm_checks
 
     _g2_msm_checks(ctx, [1, 37, 300, 5000])
+
+
+@pytest.mark.gpu
+def test_fp64_fma_multiplier_probe_is_a_correct_montgomery_product():
+    """the 5 x 52-bit FP64-FMA multiplier microbenchmark (h2hip_bench_modmul52) computes what it claims —
+    x_{t+1} = x_t * y * 2^-260 mod r — so that its measured rate is the rate of a real 254-bit Montgomery product"""
+    ctx = H.Context()
+    try:
+        y = sum(v << (52 * i) for i, v in enumerate([0x9e3779b97f4a7, 0x3c6ef372fe94f, 0x54ff53a5f1d36, 0x10e527fade682, 0x1f83d9abfb41]))
+        rinv = pow(1 << 260, -1, R)
+        for iters in (1, 2, 37):
+            ms, n, limbs = ctx.bench_modmul52(1, iters, 1)
+            got = sum(v << (52 * i) for i, v in enumerate(limbs))
+            want = y
+            for _ in range(iters):
+                want = want * y * rinv % R
+            assert got % R == want and got < 4 * R and all(v < (1 << 53) for v in limbs), (iters, hex(got), hex(want))
+        ms, n, _ = ctx.bench_modmul52(4096, 64, 2)
+        assert n == 4096 * 256 * 64 * 2 and ms > 0
+    finally:
+        ctx.close()
