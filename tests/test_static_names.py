@@ -72,3 +72,13 @@ def test_no_unbound_names(path):
     problems = []
     _check_scope(tree, set(dir(builtins)) | {"__file__", "__name__", "__doc__"}, problems, path)
     assert not problems, "\n".join(problems)
+
+
+def test_recall_table_is_current():
+    """the [UPSTREAM-RECALL] table names the product and oracle lines to change per recalled statement; its locations are
+    found by anchor strings (tools/recall_table.py) and must match the committed text"""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "recall_table.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
