@@ -922,6 +922,9 @@ int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t c, const 
     const XYZZ29 *red_in = buckets;
     if (precomp && rows > 1) {
         prof_begin(ctx, "msm_presum_kernel");
+        // (a quad-lane tree version — four quads per bucket index, two LDS levels — measured slower: 0.075 vs 0.072 ms for one column and
+        // 0.87 vs 0.53 ms per proof for the 3-4 column rounds: with 16Ki x columns independent chains this stage is throughput-bound, and a
+        // quad addition spends 16 lane-products plus its DPP traffic on the 14 products of the addition)
         if (rows <= 4) {
             hipLaunchKernelGGL(msm_presum_kernel, dim3((B + 63) / 64, ncols), dim3(64), 0, st, buckets, presum, B, rows, rows);
         } else {

@@ -15,12 +15,13 @@ def main():
     rows = [(n.split("(")[0].replace("void ", "").replace("h2::", ""), s, e) for n, s, e in rows]
     # a proof's first kernel is the q_lookup * advice product (fr_binop_kernel<2>) right before the lookup's key extraction (lk_keys_kernel)
     marks = [i for i, r in enumerate(rows) if "modmul_bench_kernel" in r[0]]
-    if marks:   # tools/prove_time.py launches the multiplier probe right before its last proof
+    if marks and any("lk_keys_kernel" in r[0] for r in rows[marks[-1] + 1:]):   # tools/prove_time.py launches the multiplier probe right before its last proof
         sel = rows[marks[-1] + 1:]
     else:
         last_keys = max(i for i, r in enumerate(rows) if "lk_keys_kernel" in r[0])
         first = max(i for i, r in enumerate(rows[:last_keys]) if "fr_binop_kernel<2>" in r[0])
-        sel = rows[first:]
+        end = min([i for i, r in enumerate(rows) if i > last_keys and "modmul" in r[0]] + [len(rows)])   # bench.py runs the multiplier probes after its last proof
+        sel = rows[first:end]
     t0, t1 = sel[0][1], max(r[2] for r in sel)
     agg = {}
     for n, s, e in sel:
