@@ -23,6 +23,7 @@ int ws_reserve(h2hip_ctx *ctx, int slot, size_t bytes, void **out) {
     if (b.cap < bytes) {
         if (b.p) {
             H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->clean_stream) H2_HIPCHK(hipStreamSynchronize(ctx->clean_stream));   // a pending zero-fill of this buffer
             H2_HIPCHK(hipFree(b.p));
             b.p = nullptr;
             b.cap = 0;
@@ -230,6 +231,12 @@ void h2hip_destroy(h2hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->clean_stream) {
+        hipStreamSynchronize(ctx->clean_stream);
+        hipStreamDestroy(ctx->clean_stream);
+        hipEventDestroy(ctx->clean_ev);
+        hipEventDestroy(ctx->used_ev);
+    }
     if (ctx->job_ring) hipHostFree(ctx->job_ring);
     for (auto &b : ctx->ws)
         if (b.p) hipFree(b.p);
@@ -678,6 +685,10 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
                           sizeof(XYZZ29) * keys_per_col * count <= ((size_t)2 << 30);
     XYZZ29 *all_buckets = nullptr;
     if (deferred) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH_BUCKETS, sizeof(XYZZ29) * keys_per_col * count, (void **)&all_buckets));
+    // the shared bucket array was zero-filled behind the previous batch's reduction (side stream): the lanes wait for that instead of filling
+    const bool buckets_zeroed = deferred && buckets_prezeroed(ctx, 1, all_buckets, sizeof(XYZZ29) * keys_per_col * count);
+    if (buckets_zeroed)
+        for (int l = 0; l < NL; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->clean_ev, 0));
     // host columns: one staging area for all of them; column j is copied on its lane's stream right before its kernels are
     // queued, so the (host-blocking, pageable) copy of column j+1 overlaps the GPU work of column j
     std::vector<const void *> staged(count, nullptr);
@@ -707,6 +718,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         hipStream_t A = ctx->split_acc, Bx = ctx->split_aux;
         H2_HIPCHK(hipStreamWaitEvent(A, ctx->fork_ev, 0));
         H2_HIPCHK(hipStreamWaitEvent(Bx, ctx->fork_ev, 0));
+        if (buckets_zeroed) H2_HIPCHK(hipStreamWaitEvent(Bx, ctx->clean_ev, 0));   // the sorts (on Bx) precede everything that touches the buckets
         hipStream_t saved[2] = {ctx->lane[0]->stream, ctx->lane[1]->stream};
         int rc = H2HIP_OK;
         auto phase = [&](size_t j, hipStream_t stream, uint32_t mask) {
@@ -714,7 +726,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
             h2hip_ctx *c = ctx->lane[j & 1];
             c->stream = stream;
             const Fr *col = (const Fr *)scalars_dev[j];
-            rc = msm_run_cols(c, bases_of(j), &col, 1, n, nullptr, all_buckets + keys_per_col * j, mask);
+            rc = msm_run_cols(c, bases_of(j), &col, 1, n, nullptr, all_buckets + keys_per_col * j, mask, buckets_zeroed);
         };
         auto sort = [&](size_t j) {
             phase(j, Bx, MSM_PHASE_SORT);
@@ -759,7 +771,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         char *outbuf = nullptr;
         H2_LANES_RC(ws_reserve(c, h2hip_ctx::WS_OUT, sizeof(XYZZ) * MSM_MAX_COLS, (void **)&outbuf));
         H2_LANES_RC(msm_run_cols(c, gb, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
-                                 deferred ? all_buckets + keys_per_col * j0 : nullptr));
+                                 deferred ? all_buckets + keys_per_col * j0 : nullptr, MSM_PHASE_ALL, buckets_zeroed));
         if (!deferred) {   // the group's results, one lane each, into their slots of the batch's result array
             prof_begin(c, "point_finish_kernel");
             hipLaunchKernelGGL(point_finish_slot_kernel, dim3((uint32_t)gsize), dim3(64), 0, c->stream, (const XYZZ *)outbuf,
@@ -779,6 +791,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
             const uint32_t cc = (uint32_t)(count - c0 < 64 ? count - c0 : 64);
             H2_CHK(msm_reduce_cols(ctx, bases, bases->window_bits, all_buckets + keys_per_col * c0, cc, sums + c0));
         }
+        H2_CHK(buckets_clean_after_use(ctx, 1, all_buckets, sizeof(XYZZ29) * keys_per_col * count));   // zero-fill for the next batch, off its critical path
         prof_begin(ctx, "point_finish_kernel");
         hipLaunchKernelGGL(point_finish_slot_kernel, dim3((uint32_t)count), dim3(64), 0, ctx->stream, (const XYZZ *)sums,
                            affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr, 0u);

@@ -121,6 +121,8 @@ static int msm_g2_run(h2hip_ctx *ctx, const G2Affine *pts_dev, const Fr *scalars
         const uint32_t chunks = (uint32_t)((n + chunk - 1) / chunk);
         G2Jac *partial = nullptr, *buckets = nullptr, *bits = nullptr;
         H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(G2Jac) * (size_t)G2_W * chunks * G2_B, (void **)&partial));
+        if (ctx->clean_stream) H2_HIPCHK(hipStreamSynchronize(ctx->clean_stream));   // a G1 MSM's zero-fill of this slot may still be pending
+        ctx->clean_bytes[0] = 0;                                                     // ... and the slot no longer holds zeros
         H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(G2Jac) * G2_W * G2_B, (void **)&buckets));
         H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(G2Jac) * G2_W * G2_C, (void **)&bits));
         prof_begin(ctx, "g2_msm_kernels");

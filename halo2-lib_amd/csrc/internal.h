@@ -127,6 +127,13 @@ struct h2hip_ctx {
     int msm_quad_seg_max = 32768;   // bucket reduction: quad-lane kernels up to this many segments (latency-bound), one-lane kernels above
     int msm_defer_reduce = 1;   // batch API, precomputed bases, > 2^17 points: one bucket reduction for all columns after the lanes join
     int msm_fuse_cols = 0;   // columns fused into one multi-column MSM by h2hip_msm_g1_batch_dev (precomputed bases): 0 = auto (4 up to 2^17 points, else 1)
+    // Bucket arrays are zero-filled AFTER their reduction has read them, on a side stream, instead of before the next MSM's sort (a 40 MB
+    // fill per 2^19-point MSM on the lane's critical path): clean_bytes[i] leading bytes of clean_ptr[i] are zero once clean_ev has fired.
+    // [0] = WS_BUCKETS (an MSM reduced by its own context), [1] = WS_BATCH_BUCKETS (a batch's deferred reduction).
+    hipStream_t clean_stream = nullptr;
+    hipEvent_t clean_ev = nullptr, used_ev = nullptr;
+    void *clean_ptr[2] = {nullptr, nullptr};
+    size_t clean_bytes[2] = {0, 0};
     hipEvent_t fork_ev = nullptr;
     hipEvent_t timer_ev[2] = {nullptr, nullptr};   // h2hip_timer_start / _stop
     bool msm_lds_attr_set = false, lookup_lds_attr_set = false;   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
@@ -183,6 +190,9 @@ constexpr uint32_t MSM_MAX_COLS = 32;   // columns one fused multi-column MSM ha
 // ext_buckets != nullptr: stop after the merge and leave the column's buckets ([sets][B], sets = window groups of msm_fold_windows; zeroed here) there for msm_reduce_cols
 enum { MSM_PHASE_SORT = 1u, MSM_PHASE_ACCUM = 2u, MSM_PHASE_MERGE = 4u, MSM_PHASE_REDUCE = 8u, MSM_PHASE_ALL = 15u };
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev,
-                 XYZZ29 *ext_buckets, uint32_t phases = MSM_PHASE_ALL);
+                 XYZZ29 *ext_buckets, uint32_t phases = MSM_PHASE_ALL, bool ext_buckets_zeroed = false);
+// zero-fill-after-use of the bucket arrays (see h2hip_ctx::clean_*): is the buffer's head already (scheduled to be) zero? / schedule the fill
+bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);
+int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes);
 int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t window_bits, const XYZZ29 *buckets, uint32_t ncols, XYZZ *out_dev);
 }  // namespace h2

@@ -56,9 +56,16 @@ constexpr uint32_t MAX_LDS_BUCKETS = 1u << 15;   // 128 KiB of u32 counters
 struct DigitCols {
     const Fr *scalars[MSM_MAX_COLS];
 };
-__global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_t n, uint32_t c, uint32_t W, uint32_t *__restrict__ digits) {
+// (the first workgroup also writes the sort's two sentinels — counts[nsort] = 0 and offsets[nsort + 1 .. nsort + ks] = ~0, read by the scan and by
+// the accumulation's boundary walk — which were two tiny memset launches per MSM on the lane's critical path)
+__global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_t n, uint32_t c, uint32_t W, uint32_t *__restrict__ digits,
+                                                         uint32_t *__restrict__ counts_tail, uint32_t *__restrict__ offsets_tail, uint32_t ks) {
     H2_SORT_PRIORITY();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (threadIdx.x == 0) counts_tail[0] = 0;
+        if (threadIdx.x < ks) offsets_tail[threadIdx.x] = 0xFFFFFFFFu;
+    }
     if (i >= n) return;
     digits += (size_t)blockIdx.y * W * n;
     Fr s = fe_from_mont(cols.scalars[blockIdx.y][i]);
@@ -974,8 +981,26 @@ int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t c, const 
     return H2HIP_OK;
 }
 
+bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes) {
+    return ctx->clean_ev && ctx->clean_ptr[which] == buf && ctx->clean_bytes[which] >= bytes;
+}
+int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes) {
+    if (!ctx->clean_stream) {
+        H2_HIPCHK(hipStreamCreateWithFlags(&ctx->clean_stream, hipStreamNonBlocking));
+        H2_HIPCHK(hipEventCreateWithFlags(&ctx->clean_ev, hipEventDisableTiming));
+        H2_HIPCHK(hipEventCreateWithFlags(&ctx->used_ev, hipEventDisableTiming));
+    }
+    H2_HIPCHK(hipEventRecord(ctx->used_ev, ctx->stream));               // everything that reads the buckets is queued on the context's stream
+    H2_HIPCHK(hipStreamWaitEvent(ctx->clean_stream, ctx->used_ev, 0));
+    H2_HIPCHK(hipMemsetAsync(buf, 0, bytes, ctx->clean_stream));
+    H2_HIPCHK(hipEventRecord(ctx->clean_ev, ctx->clean_stream));
+    ctx->clean_ptr[which] = buf;
+    ctx->clean_bytes[which] = bytes;
+    return H2HIP_OK;
+}
+
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out, XYZZ29 *ext_buckets,
-                 uint32_t phases) {
+                 uint32_t phases, bool ext_buckets_zeroed) {
     H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..32 columns per fused MSM");
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
@@ -1043,9 +1068,13 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     // streams (all derived sizes and scratch pointers are recomputed identically on every call for the same arguments)
     if (phases & MSM_PHASE_SORT) {
     if (nsort != W * B) H2_HIPCHK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nsort, st));   // padded keys: no window writes their counts
-    H2_HIPCHK(hipMemsetAsync(counts + nsort, 0, sizeof(uint32_t), st));
-    H2_HIPCHK(hipMemsetAsync(offsets + nsort + 1, 0xff, sizeof(uint32_t) * ks, st));   // sentinel offsets[(nkeys + 1) * ks] read by the boundary walk
-    H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
+    if (ext_buckets) {   // a batch's shared array: zeroed by the batch (after its previous use) or here
+        if (!ext_buckets_zeroed) H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
+    } else if (buckets_prezeroed(ctx, 0, buckets, sizeof(XYZZ29) * nkeys)) {
+        H2_HIPCHK(hipStreamWaitEvent(st, ctx->clean_ev, 0));
+    } else {
+        H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
+    }
 
     DigitCols dcols;
     for (uint32_t col = 0; col < MSM_MAX_COLS; ++col) {
@@ -1053,7 +1082,9 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         dcols.scalars[col] = col < ncols ? scalars[col] : nullptr;
     }
     prof_begin(ctx, "msm_digits_kernel");
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), ncols), dim3(256), 0, st, dcols, (uint32_t)n, c, Wcol, digits);
+    H2_REQUIRE(ks <= 256, "fold group too large");
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), ncols), dim3(256), 0, st, dcols, (uint32_t)n, c, Wcol, digits, counts + nsort,
+                       offsets + nsort + 1, ks);   // + the sentinels counts[nsort], offsets[(nkeys + 1) * ks]
     prof_end(ctx);
     const uint32_t sort_threads = (uint32_t)ctx->msm_sort_threads;
     if (!ctx->msm_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
@@ -1122,7 +1153,8 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     }   // MSM_PHASE_MERGE
 
     if (ext_buckets || !(phases & MSM_PHASE_REDUCE)) return H2HIP_OK;   // the caller reduces several MSMs' buckets together
-    return msm_reduce_cols(ctx, bases, c, buckets, ncols, out);
+    H2_CHK(msm_reduce_cols(ctx, bases, c, buckets, ncols, out));
+    return buckets_clean_after_use(ctx, 0, buckets, sizeof(XYZZ29) * nkeys);
 }
 
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
