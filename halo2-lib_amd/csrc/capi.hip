@@ -288,6 +288,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_split_streams")) return &ctx->msm_split_streams;
     if (!strcmp(name, "msm_quad_tails")) return &ctx->msm_quad_tails;
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
+    if (!strcmp(name, "msm_scatter_full_lds")) return &ctx->msm_scatter_full_lds;
     if (!strcmp(name, "msm_sort_threads")) return &ctx->msm_sort_threads;
     if (!strcmp(name, "msm_fuse_cols")) return &ctx->msm_fuse_cols;
     if (!strcmp(name, "msm_defer_reduce")) return &ctx->msm_defer_reduce;
@@ -630,6 +631,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         c->msm_table_nontemporal = ctx->msm_table_nontemporal;
         c->msm_fold_windows = ctx->msm_fold_windows;
         c->msm_scatter_split = ctx->msm_scatter_split;
+        c->msm_scatter_full_lds = ctx->msm_scatter_full_lds;
         c->msm_sort_threads = ctx->msm_sort_threads;
         c->msm_quad_tails = ctx->msm_quad_tails;
         c->msm_quad_seg_max = ctx->msm_quad_seg_max;

@@ -86,6 +86,7 @@ struct h2hip_ctx {
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
     int msm_scatter_split = 0;   // bucket sub-ranges per window in the scatter (0 = auto, power of two)
+    int msm_scatter_full_lds = 1;   // 1: the scatter declares the full 128 KiB of LDS (one workgroup per CU: one segment per XCD at a time); 0: only its cursors
     int msm_fold_windows = 0;    // precomputed bases: windows per shared bucket set (0 / 1 = one set per window: the default).  The sort is bucket-major inside a group of this many windows, so the
                                  // accumulation sums the group's entries of a bucket index into one bucket ([col][groups][B] instead of [col][windows][B]);
                                  // >= the window count: one bucket set per column and no per-index presum in the reduction.  Bit-exact, measured SLOWER
