@@ -243,8 +243,10 @@ void h2hip_destroy(h2hip_ctx *ctx) {
     for (auto &t : ctx->twiddles) {
         hipFree(t.t1);
         hipFree(t.t2);
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k) {
             if (t.direct[k]) hipFree(t.direct[k]);
+            if (t.stage[k]) hipFree(t.stage[k]);
+        }
     }
     for (auto &p : ctx->pending) {
         hipEventDestroy(p.begin);
@@ -282,6 +284,8 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_fold_windows")) return &ctx->msm_fold_windows;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_wave_local")) return &ctx->ntt_wave_local;
+    if (!strcmp(name, "ntt_radix8")) return &ctx->ntt_radix8;
+    if (!strcmp(name, "ntt_tile_bits8")) return &ctx->ntt_tile_bits8;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
@@ -315,6 +319,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_accum_variant) H2_REQUIRE(value >= 2 && value <= 5, "msm_accum_variant must be 2, 3, 4 or 5");
     if (p == &ctx->ntt_min_col_bits) H2_REQUIRE(value >= 0 && value <= 5, "ntt_min_col_bits must be 0..5");
     if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
+    if (p == &ctx->ntt_tile_bits8) H2_REQUIRE(value >= 4 && value <= 11, "ntt_tile_bits8 must be 4..11");
     *p = value;
     return H2HIP_OK;
 }

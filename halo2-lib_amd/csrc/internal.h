@@ -52,6 +52,8 @@ struct TwiddleSet {   // omega^i tables for one (log_n, omega)
     void *t2 = nullptr;   // omega^(i<<lo_bits), i < 2^(log_n-lo_bits)
     void *direct[4] = {nullptr, nullptr, nullptr, nullptr};   // per-stride direct tables omega^(t << log_s) for later passes
     uint32_t direct_log_s[4] = {0, 0, 0, 0};
+    void *stage[4] = {nullptr, nullptr, nullptr, nullptr};    // stage-twiddle tables omega_R^k, k < R/2, per sub-transform size R = 2^m (radix-8 passes)
+    uint32_t stage_m[4] = {0, 0, 0, 0};
 };
 
 struct KernelStat {
@@ -82,6 +84,12 @@ struct h2hip_ctx {
     int ntt_wave_local = 0;      // 1: full tiles with >= 4 columns are stored column-major, every wave owns whole columns and the stage pairs are separated by
                                  // wave-level ordering points instead of block barriers.  Bit-exact, measured neutral (tools/ntt_ab.py: 2^22 0.518 vs 0.527 ms,
                                  // coset 2^19->2^21 0.267 vs 0.257 ms): the barriers are not what the pass kernel waits for.  Off by default.
+    int ntt_radix8 = 0;          // 1: passes on the radix-8 kernel (ntt_pass8_kernel: three stages per LDS round trip, 8 elements per lane, 2048-element tiles of
+                                 // bare 36-byte elements, two workgroups per CU); 0 (default): the radix-4 kernel.  Bit-exact, measured SLOWER (tools/ntt_r03.py,
+                                 // profiles/r03_ntt_radix8_ab.log: 2^22 0.81 vs 0.65 ms, 2^19 0.109 vs 0.083, coset 2^19->2^21 0.39 vs 0.30): the third stage per
+                                 // round trip does not pay for what it takes — 8 waves per CU instead of 12 (175 registers per lane), nine 4-byte LDS accesses per
+                                 // element instead of three 16-byte ones, and the 8-element prefetch array in scratch.
+    int ntt_tile_bits8 = 11;     // log2 of the radix-8 kernel's tile (<= 11; smaller values only to force many passes in tests)
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
@@ -137,7 +145,7 @@ struct h2hip_ctx {
     size_t clean_bytes[2] = {0, 0};
     hipEvent_t fork_ev = nullptr;
     hipEvent_t timer_ev[2] = {nullptr, nullptr};   // h2hip_timer_start / _stop
-    bool msm_lds_attr_set = false, lookup_lds_attr_set = false;   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
+    bool msm_lds_attr_set = false, lookup_lds_attr_set = false, ntt_lds_attr_set = false;   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 };
 
 namespace h2 {

@@ -234,6 +234,193 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(NttCols cols, uint32_t lo
     }
 }
 
+// ---------------------------------------------------------------------------------------------- radix-8 pass (r03)
+// The same pass (same tile -> output index map, same fused scalings, same tables) with THREE butterfly stages per LDS round trip: every lane
+// holds 8 elements in registers and runs a radix-8 decimation-in-time group on them (12 twiddle products), so a 7-stage sub-transform is
+// 3 + 3 + 1 stages in three round trips instead of 1 + 2 + 2 + 2 in four, and an element crosses the LDS 1.33 times per stage pair instead
+// of twice.  Tile = 2^TB elements stored as bare 9-limb elements (36 B: odd word stride), T = 2^(TB-3) lanes; TB = 11: 256 lanes, 72 KiB:
+// two workgroups per CU.  The stage twiddles omega_R^k are read from a global table (t_stage, 2^(m-1) entries, L2-resident) instead of a
+// per-workgroup LDS copy.  Leftover stages (m mod 3) run as radix-2 / radix-4 groups on the same 8 registers per lane.
+struct Fr29P {   // packed LDS element
+    uint32_t l[9];
+};
+__device__ __forceinline__ Fr29 ld29(const Fr29P *p) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = p->l[i];
+    return r;
+}
+__device__ __forceinline__ void st29(Fr29P *p, const Fr29 &v) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p->l[i] = v.l[i];
+}
+// limb-wise a + (2r - b): no carries, no range assertions (a: limbs < 2^31 + 2^30, b normalised and < 2r)
+__device__ __forceinline__ Fr29 f29_sub2_lazy_wide(const Fr29 &a, const Fr29 &b) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + (R29P::sub2p(i) - b.l[i]);
+    return r;
+}
+// G butterfly stages (G = 1, 2, 3) starting at stage st on the 2^G elements x[0], x[D], ..., positions i + j*h of their block (h = 2^st).
+// tws = omega_R^k table; exponent of the pair (j, j + 2^s) at stage st + s: (i + (j mod 2^s) * h) << (m - 1 - st - s).
+template <int G>
+__device__ __forceinline__ void radix_group(Fr29 (&x)[8], const int base, const Fr29P *tws, uint32_t i, uint32_t h, uint32_t m, uint32_t st) {
+    constexpr int N = 1 << G;
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+        const int d = 1 << s;
+        if (s == 2) {   // the upper operands of the third stage carry two lazy stages: bring their limbs back below 2^31
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                if (j & d) x[base + j] = f29_norm(x[base + j]);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j & d) continue;
+            Fr29 &a = x[base + j], &b = x[base + j + d];
+            Fr29 t;
+            if (st == 0 && s == 0) {
+                t = b;   // omega^0
+            } else {
+                const uint32_t e = (i + (uint32_t)(j & (d - 1)) * h) << (m - 1 - st - s);
+                t = f29_mul_wide(b, ld29(&tws[e]));
+            }
+            const Fr29 lo = f29_add(a, t);
+            b = f29_sub2_lazy_wide(a, t);
+            a = lo;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[base + j] = f29_norm(x[base + j]);
+}
+
+// one LDS round trip: G stages on the lane's 8 / 2^G groups of 2^G elements (all register indices are compile-time constants)
+template <int G, uint32_t T>
+__device__ __forceinline__ void ntt8_round(Fr29P *lds8, const Fr29P *tstage, uint32_t tid, uint32_t elems, uint32_t cb, uint32_t m, uint32_t st) {
+    constexpr int N = 1 << G, PER = 8 >> G;   // elements per group, groups per lane
+    const uint32_t h = 1u << st, C = 1u << cb, ngroups = elems >> G;
+    Fr29 xr[8];
+    uint32_t e0s[PER], is[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        const uint32_t gi = tid + T * (uint32_t)r;
+        const uint32_t c = gi & (C - 1), p = gi >> cb;
+        const uint32_t i = p & (h - 1), blk = p >> st;
+        is[r] = i;
+        e0s[r] = gi < ngroups ? (((blk << (st + G)) + i) << cb) + c : 0xFFFFFFFFu;
+        if (e0s[r] != 0xFFFFFFFFu) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) xr[r * N + k] = ld29(&lds8[e0s[r] + (((uint32_t)k * h) << cb)]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r)
+        if (e0s[r] != 0xFFFFFFFFu) radix_group<G>(xr, r * N, tstage, is[r], h, m, st);
+#pragma unroll
+    for (int r = 0; r < PER; ++r)
+        if (e0s[r] != 0xFFFFFFFFu) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) st29(&lds8[e0s[r] + (((uint32_t)k * h) << cb)], xr[r * N + k]);
+        }
+}
+
+template <int TB>
+__global__ __launch_bounds__(1 << (TB - 3)) void ntt_pass8_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
+                                                                const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
+                                                                const Fr29L *__restrict__ tdirect, const Fr29L *__restrict__ tstage, uint64_t in_len,
+                                                                int in_mul, int out_mul, NttScale sc) {
+    HIP_DYNAMIC_SHARED(Fr29P, lds8)
+    constexpr uint32_t T = 1u << (TB - 3);
+    const Fr *__restrict__ x = cols.x[blockIdx.y];
+    Fr *__restrict__ y = cols.y[blockIdx.y];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t R = 1u << m, C = 1u << cb;
+    const uint32_t elems = R << cb;                     // <= 2^TB
+    const uint64_t rows_stride = 1ull << (log_n - m);   // N/R
+    const uint32_t ntiles = 1u << (log_n - m - cb);
+    const bool has_tw = (log_s + m) < log_n;            // the last pass has j - q == 0 everywhere
+    const uint64_t smask = (1ull << log_s) - 1;
+    __shared__ Fr29L scale_s[6];
+    if (tid < 3 && in_mul) scale_s[tid].v = fr29_from_sat(sc.in3[tid]);
+    if (tid >= 3 && tid < 6 && out_mul) scale_s[tid].v = fr29_from_sat(sc.out3[tid - 3]);
+    // the sub-transform's stage twiddles omega_R^k, k < R/2, behind the tile (R <= 256: 4.5 KiB)
+    Fr29P *tw8 = lds8 + elems;
+    for (uint32_t k = tid; k < (R >> 1); k += T) st29(&tw8[k], tstage[k].v);
+
+    Fr pre[8];
+    auto fetch = [&](uint32_t tile) {
+        const uint64_t j0 = (uint64_t)tile << cb;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t e = tid + T * k;
+            const uint64_t idx = j0 + (e & (C - 1)) + (uint64_t)(e >> cb) * rows_stride;
+            pre[k] = (e < elems && idx < in_len) ? x[idx] : Fr::zero();
+        }
+    };
+    uint32_t tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    __syncthreads();   // scale_s visible
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const uint64_t j0 = (uint64_t)tile << cb;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t e = tid + T * k;
+            if (e < elems) {
+                const uint32_t t = e >> cb, c = e & (C - 1);
+                Fr29 v = f29_split<R29P>(pre[k]);
+                if (in_mul) {
+                    const uint64_t idx = j0 + c + (uint64_t)t * rows_stride;
+                    v = f29_mul(v, scale_s[idx % 3].v);   // zero padding stays zero
+                }
+                st29(&lds8[(bitrev_m(t, m) << cb) + c], v);   // DIT: bit-reversed rows in, natural rows out
+            }
+        }
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);   // next tile's loads overlap this tile's arithmetic
+
+        for (uint32_t st = 0; st < m;) {
+            const uint32_t g = m - st >= 3 ? 3u : m - st;   // stages of this round
+            __syncthreads();
+            if (g == 3) ntt8_round<3, T>(lds8, tw8, tid, elems, cb, m, st);
+            else if (g == 2) ntt8_round<2, T>(lds8, tw8, tid, elems, cb, m, st);
+            else ntt8_round<1, T>(lds8, tw8, tid, elems, cb, m, st);
+            st += g;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t e = tid + T * k;
+            if (e >= elems) continue;
+            uint32_t u, c;
+            if (log_s == 0) {   // first pass: output (j0+c)*R + u is contiguous in u
+                c = e >> m;
+                u = e & (R - 1);
+            } else {            // later passes: contiguous in q (i.e. in c)
+                u = e >> cb;
+                c = e & (C - 1);
+            }
+            const uint64_t j = j0 + c, q = j & smask, jq = j - q;
+            Fr29 v = ld29(&lds8[(u << cb) + c]);
+            const uint64_t oidx = (jq << m) + q + ((uint64_t)u << log_s);
+            if (has_tw) {
+                const Fr29 w = tdirect ? tdirect[(jq >> log_s) * u].v : tw_lookup(t1, t2, lo_bits, jq * u);   // log_s = 0: jq = j
+                v = f29_mul(v, w);
+            }
+            if (out_mul) v = f29_mul(v, scale_s[3 + oidx % 3].v);
+            if (!has_tw && !out_mul) v = f29_weak_reduce(v);   // weak bound -> < 2 r before packing, no multiply
+            y[oidx] = f29_pack_canonical<FrP>(v);
+        }
+        __syncthreads();   // LDS is overwritten by the next tile
+    }
+}
+
+// stage-twiddle table of a pass: out[k] = omega^(k << (log_n - m)) = omega_R^k, k < 2^(m-1)
+__global__ void ntt_stage_twiddle_kernel(Fr29L *out, Fr omega, uint32_t shift, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i].v = fr29_from_sat(fe_pow_u64(omega, (uint64_t)i << shift));
+}
+
 // direct inter-pass twiddle table for a pass with stride 2^log_s: out[t] = omega^(t << log_s), t < count
 __global__ void ntt_direct_twiddle_kernel(Fr29L *out, Fr omega, uint32_t log_s, uint32_t count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -262,8 +449,10 @@ static int get_twiddles(h2hip_ctx *ctx, uint32_t log_n, const Fr &omega, Twiddle
         H2_HIPCHK(hipStreamSynchronize(ctx->stream));
         hipFree(ctx->twiddles.front().t1);
         hipFree(ctx->twiddles.front().t2);
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k) {
             if (ctx->twiddles.front().direct[k]) hipFree(ctx->twiddles.front().direct[k]);
+            if (ctx->twiddles.front().stage[k]) hipFree(ctx->twiddles.front().stage[k]);
+        }
         ctx->twiddles.erase(ctx->twiddles.begin());
     }
     ctx->twiddles.push_back(t);
@@ -299,6 +488,36 @@ static int get_direct_table(h2hip_ctx *ctx, TwiddleSet *tw, uint32_t log_s, cons
     return H2HIP_OK;   // all slots taken: fall back to the composed lookup
 }
 
+// stage-twiddle table omega_R^k, k < R/2, for sub-transforms of size R = 2^m (one per distinct m of a transform's passes)
+static int get_stage_table(h2hip_ctx *ctx, TwiddleSet *tw, uint32_t m, const Fr29L **out) {
+    for (int k = 0; k < 4; ++k)
+        if (tw->stage[k] && tw->stage_m[k] == m) {
+            *out = (const Fr29L *)tw->stage[k];
+            return H2HIP_OK;
+        }
+    for (int k = 0; k < 4; ++k)
+        if (!tw->stage[k]) {
+            const uint32_t count = m ? 1u << (m - 1) : 1u;
+            H2_HIPCHK(hipMalloc(&tw->stage[k], sizeof(Fr29L) * count));
+            tw->stage_m[k] = m;
+            prof_begin(ctx, "ntt_twiddle_kernel");
+            hipLaunchKernelGGL(ntt_stage_twiddle_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, (Fr29L *)tw->stage[k], tw->omega, tw->log_n - m, count);
+            prof_end(ctx);
+            H2_HIPCHK(hipGetLastError());
+            *out = (const Fr29L *)tw->stage[k];
+            return H2HIP_OK;
+        }
+    // all four slots hold other sizes (only when the tile size changes between calls: tuning sweeps, tests): replace the first one
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(tw->stage[0]);
+    for (int k = 0; k < 3; ++k) {
+        tw->stage[k] = tw->stage[k + 1];
+        tw->stage_m[k] = tw->stage_m[k + 1];
+    }
+    tw->stage[3] = nullptr;
+    return get_stage_table(ctx, tw, m, out);
+}
+
 // a[j]: N = 2^log_n device elements each (results land there), ncols equal-size columns transformed together.  in_override (optional):
 // column j reads its input from in_override[j] (in_len valid elements, implicit zeros beyond).  in_scale3 / out_scale3 (optional, host
 // pointers to 3 Fr): multiply input / output element i by scale[i mod 3].
@@ -314,13 +533,16 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
         sc.in3[i] = in_scale3 ? in_scale3[i] : Fr::one();
         sc.out3[i] = out_scale3 ? out_scale3[i] : Fr::one();
     }
-    const uint32_t LT = (uint32_t)ctx->ntt_tile_bits;
+    constexpr uint32_t TB8 = 11;   // radix-8 passes: 2048-element tiles (72 KiB of LDS: two 256-lane workgroups per CU)
+    const bool radix8 = ctx->ntt_radix8 != 0;
+    const uint32_t LT = radix8 ? (uint32_t)ctx->ntt_tile_bits8 : (uint32_t)ctx->ntt_tile_bits;
     uint32_t mlist[8], P;
     if (log_n <= LT) {
         P = 1;
         mlist[0] = log_n;
     } else {
         uint32_t maxm = LT - (uint32_t)ctx->ntt_min_col_bits;   // at least 2^min_col_bits adjacent columns per tile (row segments of 32 B each)
+        if (radix8 && maxm > 8) maxm = 8;                       // the radix-8 kernel keeps omega_R^k, k < R/2, in LDS behind its 72 KiB tile
         P = (log_n + maxm - 1) / maxm;
         for (uint32_t i = 0; i < P; ++i) mlist[i] = log_n / P + (i < log_n % P ? 1 : 0);
     }
@@ -352,6 +574,24 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
             const uint32_t grid = tiles < (uint32_t)ctx->num_cus * 3 ? tiles : (uint32_t)ctx->num_cus * 3;
             const Fr29L *tdirect = nullptr;
             if (i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
+            if (radix8) {
+                const Fr29L *tstage = nullptr;
+                H2_CHK(get_stage_table(ctx, tw, m, &tstage));
+                if (!ctx->ntt_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
+                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_pass8_kernel<TB8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(Fr29P) * ((1u << TB8) + 1024u))));
+                    ctx->ntt_lds_attr_set = true;
+                }
+                const uint32_t grid8 = tiles < (uint32_t)ctx->num_cus * 2 ? tiles : (uint32_t)ctx->num_cus * 2;
+                prof_begin(ctx, "ntt_pass_kernel");
+                hipLaunchKernelGGL(ntt_pass8_kernel<TB8>, dim3(grid8, gc), dim3(1u << (TB8 - 3)), sizeof(Fr29P) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0))), ctx->stream, cols, log_n, m, log_s, cb,
+                                   (const Fr29L *)tw->t1, (const Fr29L *)tw->t2, tw->lo_bits, tdirect, tstage, first ? in_len : N,
+                                   (first && in_scale3) ? 1 : 0, (last && out_scale3) ? 1 : 0, sc);
+                prof_end(ctx);
+                H2_HIPCHK(hipGetLastError());
+                in_scratch = to_scratch;
+                log_s += m;
+                continue;
+            }
             const int wave_local = (ctx->ntt_wave_local && cb >= 2 && m + cb == 10 && m >= 2) ? 1 : 0;
             const size_t shmem = sizeof(Fr29L) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)) + 8 + (wave_local ? ((size_t)1 << cb) : 0));
             prof_begin(ctx, "ntt_pass_kernel");

@@ -45,16 +45,45 @@ def test_ntt_wave_local_variant(ctx):
         ctx.set_param("ntt_wave_local", 0)
 
 
+@pytest.mark.parametrize("radix8", [1, 0])
 @pytest.mark.parametrize("tile", [4, 6, 8])
-def test_ntt_small_tiles_force_many_passes(ctx, tile):
-    ctx.set_param("ntt_tile_bits", tile)
+def test_ntt_small_tiles_force_many_passes(ctx, tile, radix8):
+    """both pass kernels — radix-8 (three stages per LDS round trip, the default) and radix-4 — with tiles small enough that a 2^12 transform
+    takes up to six passes: every (stages per pass, columns per tile, leftover-stage) combination, the fused coset scalings included"""
+    ctx.set_param("ntt_radix8", radix8)
+    ctx.set_param("ntt_tile_bits8" if radix8 else "ntt_tile_bits", tile)
     try:
         for log_n in (7, 12):
             a = rand_fr(1 << log_n, 3)
-            w, _, _ = domain_consts(log_n)
-            assert np.array_equal(ctx.best_fft(a, w, log_n), CO.best_fft(a, log_n, w))
+            w, winv, div = domain_consts(log_n)
+            got = ctx.best_fft(a, w, log_n)
+            assert np.array_equal(got, CO.best_fft(a, log_n, w))
+            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
+        a = rand_fr(1 << 9, 8)
+        we, weinv, ediv = domain_consts(11)
+        z, zinv = fr([O.ZETA]), fr([O.ZETA * O.ZETA % R])
+        ext = ctx.coeff_to_extended(a, 9, 11, we, z)
+        assert np.array_equal(ext, CO.coeff_to_extended(a, 9, 11, we, z, threads=4))
+        assert np.array_equal(ctx.extended_to_coeff(ext, 11, weinv, ediv, zinv)[: 1 << 9], a)
     finally:
+        ctx.set_param("ntt_tile_bits8", 11)
         ctx.set_param("ntt_tile_bits", 10)
+        ctx.set_param("ntt_radix8", 0)
+
+
+def test_ntt_radix8_kernel_matches(ctx):
+    """ntt_radix8 = 1: the radix-8 pass kernel (selectable; measured slower than the default radix-4 kernel on MI355X) against the oracle at the
+    sizes of the default test, with its 2048-element tiles"""
+    ctx.set_param("ntt_radix8", 1)
+    try:
+        for log_n in (0, 1, 5, 10, 11, 13, 15):
+            a = rand_fr(1 << log_n, log_n)
+            w, winv, div = domain_consts(log_n)
+            got = ctx.best_fft(a, w, log_n)
+            assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=4))
+            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
+    finally:
+        ctx.set_param("ntt_radix8", 0)
 
 
 @pytest.mark.parametrize("k,ek", [(0, 2), (3, 5), (9, 11), (12, 14)])
