@@ -102,7 +102,7 @@ struct h2hip_ctx {
                                  // between; create_proof k=19 16.9 vs 16.2 ms): runs 16x longer make the segmented merge of the partial sums run ~5 doubling
                                  // steps instead of ~2.5, which costs more than the presum it removes.
     int msm_table_nontemporal = 1;   // accumulation: gather the base-table entries with non-temporal loads (no reuse; keeps the reused lines in L2)
-    int msm_accum_variant = 3;   // accumulate kernel build: 5 = two waves per SIMD by launch bounds (no spills in the wave-level merge; measured 2 % slower than 3), 3 / 4 = min waves per SIMD it is compiled for, 2 = registers padded to two waves per SIMD
+    int msm_accum_variant = 3;   // accumulate kernel build: 6 / 7 = the next table entry requested before the current addition, at 2 / 3 waves per SIMD (measured 5 % slower), 5 = two waves per SIMD by launch bounds (no spills in the wave-level merge; measured 2 % slower than 3), 3 / 4 = min waves per SIMD it is compiled for, 2 = registers padded to two waves per SIMD
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]
     // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled
     bool profiling = false;

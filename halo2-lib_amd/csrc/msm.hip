@@ -354,7 +354,7 @@ __device__ __forceinline__ XYZZ29 xyzz29_shfl(const XYZZ29 &v, uint32_t src) {
 // boundaries leave as (key, XYZZ) partials — slot 2*wave (left) and 2*wave + 1 (right) of a sorted, hole-free list that msm_merge_kernel
 // finishes: 2 slots per 64 lanes instead of 2 per lane (r02: 0.5 M partials of 144 B per 2^19-point MSM through HBM and a first merge level
 // of 2048 workgroups).  No lane leaves early: lanes without entries take part in the shuffles with empty sums.
-template <bool NT>
+template <bool NT, bool PF = false>
 __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
                                                const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t ks, uint32_t K,
                                                XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals,
@@ -377,7 +377,32 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
     bool l_open = false;                                     // the lane's first run began before `start`
     if (valid) l_open = offsets[(size_t)cur * ks] < start;
     uint4 sv4 = {0u, 0u, 0u, 0u};
+    auto entry = [&](uint32_t e) -> uint32_t {   // sorted entry e (called for consecutive e)
+        if (NT) {   // the lane's entries 16 bytes at a time: a quarter of the loads (and of the chances to find the line evicted)
+            if ((e & 3u) == 0 || e == start) sv4 = reinterpret_cast<const uint4 *>(sval)[e >> 2];
+            const uint32_t sel = e & 3u;
+            return sel == 0 ? sv4.x : sel == 1 ? sv4.y : sel == 2 ? sv4.z : sv4.w;
+        }
+        return sval[e];
+    };
+    // PF: the table entry of the NEXT addition is requested before this one is computed (the gather's ~2 us then overlap ~2400 instructions)
+    uint32_t v_nxt = 0;
+    G1Affine p_nxt;
+    if (PF && start < end) {
+        v_nxt = entry(start);
+        p_nxt = load_table_entry<NT>(bases + (v_nxt & 0x7fffffffu));
+    }
     for (uint32_t e = start; e < end; ++e) {
+        uint32_t v;
+        G1Affine p;
+        if (PF) {
+            v = v_nxt;
+            p = p_nxt;
+            if (e + 1 < end) {
+                v_nxt = entry(e + 1);
+                p_nxt = load_table_entry<NT>(bases + (v_nxt & 0x7fffffffu));
+            }
+        }
         if (e >= next) {   // bucket boundary: close the run
             if (first) {
                 lsave[threadIdx.x] = acc;
@@ -390,15 +415,10 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
             cur = (offsets[(size_t)(cur + 2) * ks] > e) ? cur + 1 : find_key(offsets, ks, cur + 1, nkeys, e);
             next = offsets[(size_t)(cur + 1) * ks];
         }
-        uint32_t v;
-        if (NT) {   // the lane's entries 16 bytes at a time: a quarter of the loads (and of the chances to find the line evicted)
-            if ((e & 3u) == 0 || e == start) sv4 = reinterpret_cast<const uint4 *>(sval)[e >> 2];
-            const uint32_t sel = e & 3u;
-            v = sel == 0 ? sv4.x : sel == 1 ? sv4.y : sel == 2 ? sv4.z : sv4.w;
-        } else {
-            v = sval[e];
+        if (!PF) {
+            v = entry(e);
+            p = load_table_entry<NT>(bases + (v & 0x7fffffffu));   // packed R'-domain point, one aligned 64-byte gather
         }
-        G1Affine p = load_table_entry<NT>(bases + (v & 0x7fffffffu));   // packed R'-domain point, one aligned 64-byte gather
         if (!p.is_identity()) xyzz29_add_affine(acc, f29_split<Q29P>(p.x), f29_split<Q29P>(p.y), (v >> 31) != 0);
     }
     // ---- close the shared runs inside the wave
@@ -477,12 +497,12 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
     }
 }
 
-template <int MINW, bool NT>
+template <int MINW, bool NT, bool PF = false>
 __global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
                                                         const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t ks, uint32_t K,
                                                         XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
                                                         XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
-    msm_accum_body<NT>(sval, bases, offsets, nkeys, ks, K, buckets, out_keys, out_vals, nthreads);
+    msm_accum_body<NT, PF>(sval, bases, offsets, nkeys, ks, K, buckets, out_keys, out_vals, nthreads);
 }
 // Same body with the register allocation padded to 176 per lane: two waves per SIMD instead of three, which leaves a
 // third of every SIMD's register file free at all times for the tail / sort kernels of the neighbouring pipelined MSMs
@@ -1117,7 +1137,14 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 
     if (phases & MSM_PHASE_ACCUM) {
     prof_begin(ctx, "msm_accum_kernel");
-    if (ctx->msm_accum_variant == 5)   // two waves per SIMD by launch bounds (256 registers: the wave-level merge's epilogue then spills nothing)
+    if (ctx->msm_accum_variant == 6 || ctx->msm_accum_variant == 7) {   // software-prefetched table gather at 2 / 3 waves per SIMD
+        if (ctx->msm_accum_variant == 6)
+            hipLaunchKernelGGL((msm_accum_kernel<2, true, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+                               (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
+        else
+            hipLaunchKernelGGL((msm_accum_kernel<3, true, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+                               (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
+    } else if (ctx->msm_accum_variant == 5)   // two waves per SIMD by launch bounds (256 registers: the wave-level merge's epilogue then spills nothing)
         hipLaunchKernelGGL((msm_accum_kernel<2, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
                            (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     else if (ctx->msm_accum_variant == 2)

@@ -557,3 +557,18 @@ def test_msm_batch_split_streams_and_mixed_bases(ctx):
         ctx.free(d)
     ba.free()
     bb.free()
+
+
+@pytest.mark.parametrize("variant", [6, 7, 5])
+def test_msm_accumulate_variants_agree(ctx, variant):
+    """msm_accum_variant 6 / 7 (the next table entry is requested before the current addition) and 5 (two waves per SIMD) against the oracle"""
+    n = 3000
+    bases = CO.known_dlog_bases(n, fr([11]), fr([7]))
+    b = ctx.bases_upload(bases)
+    ctx.set_param("msm_accum_variant", variant)
+    try:
+        for s in (rand_fr(n, 31), circuit_like_fr(n, 32)):
+            assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=4))
+    finally:
+        ctx.set_param("msm_accum_variant", 3)
+        b.free()
