@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="N > 1, top-level line: strong = ONE k=19 proof per step, sharded over the N GPUs (north star; default); weak = every rank "
                          "proves its own circuit (independent replicas, no exchange).  The MSM block follows the same choice.")
+    ap.add_argument("--sharded-proof", action="store_true", help="accepted for compatibility: with --gpus N > 1 the top-level line already IS the sharded k=19 proof (--scaling strong)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (exchange staged through the host; testing)")
     ap.add_argument("--share-device", action="store_true", help="testing on a 1-GPU box: every rank uses GPU 0 (requires --dist-backend gloo)")
     ap.add_argument("--param", action="append", default=[], help="name=value tuning knob passed to h2hip_set_param (repeatable)")
