@@ -246,16 +246,17 @@ def main():
         if world == 1:
             raise
         err = repr(e)
-    sk = None
+    sk, comm = None, None
     if world > 1:
         oks = [None] * world
         dist.all_gather_object(oks, err)
         if any(o is not None for o in oks):
             raise SystemExit("bench.py: set-up failed on some rank: %r" % (oks,))
-        if sharded:
-            from halo2_lib_amd.multi_gpu import shard_proving_key
+        from halo2_lib_amd.multi_gpu import Comm, shard_proving_key
 
-            sk = shard_proving_key(pk, ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange), device=xdev, precompute=True)
+        comm = Comm(ctx, rccl=args.dist_backend == "nccl", device=xdev)   # libh2hip's own communicator (RCCL over xGMI / a gloo callback)
+        if sharded:
+            sk = shard_proving_key(pk, ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange), device=xdev, precompute=True, comm=comm)
 
     prove = lambda stages=None: PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws), stages)
     t0 = time.perf_counter()
@@ -397,7 +398,7 @@ def main():
     # ------------------------------------------------------------------ extra blocks (never part of the timed region above)
     if not args.no_replay:
         try:
-            blk = msm_block(ctx, args, torch, dev, world, rank, dist, xdev)
+            blk = msm_block(ctx, args, torch, dev, world, rank, dist, xdev, comm)
         except Exception as e:
             blk = {"error": repr(e)}
         if rank == 0:
@@ -419,12 +420,14 @@ def main():
                 out["create_proof_config_sweep"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.destroy()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def msm_block(ctx, args, torch, dev, world, rank, dist, xdev):
+def msm_block(ctx, args, torch, dev, world, rank, dist, xdev, comm=None):
     """BASELINE configs[1]: 2^log_n-point G1 MSMs on resident scalars and bases (the other half of the metric: G1-adds/s), verified in-run against
     the closed form of known-dlog bases.  N > 1: point-range sharding — weak (every rank a 2^log_n slice of an N*2^log_n-point MSM) or strong."""
     from halo2_lib_amd.multi_gpu import sharded_msm, sharded_msm_batch
@@ -447,15 +450,15 @@ def msm_block(ctx, args, torch, dev, world, rank, dist, xdev):
 
     def run_steps(cnt):
         """cnt MSMs over this rank's slice, issued in batches of --batch (pipelined over the context's lanes);
-        N>1: one RCCL all-gather of the 96 B partials per batch + on-GPU sums."""
+        N>1: one all-gather of the 96 B partials per batch through libh2hip's communicator + one host-side summation call."""
         done = 0
         res = None
         while done < cnt:
             b = min(args.batch, cnt - done)
             if b == 1:
-                res = sharded_msm(ctx, bases, scal_d.data_ptr(), n, device=xdev if world > 1 else None)
+                res = sharded_msm(ctx, bases, scal_d.data_ptr(), n, comm=comm)
             else:
-                res = sharded_msm_batch(ctx, bases, [t.data_ptr() for t in scal_cols_d[:b]], n, device=xdev if world > 1 else None)
+                res = sharded_msm_batch(ctx, bases, [t.data_ptr() for t in scal_cols_d[:b]], n, comm=comm)
             last["cols"] = b
             done += b
         return res

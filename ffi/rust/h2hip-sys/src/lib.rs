@@ -109,6 +109,7 @@ extern "C" {
     pub fn h2hip_msm_g1_batch_dev(ctx: *mut h2hip_ctx, bases: *const h2hip_bases, scalars_dev: *const *const c_void, n: usize, count: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     pub fn h2hip_msm_g1_multi_dev(ctx: *mut h2hip_ctx, bases_per_column: *const *const h2hip_bases, scalars_dev: *const *const c_void, n: usize, count: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
     pub fn h2hip_g1_sum_jacobian_dev(ctx: *mut h2hip_ctx, points_dev: *const c_void, n: usize, point_format: c_int, out_host: *mut c_void) -> c_int;
+    pub fn h2hip_g1_sum_partials_host(gathered_jacobian: *const c_void, world: usize, count: usize, point_format: c_int, out: *mut c_void) -> c_int;
     pub fn h2hip_msm_g2(ctx: *mut h2hip_ctx, g2_affine_host: *const c_void, scalars_host: *const c_void, n: usize, out_affine_host: *mut c_void) -> c_int;
     pub fn h2hip_msm_g2_dev(ctx: *mut h2hip_ctx, g2_affine_dev: *const c_void, scalars_dev: *const c_void, n: usize, out_affine_host: *mut c_void) -> c_int;
     // a2 — ParamsKZG::setup

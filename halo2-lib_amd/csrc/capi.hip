@@ -877,6 +877,40 @@ int h2hip_g1_sum_jacobian_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, 
     return finish_point(ctx, outbuf, point_format, out_host);
 }
 
+// The host half of a point-range sharded commitment round: out[j] = sum over ranks r of gathered[r * count + j] (Jacobian partials as
+// h2hip_comm_allgather_host leaves them, rank-major), for all `count` columns in one call — a few dozen point additions on the host,
+// no device round trip.  point_format of the OUTPUT: Jacobian (z = 1 or 0) or affine.
+int h2hip_g1_sum_partials_host(const void *gathered_jacobian, size_t world, size_t count, int point_format, void *out) {
+    H2_REQUIRE((count == 0 || (gathered_jacobian && out)) && world >= 1, "bad argument");
+    H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
+    const G1Jac *in = (const G1Jac *)gathered_jacobian;
+    for (size_t j = 0; j < count; ++j) {
+        XYZZ acc = XYZZ::identity();
+        for (size_t r = 0; r < world; ++r) {
+            G1Jac p;
+            memcpy(&p, &in[r * count + j], sizeof(G1Jac));
+            if (p.z.is_zero()) continue;
+            XYZZ q;
+            q.x = p.x;
+            q.y = p.y;
+            q.zz = fe_sqr(p.z);
+            q.zzz = fe_mul(q.zz, p.z);
+            xyzz_add(acc, q);
+        }
+        const G1Affine a = xyzz_to_affine(acc);
+        if (point_format == H2HIP_POINT_AFFINE) {
+            memcpy((char *)out + sizeof(G1Affine) * j, &a, sizeof(G1Affine));
+        } else {
+            G1Jac o;
+            o.x = a.x;
+            o.y = a.y;
+            o.z = a.is_identity() ? Fq::zero() : Fq::one();
+            memcpy((char *)out + sizeof(G1Jac) * j, &o, sizeof(G1Jac));
+        }
+    }
+    return H2HIP_OK;
+}
+
 // ------------------------------------------------------------------ NTT family
 static Fr load_fr(const void *p) {
     Fr r;

@@ -60,6 +60,7 @@ _PROTOS = {
     "h2hip_g1_validate_dev": (_int, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "h2hip_g1_decompress_batch_dev": (_int, [_vp, _vp, _sz, _vp, _u32, _u32]),
     "h2hip_g1_sum_jacobian_dev": (_int, [_vp, _vp, _sz, _int, _vp]),
+    "h2hip_g1_sum_partials_host": (_int, [_vp, _sz, _sz, _int, _vp]),
     "h2hip_best_fft": (_int, [_vp, _vp, _vp, _u32]),
     "h2hip_best_fft_dev": (_int, [_vp, _vp, _vp, _u32]),
     "h2hip_ifft": (_int, [_vp, _vp, _vp, _u32, _vp]),

@@ -4,7 +4,8 @@ over xGMI on ROCm; "gloo" in CPU tests).
 * MSM — point-range sharding: rank g keeps bases[g*n/N .. (g+1)*n/N) resident and receives the matching
   scalar slice; it computes a full partial MSM locally (no data-path collective).  The only exchange is an
   all-gather of the N partial results (96 B Jacobian each — RCCL has no elliptic-curve reduction op), after
-  which every rank sums the N points on its own GPU (h2hip_g1_sum_jacobian_dev).
+  which every rank sums the N points (h2hip_g1_sum_partials_host: all columns of a round in one host call; the exchange itself is
+  libh2hip's `Comm`).
 * NTT — independent columns are dealt round-robin to ranks (`columns_for_rank`); `sharded_ntt_columns` runs each rank's transforms
   on its own GPU and leaves the results there (where the matching commitments / quotient terms are computed), or, on request,
   all-gathers them so that every rank holds every transformed column.
@@ -30,12 +31,16 @@ def columns_for_rank(num_columns: int, rank: int, world: int):
     return list(range(rank, num_columns, world))
 
 
-def sharded_msm(ctx: Context, bases: Bases, scalars_dptr: int, n_local: int, group=None, device=None, point_format: int = POINT_JACOBIAN) -> np.ndarray:
-    """Partial MSM over this rank's slice, all-gather of the partials, local sum.  Every rank returns the full result."""
+def sharded_msm(ctx: Context, bases: Bases, scalars_dptr: int, n_local: int, group=None, device=None, point_format: int = POINT_JACOBIAN, comm=None) -> np.ndarray:
+    """Partial MSM over this rank's slice, all-gather of the partials, local sum.  Every rank returns the full result.  With `comm` (a
+    `Comm`: libh2hip's RCCL communicator or callback transport) the exchange and the sum run inside the library; without it, over
+    torch.distributed tensors (kept for hosts that already hold a torch process group and no h2hip_comm)."""
     import torch
     import torch.distributed as dist
 
     part = ctx.msm_dev(bases, scalars_dptr, n_local, POINT_JACOBIAN)
+    if comm is not None:
+        return _gather_and_sum(ctx, comm, part, point_format)[0:1]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         if point_format == POINT_JACOBIAN:
             return part
@@ -77,7 +82,21 @@ def _sum_gathered(ctx: Context, allp, world: int, count: int, point_format: int,
     return out
 
 
-def sharded_msm_batch(ctx: Context, bases: Bases, scalar_dptrs, n_local: int, group=None, device=None) -> np.ndarray:
+def _gather_and_sum(ctx: Context, comm, parts: np.ndarray, point_format: int) -> np.ndarray:
+    """parts: (count, 12) Jacobian partials of this rank -> (count, 12 | 8) sums over all ranks: ONE all-gather through libh2hip's
+    communicator (RCCL over xGMI, or the host callback) and ONE host-side summation call for all columns"""
+    import ctypes as C
+
+    count = len(parts)
+    parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(count, 12)
+    allp = np.zeros((comm.world, count, 12), dtype=np.uint64)
+    ctx._chk(ctx.lib.h2hip_comm_allgather_host(comm.handle, ctx.handle, parts.ctypes.data, parts.nbytes, allp.ctypes.data))
+    out = np.zeros((count, 12 if point_format == POINT_JACOBIAN else 8), dtype=np.uint64)
+    ctx._chk(ctx.lib.h2hip_g1_sum_partials_host(allp.ctypes.data, comm.world, count, point_format, out.ctypes.data))
+    return out
+
+
+def sharded_msm_batch(ctx: Context, bases: Bases, scalar_dptrs, n_local: int, group=None, device=None, comm=None) -> np.ndarray:
     """`len(scalar_dptrs)` independent MSMs (e.g. all columns of a phase) over this rank's slice, pipelined on two
     streams; ONE all-gather carries all the partials (count x 96 B per rank); every rank returns all full results
     as a (count, 12) Jacobian array."""
@@ -86,6 +105,8 @@ def sharded_msm_batch(ctx: Context, bases: Bases, scalar_dptrs, n_local: int, gr
 
     count = len(scalar_dptrs)
     parts = ctx.msm_batch_dev(bases, scalar_dptrs, n_local, POINT_JACOBIAN)
+    if comm is not None:   # libh2hip's own exchange: no torch tensors, no per-column device calls
+        return parts if comm.world == 1 else _gather_and_sum(ctx, comm, parts, POINT_JACOBIAN)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return parts
     world = dist.get_world_size(group)
@@ -199,18 +220,19 @@ SHARD_QUOTIENT = 1
 class ShardedKey:
     """keeps the shard base sets and the communicator of a sharded proving key alive"""
 
-    def __init__(self, pk, g_shard, g_lagrange_shard, comm):
-        self.pk, self.g_shard, self.g_lagrange_shard, self.comm = pk, g_shard, g_lagrange_shard, comm
+    def __init__(self, pk, g_shard, g_lagrange_shard, comm, own_comm=True):
+        self.pk, self.g_shard, self.g_lagrange_shard, self.comm, self.own_comm = pk, g_shard, g_lagrange_shard, comm, own_comm
 
     def free(self):
         self.pk.ctx._chk(self.pk.ctx.lib.h2hip_plonk_pk_set_sharding(self.pk.handle, None, None, None, 0, 0, 0))
         self.g_shard.free()
         self.g_lagrange_shard.free()
-        self.comm.destroy()
+        if self.own_comm:
+            self.comm.destroy()
 
 
 def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, group=None, device=None, precompute: bool = True,
-                      rccl: bool = None, shard_quotient: bool = True) -> ShardedKey:
+                      rccl: bool = None, shard_quotient: bool = True, comm=None) -> ShardedKey:
     """Shards a proving key's create_proof over the process group (h2hip_plonk_pk_set_sharding): this rank uploads ONLY its point range of
     the SRS (g_points / g_lagrange_points: the full (n, 8) affine arrays or anything sliceable that yields them) as base sets with their own
     window tables; h(X)'s numerator is evaluated by cosets of the extended domain (shard_quotient).  The exchange runs inside libh2hip:
@@ -225,11 +247,13 @@ def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, g
     n = 1 << pk.params.k
     lo, hi = shard_range(n, rank, world)
     ctx = pk.ctx
-    if rccl is None:
-        rccl = dist.get_backend(group) == "nccl"
-    comm = Comm(ctx, group=group, rccl=rccl, device=device)
+    own_comm = comm is None
+    if own_comm:
+        if rccl is None:
+            rccl = dist.get_backend(group) == "nccl"
+        comm = Comm(ctx, group=group, rccl=rccl, device=device)
     flags = BASES_PRECOMPUTE if precompute else BASES_PLAIN
     gs = ctx.bases_upload(np.ascontiguousarray(g_points[lo:hi]), flags)
     gls = ctx.bases_upload(np.ascontiguousarray(g_lagrange_points[lo:hi]), flags)
     ctx._chk(ctx.lib.h2hip_plonk_pk_set_sharding(pk.handle, comm.handle, gs.handle, gls.handle, lo, hi - lo, SHARD_QUOTIENT if shard_quotient else 0))
-    return ShardedKey(pk, gs, gls, comm)
+    return ShardedKey(pk, gs, gls, comm, own_comm)

@@ -151,6 +151,9 @@ int h2hip_g1_decompress_batch_dev(h2hip_ctx *ctx, const void *compressed_dev, si
 /* Sum of n Jacobian points resident on the device (multi-GPU: the all-gathered per-GPU partial MSM results;
  * RCCL has no group-law reduction). */
 int h2hip_g1_sum_jacobian_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, int point_format, void *out_host);
+/* the host half of a point-range sharded round: out[j] = sum_r gathered[r * count + j] over `world` ranks' Jacobian partials (the layout
+ * h2hip_comm_allgather_host leaves), all `count` columns in one call, host arithmetic (no device round trip).  Output Jacobian (z in {0, 1}) or affine. */
+int h2hip_g1_sum_partials_host(const void *gathered_jacobian, size_t world, size_t count, int point_format, void *out);
 
 /* ---- K2/K3: NTT family  (replaces arithmetic::best_fft and EvaluationDomain::{ifft, coeff_to_extended,
  *      extended_to_coeff} [UPSTREAM]) ------------------------------------------------ */

@@ -40,6 +40,16 @@ def _worker(rank, world, port, n, q):
         gotb = sharded_msm_batch(ctx, b, [ds, ds2, ds], hi - lo)
         want2 = CO.best_multiexp(scal2, bases, threads=2)
         ok = ok and [jac_to_affine_ints(gotb[j]) for j in range(3)] == O.limbs_to_points(np.concatenate([want, want2, want]))
+        # the same through libh2hip's own communicator (callback transport over gloo here, RCCL on a multi-GPU node) and its host-side sum
+        from halo2_lib_amd.multi_gpu import Comm
+
+        comm = Comm(ctx)
+        got_c = sharded_msm(ctx, b, ds, hi - lo, comm=comm)
+        ok = ok and [jac_to_affine_ints(got_c)] == O.limbs_to_points(want)
+        ok = ok and np.array_equal(sharded_msm(ctx, b, ds, hi - lo, point_format=H.POINT_AFFINE, comm=comm), want)
+        gotc = sharded_msm_batch(ctx, b, [ds, ds2, ds], hi - lo, comm=comm)
+        ok = ok and [jac_to_affine_ints(gotc[j]) for j in range(3)] == O.limbs_to_points(np.concatenate([want, want2, want]))
+        comm.destroy()
         ctx.free(ds2)
         cols = columns_for_rank(7, rank, world)
         q.put((rank, ok, cols))
