@@ -283,6 +283,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_table_nontemporal")) return &ctx->msm_table_nontemporal;
     if (!strcmp(name, "msm_fold_windows")) return &ctx->msm_fold_windows;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
+    if (!strcmp(name, "msm_debug_reorder")) return &ctx->msm_debug_reorder;
     if (!strcmp(name, "ntt_wave_local")) return &ctx->ntt_wave_local;
     if (!strcmp(name, "ntt_radix8")) return &ctx->ntt_radix8;
     if (!strcmp(name, "ntt_tile_bits8")) return &ctx->ntt_tile_bits8;
@@ -292,6 +293,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_split_streams")) return &ctx->msm_split_streams;
     if (!strcmp(name, "msm_quad_tails")) return &ctx->msm_quad_tails;
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
+    if (!strcmp(name, "msm_sort_mode")) return &ctx->msm_sort_mode;
     if (!strcmp(name, "msm_scatter_full_lds")) return &ctx->msm_scatter_full_lds;
     if (!strcmp(name, "msm_sort_threads")) return &ctx->msm_sort_threads;
     if (!strcmp(name, "msm_fuse_cols")) return &ctx->msm_fuse_cols;
@@ -316,6 +318,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_sort_threads) H2_REQUIRE(value == 256 || value == 512 || value == 1024, "msm_sort_threads must be 256, 512 or 1024");
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
     if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 0 && value <= 4, "msm_lanes must be 0 (auto) or 1..4");
+    if (p == &ctx->msm_sort_mode) H2_REQUIRE(value >= 0 && value <= 2, "msm_sort_mode must be 0 (auto), 1 (one-pass sort) or 2 (two-level sort)");
     if (p == &ctx->msm_accum_variant) H2_REQUIRE(value >= 2 && value <= 7, "msm_accum_variant must be 2..7");
     if (p == &ctx->ntt_min_col_bits) H2_REQUIRE(value >= 0 && value <= 5, "ntt_min_col_bits must be 0..5");
     if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
@@ -636,6 +639,8 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         c->msm_table_nontemporal = ctx->msm_table_nontemporal;
         c->msm_fold_windows = ctx->msm_fold_windows;
         c->msm_scatter_split = ctx->msm_scatter_split;
+        c->msm_sort_mode = ctx->msm_sort_mode;
+        c->msm_debug_reorder = ctx->msm_debug_reorder;
         c->msm_scatter_full_lds = ctx->msm_scatter_full_lds;
         c->msm_sort_threads = ctx->msm_sort_threads;
         c->msm_quad_tails = ctx->msm_quad_tails;

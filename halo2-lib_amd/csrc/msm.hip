@@ -290,6 +290,176 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     }
 }
 
+// ------------------------------------------------------------------ 4b. two-level sort with coalesced writes (r03)
+// The one-pass counting sort above writes every entry on its own (a 4-byte store to its final position): 8.9 M scattered write transactions
+// per 2^19-point MSM, which is what its 76 us are made of (the L2 retires them per transaction, not per byte), plus W*G full-window
+// histograms (35 MB) written, prefixed in place and read back.  Here every write is a coalesced run:
+//   A  msm_csort_hist      (window, chunk) workgroups count their entries per COARSE bucket (key >> LB: 128 per window)
+//      exclusive scan over (window, coarse bucket, chunk)
+//   B  msm_csort_scatter   the workgroup sorts its chunk by coarse bucket IN LDS and copies the runs out: a run of ~64 entries per
+//                          (chunk, coarse bucket) is contiguous in the coarse array; entries carry (point index, sign, fine key)
+//   C  msm_csort_fine      one workgroup per coarse bucket (~4Ki entries): histogram of the fine keys -> the window's bucket offsets (written
+//                          directly: no global scan over W * 2^(c-1) counts), counting sort in LDS, one contiguous copy-out.  Buckets that
+//                          do not fit the LDS buffer (0/1-heavy circuit columns put a quarter of a window into one key) are placed directly.
+// Traffic: the digits are read twice, the entries written twice and read once — all of it coalesced.
+constexpr uint32_t CS_THREADS = 512, CS_CHUNK = 8192, CS_MAX_NC = 128, CS_MAX_NF = 256, CS_BUF = 8192;
+struct CSortGeom {
+    uint32_t LB, NC, NF;   // fine bits, coarse buckets per window, fine keys per coarse bucket (NC * NF = B)
+};
+__global__ __launch_bounds__(CS_THREADS) void msm_csort_hist_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t G, CSortGeom cg,
+                                                                    uint32_t *__restrict__ chist) {
+    H2_SORT_PRIORITY();
+    __shared__ uint32_t hist[CS_THREADS / 64][CS_MAX_NC];   // one sub-histogram per wave: no cross-wave contention on 128 counters
+    const uint32_t w = blockIdx.x / G, g = blockIdx.x - w * G, tid = threadIdx.x, wave = tid >> 6;
+    for (uint32_t k = tid; k < (CS_THREADS / 64) * CS_MAX_NC; k += CS_THREADS) (&hist[0][0])[k] = 0;
+    __syncthreads();
+    const uint32_t lo = g * CS_CHUNK, hi = lo + CS_CHUNK < n ? lo + CS_CHUNK : n;
+    const uint32_t *dw = digits + (size_t)w * n;
+    for (uint32_t i = lo + tid; i < hi; i += 8 * CS_THREADS) {
+        uint32_t d[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) d[k] = i + k * CS_THREADS < hi ? dw[i + k * CS_THREADS] & 0x7fffffffu : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            if (d[k]) atomicAdd(&hist[wave][(d[k] - 1) >> cg.LB], 1u);
+    }
+    __syncthreads();
+    for (uint32_t cb = tid; cb < cg.NC; cb += CS_THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t v = 0; v < CS_THREADS / 64; ++v) sum += hist[v][cb];
+        chist[((size_t)w * cg.NC + cb) * G + g] = sum;
+    }
+}
+__global__ __launch_bounds__(CS_THREADS) void msm_csort_scatter_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t G, CSortGeom cg,
+                                                                       const uint32_t *__restrict__ cscan, uint32_t *__restrict__ centries) {
+    H2_SORT_PRIORITY();
+    __shared__ uint32_t lbase[CS_MAX_NC + 1], cursor[CS_MAX_NC], gbase[CS_MAX_NC];
+    __shared__ uint32_t sorted[CS_CHUNK];
+    const uint32_t w = blockIdx.x / G, g = blockIdx.x - w * G, tid = threadIdx.x;
+    // this chunk's count per coarse bucket = the difference of neighbouring entries of the scanned array; local exclusive prefix by one wave
+    if (tid < 64) {
+        uint32_t run = 0;
+        for (uint32_t c0 = 0; c0 < cg.NC; c0 += 64) {
+            const uint32_t cb = c0 + tid;
+            uint32_t cnt = 0, gb = 0;
+            if (cb < cg.NC) {
+                const size_t idx = ((size_t)w * cg.NC + cb) * G + g;
+                gb = cscan[idx];
+                cnt = cscan[idx + 1] - gb;
+            }
+            uint32_t incl = cnt;   // inclusive scan over the wave by shuffles
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl(incl, (int)(tid >= d ? tid - d : tid));
+                if (tid >= d) incl += up;
+            }
+            if (cb < cg.NC) {
+                lbase[cb] = run + incl - cnt;
+                cursor[cb] = run + incl - cnt;
+                gbase[cb] = gb;
+            }
+            run += __shfl(incl, 63);
+        }
+        if (tid == 0) lbase[cg.NC] = run;
+    }
+    __syncthreads();
+    const uint32_t lo = g * CS_CHUNK, hi = lo + CS_CHUNK < n ? lo + CS_CHUNK : n;
+    const uint32_t *dw = digits + (size_t)w * n;
+    const uint32_t fmask = cg.NF - 1;
+    for (uint32_t i = lo + tid; i < hi; i += 8 * CS_THREADS) {
+        uint32_t dv[8], pos[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) dv[k] = i + k * CS_THREADS < hi ? dw[i + k * CS_THREADS] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t d = dv[k] & 0x7fffffffu;
+            pos[k] = d ? atomicAdd(&cursor[(d - 1) >> cg.LB], 1u) : KEY_INVALID;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            if (pos[k] != KEY_INVALID)
+                sorted[pos[k]] = ((i + k * CS_THREADS) << cg.LB) | (((dv[k] & 0x7fffffffu) - 1) & fmask) | (dv[k] & 0x80000000u);
+    }
+    __syncthreads();
+    const uint32_t total = lbase[cg.NC];
+    for (uint32_t p = tid; p < total; p += CS_THREADS) {
+        uint32_t a = 0, b = cg.NC;   // largest cb with lbase[cb] <= p
+        while (b - a > 1) {
+            const uint32_t mid = (a + b) >> 1;
+            if (lbase[mid] <= p) a = mid;
+            else b = mid;
+        }
+        centries[gbase[a] + (p - lbase[a])] = sorted[p];
+    }
+}
+__global__ __launch_bounds__(CS_THREADS) void msm_csort_fine_kernel(const uint32_t *__restrict__ centries, const uint32_t *__restrict__ cscan, uint32_t G,
+                                                                    CSortGeom cg, uint32_t B, uint32_t Wcol, uint32_t table_stride, uint32_t nsort,
+                                                                    uint32_t *__restrict__ sval, uint32_t *__restrict__ offsets) {
+    H2_SORT_PRIORITY();
+    __shared__ uint32_t fh[CS_MAX_NF], cur[CS_MAX_NF], buf[CS_BUF];
+    const uint32_t tid = threadIdx.x, cbi = blockIdx.x, w = cbi / cg.NC, cb = cbi - w * cg.NC;
+    const uint32_t cstart = cscan[(size_t)cbi * G], cend = cscan[(size_t)(cbi + 1) * G], size = cend - cstart;
+    const uint32_t fmask = cg.NF - 1;
+    for (uint32_t f = tid; f < cg.NF; f += CS_THREADS) fh[f] = 0;
+    __syncthreads();
+    for (uint32_t e = tid; e < size; e += CS_THREADS) atomicAdd(&fh[centries[cstart + e] & fmask], 1u);
+    __syncthreads();
+    // exclusive prefix over the NF <= 256 fine counts (Hillis-Steele over the first NF lanes)
+    uint32_t mine = tid < cg.NF ? fh[tid] : 0u, incl = mine;
+    if (tid < CS_MAX_NF) cur[tid] = incl;
+    __syncthreads();
+    for (uint32_t d = 1; d < cg.NF; d <<= 1) {
+        uint32_t up = 0;
+        if (tid < cg.NF && tid >= d) up = cur[tid - d];
+        __syncthreads();
+        if (tid < cg.NF) {
+            incl += up;
+            cur[tid] = incl;
+        }
+        __syncthreads();
+    }
+    if (tid < cg.NF) {
+        const uint32_t excl = incl - mine;
+        offsets[(size_t)w * B + cb * cg.NF + tid] = cstart + excl;   // the bucket boundaries the accumulation walks
+        cur[tid] = excl;
+    }
+    if (cbi + 1 == gridDim.x && tid == 0) offsets[nsort] = cend;      // total number of entries
+    __syncthreads();
+    const uint32_t idx_base = (w % Wcol) * table_stride;   // precomputed bases: window w of a column reads table level w
+    const bool fits = size <= CS_BUF;
+    for (uint32_t e = tid; e < size; e += CS_THREADS) {
+        const uint32_t v = centries[cstart + e];
+        const uint32_t pos = atomicAdd(&cur[v & fmask], 1u);
+        const uint32_t out = (idx_base + ((v & 0x7fffffffu) >> cg.LB)) | (v & 0x80000000u);
+        if (fits) buf[pos] = out;
+        else sval[cstart + pos] = out;
+    }
+    if (!fits) return;
+    __syncthreads();
+    for (uint32_t p = tid; p < size; p += CS_THREADS) sval[cstart + p] = buf[p];
+}
+
+// diagnostics (msm_debug_reorder): reorder the entries INSIDE every bucket — 1: ascending point index, 2: hashed (no order at all).  The
+// sum of a bucket does not depend on it; the accumulation's table gather does (tools/msm_r03.py measures how much).  One thread per
+// bucket, insertion sort in place; buckets above 1024 entries are left alone.
+__global__ __launch_bounds__(256) void msm_debug_reorder_kernel(uint32_t *__restrict__ sval, const uint32_t *__restrict__ offsets, uint32_t nkeys, int mode) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nkeys) return;
+    const uint32_t lo = offsets[k], hi = offsets[k + 1];
+    if (hi - lo > 1024) return;
+    for (uint32_t i = lo + 1; i < hi; ++i) {
+        const uint32_t v = sval[i], kv = mode == 1 ? (v & 0x7fffffffu) : (v & 0x7fffffffu) * 2654435761u;
+        uint32_t j = i;
+        while (j > lo) {
+            const uint32_t u = sval[j - 1], ku = mode == 1 ? (u & 0x7fffffffu) : (u & 0x7fffffffu) * 2654435761u;
+            if (ku <= kv) break;
+            sval[j] = u;
+            --j;
+        }
+        sval[j] = v;
+    }
+}
+
 // ------------------------------------------------------------------ 5. chunked bucket accumulation
 // largest k in [lo, nkeys) with offsets[k] <= e   (offsets has nkeys+1 entries, e < offsets[nkeys])
 // (ks = stride between consecutive run keys in `offsets`: 1, or the number of windows folded into one bucket)
@@ -1070,8 +1240,29 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     uint32_t *digits, *bhist, *counts, *offsets, *sval, *pkey[2];
     XYZZ29 *buckets, *pval[2];
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_DIGITS, sizeof(uint32_t) * emax, (void **)&digits));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * (nsort + 1), (void **)&counts));
+    // two-level sort (r03, the default): coarse buckets of a window = the top 7 bits of the key (fewer for small windows), fine keys below
+    CSortGeom cg;
+    cg.LB = c - 1 > 7 ? c - 1 - 7 : (c - 1) / 2;
+    cg.NF = 1u << cg.LB;
+    cg.NC = B >> cg.LB;
+    const uint32_t Gc = (uint32_t)((n + CS_CHUNK - 1) / CS_CHUNK);
+    const size_t ncoarse = (size_t)W * cg.NC * Gc;
+    // measured (profiles/r03_msm_sort_ab.log, r03_msm_reorder.log): the sort itself is ahead from 2^18 points on (2^19: 0.124 -> 0.087 ms per
+    // MSM; 2^16: many tiny coarse buckets, 0.03 -> 0.10 ms), but at 2^19 the accumulation that follows runs 5-9 % slower on its output
+    // (0.70 -> 0.74-0.76 ms; the entry order inside a bucket moves the gather by that much: ascending 0.70, hashed 0.74) and a k = 19 proof
+    // does not gain (15.4 -> 15.5-15.7 ms).  From 2^20 on both the sort and the accumulation are level or ahead (batch of 4: 1.66-1.68 vs
+    // 1.67-1.76 ms per MSM at 2^20, 3.27 vs 3.36 at 2^21): auto selects it there.  msm_sort_mode 2 forces it at every size, 1 never uses it.
+    const bool two_level = (ctx->msm_sort_mode == 2 || (ctx->msm_sort_mode == 0 && n >= ((size_t)1 << 20))) && !fold_w.fg && n <= ((size_t)1 << (31 - cg.LB)) && cg.NC <= CS_MAX_NC && cg.NF <= CS_MAX_NF &&
+                           ncoarse + 1 <= (size_t)nsort + 1 + (1u << 20);
+    uint32_t *centries = nullptr, *cscan = nullptr;
+    if (two_level) {
+        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (ncoarse + 2), (void **)&cscan));
+        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SKEY, sizeof(uint32_t) * (emax + 4), (void **)&centries));
+        bhist = nullptr;
+    } else {
+        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
+    }
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * ((size_t)nsort + 1 + (1u << 20)), (void **)&counts));   // (+ room for the two-level sort's coarse counts)
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * ((size_t)nsort + ks + 1), (void **)&offsets));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SVAL, sizeof(uint32_t) * (emax + 4), (void **)&sval));   // + 4: the accumulation reads aligned 16-byte groups
     if (ext_buckets) buckets = ext_buckets;
@@ -1103,9 +1294,23 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     }
     prof_begin(ctx, "msm_digits_kernel");
     H2_REQUIRE(ks <= 256, "fold group too large");
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), ncols), dim3(256), 0, st, dcols, (uint32_t)n, c, Wcol, digits, counts + nsort,
-                       offsets + nsort + 1, ks);   // + the sentinels counts[nsort], offsets[(nkeys + 1) * ks]
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), ncols), dim3(256), 0, st, dcols, (uint32_t)n, c, Wcol, digits,
+                       two_level ? counts + ncoarse : counts + nsort, offsets + nsort + 1, ks);   // + the sentinels counts[last], offsets[(nkeys + 1) * ks]
     prof_end(ctx);
+    if (two_level) {
+        prof_begin(ctx, "msm_hist_kernel");
+        hipLaunchKernelGGL(msm_csort_hist_kernel, dim3(W * Gc), dim3(CS_THREADS), 0, st, (const uint32_t *)digits, (uint32_t)n, Gc, cg, counts);
+        prof_end(ctx);
+        H2_HIPCHK(hipGetLastError());
+        H2_CHK(exclusive_scan_u32(ctx, counts, cscan, (uint32_t)(ncoarse + 1)));   // (window, coarse bucket, chunk) order; the last entry is the total
+        prof_begin(ctx, "msm_scatter_kernel");
+        hipLaunchKernelGGL(msm_csort_scatter_kernel, dim3(W * Gc), dim3(CS_THREADS), 0, st, (const uint32_t *)digits, (uint32_t)n, Gc, cg, (const uint32_t *)cscan,
+                           centries);
+        hipLaunchKernelGGL(msm_csort_fine_kernel, dim3(W * cg.NC), dim3(CS_THREADS), 0, st, (const uint32_t *)centries, (const uint32_t *)cscan, Gc, cg, B, Wcol,
+                           precomp ? (uint32_t)bases->n : 0u, nsort, sval, offsets);
+        prof_end(ctx);
+        H2_HIPCHK(hipGetLastError());
+    } else {
     const uint32_t sort_threads = (uint32_t)ctx->msm_sort_threads;
     if (!ctx->msm_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
         H2_HIPCHK(hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
@@ -1133,6 +1338,12 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
                        precomp ? (uint32_t)bases->n : 0u, Wcol, fold_w, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
+    }   // one-pass sort
+    if (ctx->msm_debug_reorder && ks == 1) {
+        prof_begin(ctx, "msm_debug_reorder_kernel");
+        hipLaunchKernelGGL(msm_debug_reorder_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, sval, (const uint32_t *)offsets, nkeys, ctx->msm_debug_reorder);
+        prof_end(ctx);
+    }
     }   // MSM_PHASE_SORT
 
     if (phases & MSM_PHASE_ACCUM) {

@@ -572,3 +572,26 @@ def test_msm_accumulate_variants_agree(ctx, variant):
     finally:
         ctx.set_param("msm_accum_variant", 3)
         b.free()
+
+
+def test_msm_two_level_sort_paths(ctx):
+    """the two-level sort (the default from 2^20 points on; msm_sort_mode 2 forces it here): several chunks per window, a coarse bucket larger than the LDS buffer (all scalars equal:
+    every entry of a window lands in ONE key, placed directly), windows with no entries at all — and the one-pass sort (msm_sort_mode 1) on
+    the same inputs"""
+    n = 20000
+    bases = CO.known_dlog_bases(n, fr([3]), fr([11]))
+    b = ctx.bases_upload(bases)
+    ones = np.repeat(fr([1]), n, axis=0)
+    big = np.repeat(fr([R - 5]), n, axis=0)
+    mixed = np.concatenate([ones[: n // 2], rand_fr(n - n // 2, 91)])
+    try:
+        for mode in (2, 1):
+            ctx.set_param("msm_sort_mode", mode)
+            for c in (0, 12):
+                ctx.set_param("msm_window_bits", c)
+                for s in (ones, big, mixed):
+                    assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=8)), (mode, c)
+    finally:
+        ctx.set_param("msm_sort_mode", 0)
+        ctx.set_param("msm_window_bits", 0)
+        b.free()

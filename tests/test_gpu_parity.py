@@ -119,6 +119,26 @@ def test_msm_many_duplicates_and_single_bucket(ctx):
     b.free()
 
 
+def test_msm_both_sorts_at_every_size(ctx):
+    """msm_sort_mode 2 forces the two-level sort below its 2^20-point threshold (small windows: few coarse buckets, few fine keys; one
+    chunk; a coarse bucket past the LDS buffer), 1 forces the one-pass sort: both against the oracle on the same inputs"""
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    try:
+        for n, flags in ((1, 0), (777, 0), (1 << 10, 0), (20000, 0), (1 << 14, BASES_PRECOMPUTE), (70001, BASES_PRECOMPUTE)):
+            bases = CO.known_dlog_bases(n, fr([5]), fr([13]))
+            b = ctx.bases_upload(bases, flags)
+            cols = [rand_fr(n, n), circuit_like_fr(n, n + 1), np.repeat(fr([1]), n, axis=0)]
+            want = [CO.best_multiexp(s, bases, threads=NT) for s in cols]
+            for mode in (2, 1):
+                ctx.set_param("msm_sort_mode", mode)
+                for s, w in zip(cols, want):
+                    assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), w), (n, flags, mode)
+            b.free()
+    finally:
+        ctx.set_param("msm_sort_mode", 0)
+
+
 def test_fr_batches(ctx):
     a, b, c = rand_fr(100003, 1), rand_fr(100003, 2), rand_fr(100003, 3)
     assert np.array_equal(ctx.fr_mul(a, b), CO.fr_mul(a, b))
