@@ -318,7 +318,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_sort_threads) H2_REQUIRE(value == 256 || value == 512 || value == 1024, "msm_sort_threads must be 256, 512 or 1024");
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
     if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 0 && value <= 4, "msm_lanes must be 0 (auto) or 1..4");
-    if (p == &ctx->msm_sort_mode) H2_REQUIRE(value >= 0 && value <= 2, "msm_sort_mode must be 0 (auto), 1 (one-pass sort) or 2 (two-level sort)");
+    if (p == &ctx->msm_sort_mode) H2_REQUIRE(value >= 0 && value <= 2, "msm_sort_mode must be 0 or 1 (one-pass sort) or 2 (two-level sort)");
     if (p == &ctx->msm_accum_variant) H2_REQUIRE(value >= 2 && value <= 7, "msm_accum_variant must be 2..7");
     if (p == &ctx->ntt_min_col_bits) H2_REQUIRE(value >= 0 && value <= 5, "ntt_min_col_bits must be 0..5");
     if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");

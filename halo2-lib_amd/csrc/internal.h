@@ -94,7 +94,7 @@ struct h2hip_ctx {
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
-    int msm_sort_mode = 0;       // 0: auto (two-level sort with coalesced writes, msm_csort_*, from 2^20 points on); 1: always the one-pass LDS-histogram counting sort (r01/r02); 2: always two-level
+    int msm_sort_mode = 0;       // 0 / 1: the one-pass LDS-histogram counting sort (default); 2: the two-level sort with coalesced writes (msm_csort_*; measured level or behind inside proofs)
     int msm_scatter_split = 0;   // bucket sub-ranges per window in the scatter (0 = auto, power of two)
     int msm_scatter_full_lds = 1;   // 1: the scatter declares the full 128 KiB of LDS (one workgroup per CU: one segment per XCD at a time); 0: only its cursors
     int msm_fold_windows = 0;    // precomputed bases: windows per shared bucket set (0 / 1 = one set per window: the default).  The sort is bucket-major inside a group of this many windows, so the

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     }
 }
 
-// ------------------------------------------------------------------ 4b. two-level sort with coalesced writes (r03)
+// ------------------------------------------------------------------ 4b. two-level sort with coalesced writes (r03; selectable, not the default — see msm_run_cols)
 // The one-pass counting sort above writes every entry on its own (a 4-byte store to its final position): 8.9 M scattered write transactions
 // per 2^19-point MSM, which is what its 76 us are made of (the L2 retires them per transaction, not per byte), plus W*G full-window
 // histograms (35 MB) written, prefixed in place and read back.  Here every write is a coalesced run:
@@ -1247,12 +1247,13 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     cg.NC = B >> cg.LB;
     const uint32_t Gc = (uint32_t)((n + CS_CHUNK - 1) / CS_CHUNK);
     const size_t ncoarse = (size_t)W * cg.NC * Gc;
-    // measured (profiles/r03_msm_sort_ab.log, r03_msm_reorder.log): the sort itself is ahead from 2^18 points on (2^19: 0.124 -> 0.087 ms per
-    // MSM; 2^16: many tiny coarse buckets, 0.03 -> 0.10 ms), but at 2^19 the accumulation that follows runs 5-9 % slower on its output
-    // (0.70 -> 0.74-0.76 ms; the entry order inside a bucket moves the gather by that much: ascending 0.70, hashed 0.74) and a k = 19 proof
-    // does not gain (15.4 -> 15.5-15.7 ms).  From 2^20 on both the sort and the accumulation are level or ahead (batch of 4: 1.66-1.68 vs
-    // 1.67-1.76 ms per MSM at 2^20, 3.27 vs 3.36 at 2^21): auto selects it there.  msm_sort_mode 2 forces it at every size, 1 never uses it.
-    const bool two_level = (ctx->msm_sort_mode == 2 || (ctx->msm_sort_mode == 0 && n >= ((size_t)1 << 20))) && !fold_w.fg && n <= ((size_t)1 << (31 - cg.LB)) && cg.NC <= CS_MAX_NC && cg.NF <= CS_MAX_NF &&
+    // measured (profiles/r03_msm_sort_ab.log, r03_msm_reorder.log): on uniform scalars the sort itself is ahead from 2^18 points on (2^19:
+    // 0.124 -> 0.087 ms per MSM, 2^20: 0.24 -> 0.18; 2^16: many tiny coarse buckets, 0.03 -> 0.10 ms), but at 2^19 the accumulation that
+    // follows runs 5-9 % slower on its output (the entry order inside a bucket moves the gather by that much: ascending 0.70, hashed 0.74 ms)
+    // and the k = 19 proof does not gain (15.4 -> 15.5-15.7 ms); on a circuit's 0/1-heavy columns ONE workgroup walks the coarse bucket that
+    // holds a quarter of a window (0.5 M entries at 2^21) and the proofs at k >= 20 lose 15-20 % (k = 21: 62 -> 76 ms).  So the one-pass sort
+    // stays the default at every size; msm_sort_mode 2 selects this one (it would need heavy coarse buckets dealt over several workgroups).
+    const bool two_level = ctx->msm_sort_mode == 2 && !fold_w.fg && n <= ((size_t)1 << (31 - cg.LB)) && cg.NC <= CS_MAX_NC && cg.NF <= CS_MAX_NF &&
                            ncoarse + 1 <= (size_t)nsort + 1 + (1u << 20);
     uint32_t *centries = nullptr, *cscan = nullptr;
     if (two_level) {

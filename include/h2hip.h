@@ -57,8 +57,8 @@ int h2hip_init(int device, void *hip_stream, h2hip_ctx **out);
 void h2hip_destroy(h2hip_ctx *ctx);
 int h2hip_sync(h2hip_ctx *ctx);
 /* tuning knobs (defaults are the tuned values): "msm_window_bits" (0 = auto), "msm_chunk" (0 = auto), "msm_seg",
- * "msm_scatter_split" (0 = auto), "msm_lanes", "msm_quad_tails", "msm_accum_variant", "msm_sort_mode" (0 = auto: the two-level sort from
- * 2^20 points on, 1 = always the one-pass sort, 2 = always two-level), "ntt_tile_bits", "ntt_min_col_bits", "ntt_full_table";
+ * "msm_scatter_split" (0 = auto), "msm_lanes", "msm_quad_tails", "msm_accum_variant", "msm_sort_mode" (0 / 1 = the one-pass counting sort,
+ * 2 = the two-level sort with coalesced writes: ahead on uniform scalars from 2^18 points on, behind on a circuit's 0/1-heavy columns), "ntt_tile_bits", "ntt_min_col_bits", "ntt_full_table";
  * profiling aids: "ntt_debug_skip" (produces wrong results), "msm_debug_reorder" (reorders the entries inside the buckets, results unchanged) */
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value);
 int h2hip_get_param(h2hip_ctx *ctx, const char *name, int *value);

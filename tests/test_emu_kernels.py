@@ -575,7 +575,7 @@ def test_msm_accumulate_variants_agree(ctx, variant):
 
 
 def test_msm_two_level_sort_paths(ctx):
-    """the two-level sort (the default from 2^20 points on; msm_sort_mode 2 forces it here): several chunks per window, a coarse bucket larger than the LDS buffer (all scalars equal:
+    """the two-level sort (msm_sort_mode 2; selectable, not the default): several chunks per window, a coarse bucket larger than the LDS buffer (all scalars equal:
     every entry of a window lands in ONE key, placed directly), windows with no entries at all — and the one-pass sort (msm_sort_mode 1) on
     the same inputs"""
     n = 20000

@@ -120,7 +120,7 @@ def test_msm_many_duplicates_and_single_bucket(ctx):
 
 
 def test_msm_both_sorts_at_every_size(ctx):
-    """msm_sort_mode 2 forces the two-level sort below its 2^20-point threshold (small windows: few coarse buckets, few fine keys; one
+    """msm_sort_mode 2 selects the two-level sort (small windows: few coarse buckets, few fine keys; one
     chunk; a coarse bucket past the LDS buffer), 1 forces the one-pass sort: both against the oracle on the same inputs"""
     from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
 
