@@ -290,3 +290,15 @@ def test_create_proof_gpu_k21_pairing_shape():
         kzg.free()
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_create_proof_gpu_random_shapes():
+    """tools/fuzz_shapes.py for 25 s with a fixed seed: randomly drawn shapes (narrow / wide, with and without lookups, instances, precomputed
+    bases), proof bytes equal to the oracle prover's for every one (a longer run: profiles/r03_fuzz_shapes.log)"""
+    import subprocess, sys, os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_shapes.py"), "25", "11"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "proof bytes equal to the oracle prover's for every one" in r.stdout

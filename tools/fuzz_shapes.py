@@ -1,0 +1,40 @@
+"""Random circuit shapes against the oracle prover on the GPU: for every drawn (k, advice, lookup advice, fixed, instance, lookup bits) the HIP
+create_proof's bytes must equal the oracle prover's on the same SRS / witness / RNG stream, and both verifiers must accept (the checks of
+tests/test_plonk_prover.py::_check).  Shapes are drawn over the whole range the small oracle finishes in about a second — narrow and wide,
+with and without lookups / instances / precomputed bases — so that batching boundaries the fixed test list does not name are crossed too.
+
+    python tools/fuzz_shapes.py [seconds=120] [seed=1]
+"""
+import os, random, sys, time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import halo2_lib_amd as H
+from tests.test_plonk_prover import _check
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = H.Context()
+t0, done, ks = time.time(), 0, {}
+while time.time() - t0 < budget:
+    k = rnd.choice([6, 7, 8, 8, 9, 9, 10, 10, 11, 12])
+    wide = rnd.random() < 0.25
+    na = rnd.randint(1, 40 if wide and k <= 9 else 6)
+    nl = rnd.choice([0, 1, 1, 2, 3]) if not wide else rnd.randint(0, 36 if k <= 8 else 4)
+    nf = rnd.randint(1, 3)
+    ni = rnd.choice([0, 0, 1, 2])
+    lb = None if nl == 0 else rnd.randint(max(1, k - 4), k - 1)
+    pre = rnd.random() < 0.5
+    seed = rnd.randint(1, 1 << 20)
+    shape = (k, na, nl, nf, ni, lb)
+    try:
+        out = _check(ctx, *shape, seed=seed, threads=8, oracle_prover=True, precompute=pre, second_proof=rnd.random() < 0.3)
+    except Exception as e:   # noqa: BLE001 — report the shape, then fail
+        print("FAIL shape", shape, "seed", seed, "precompute", pre, "->", repr(e)[:400], flush=True)
+        sys.exit(1)
+    out[6].free()
+    out[7].free()
+    done += 1
+    ks[k] = ks.get(k, 0) + 1
+    if done % 10 == 0:
+        print("%d shapes ok, %.0f s (last %s precompute=%s)" % (done, time.time() - t0, shape, pre), flush=True)
+print("fuzz_shapes: %d random shapes, proof bytes equal to the oracle prover's for every one; per k: %s; %.0f s" % (done, dict(sorted(ks.items())), time.time() - t0))
