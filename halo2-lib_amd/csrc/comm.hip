@@ -10,6 +10,8 @@
 // The reference has no counterpart (its prover is single-process, rayon threads): the north star adds the 8-GPU split.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "internal.h"
 
 namespace h2 {
@@ -31,7 +33,9 @@ struct RcclApi {
     nccl_get_error_string_fn get_error_string = nullptr;
 };
 static RcclApi g_rccl;
+static std::mutex g_rccl_mutex;   // contexts of different threads may create their communicators at the same time
 static int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return H2HIP_OK;
     const char *names[] = {getenv("H2HIP_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
