@@ -67,3 +67,152 @@ def test_rust_sys_crate_declares_every_header_symbol():
     in_header = set(re.findall(r"\b(h2hip_[a-z0-9_]+)\s*\(", hdr))
     in_rust = set(re.findall(r"pub fn (h2hip_[a-z0-9_]+)", rs))
     assert in_header == in_rust, (sorted(in_header - in_rust), sorted(in_rust - in_header))
+
+
+# ---- signature level: arity and ABI class (pointer / 32-bit int / 64-bit int / size / double) of every parameter and of the return value
+def _strip_c(src):
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.sub(r"//[^\n]*", "", src)
+
+
+def _split_params(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "(<[":
+            depth += 1
+        elif ch in ")>]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+_C_FN_TYPES = ("h2hip_rng_fill_fn", "h2hip_allgather_fn", "h2hip_exchange_fn")
+
+
+def _c_class(t):
+    t = t.strip()
+    if "*" in t or any(f in t for f in _C_FN_TYPES):
+        return "ptr"
+    t = re.sub(r"\bconst\b", "", t).split()
+    t = " ".join(t[:-1]) if len(t) > 1 else t[0]   # drop the parameter name
+    return {"int": "i32", "unsigned": "u32", "unsigned int": "u32", "uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "int64_t": "i64",
+            "size_t": "usize", "double": "f64", "void": "void", "uint8_t": "u8"}[t]
+
+
+def _c_protos():
+    src = _strip_c(open(os.path.join(ROOT, "include", "h2hip.h")).read())
+    protos = {}
+    for m in re.finditer(r"(?:^|\n)\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(h2hip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        if "typedef" in ret:
+            continue
+        ps = [] if params.strip() in ("", "void") else [_c_class(p) for p in _split_params(params)]
+        protos[name] = ("ptr" if "*" in ret else _c_class(ret + " x"), ps)
+    return protos
+
+
+def _rs_class(t):
+    t = t.strip()
+    if t.startswith("*") or t.startswith("Option<") or t.endswith("_fn"):
+        return "ptr"
+    return {"c_int": "i32", "i32": "i32", "c_uint": "u32", "u32": "u32", "u64": "u64", "i64": "i64", "usize": "usize", "f64": "f64", "u8": "u8"}[t]
+
+
+def _rs_protos():
+    src = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "ffi", "rust", "h2hip-sys", "src", "lib.rs")).read())
+    protos = {}
+    for m in re.finditer(r"pub fn (h2hip_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->\s*([^;]+?))?\s*;", src, flags=re.S):
+        name, params, ret = m.group(1), m.group(2), m.group(3)
+        ps = [_rs_class(p.split(":", 1)[1]) for p in _split_params(params)] if params.strip() else []
+        protos[name] = ("void" if ret is None else _rs_class(ret), ps)
+    return protos
+
+
+def _py_class(t):
+    if t is None:
+        return "void"
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or issubclass(t, ctypes._Pointer) or issubclass(t, ctypes._CFuncPtr):
+        return "ptr"
+    return {ctypes.c_int: "i32", ctypes.c_uint: "u32", ctypes.c_uint32: "u32", ctypes.c_int32: "i32", ctypes.c_uint64: "u64", ctypes.c_int64: "i64",
+            ctypes.c_size_t: "usize", ctypes.c_double: "f64", ctypes.c_uint8: "u8"}[t]
+
+
+def _same(a, b):
+    # size_t and uint64_t are the same ABI class on the one target (x86-64 Linux); ctypes aliases them (c_size_t is c_ulong is c_uint64)
+    norm = lambda x: "u64" if x == "usize" else x
+    return norm(a) == norm(b)
+
+
+def test_rust_declarations_match_the_header_signatures():
+    """the Rust -sys crate cannot be compiled here: check every extern declaration against the C prototype — number of parameters, and for
+    each parameter and the return value whether it is a pointer, a 32-bit or 64-bit integer, a size or a double"""
+    c, rs = _c_protos(), _rs_protos()
+    assert sorted(c) == _declared() and sorted(rs) == sorted(c)
+    bad = []
+    for name, (cret, cps) in c.items():
+        rret, rps = rs[name]
+        if len(cps) != len(rps) or not _same(cret, rret) or any(not _same(a, b) for a, b in zip(cps, rps)):
+            bad.append((name, (cret, cps), (rret, rps)))
+    assert not bad, bad
+
+
+def test_ctypes_prototypes_match_the_header_signatures():
+    import halo2_lib_amd.h2hip as B
+
+    c = _c_protos()
+    bad = []
+    for name, (cret, cps) in c.items():
+        pret, pargs = B._PROTOS[name]
+        pps = [_py_class(t) for t in pargs]
+        if len(cps) != len(pps) or not _same(cret, _py_class(pret)) or any(not _same(a, b) for a, b in zip(cps, pps)):
+            bad.append((name, (cret, cps), (_py_class(pret), pps)))
+    assert not bad, bad
+
+
+def _c_structs():
+    src = _strip_c(open(os.path.join(ROOT, "include", "h2hip.h")).read())
+    out = {}
+    for m in re.finditer(r"typedef struct\s*\{(.*?)\}\s*(h2hip_[a-z0-9_]+)\s*;", src, flags=re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ty, names = decl.rsplit(None, 1)[0], decl
+            first = decl.split(",")[0].rsplit(None, 1)
+            ty = first[0]
+            names = [first[1]] + [n.strip() for n in decl.split(",")[1:]]
+            for nm in names:
+                ptr = "*" in ty or nm.startswith("*")
+                fields.append((nm.lstrip("*"), "ptr" if ptr else _c_class(ty + " x")))
+        out[m.group(2)] = fields
+    return out
+
+
+def _rs_structs():
+    src = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "ffi", "rust", "h2hip-sys", "src", "lib.rs")).read())
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\](?:\s*#\[[^\]]*\])*\s*pub struct (h2hip_[a-z0-9_]+)\s*\{(.*?)\}", src, flags=re.S):
+        if "_private" in m.group(2):   # opaque handle
+            continue
+        out[m.group(1)] = [(f.split(":")[0].replace("pub", "").strip(), _rs_class(f.split(":", 1)[1])) for f in _split_params(m.group(2)) if ":" in f]
+    return out
+
+
+def test_struct_layouts_agree():
+    """the by-value / by-pointer structs of the ABI: same field names, order and types in the header, the Rust repr(C) structs and ctypes"""
+    import halo2_lib_amd.plonk as PL
+
+    c, rs = _c_structs(), _rs_structs()
+    assert set(c) == {"h2hip_base_circuit_params", "h2hip_plonk_shape", "h2hip_array_rng"}, sorted(c)
+    py = {"h2hip_base_circuit_params": PL.BaseCircuitParams, "h2hip_plonk_shape": PL.ConstraintSystemShape, "h2hip_array_rng": PL._ArrayRngState}
+    for name, fields in c.items():
+        assert [(n, "u64" if t == "usize" else t) for n, t in rs[name]] == [(n, "u64" if t == "usize" else t) for n, t in fields], name
+        pf = [(n, _py_class(t)) for n, t in py[name]._fields_]
+        assert [(n, "u64" if t == "usize" else t) for n, t in pf] == [(n, "u64" if t == "usize" else t) for n, t in fields], name
