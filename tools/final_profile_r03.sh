@@ -15,5 +15,12 @@ cd $REPO
 python tools/rocprof_summary.py $(ls $OUT/trace/*.db | head -1) > $OUT/kernel_trace.md 2>&1
 python tools/rocprof_proof.py $(ls $OUT/trace/*.db | head -1) > $OUT/create_proof_kernels.md 2>&1
 python tools/rocprof_pmc.py $(ls $OUT/pmc_fetch/*.db | head -1) $(ls $OUT/pmc_write/*.db | head -1) $OUT/pmc_hbm.md $OUT/pmc_hbm.json > /dev/null 2>&1
+python - <<'PY'
+import json, os
+out = os.path.join(os.getcwd(), "gpurun_out", "final")
+d = json.load(open(os.path.join(out, "pmc_hbm.json")))
+k = [n for n in d if n.startswith("msm_accum_kernel")][0]
+json.dump({"kernel": k, **d[k]}, open(os.path.join(out, "pmc_accum.json"), "w"), indent=1)   # -> profiles/r03_create_proof_k19_pmc_hbm.json (+ the "how" note)
+PY
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
 head -c 600 $OUT/bench.json; echo; head -12 $OUT/kernel_trace.md; head -8 $OUT/pmc_hbm.md
