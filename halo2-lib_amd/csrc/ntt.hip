@@ -21,7 +21,7 @@ namespace h2 {
 // ordering point between LDS writes and reads of the lanes of ONE wave: the wave issues its LDS operations in order, so only the
 // compiler has to be kept from moving them across (the emulated build, where lanes are fibers, needs a real barrier)
 #ifdef H2_HIPEMU
-#define H2_WAVE_SYNC() __syncthreads()
+#define H2_WAVE_SYNC() hipemu_wave_sync()
 #else
 #define H2_WAVE_SYNC()                                         \
     do {                                                       \

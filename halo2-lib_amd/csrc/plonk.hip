@@ -1465,7 +1465,7 @@ int h2hip_plonk_pk_set_sharding(h2hip_plonk_pk *pk, h2hip_comm *comm, const h2hi
     if (comm) H2_CHK(h2hip_comm_info(comm, &world, &rank, nullptr));
     if (!comm || (world <= 1 && !(flags & H2HIP_SHARD_FORCE))) return H2HIP_OK;
     H2_REQUIRE(g_shard && g_lagrange_shard, "NULL argument");
-    H2_REQUIRE(offset + len <= pk->sh.n && g_shard->n >= len && g_lagrange_shard->n >= len, "shard range outside the SRS / shard base sets too small");
+    H2_REQUIRE(offset <= pk->sh.n && len <= pk->sh.n - offset && g_shard->n >= len && g_lagrange_shard->n >= len, "shard range outside the SRS / shard base sets too small");
     pk->g_shard = g_shard;
     pk->g_lagrange_shard = g_lagrange_shard;
     pk->shard_offset = offset;

@@ -18,6 +18,25 @@
 #include <vector>
 
 #define H2_HIPEMU 1
+// H2_EMU_TSAN (tools/emu_tsan.sh): every emulated GPU thread is a ThreadSanitizer *fiber*, i.e. a logical thread of its own.  Switching between
+// fibers creates no happens-before edge; __syncthreads (block-wide), the cross-lane operations and H2_WAVE_SYNC (both wave-wide) do, as do kernel
+// boundaries.  Two lanes touching the same LDS or global word without such an edge between them — a data race on the GPU — then show up as a
+// ThreadSanitizer report although the fibers of a block never run at the same time.
+#ifdef H2_EMU_TSAN
+extern "C" {
+void *__tsan_get_current_fiber(void);
+void *__tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void *fiber);
+void __tsan_switch_to_fiber(void *fiber, unsigned flags);
+void __tsan_acquire(void *addr);
+void __tsan_release(void *addr);
+}
+#define H2_NO_TSAN __attribute__((no_sanitize("thread")))
+#define H2_TSAN(...) __VA_ARGS__
+#else
+#define H2_NO_TSAN
+#define H2_TSAN(...)
+#endif
 #define __global__
 #define __device__
 #define __host__
@@ -54,21 +73,33 @@ struct Worker {
     // cross-lane support (__shfl / __any): double-buffered slots + per-fiber call counters, wave-wide rendezvous
     std::vector<uint32_t> xl_slot[2];   // 16 words per lane
     std::vector<uint32_t> xl_calls;
-    ~Worker() { for (char *p : stacks) free(p); }
+#ifdef H2_EMU_TSAN
+    std::vector<void *> tfiber;
+    void *tmain = nullptr;
+    std::vector<uint32_t> bar_calls;
+    unsigned blocks_on_fibers = 0;
+    char tag_block = 0, tag_done = 0, tag_barrier[2] = {0, 0}, tag_wave[64][2] = {};
+#endif
+    ~Worker() {
+        for (char *p : stacks) free(p);
+        H2_TSAN(for (void *f : tfiber) __tsan_destroy_fiber(f);)
+    }
 };
 inline thread_local Worker *t_worker = nullptr;
-inline void set_thread_idx(Worker *w, unsigned i) {
+H2_NO_TSAN inline void set_thread_idx(Worker *w, unsigned i) {
     w->cur = (int)i;
     t_threadIdx = dim3(i % w->bdim.x, (i / w->bdim.x) % w->bdim.y, i / (w->bdim.x * w->bdim.y));
 }
-inline void fiber_entry() {
+H2_NO_TSAN inline void fiber_entry() {
     Worker *w = t_worker;
+    H2_TSAN(__tsan_acquire(&w->tag_block);)
     w->body();
     w->state[w->cur] = FIBER_DONE;
+    H2_TSAN(__tsan_release(&w->tag_done); __tsan_switch_to_fiber(w->tmain, 1);)
     swapcontext(&w->ctx[w->cur], &w->main_ctx);
 }
 constexpr size_t kStack = 256 * 1024;
-inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
+H2_NO_TSAN inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
     if (w.ctx.size() < nthreads) {
         size_t old = w.ctx.size();
         w.ctx.resize(nthreads);
@@ -90,12 +121,25 @@ inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
     w.xl_slot[0].assign((size_t)nthreads * 16, 0);
     w.xl_slot[1].assign((size_t)nthreads * 16, 0);
     w.xl_calls.assign(nthreads, 0);
+#ifdef H2_EMU_TSAN
+    w.tmain = __tsan_get_current_fiber();
+    if (w.blocks_on_fibers >= 1024) {   // a fiber's last switch never returns: its shadow stack keeps a frame or two per block
+        for (void *f : w.tfiber) __tsan_destroy_fiber(f);
+        w.tfiber.clear();
+        w.blocks_on_fibers = 0;
+    }
+    while (w.tfiber.size() < nthreads) w.tfiber.push_back(__tsan_create_fiber(0));
+    w.blocks_on_fibers++;
+    w.bar_calls.assign(nthreads, 0);
+    __tsan_release(&w.tag_block);
+#endif
     for (;;) {
         bool ran = false, alive = false;
         for (unsigned i = 0; i < nthreads; ++i) {
             if (w.state[i] != FIBER_READY) continue;
             ran = true;
             set_thread_idx(&w, i);
+            H2_TSAN(__tsan_switch_to_fiber(w.tfiber[i], 1);)   // 1 = no synchronisation: a switch orders nothing
             swapcontext(&w.main_ctx, &w.ctx[i]);
         }
         for (unsigned i = 0; i < nthreads; ++i) alive |= (w.state[i] != FIBER_DONE);
@@ -104,28 +148,42 @@ inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
             for (unsigned i = 0; i < nthreads; ++i)
                 if (w.state[i] == FIBER_AT_BARRIER) w.state[i] = FIBER_READY;
     }
+    H2_TSAN(__tsan_acquire(&w.tag_done);)
 }
 inline void *dyn_smem_ptr() { return t_worker->dyn_smem.data(); }
-inline void syncthreads() {
+// wave_only: the scheduling barrier is block-wide either way (the emulator has nothing finer), the happens-before edge is not — H2_WAVE_SYNC
+// orders the lanes of ONE wave on the GPU, and the race check must not credit it with more
+H2_NO_TSAN inline void syncthreads(bool wave_only = false) {
     Worker *w = t_worker;
+#ifdef H2_EMU_TSAN
+    const uint32_t k = w->bar_calls[w->cur]++;
+    char *tag = wave_only ? &w->tag_wave[(unsigned)w->cur >> 6][k & 1] : &w->tag_barrier[k & 1];
+    __tsan_release(tag);
+#endif
     w->state[w->cur] = FIBER_AT_BARRIER;
+    H2_TSAN(__tsan_switch_to_fiber(w->tmain, 1);)
     swapcontext(&w->ctx[w->cur], &w->main_ctx);
+    H2_TSAN(__tsan_acquire(tag);)
 }
 // run fiber j (a lane this fiber is waiting for) right now; returns when somebody resumes this fiber again
-inline void switch_to(unsigned j) {
+H2_NO_TSAN inline void switch_to(unsigned j) {
     Worker *w = t_worker;
     int me = w->cur;
     if (w->state[j] != FIBER_READY) abort();   // a lane reached a barrier / exited before the cross-lane op: non-uniform control flow
     set_thread_idx(w, j);
+    H2_TSAN(__tsan_switch_to_fiber(w->tfiber[j], 1);)
     swapcontext(&w->ctx[me], &w->ctx[j]);
 }
 // wave-wide rendezvous: post `v`, wait until every live lane of this wave has posted its call #k, return the slot array
-inline const uint32_t *crosslane_exchange(const uint32_t *v, unsigned nwords, unsigned &wave_lo, unsigned &wave_hi) {
+H2_NO_TSAN inline const uint32_t *crosslane_exchange(const uint32_t *v, unsigned nwords, unsigned &wave_lo, unsigned &wave_hi) {
     Worker *w = t_worker;
     const unsigned me = (unsigned)w->cur;
     const uint32_t k = w->xl_calls[me];
     for (unsigned i = 0; i < nwords; ++i) w->xl_slot[k & 1][(size_t)me * 16 + i] = v[i];
     w->xl_calls[me] = k + 1;
+    // a cross-lane operation is one instruction of the wave: what its lanes did before it is ordered before what they do after it.  (Its own
+    // parity of tags: barrier-type and exchange-type edges of a wave never share one.)
+    H2_TSAN(char *xtag = &w->tag_wave[32 + (me >> 6)][k & 1]; __tsan_release(xtag);)
     wave_lo = me & ~63u;
     wave_hi = wave_lo + 64 < w->nthreads ? wave_lo + 64 : w->nthreads;
     for (;;) {
@@ -138,6 +196,7 @@ inline const uint32_t *crosslane_exchange(const uint32_t *v, unsigned nwords, un
         }
         if (all) break;
     }
+    H2_TSAN(__tsan_acquire(xtag);)
     return w->xl_slot[k & 1].data();
 }
 }  // namespace hipemu
@@ -148,7 +207,9 @@ inline const uint32_t *crosslane_exchange(const uint32_t *v, unsigned nwords, un
 #define blockDim (hipemu::t_blockDim)
 #define gridDim (hipemu::t_gridDim)
 inline void __syncthreads() { hipemu::syncthreads(); }
-inline unsigned __shfl(unsigned v, int src_lane, int /*width*/ = 64) {
+// the emulated build's stand-in for a wave-level ordering point (H2_WAVE_SYNC): every lane has to get there, but only the lanes of one wave are ordered
+inline void hipemu_wave_sync() { hipemu::syncthreads(true); }
+H2_NO_TSAN inline unsigned __shfl(unsigned v, int src_lane, int /*width*/ = 64) {
     unsigned lo, hi;
     const uint32_t *slots = hipemu::crosslane_exchange(&v, 1, lo, hi);
     unsigned src = lo + ((unsigned)src_lane & 63u);
@@ -156,7 +217,7 @@ inline unsigned __shfl(unsigned v, int src_lane, int /*width*/ = 64) {
 }
 // emulation-speed helper: shuffle up to 16 words with ONE rendezvous (the HIP build issues one __shfl per word)
 template <int N>
-inline void hipemu_shfl_words(uint32_t (&out)[N], const uint32_t (&in)[N], unsigned src_lane) {
+H2_NO_TSAN inline void hipemu_shfl_words(uint32_t (&out)[N], const uint32_t (&in)[N], unsigned src_lane) {
     static_assert(N <= 16, "at most 16 words");
     unsigned lo, hi;
     const uint32_t *slots = hipemu::crosslane_exchange(in, N, lo, hi);
@@ -164,7 +225,7 @@ inline void hipemu_shfl_words(uint32_t (&out)[N], const uint32_t (&in)[N], unsig
     for (int i = 0; i < N; ++i) out[i] = src < hi ? slots[(size_t)src * 16 + i] : in[i];
 }
 inline int __shfl(int v, int src_lane, int width = 64) { return (int)__shfl((unsigned)v, src_lane, width); }
-inline int __any(int pred) {
+H2_NO_TSAN inline int __any(int pred) {
     unsigned lo, hi;
     uint32_t pv = pred ? 1u : 0u;
     const uint32_t *slots = hipemu::crosslane_exchange(&pv, 1, lo, hi);
@@ -174,7 +235,7 @@ inline int __any(int pred) {
         if (w->state[j] != hipemu::FIBER_DONE) r |= (int)slots[(size_t)j * 16];
     return r;
 }
-inline int __syncthreads_or(int pred) {
+H2_NO_TSAN inline int __syncthreads_or(int pred) {
     hipemu::Worker *w = hipemu::t_worker;
     int k = w->or_calls[w->cur]++;
     w->or_val[k % 3] |= (pred != 0);
@@ -259,6 +320,7 @@ inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hi
     unsigned nblocks = grid.x * grid.y * grid.z, nthreads = block.x * block.y * block.z;
     if (!nblocks || !nthreads) return;
     unsigned nworkers = std::min<unsigned>(nblocks, std::max(1u, std::thread::hardware_concurrency()));
+    H2_TSAN(nworkers = std::min(nworkers, 4u);)   // every fiber costs the sanitizer a few mappings: stay far below vm.max_map_count
     std::atomic<unsigned> next{0};
     auto work = [&]() {
         static thread_local hipemu::Worker worker;

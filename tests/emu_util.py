@@ -10,4 +10,5 @@ def emu_context():
     import build_emu
     import halo2_lib_amd as H
 
-    return H.Context(lib_path=build_emu.build())
+    # H2HIP_EMU_LIB: an alternative build of the same sources (e.g. with -fsanitize=address, see tools/README.md) instead of the default one
+    return H.Context(lib_path=os.environ.get("H2HIP_EMU_LIB") or build_emu.build())
