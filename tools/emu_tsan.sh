@@ -19,7 +19,7 @@ $CXX -shared -fPIC -fsanitize=thread -shared-libsan -o $OUT/libh2hip_emu_tsan.so
 rm -f $OUT/report.*
 [ $# -gt 0 ] || set -- tests/test_emu_kernels.py
 rc=0
-H2HIP_EMU_LIB=$OUT/libh2hip_emu_tsan.so LD_PRELOAD=$TSAN TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 log_path=$OUT/report" \
+H2HIP_EMU_LIB=$OUT/libh2hip_emu_tsan.so LD_PRELOAD=$TSAN TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 log_path=$OUT/report suppressions=$PWD/tests/emu/tsan.supp" \
     python -m pytest -q -s -m "not gpu" -n 3 -p no:cacheprovider "$@" || rc=$?
 echo "ThreadSanitizer reports: $(cat $OUT/report.* 2>/dev/null | grep -c 'WARNING: ThreadSanitizer' || true)  (pytest rc $rc; 66 = reports were written)"
 cat $OUT/report.* 2>/dev/null | grep -A3 "WARNING: ThreadSanitizer" | grep "#0" | sed 's/(.*//' | sort | uniq -c | sort -rn | head -40
