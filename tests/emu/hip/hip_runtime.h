@@ -11,9 +11,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
+#include <unistd.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -55,14 +58,40 @@ struct dim3 {
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 
+// Fiber switches: glibc's swapcontext makes a rt_sigprocmask system call per switch — with a switch per lane and barrier that was 40 % of the CPU
+// suite's time.  The plain build switches stacks itself (x86-64 SysV: the callee-saved registers and the stack pointer are the whole context of
+// a function call); the sanitizer builds keep ucontext, which ThreadSanitizer / AddressSanitizer know how to follow.
+#if !defined(H2_EMU_UCONTEXT) && (defined(H2_EMU_TSAN) || !defined(__x86_64__))
+#define H2_EMU_UCONTEXT 1
+#endif
+#if !defined(H2_EMU_UCONTEXT) && defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define H2_EMU_UCONTEXT 1
+#endif
+#endif
+#ifndef H2_EMU_UCONTEXT
+// saves the caller's callee-saved registers on its stack, stores that stack pointer to *from_sp, continues on to_sp
+__attribute__((naked, noinline)) static void hipemu_ctx_switch(void ** /*from_sp: rdi*/, void * /*to_sp: rsi*/) {
+    __asm__ volatile(
+        "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\tmovq %rsi, %rsp\n\t"
+        "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret");
+}
+#endif
+
 namespace hipemu {
 inline thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 enum { FIBER_READY = 0, FIBER_AT_BARRIER = 1, FIBER_DONE = 2 };
 struct Worker {
+#ifdef H2_EMU_UCONTEXT
     std::vector<ucontext_t> ctx;
+    ucontext_t main_ctx;
+#else
+    std::vector<void *> sp;     // a suspended fiber's stack pointer
+    void *main_sp = nullptr;
+#endif
     std::vector<char *> stacks;
     std::vector<char> state;
-    ucontext_t main_ctx;
     int cur = 0;
     unsigned nthreads = 0;
     dim3 bdim;
@@ -86,6 +115,15 @@ struct Worker {
     }
 };
 inline thread_local Worker *t_worker = nullptr;
+#ifdef H2_EMU_UCONTEXT
+#define H2_EMU_TO_MAIN(w, me) swapcontext(&(w)->ctx[me], &(w)->main_ctx)
+#define H2_EMU_FROM_MAIN(w, i) swapcontext(&(w)->main_ctx, &(w)->ctx[i])
+#define H2_EMU_FIBER_TO_FIBER(w, me, j) swapcontext(&(w)->ctx[me], &(w)->ctx[j])
+#else
+#define H2_EMU_TO_MAIN(w, me) hipemu_ctx_switch(&(w)->sp[me], (w)->main_sp)
+#define H2_EMU_FROM_MAIN(w, i) hipemu_ctx_switch(&(w)->main_sp, (w)->sp[i])
+#define H2_EMU_FIBER_TO_FIBER(w, me, j) hipemu_ctx_switch(&(w)->sp[me], (w)->sp[j])
+#endif
 H2_NO_TSAN inline void set_thread_idx(Worker *w, unsigned i) {
     w->cur = (int)i;
     t_threadIdx = dim3(i % w->bdim.x, (i / w->bdim.x) % w->bdim.y, i / (w->bdim.x * w->bdim.y));
@@ -96,13 +134,18 @@ H2_NO_TSAN inline void fiber_entry() {
     w->body();
     w->state[w->cur] = FIBER_DONE;
     H2_TSAN(__tsan_release(&w->tag_done); __tsan_switch_to_fiber(w->tmain, 1);)
-    swapcontext(&w->ctx[w->cur], &w->main_ctx);
+    H2_EMU_TO_MAIN(w, w->cur);
+    abort();   // a finished fiber is never resumed
 }
 constexpr size_t kStack = 256 * 1024;
 H2_NO_TSAN inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
-    if (w.ctx.size() < nthreads) {
-        size_t old = w.ctx.size();
+    if (w.stacks.size() < nthreads) {
+        size_t old = w.stacks.size();
+#ifdef H2_EMU_UCONTEXT
         w.ctx.resize(nthreads);
+#else
+        w.sp.resize(nthreads, nullptr);
+#endif
         w.stacks.resize(nthreads, nullptr);
         for (size_t i = old; i < nthreads; ++i) w.stacks[i] = (char *)malloc(kStack);
     }
@@ -110,11 +153,21 @@ H2_NO_TSAN inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
     w.bdim = bdim;
     w.state.assign(nthreads, FIBER_READY);
     for (unsigned i = 0; i < nthreads; ++i) {
+#ifdef H2_EMU_UCONTEXT
         getcontext(&w.ctx[i]);
         w.ctx[i].uc_stack.ss_sp = w.stacks[i];
         w.ctx[i].uc_stack.ss_size = kStack;
         w.ctx[i].uc_link = &w.main_ctx;
         makecontext(&w.ctx[i], (void (*)())fiber_entry, 0);
+#else
+        // a fresh fiber looks like one suspended in hipemu_ctx_switch at the first instruction of fiber_entry: six register slots, the entry
+        // address as the return address, and above it the (never used) return address of fiber_entry — rsp = 8 mod 16 at entry, as after a call
+        void **top = (void **)(((uintptr_t)w.stacks[i] + kStack) & ~(uintptr_t)15);
+        top[-1] = nullptr;
+        top[-2] = (void *)&fiber_entry;
+        for (int r = 3; r <= 8; ++r) top[-r] = nullptr;
+        w.sp[i] = (void *)(top - 8);
+#endif
     }
     w.or_calls.assign(nthreads, 0);
     w.or_val[0] = w.or_val[1] = w.or_val[2] = 0;
@@ -140,7 +193,7 @@ H2_NO_TSAN inline void run_block(Worker &w, unsigned nthreads, dim3 bdim) {
             ran = true;
             set_thread_idx(&w, i);
             H2_TSAN(__tsan_switch_to_fiber(w.tfiber[i], 1);)   // 1 = no synchronisation: a switch orders nothing
-            swapcontext(&w.main_ctx, &w.ctx[i]);
+            H2_EMU_FROM_MAIN(&w, i);
         }
         for (unsigned i = 0; i < nthreads; ++i) alive |= (w.state[i] != FIBER_DONE);
         if (!alive) break;
@@ -162,7 +215,7 @@ H2_NO_TSAN inline void syncthreads(bool wave_only = false) {
 #endif
     w->state[w->cur] = FIBER_AT_BARRIER;
     H2_TSAN(__tsan_switch_to_fiber(w->tmain, 1);)
-    swapcontext(&w->ctx[w->cur], &w->main_ctx);
+    H2_EMU_TO_MAIN(w, w->cur);
     H2_TSAN(__tsan_acquire(tag);)
 }
 // run fiber j (a lane this fiber is waiting for) right now; returns when somebody resumes this fiber again
@@ -172,7 +225,7 @@ H2_NO_TSAN inline void switch_to(unsigned j) {
     if (w->state[j] != FIBER_READY) abort();   // a lane reached a barrier / exited before the cross-lane op: non-uniform control flow
     set_thread_idx(w, j);
     H2_TSAN(__tsan_switch_to_fiber(w->tfiber[j], 1);)
-    swapcontext(&w->ctx[me], &w->ctx[j]);
+    H2_EMU_FIBER_TO_FIBER(w, me, j);
 }
 // wave-wide rendezvous: post `v`, wait until every live lane of this wave has posted its call #k, return the slot array
 H2_NO_TSAN inline const uint32_t *crosslane_exchange(const uint32_t *v, unsigned nwords, unsigned &wave_lo, unsigned &wave_hi) {
@@ -315,6 +368,71 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
     return hipSuccess;
 }
 
+namespace hipemu {
+// ONE worker state per OS thread, shared by every kernel (a function-local thread_local inside the launch template would be one per kernel
+// instantiation: a hundred sets of fiber stacks per thread)
+inline Worker &thread_worker() {
+    static thread_local Worker w;
+    return w;
+}
+// Persistent worker threads: a fresh std::thread per launch meant fresh fiber stacks (page faults, mmap / munmap) for every kernel launch.
+struct Pool {
+    std::mutex m, launch_m;
+    std::condition_variable cv, done_cv;
+    std::vector<std::thread> *threads = new std::vector<std::thread>();
+    std::function<void()> job;
+    uint64_t gen = 0;
+    unsigned want = 0, active = 0;
+    bool stop = false;
+    pid_t owner = getpid();
+    H2_NO_TSAN void loop(unsigned idx) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || (gen != seen && idx < want); });
+            if (stop) return;
+            seen = gen;
+            std::function<void()> f = job;
+            lk.unlock();
+            f();
+            lk.lock();
+            if (--active == 0) done_cv.notify_all();
+        }
+    }
+    void run(unsigned nworkers, const std::function<void()> &f) {
+        std::lock_guard<std::mutex> one_launch(launch_m);
+        std::unique_lock<std::mutex> lk(m);
+        if (owner != getpid()) {   // forked: the parent's threads do not exist here
+            threads = new std::vector<std::thread>();
+            owner = getpid();
+        }
+        while (threads->size() < nworkers) {
+            const unsigned idx = (unsigned)threads->size();
+            threads->emplace_back([this, idx] { loop(idx); });
+        }
+        job = f;
+        want = active = nworkers;
+        ++gen;
+        cv.notify_all();
+        done_cv.wait(lk, [&] { return active == 0; });
+        want = 0;
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        if (owner == getpid())
+            for (auto &t : *threads) t.join();
+    }
+};
+inline Pool &pool() {
+    static Pool p;
+    return p;
+}
+}  // namespace hipemu
+
 template <class K, class... A>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t /*stream*/, A... args) {
     unsigned nblocks = grid.x * grid.y * grid.z, nthreads = block.x * block.y * block.z;
@@ -323,7 +441,7 @@ inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hi
     H2_TSAN(nworkers = std::min(nworkers, 4u);)   // every fiber costs the sanitizer a few mappings: stay far below vm.max_map_count
     std::atomic<unsigned> next{0};
     auto work = [&]() {
-        static thread_local hipemu::Worker worker;
+        hipemu::Worker &worker = hipemu::thread_worker();
         hipemu::t_worker = &worker;
         hipemu::t_blockDim = block;
         hipemu::t_gridDim = grid;
@@ -335,9 +453,8 @@ inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t shmem, hi
             hipemu::t_blockIdx = dim3(b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y));
             hipemu::run_block(worker, nthreads, block);
         }
+        worker.body = nullptr;
     };
     if (nworkers == 1) { work(); return; }
-    std::vector<std::thread> th;
-    for (unsigned i = 0; i < nworkers; ++i) th.emplace_back(work);
-    for (auto &t : th) t.join();
+    hipemu::pool().run(nworkers, work);
 }
