@@ -3,7 +3,7 @@ create_proof's bytes must equal the oracle prover's on the same SRS / witness / 
 tests/test_plonk_prover.py::_check).  Shapes are drawn over the whole range the small oracle finishes in about a second — narrow and wide,
 with and without lookups / instances / precomputed bases — so that batching boundaries the fixed test list does not name are crossed too.
 
-    python tools/fuzz_shapes.py [seconds=120] [seed=1]
+    python tools/fuzz_shapes.py [seconds=120] [seed=1] [kmin kmax]      (kmin kmax: draw k uniformly from that range instead, e.g. 13 16)
 """
 import os, random, sys, time
 
@@ -13,10 +13,11 @@ from tests.test_plonk_prover import _check
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+krange = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else None
 ctx = H.Context()
 t0, done, ks = time.time(), 0, {}
 while time.time() - t0 < budget:
-    k = rnd.choice([6, 7, 8, 8, 9, 9, 10, 10, 11, 12])
+    k = rnd.randint(*krange) if krange else rnd.choice([6, 7, 8, 8, 9, 9, 10, 10, 11, 12])
     wide = rnd.random() < 0.25
     na = rnd.randint(1, 40 if wide and k <= 9 else 6)
     nl = rnd.choice([0, 1, 1, 2, 3]) if not wide else rnd.randint(0, 36 if k <= 8 else 4)
@@ -27,7 +28,7 @@ while time.time() - t0 < budget:
     seed = rnd.randint(1, 1 << 20)
     shape = (k, na, nl, nf, ni, lb)
     try:
-        out = _check(ctx, *shape, seed=seed, threads=8, oracle_prover=True, precompute=pre, second_proof=rnd.random() < 0.3)
+        out = _check(ctx, *shape, seed=seed, threads=16 if krange else 8, oracle_prover=True, precompute=pre, second_proof=rnd.random() < 0.3)
     except Exception as e:   # noqa: BLE001 — report the shape, then fail
         print("FAIL shape", shape, "seed", seed, "precompute", pre, "->", repr(e)[:400], flush=True)
         sys.exit(1)
