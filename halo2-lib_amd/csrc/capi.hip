@@ -284,6 +284,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_fold_windows")) return &ctx->msm_fold_windows;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "msm_debug_reorder")) return &ctx->msm_debug_reorder;
+    if (!strcmp(name, "msm_split_windows")) return &ctx->msm_split_windows;
     if (!strcmp(name, "ntt_wave_local")) return &ctx->ntt_wave_local;
     if (!strcmp(name, "ntt_radix8")) return &ctx->ntt_radix8;
     if (!strcmp(name, "ntt_tile_bits8")) return &ctx->ntt_tile_bits8;
@@ -318,6 +319,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_sort_threads) H2_REQUIRE(value == 256 || value == 512 || value == 1024, "msm_sort_threads must be 256, 512 or 1024");
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
     if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 0 && value <= 4, "msm_lanes must be 0 (auto) or 1..4");
+    if (p == &ctx->msm_split_windows) H2_REQUIRE(value >= 0 && value <= 2, "msm_split_windows must be 0, 1 (from 2^18 points on) or 2 (every size: tests)");
     if (p == &ctx->msm_sort_mode) H2_REQUIRE(value >= 0 && value <= 2, "msm_sort_mode must be 0 or 1 (one-pass sort) or 2 (two-level sort)");
     if (p == &ctx->msm_accum_variant) H2_REQUIRE(value >= 2 && value <= 7, "msm_accum_variant must be 2..7");
     if (p == &ctx->ntt_min_col_bits) H2_REQUIRE(value >= 0 && value <= 5, "ntt_min_col_bits must be 0..5");
@@ -562,10 +564,14 @@ void h2hip_bases_free(h2hip_ctx *ctx, h2hip_bases *bases) {
 size_t h2hip_bases_len(const h2hip_bases *bases) { return bases ? bases->n : 0; }
 
 static int finish_point(h2hip_ctx *ctx, char *outbuf, int point_format, void *out_host);
+static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_bases *const *bases_per_col, const void *const *scalars_in,
+                          bool scalars_on_host, size_t n, size_t count, int point_format, void *out_host);
 int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_dev, size_t n, int point_format, void *out_host) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_dev), "NULL argument");
     H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
+    if (ctx->msm_split_windows && bases->tables > 1 && n >= (ctx->msm_split_windows >= 2 ? (size_t)1 : (size_t)1 << 18) && n <= bases->n)   // one MSM as two half jobs on two lanes
+        return msm_batch_impl(ctx, bases, nullptr, &scalars_dev, false, n, 1, point_format, out_host);
     char *outbuf = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, 1024, (void **)&outbuf));
     H2_CHK(msm_run(ctx, bases, (const Fr *)scalars_dev, n, (XYZZ *)outbuf));
@@ -623,6 +629,11 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     int NL = ctx->msm_lanes;
     if (NL <= 0) NL = n >= ((size_t)1 << 20) ? 1 : 3;   // (2^18 / 2^19 were on 2 lanes until the window model moved them to c = 15: 3 lanes now win by 2 %, k = 18 / 19 proofs)
     if (NL > 4) NL = 4;
+    // msm_split_windows: a column's windows are dealt to two lanes (half jobs that add into the column's one bucket array) — the first sort
+    // and the last merge of a round are half as long, and a single MSM overlaps with itself
+    const bool want_split_w = ctx->msm_split_windows && bases->tables > 1 && !scalars_on_host && n >= (ctx->msm_split_windows >= 2 ? (size_t)1 : (size_t)1 << 18) && ctx->msm_fold_windows <= 1 &&
+                              ctx->msm_fuse_cols <= 1 && !ctx->msm_split_streams && count <= 64;
+    if (want_split_w && NL < 2) NL = 2;
     if (NL < 2 && ctx->msm_split_streams && !scalars_on_host && count >= 2 && n > ((size_t)1 << 17)) NL = 2;   // the split-stream schedule alternates two scratch sets
     for (int l = 0; l < NL; ++l) {
         if (!ctx->lane[l]) {
@@ -693,8 +704,9 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         if (ctx->msm_fold_windows > 1) sets = (wcol + std::min<uint32_t>((uint32_t)ctx->msm_fold_windows, wcol) - 1) / std::min<uint32_t>((uint32_t)ctx->msm_fold_windows, wcol);
         keys_per_col = (size_t)sets << (cw - 1);
     }
-    const bool deferred = precomp && ctx->msm_defer_reduce && count >= 2 && n > 0 && (fuse == 1 ? count <= 64 : true) &&
-                          sizeof(XYZZ29) * keys_per_col * count <= ((size_t)2 << 30);
+    const bool split_w = want_split_w && fuse == 1 && sizeof(XYZZ29) * keys_per_col * count <= ((size_t)2 << 30);
+    const bool deferred = split_w || (precomp && ctx->msm_defer_reduce && count >= 2 && n > 0 && (fuse == 1 ? count <= 64 : true) &&
+                                      sizeof(XYZZ29) * keys_per_col * count <= ((size_t)2 << 30));
     XYZZ29 *all_buckets = nullptr;
     if (deferred) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH_BUCKETS, sizeof(XYZZ29) * keys_per_col * count, (void **)&all_buckets));
     // the shared bucket array was zero-filled behind the previous batch's reduction (side stream): the lanes wait for that instead of filling
@@ -772,7 +784,19 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
             return rc;
         }
     }
-    const size_t ngroups = split ? 0 : groups.size();
+    if (split_w) {   // two half jobs per column, dealt over the lanes in issue order
+        const uint32_t cw = bases->window_bits, wcol = (255 + cw - 1) / cw, half = (wcol + 1) / 2, B = 1u << (cw - 1);
+        size_t t = 0;
+        for (size_t j = 0; j < count; ++j)
+            for (int h = 0; h < 2; ++h, ++t) {
+                h2hip_ctx *c = ctx->lane[t % NL];
+                const Fr *col = (const Fr *)scalars_dev[j];
+                const uint32_t w_lo = h ? half : 0u, w_cnt = h ? wcol - half : half;
+                H2_LANES_RC(msm_run_cols(c, bases_of(j), &col, 1, n, nullptr, all_buckets + keys_per_col * j + (size_t)w_lo * B, MSM_PHASE_ALL, buckets_zeroed,
+                                         w_lo, w_cnt));
+            }
+    }
+    const size_t ngroups = (split || split_w) ? 0 : groups.size();
     for (size_t g = 0; g < ngroups; ++g) {
         const size_t j0 = groups[g].first, gsize = groups[g].second;
         h2hip_ctx *c = ctx->lane[g % NL];

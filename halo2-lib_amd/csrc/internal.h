@@ -90,6 +90,7 @@ struct h2hip_ctx {
                                  // round trip does not pay for what it takes — 8 waves per CU instead of 12 (175 registers per lane), nine 4-byte LDS accesses per
                                  // element instead of three 16-byte ones, and the 8-element prefetch array in scratch.
     int ntt_tile_bits8 = 11;     // log2 of the radix-8 kernel's tile (<= 11; smaller values only to force many passes in tests)
+    int msm_split_windows = 0;   // batch API, large precomputed MSMs: 1 = every column's windows are dealt to two lanes (two half jobs adding into the column's one bucket array)
     int msm_debug_reorder = 0;   // diagnostics only: reorder the entries inside every bucket after the sort (1 ascending point index, 2 hashed); results unchanged
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
@@ -201,7 +202,7 @@ constexpr uint32_t MSM_MAX_COLS = 32;   // columns one fused multi-column MSM ha
 // ext_buckets != nullptr: stop after the merge and leave the column's buckets ([sets][B], sets = window groups of msm_fold_windows; zeroed here) there for msm_reduce_cols
 enum { MSM_PHASE_SORT = 1u, MSM_PHASE_ACCUM = 2u, MSM_PHASE_MERGE = 4u, MSM_PHASE_REDUCE = 8u, MSM_PHASE_ALL = 15u };
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev,
-                 XYZZ29 *ext_buckets, uint32_t phases = MSM_PHASE_ALL, bool ext_buckets_zeroed = false);
+                 XYZZ29 *ext_buckets, uint32_t phases = MSM_PHASE_ALL, bool ext_buckets_zeroed = false, uint32_t w_lo = 0, uint32_t w_cnt = 0);   // w_cnt != 0: only the column's windows [w_lo, w_lo + w_cnt)
 // zero-fill-after-use of the bucket arrays (see h2hip_ctx::clean_*): is the buffer's head already (scheduled to be) zero? / schedule the fill
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);
 int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes);

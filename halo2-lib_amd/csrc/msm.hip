@@ -58,8 +58,11 @@ struct DigitCols {
 };
 // (the first workgroup also writes the sort's two sentinels — counts[nsort] = 0 and offsets[nsort + 1 .. nsort + ks] = ~0, read by the scan and by
 // the accumulation's boundary walk — which were two tiny memset launches per MSM on the lane's critical path)
+// (w_lo: only the windows [w_lo, w_lo + W) are written — a column whose windows are dealt to two lanes; the signed-digit carry still runs
+// through the windows below)
 __global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_t n, uint32_t c, uint32_t W, uint32_t *__restrict__ digits,
-                                                         uint32_t *__restrict__ counts_tail, uint32_t *__restrict__ offsets_tail, uint32_t ks) {
+                                                         uint32_t *__restrict__ counts_tail, uint32_t *__restrict__ offsets_tail, uint32_t ks,
+                                                         uint32_t w_lo) {
     H2_SORT_PRIORITY();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_
     const uint32_t B = 1u << (c - 1);
     const uint64_t mask = (1ull << c) - 1;
     uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; ++w) {
+    for (uint32_t w = 0; w < w_lo + W; ++w) {
         uint32_t bit = w * c, limb = bit >> 5, off = bit & 31;
         uint64_t lo = 0, hi = 0;
         // static selection keeps s in registers (a runtime-indexed array would live in scratch)
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_
         uint32_t neg = v > B ? 1u : 0u;
         uint32_t d = neg ? (1u << c) - v : v;
         carry = neg;
-        digits[(size_t)w * n + i] = d | (neg << 31);
+        if (w >= w_lo) digits[(size_t)(w - w_lo) * n + i] = d | (neg << 31);
     }
 }
 
@@ -1190,7 +1193,7 @@ int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes) 
 }
 
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out, XYZZ29 *ext_buckets,
-                 uint32_t phases, bool ext_buckets_zeroed) {
+                 uint32_t phases, bool ext_buckets_zeroed, uint32_t w_lo, uint32_t w_cnt) {
     H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..32 columns per fused MSM");
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
@@ -1205,13 +1208,18 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     H2_REQUIRE(ncols == 1 || precomp, "a fused multi-column MSM needs precomputed bases");
     const uint32_t c = precomp ? bases->window_bits : (ctx->msm_window_bits ? (uint32_t)ctx->msm_window_bits : pick_window(n));
     H2_REQUIRE(c >= 2 && c <= 16, "window bits must be 2..16 (a window's bucket histogram lives in LDS)");
-    const uint32_t Wcol = (255 + c - 1) / c;   // windows of one column
-    H2_REQUIRE(Wcol <= 64, "too many windows");
+    const uint32_t Wfull = (255 + c - 1) / c;   // windows of one column
+    H2_REQUIRE(Wfull <= 64, "too many windows");
+    H2_REQUIRE(!precomp || bases->tables >= Wfull, "precomputed table has too few windows");
+    // w_cnt != 0: only the windows [w_lo, w_lo + w_cnt) of the one column, their buckets into ext_buckets (= the column's array + w_lo * B):
+    // table level w_lo + w is reached by handing the kernels the table from that level on
+    H2_REQUIRE(w_cnt == 0 || (ncols == 1 && precomp && ext_buckets && w_lo + w_cnt <= Wfull), "a window sub-range needs one column, precomputed bases and a shared bucket array");
+    const uint32_t Wcol = w_cnt ? w_cnt : Wfull;
     const uint32_t W = Wcol * ncols;           // windows the sort / accumulation see
-    H2_REQUIRE(!precomp || bases->tables >= Wcol, "precomputed table has too few windows");
+    const G1Affine *table = (const G1Affine *)bases->pts29 + (w_cnt ? (size_t)w_lo * bases->n : 0);
     const uint32_t B = 1u << (c - 1);
     FoldKeys fold_w;
-    fold_w.fg = fold_group(ctx, precomp, Wcol);
+    fold_w.fg = w_cnt ? 0u : fold_group(ctx, precomp, Wcol);
     fold_w.ng = fold_w.fg ? (Wcol + fold_w.fg - 1) / fold_w.fg : 0u;
     fold_w.wcol = Wcol;
     const uint32_t ks = fold_w.fg ? fold_w.fg : 1u;
@@ -1296,7 +1304,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     prof_begin(ctx, "msm_digits_kernel");
     H2_REQUIRE(ks <= 256, "fold group too large");
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), ncols), dim3(256), 0, st, dcols, (uint32_t)n, c, Wcol, digits,
-                       two_level ? counts + ncoarse : counts + nsort, offsets + nsort + 1, ks);   // + the sentinels counts[last], offsets[(nkeys + 1) * ks]
+                       two_level ? counts + ncoarse : counts + nsort, offsets + nsort + 1, ks, w_lo);   // + the sentinels counts[last], offsets[(nkeys + 1) * ks]
     prof_end(ctx);
     if (two_level) {
         prof_begin(ctx, "msm_hist_kernel");
@@ -1351,25 +1359,25 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     prof_begin(ctx, "msm_accum_kernel");
     if (ctx->msm_accum_variant == 6 || ctx->msm_accum_variant == 7) {   // software-prefetched table gather at 2 / 3 waves per SIMD
         if (ctx->msm_accum_variant == 6)
-            hipLaunchKernelGGL((msm_accum_kernel<2, true, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+            hipLaunchKernelGGL((msm_accum_kernel<2, true, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
                                (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
         else
-            hipLaunchKernelGGL((msm_accum_kernel<3, true, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+            hipLaunchKernelGGL((msm_accum_kernel<3, true, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
                                (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     } else if (ctx->msm_accum_variant == 5)   // two waves per SIMD by launch bounds (256 registers: the wave-level merge's epilogue then spills nothing)
-        hipLaunchKernelGGL((msm_accum_kernel<2, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+        hipLaunchKernelGGL((msm_accum_kernel<2, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
                            (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     else if (ctx->msm_accum_variant == 2)
-        hipLaunchKernelGGL(msm_accum_w2_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+        hipLaunchKernelGGL(msm_accum_w2_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
                            (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     else if (ctx->msm_accum_variant == 4)
-        hipLaunchKernelGGL((msm_accum_kernel<4, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+        hipLaunchKernelGGL((msm_accum_kernel<4, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
                            (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     else if (ctx->msm_table_nontemporal)
-        hipLaunchKernelGGL((msm_accum_kernel<3, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+        hipLaunchKernelGGL((msm_accum_kernel<3, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
                            (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     else
-        hipLaunchKernelGGL((msm_accum_kernel<3, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, (const G1Affine *)bases->pts29,
+        hipLaunchKernelGGL((msm_accum_kernel<3, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
                            (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
@@ -1397,7 +1405,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 }
 
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
-    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr, MSM_PHASE_ALL);
+    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr, MSM_PHASE_ALL, false, 0, 0);
 }
 
 }  // namespace h2

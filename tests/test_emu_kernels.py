@@ -574,6 +574,33 @@ def test_msm_accumulate_variants_agree(ctx, variant):
         b.free()
 
 
+def test_msm_split_windows(ctx):
+    """msm_split_windows: a column's windows dealt to two lanes as half jobs that add into the column's one bucket array — the single MSM, a
+    batch of one and a batch of three, against the oracle and against the unsplit path"""
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+
+    n = 3000
+    bases = CO.known_dlog_bases(n, fr([7]), fr([5]))
+    b = ctx.bases_upload(bases, BASES_PRECOMPUTE)
+    cols = [rand_fr(n, 51), circuit_like_fr(n, 52), np.repeat(fr([R - 1]), n, axis=0)]
+    want = [CO.best_multiexp(s, bases, threads=8) for s in cols]
+    dcols = [ctx.to_device(s) for s in cols]
+    try:
+        for mode in (2, 0):
+            ctx.set_param("msm_split_windows", mode)
+            for s, w in zip(cols, want):
+                assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), w), mode
+            got = ctx.msm_batch_dev(b, dcols, n, H.POINT_AFFINE)
+            assert all(np.array_equal(g, w.reshape(-1)) for g, w in zip(got, want)), mode
+            assert np.array_equal(ctx.msm_batch_dev(b, dcols[:1], n, H.POINT_AFFINE)[0], want[0].reshape(-1)), mode
+            assert np.array_equal(ctx.msm(b, cols[0][:777], H.POINT_AFFINE), CO.best_multiexp(cols[0][:777], bases[:777], threads=4)), mode
+    finally:
+        ctx.set_param("msm_split_windows", 0)
+        for d in dcols:
+            ctx.free(d)
+        b.free()
+
+
 def test_msm_two_level_sort_paths(ctx):
     """the two-level sort (msm_sort_mode 2; selectable, not the default): several chunks per window, a coarse bucket larger than the LDS buffer (all scalars equal:
     every entry of a window lands in ONE key, placed directly), windows with no entries at all — and the one-pass sort (msm_sort_mode 1) on
