@@ -4,6 +4,8 @@ tests/test_plonk_prover.py::_check).  Shapes are drawn over the whole range the 
 with and without lookups / instances / precomputed bases — so that batching boundaries the fixed test list does not name are crossed too.
 
     python tools/fuzz_shapes.py [seconds=120] [seed=1] [kmin kmax]      (kmin kmax: draw k uniformly from that range instead, e.g. 13 16)
+    H2HIP_FUZZ_KNOBS=1: every shape also draws the selectable kernel paths (two-level sort, window split, accumulation variants, radix-8 NTT,
+    fused columns, lanes) — the non-default code on the real GPU, where an LDS race shows
 """
 import os, random, sys, time
 
@@ -27,10 +29,16 @@ while time.time() - t0 < budget:
     pre = rnd.random() < 0.5
     seed = rnd.randint(1, 1 << 20)
     shape = (k, na, nl, nf, ni, lb)
+    knobs = {}
+    if os.environ.get("H2HIP_FUZZ_KNOBS"):
+        knobs = {"msm_sort_mode": rnd.choice([0, 2]), "msm_split_windows": rnd.choice([0, 2]), "msm_accum_variant": rnd.choice([3, 3, 2, 5, 6]),
+                 "ntt_radix8": rnd.choice([0, 1]), "msm_fuse_cols": rnd.choice([0, 1, 4]), "msm_lanes": rnd.choice([0, 1, 2])}
+        for name, val in knobs.items():
+            ctx.set_param(name, val)
     try:
         out = _check(ctx, *shape, seed=seed, threads=16 if krange else 8, oracle_prover=True, precompute=pre, second_proof=rnd.random() < 0.3)
     except Exception as e:   # noqa: BLE001 — report the shape, then fail
-        print("FAIL shape", shape, "seed", seed, "precompute", pre, "->", repr(e)[:400], flush=True)
+        print("FAIL shape", shape, "seed", seed, "precompute", pre, "knobs", knobs, "->", repr(e)[:400], flush=True)
         sys.exit(1)
     out[6].free()
     out[7].free()
