@@ -130,13 +130,15 @@ def test_msm_both_sorts_at_every_size(ctx):
             b = ctx.bases_upload(bases, flags)
             cols = [rand_fr(n, n), circuit_like_fr(n, n + 1), np.repeat(fr([1]), n, axis=0)]
             want = [CO.best_multiexp(s, bases, threads=NT) for s in cols]
-            for mode in (2, 1):
+            for mode, split in ((2, 0), (1, 0), (1, 2), (2, 2)):   # split 2: a column's windows as two half jobs on two lanes (precomputed bases only)
                 ctx.set_param("msm_sort_mode", mode)
+                ctx.set_param("msm_split_windows", split)
                 for s, w in zip(cols, want):
-                    assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), w), (n, flags, mode)
+                    assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), w), (n, flags, mode, split)
             b.free()
     finally:
         ctx.set_param("msm_sort_mode", 0)
+        ctx.set_param("msm_split_windows", 0)
 
 
 def test_fr_batches(ctx):
