@@ -142,6 +142,14 @@ def g1_mul(p, scalar_mont):
     return out
 
 
+def g1_fixed_base_batch(base, scalars_mont, threads=1):
+    """scalars[i] * base for every i (8-bit fixed-base windows + batch normalisation; h2_oracle.c:orc_g1_fixed_base_batch)"""
+    s = _fe(scalars_mont)
+    out = np.empty((len(s), 8), dtype=np.uint64)
+    lib().orc_g1_fixed_base_batch(_p(out), _p(_pt(base)), _p(s), C.c_size_t(len(s)), C.c_int(threads))
+    return out
+
+
 def g1_is_on_curve(p) -> bool:
     return bool(lib().orc_g1_is_on_curve(_p(_pt(p))))
 

@@ -417,6 +417,63 @@ void orc_known_dlog_bases(g1a *out, size_t n, const fe *k0_mont, const fe *d_mon
     free(pre); free(J);
 }
 
+/* out[i] = scalars[i] * base for n Montgomery scalars (the SRS definition g[i] = s^i G, g_lagrange[i] = L_i(s) G evaluated point by point:
+   ParamsKZG::setup).  Fixed-base windows of 8 bits: T[w][d] = d * 2^(8w) * base (32 x 255 affine points), 32 mixed additions
+   per scalar, Montgomery's trick for the final normalisation of every thread's range.  Independent of best_multiexp. */
+typedef struct { g1a *out; const fe *scalars; const g1a *table; size_t lo, hi; } fb_job;
+static void *fb_worker(void *p) {
+    fb_job *j = (fb_job *)p;
+    size_t n = j->hi - j->lo;
+    if (!n) return NULL;
+    g1j *J = (g1j *)malloc(sizeof(g1j) * n);
+    fe *pre = (fe *)malloc(sizeof(fe) * n);
+    for (size_t i = 0; i < n; ++i) {
+        fe s; fe_from_mont(&s, &j->scalars[j->lo + i], &FR);
+        g1j acc; g1j_set_id(&acc);
+        for (int w = 0; w < 32; ++w) {
+            unsigned d = (unsigned)((s.l[w >> 3] >> ((w & 7) * 8)) & 0xff);
+            if (d) g1j_add_affine(&acc, &acc, &j->table[(size_t)w * 256 + d]);
+        }
+        J[i] = acc;
+    }
+    fe acc = FQ.r1;
+    for (size_t i = 0; i < n; ++i) { pre[i] = acc; if (!fe_is_zero(&J[i].z)) fe_mul(&acc, &acc, &J[i].z, &FQ); }
+    fe_inv(&acc, &acc, &FQ);
+    for (size_t i = n; i-- > 0;) {
+        g1a *o = &j->out[j->lo + i];
+        if (fe_is_zero(&J[i].z)) { memset(o, 0, sizeof(g1a)); continue; }
+        fe zi, zi2, zi3;
+        fe_mul(&zi, &acc, &pre[i], &FQ);
+        fe_mul(&acc, &acc, &J[i].z, &FQ);
+        fe_sqr(&zi2, &zi, &FQ); fe_mul(&zi3, &zi2, &zi, &FQ);
+        fe_mul(&o->x, &J[i].x, &zi2, &FQ);
+        fe_mul(&o->y, &J[i].y, &zi3, &FQ);
+    }
+    free(pre); free(J);
+    return NULL;
+}
+void orc_g1_fixed_base_batch(g1a *out, const g1a *base, const fe *scalars_mont, size_t n, int threads) {
+    g1a *table = (g1a *)calloc((size_t)32 * 256, sizeof(g1a));
+    g1j cur; g1j_from_affine(&cur, base);                 /* 2^(8w) * base */
+    for (int w = 0; w < 32; ++w) {
+        g1j acc; g1j_set_id(&acc);
+        g1a step; g1j_to_affine(&step, &cur);
+        for (int d = 1; d < 256; ++d) { g1j_add_affine(&acc, &acc, &step); g1j_to_affine(&table[(size_t)w * 256 + d], &acc); }
+        for (int b = 0; b < 8; ++b) g1j_double(&cur, &cur);
+    }
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    pthread_t th[64]; fb_job jobs[64];
+    size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    for (int t = 0; t < threads; ++t) {
+        size_t lo = (size_t)t * per, hi = lo + per; if (lo > n) lo = n; if (hi > n) hi = n;
+        jobs[t] = (fb_job){out, scalars_mont, table, lo, hi};
+        pthread_create(&th[t], NULL, fb_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    free(table);
+}
+
 /* ------------------------------------------------------------------ best_multiexp restatement */
 static inline size_t get_at(size_t segment, size_t c, const fe *canon) {
     size_t skip_bits = segment * c;

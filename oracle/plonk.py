@@ -164,30 +164,24 @@ class Params:
     s_g2: tuple = None
 
     @classmethod
-    def setup(cls, k: int, s: int, g=None, g_lagrange=None):
+    def setup(cls, k: int, s: int, g=None, g_lagrange=None, threads: int = 4):
         """ParamsKZG::setup with the toxic waste given explicitly: g[i] = s^i G, g_lagrange[i] = L_i(s) G  (SURVEY.md A.8).
         The base arrays may be supplied (e.g. downloaded from the GPU setup, itself tested against this definition)."""
         n = 1 << k
+        G = O.points_to_limbs([O.G1_GEN])
         if g is None:
-            lib = CO.lib()
-            import ctypes as C
-
-            G = O.points_to_limbs([O.G1_GEN])
-            powers = CO.fr_geom(fr1(1), fr1(s), n)
-            g = np.empty((n, 8), dtype=np.uint64)
-            for i in range(n):     # small k only
-                g[i] = CO.g1_mul(G, powers[i:i + 1])[0]
+            g = CO.g1_fixed_base_batch(G, CO.fr_geom(fr1(1), fr1(s), n, threads), threads)
         if g_lagrange is None:
-            # L_i(s) = (s^n - 1) * omega^i / (n * (s - omega^i))
+            # L_i(s) = (s^n - 1) * omega^i / (n * (s - omega^i)); s in the domain: L_i(s) = [omega^i == s]
             w = O.omega_for(k)
-            G = O.points_to_limbs([O.G1_GEN])
-            num = (pow(s, n, R) - 1) * O.inv_mod(n, R) % R
-            g_lagrange = np.empty((n, 8), dtype=np.uint64)
-            wi = 1
-            for i in range(n):
-                li = num * wi % R * O.inv_mod(s - wi, R) % R
-                g_lagrange[i] = CO.g1_mul(G, fr1(li))[0]
-                wi = wi * w % R
+            wi = CO.fr_geom(fr1(1), fr1(w), n, threads)
+            den = CO.fr_sub(np.repeat(fr1(s), n, axis=0), wi)
+            if not den.any(axis=1).all():
+                li = np.where(den.any(axis=1)[:, None], np.zeros((n, 4), dtype=np.uint64), np.repeat(fr1(1), n, axis=0))
+            else:
+                num = (pow(s, n, R) - 1) * O.inv_mod(n, R) % R
+                li = CO.fr_mul_mt(CO.fr_mul_mt(wi, CO.fr_batch_invert_mt(den, threads), threads), np.repeat(fr1(num), n, axis=0), threads)
+            g_lagrange = CO.g1_fixed_base_batch(G, li, threads)
         return cls(k, np.ascontiguousarray(g), np.ascontiguousarray(g_lagrange), PR.G2_GEN, PR.g2_mul(PR.G2_GEN, s))
 
     def commit(self, coeffs, threads=1):

@@ -622,3 +622,16 @@ def test_msm_two_level_sort_paths(ctx):
         ctx.set_param("msm_sort_mode", 0)
         ctx.set_param("msm_window_bits", 0)
         b.free()
+
+
+def test_full_range_field_inputs(ctx):
+    """limb patterns from the whole of [0, r) plus the edge patterns through every kernel family (tests/full_range_checks.py); the GPU suite
+    runs the same checks at BASELINE sizes"""
+    from tests import full_range_checks as F
+
+    F.check_ntt(ctx, [3, 9, 11, 13], threads=4)
+    F.check_coset(ctx, [(5, 7), (10, 12)], threads=4)
+    F.check_msm_scalars(ctx, [33, 3000], threads=4, flags_list=(0, 1))
+    F.check_pointwise(ctx, 2000)
+    F.check_inverse_and_products(ctx, [1, 37, 3000])
+    F.check_eval_and_division(ctx, [1, 9, 2049])

@@ -469,3 +469,31 @@ def test_fp64_fma_multiplier_probe_is_a_correct_montgomery_product():
         assert n == 4096 * 256 * 64 * 2 and ms > 0
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_full_range_field_inputs_ntt(ctx):
+    """rand_fr never leaves [0, 2^252).  The transforms on limb patterns uniform over [0, r) plus the edge patterns
+    (r-1, r-2, 2^252 +- 1, R mod r, ...), up to BASELINE configs[2]'s 2^22 and the k = 19 coset extension"""
+    from tests import full_range_checks as F
+
+    F.check_ntt(ctx, [4, 10, 11, 14, 19, 20, 22], threads=NT)
+    F.check_coset(ctx, [(5, 7), (12, 14), (19, 21)], threads=NT)
+
+
+@pytest.mark.gpu
+def test_full_range_field_inputs_msm(ctx):
+    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
+    from tests import full_range_checks as F
+
+    F.check_msm_scalars(ctx, [33, 5000, 1 << 16], threads=NT, flags_list=(0, BASES_PRECOMPUTE))
+    F.check_msm_scalars(ctx, [1 << 20], threads=NT, flags_list=(BASES_PRECOMPUTE,))
+
+
+@pytest.mark.gpu
+def test_full_range_field_inputs_pointwise(ctx):
+    from tests import full_range_checks as F
+
+    F.check_pointwise(ctx, 100003)
+    F.check_inverse_and_products(ctx, [1, 257, 70001, 1 << 19])
+    F.check_eval_and_division(ctx, [1, 2049, 1 << 19, (1 << 21) + 5])

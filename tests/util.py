@@ -19,6 +19,44 @@ def rand_fr(n, seed):
     return a
 
 
+def edge_fr_values():
+    """the limb patterns rand_fr never produces: values in [2^252, r), the top of the range, the Montgomery
+    constants — as RAW limb patterns (what the kernels see; as Montgomery residues they stand for value * 2^-256 mod r)"""
+    return [0, 1, 2, R - 1, R - 2, R - 3, (1 << 252) - 1, 1 << 252, (1 << 252) + 1, (1 << 253) - 1, 1 << 253, (1 << 253) + 1,
+            (1 << 256) % R, (1 << 512) % R, (R - (1 << 256) % R) % R, (R + 1) // 2, (R - 1) // 2, R - (1 << 64), R - (1 << 128), R - (1 << 192),
+            (1 << 64) - 1, (1 << 128) - 1, (1 << 192) - 1, ((1 << 253) | ((1 << 192) - 1)) % R, 0x30644e72e131a029 << 192]
+
+
+def full_range_fr(n, seed, edges=True):
+    """n raw limb patterns UNIFORM over the whole of [0, r) (rejection sampling on 254-bit draws, numpy-vectorised), with the edge patterns
+    of edge_fr_values() written over pseudo-random positions (and positions 0 / n-1) when `edges`: two thirds of the draws lie in
+    [2^252, r), the range rand_fr leaves out."""
+    g = np.random.default_rng([seed, 0xF011])
+    out = np.empty((0, 4), dtype=np.uint64)
+    rl = np.array([(R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    while len(out) < n:
+        m = max(16, int((n - len(out)) * 1.4) + 8)
+        a = g.integers(0, 1 << 64, size=(m, 4), dtype=np.uint64, endpoint=False)
+        a[:, 3] &= np.uint64((1 << 62) - 1)
+        lt = np.zeros(m, dtype=bool)
+        eq = np.ones(m, dtype=bool)
+        for i in (3, 2, 1, 0):
+            lt |= eq & (a[:, i] < rl[i])
+            eq &= a[:, i] == rl[i]
+        out = np.concatenate([out, a[lt]])
+    out = np.ascontiguousarray(out[:n])
+    if edges and n:
+        ev = _raw_limbs(edge_fr_values())
+        pos = g.integers(0, n, size=len(ev))
+        pos[0], pos[1] = 0, n - 1
+        out[pos] = ev[: len(pos)]
+    return out
+
+
+def _raw_limbs(vals):
+    return np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in vals], dtype=np.uint64)
+
+
 def circuit_like_fr(n, seed):
     """advice-column-shaped scalars: ~50% zero, ~25% one, rest < 2^88, Montgomery limbs."""
     g = np.random.default_rng(seed)
