@@ -26,13 +26,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     objs = []
     procs = []
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in HEADERS if os.path.exists(os.path.join(CSRC, f)))
     for s in srcs:
         o = s[:-4] + ".o"
+        objs.append(o)
+        # incremental: an object newer than its source and than every header is kept
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_time):
+            continue
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value", "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(o)
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))

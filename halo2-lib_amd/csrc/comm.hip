@@ -101,6 +101,14 @@ static int comm_dev_stage(h2hip_comm *c, size_t bytes) {
     return H2HIP_OK;
 }
 
+// every fallible preparation of a later h2hip_comm_allgather_dev(bytes per rank) — the callback transport's pinned staging area — done NOW, so
+// that a caller can put it before the go-ahead exchange that precedes the collective (plonk.hip: the coset all-gather)
+int h2::comm_reserve_allgather_dev(h2hip_comm *c, size_t bytes) {
+    H2_REQUIRE(c, "NULL argument");
+    if (c->nccl || !bytes) return H2HIP_OK;
+    return comm_host_stage(c, bytes + bytes * (size_t)c->world);
+}
+
 extern "C" {
 
 int h2hip_comm_rccl_unique_id(void *out128) {

@@ -203,8 +203,11 @@ constexpr uint32_t MSM_MAX_COLS = 32;   // columns one fused multi-column MSM ha
 enum { MSM_PHASE_SORT = 1u, MSM_PHASE_ACCUM = 2u, MSM_PHASE_MERGE = 4u, MSM_PHASE_REDUCE = 8u, MSM_PHASE_ALL = 15u };
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev,
                  XYZZ29 *ext_buckets, uint32_t phases = MSM_PHASE_ALL, bool ext_buckets_zeroed = false, uint32_t w_lo = 0, uint32_t w_cnt = 0);   // w_cnt != 0: only the column's windows [w_lo, w_lo + w_cnt)
-// zero-fill-after-use of the bucket arrays (see h2hip_ctx::clean_*): is the buffer's head already (scheduled to be) zero? / schedule the fill
+// zero-fill-after-use of the bucket arrays (see h2hip_ctx::clean_*): is the buffer's head already (scheduled to be) zero?  (a true answer
+// CONSUMES the state: the caller dirties the array) / schedule the fill
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);
 int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes);
+// comm.hip: the fallible preparations of a later h2hip_comm_allgather_dev of `bytes` per rank, done ahead of time
+int comm_reserve_allgather_dev(h2hip_comm *comm, size_t bytes);
 int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t window_bits, const XYZZ29 *buckets, uint32_t ncols, XYZZ *out_dev);
 }  // namespace h2

@@ -1174,8 +1174,12 @@ int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t c, const 
     return H2HIP_OK;
 }
 
+// CONSUMES the pre-zeroed state: the caller is about to dirty the array, and only a completed buckets_clean_after_use re-arms it — a call
+// that fails between the accumulation and its reduction must not leave the dirty array marked as zero
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes) {
-    return ctx->clean_ev && ctx->clean_ptr[which] == buf && ctx->clean_bytes[which] >= bytes;
+    const bool ok = ctx->clean_ev && ctx->clean_ptr[which] == buf && ctx->clean_bytes[which] >= bytes;
+    if (ok) ctx->clean_bytes[which] = 0;
+    return ok;
 }
 int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes) {
     if (!ctx->clean_stream) {

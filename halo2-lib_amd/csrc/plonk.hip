@@ -1103,11 +1103,14 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         }
         // every rank needs all of h's coefficients (its slices of the pieces are committed next, its evaluations opened later): one go-ahead
         // exchange (status only), then ONE all-gather of the cosets, device to device, and the interleave into extended-domain order
-        std::vector<uint8_t> all;
-        H2_CHK(exchange_host(nullptr, 0, all));
+        // Everything that can fail on this rank alone — the gathered buffer (256 MiB at k = 21), the transport's staging area — is done BEFORE
+        // the go-ahead: a rank that fails here reports it through that exchange; after it only the collective itself is left
         Fr *gathered = nullptr;
         const size_t slot_elems = (size_t)pk->max_cosets * n;
         H2_CHK(sc.take(slot_elems * pk->shard_world, &gathered));
+        H2_CHK(comm_reserve_allgather_dev(pk->comm, sizeof(Fr) * slot_elems));
+        std::vector<uint8_t> all;
+        H2_CHK(exchange_host(nullptr, 0, all));
         H2_CHK(h2hip_comm_allgather_dev(pk->comm, ctx, acc_loc, sizeof(Fr) * slot_elems, gathered));
         const uint32_t log_c = ek - k;
         uint32_t slots[16] = {0};
