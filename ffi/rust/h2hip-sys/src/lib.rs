@@ -37,6 +37,15 @@ pub struct h2hip_array_rng {
     pub pos: usize,
     pub exhausted: c_int,
 }
+/// state of libh2hip's seeded ChaCha generator (`h2hip_chacha_rng_fill` as the `h2hip_rng_fill_fn`): the `Fr::random` stream of
+/// `StdRng` (rounds = 12) / `ChaCha20Rng` (rounds = 20); `pos` = elements drawn so far
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct h2hip_chacha_rng {
+    pub seed: [u8; 32],
+    pub rounds: i32,
+    pub pos: u64,
+}
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct h2hip_plonk_shape {
@@ -215,6 +224,11 @@ extern "C" {
                                      n: usize) -> c_int;
     pub fn h2hip_fr_coset_interleave_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, in_dev: *const c_void, slots: *const u32, log_cosets: u32, n: usize) -> c_int;
     pub fn h2hip_array_rng_fill(user: *mut c_void, out_fr: *mut c_void, n: usize);
+    pub fn h2hip_rng_seed_from_u64(state: u64, seed_out32: *mut u8);
+    pub fn h2hip_chacha_rng_init(rng: *mut h2hip_chacha_rng, seed32: *const u8, rounds: c_int);
+    pub fn h2hip_chacha_block(seed32: *const u8, counter: u64, stream: u64, rounds: c_int, out64: *mut u8);
+    pub fn h2hip_chacha_rng_fill(user: *mut c_void, out_fr: *mut c_void, n: usize);
+    pub fn h2hip_rng_chacha_fill_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, n: usize, seed32: *const u8, rounds: c_int, first_block: u64) -> c_int;
     pub fn h2hip_plonk_stage_name(stage: c_int) -> *const c_char;
     pub fn h2hip_plonk_create_proof(ctx: *mut h2hip_ctx, pk: *mut h2hip_plonk_pk, advice: *const *const c_void, advice_on_device: c_int,
                                     instances_host: *const *const c_void, instance_lens: *const usize, rng: h2hip_rng_fill_fn, rng_user: *mut c_void,

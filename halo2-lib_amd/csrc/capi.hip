@@ -283,6 +283,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_table_nontemporal")) return &ctx->msm_table_nontemporal;
     if (!strcmp(name, "msm_fold_windows")) return &ctx->msm_fold_windows;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
+    if (!strcmp(name, "ntt_tile_kernel")) return &ctx->ntt_tile_kernel;
     if (!strcmp(name, "msm_debug_reorder")) return &ctx->msm_debug_reorder;
     if (!strcmp(name, "msm_split_windows")) return &ctx->msm_split_windows;
     if (!strcmp(name, "ntt_wave_local")) return &ctx->ntt_wave_local;

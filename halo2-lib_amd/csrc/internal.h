@@ -92,6 +92,7 @@ struct h2hip_ctx {
     int ntt_tile_bits8 = 11;     // log2 of the radix-8 kernel's tile (<= 11; smaller values only to force many passes in tests)
     int msm_split_windows = 0;   // batch API, large precomputed MSMs: 1 = every column's windows are dealt to two lanes (two half jobs adding into the column's one bucket array)
     int msm_debug_reorder = 0;   // diagnostics only: reorder the entries inside every bucket after the sort (1 ascending point index, 2 hashed); results unchanged
+    int ntt_tile_kernel = 1;     // 1 (default): full 1024-element tiles go through ntt_tile_kernel (r04: no exposed global-memory latency); 0: the generic pass kernel
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
@@ -207,6 +208,8 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 // CONSUMES the state: the caller dirties the array) / schedule the fill
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);
 int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes);
+// rng.hip: n elements of the ChaCha Fr::random stream from element first_block on, on `stream`
+int rng_chacha_fill_dev(h2hip_ctx *ctx, Fr *out_dev, size_t n, const uint8_t seed[32], int rounds, uint64_t first_block, hipStream_t stream);
 // comm.hip: the fallible preparations of a later h2hip_comm_allgather_dev of `bytes` per rank, done ahead of time
 int comm_reserve_allgather_dev(h2hip_comm *comm, size_t bytes);
 int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t window_bits, const XYZZ29 *buckets, uint32_t ncols, XYZZ *out_dev);

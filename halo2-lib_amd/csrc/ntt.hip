@@ -234,6 +234,169 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(NttCols cols, uint32_t lo
     }
 }
 
+// ---------------------------------------------------------------------------------------------- full-tile pass (r04)
+// The same pass for the case every large transform is made of — a FULL 1024-element tile (m + cb = 10), the inter-pass twiddles from a
+// direct table — specialised so that no global-memory latency is left exposed.  What the generic kernel's ISA showed (r04, hipcc -S):
+//   * its "prefetch" of the next tile was per-lane conditional (zero padding), the compiler merged the zero / loaded values with moves
+//     and put `s_waitcnt vmcnt(1)` right behind the loads: every tile paid a full HBM round trip with all four waves of the workgroup
+//     waiting at the same place;
+//   * its read-out was a runtime loop, one element per trip: LDS read -> twiddle load -> wait -> product -> pack -> store, i.e. four
+//     more serialised L2 / HBM latencies per tile.  (rocprofv3: pass time = VALU time + streaming time, no overlap at all.)
+// Here the next tile's loads are unconditional (clamped address, the padding zeros are selected at use), issued before the butterflies and
+// first waited for at the next tile's fill; the four read-out twiddles of a lane are requested together, before the barrier that ends the
+// last butterfly round, so that one latency (hidden behind that barrier and the LDS reads) is paid instead of four; every per-lane loop is
+// four compile-time iterations.  Same LDS layout, same arithmetic, bit-identical results.
+// KIND: 0 = first pass (log_s = 0; IN_MUL: fused coset scaling with implicit zero padding), 1 = middle pass, 2 = last pass (no
+// inter-pass twiddles; OUT_MUL: fused ifft divisor / zeta^-i scaling).
+template <int KIND, bool MUL>
+__global__ __launch_bounds__(256) void ntt_tile_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
+                                                       const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
+                                                       const Fr29L *__restrict__ tdirect, uint32_t in_len, NttScale sc) {
+    HIP_DYNAMIC_SHARED(Fr29L, lds)
+    constexpr bool FIRST = KIND == 0, LAST = KIND == 2;
+    const Fr *__restrict__ x = cols.x[blockIdx.y];
+    Fr *__restrict__ y = cols.y[blockIdx.y];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t R = 1u << m, C = 1u << cb;   // R * C = 1024
+    Fr29L *tw_s = lds + 1024;                   // omega_R^k, k < R/2
+    Fr29L *scale_s = tw_s + (R >> 1) + 1;       // [0..3) the three scales (R' form)
+    const uint32_t rows_stride = 1u << (log_n - m);
+    const uint32_t ntiles = 1u << (log_n - 10);
+    const uint32_t smask = (1u << log_s) - 1;
+    for (uint32_t k = tid; k < (R >> 1); k += 256) tw_s[k].v = tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m));
+    if (MUL && tid < 3) scale_s[tid].v = fr29_from_sat(FIRST ? sc.in3[tid] : sc.out3[tid]);
+
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    v4u pre[4][2];
+    auto fetch = [&](uint32_t tile) {
+        const uint32_t j0 = tile << cb;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t e = tid + 256 * k;
+            uint32_t idx = j0 + (e & (C - 1)) + (e >> cb) * rows_stride;
+            if (FIRST) idx = idx < in_len ? idx : 0u;   // implicit zero padding: a harmless in-range address, the zero is selected at the fill
+            const v4u *q = reinterpret_cast<const v4u *>(x + idx);
+            pre[k][0] = q[0];
+            pre[k][1] = q[1];
+        }
+    };
+    uint32_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    fetch(tile);
+    __syncthreads();   // tw_s / scale_s visible
+
+    // one radix-4 group per lane and round
+    const uint32_t gc = tid & (C - 1), gp = tid >> cb;
+    auto round4 = [&](uint32_t st) {
+        const uint32_t h = 1u << st;
+        const uint32_t i = gp & (h - 1), blk = gp >> st;
+        const uint32_t e0 = (((blk << (st + 2)) + i) << cb) + gc, stride = h << cb;
+        Fr29 x0 = lds[e0].v, x1 = lds[e0 + stride].v, x2 = lds[e0 + 2 * stride].v, x3 = lds[e0 + 3 * stride].v;
+        if (st) {   // stage st: omega_{2h}^i (for st == 0 it is 1)
+            const Fr29 w1 = tw_s[i << (m - 1 - st)].v;
+            x1 = f29_mul(x1, w1);
+            x3 = f29_mul(x3, w1);
+        }
+        const Fr29 y0 = f29_add(x0, x1), y1 = f29_sub_lazy<2>(x0, x1);
+        // stage st+1 (half = 2h): omega_{4h}^i and omega_{4h}^(i+h)
+        const Fr29 y2 = f29_mul_wide(f29_add(x2, x3), tw_s[i << (m - 2 - st)].v);
+        const Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), tw_s[(i + h) << (m - 2 - st)].v);
+        lds[e0].v = f29_norm(f29_add(y0, y2));
+        lds[e0 + 2 * stride].v = f29_sub<2>(y0, y2);
+        lds[e0 + stride].v = f29_norm(f29_add(y1, y3));
+        lds[e0 + 3 * stride].v = f29_sub<2>(y1, y3);
+    };
+
+    for (;;) {
+        const uint32_t j0 = tile << cb;
+        // ---- fill: the prefetched rows go to LDS bit-reversed (DIT: bit-reversed rows in, natural rows out)
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t e = tid + 256 * k;
+            const uint32_t t = e >> cb, c = e & (C - 1);
+            Fr s;
+            s.l[0] = pre[k][0].x; s.l[1] = pre[k][0].y; s.l[2] = pre[k][0].z; s.l[3] = pre[k][0].w;
+            s.l[4] = pre[k][1].x; s.l[5] = pre[k][1].y; s.l[6] = pre[k][1].z; s.l[7] = pre[k][1].w;
+            Fr29 v = f29_split<R29P>(s);
+            if (FIRST) {
+                const uint32_t idx = j0 + c + t * rows_stride;
+                if (MUL) v = f29_mul(v, scale_s[idx % 3u].v);
+                if (idx >= in_len) v = Fr29::zero();
+            }
+            lds[(bitrev_m(t, m) << cb) + c].v = v;
+        }
+        const uint32_t next = tile + gridDim.x;
+        const bool has_next = next < ntiles;   // wave-uniform
+        if (has_next) fetch(next);             // in flight during the whole transform of this tile
+        __syncthreads();
+        uint32_t st = 0;
+        if (m & 1) {   // odd number of stages: one radix-2 stage (twiddle 1) first
+#pragma unroll
+            for (uint32_t k = 0; k < 2; ++k) {
+                const uint32_t b = tid + 256 * k;
+                const uint32_t c = b & (C - 1), p = b >> cb;
+                const uint32_t e0 = ((p << 1) << cb) + c, e1 = e0 + C;
+                const Fr29 a = lds[e0].v, t = lds[e1].v;
+                lds[e0].v = f29_norm(f29_add(a, t));
+                lds[e1].v = f29_sub<2>(a, t);
+            }
+            st = 1;
+            __syncthreads();
+        }
+        for (; st + 2 < m; st += 2) {
+            round4(st);
+            __syncthreads();
+        }
+        round4(st);   // st == m - 2
+        // ---- the lane's four read-out positions and their inter-pass twiddles, requested between the last round's LDS writes and the barrier that ends it (the round's
+        // temporaries are dead by then: requesting them before the round costs 40 more registers per lane, i.e. a wave per SIMD)
+        uint32_t oidx[4], lidx[4];
+        Fr29 twr[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t e = tid + 256 * k;
+            uint32_t u, c;
+            if (FIRST) {   // first pass: output (j0 + c) * R + u is contiguous in u
+                c = e >> m;
+                u = e & (R - 1);
+            } else {       // later passes: contiguous in q (i.e. in c)
+                u = e >> cb;
+                c = e & (C - 1);
+            }
+            const uint32_t j = j0 + c, q = j & smask, jq = j - q;
+            lidx[k] = (u << cb) + c;
+            oidx[k] = (jq << m) + q + (u << log_s);
+            if (!LAST) {   // omega^(jq*u): jq is a multiple of s, the table holds omega^(s*t)
+                const v4u *tp = reinterpret_cast<const v4u *>(tdirect + (size_t)(jq >> log_s) * u);
+                const v4u a = tp[0], b = tp[1];
+                const uint32_t c8 = reinterpret_cast<const uint32_t *>(tp)[8];
+                twr[k].l[0] = a.x; twr[k].l[1] = a.y; twr[k].l[2] = a.z; twr[k].l[3] = a.w;
+                twr[k].l[4] = b.x; twr[k].l[5] = b.y; twr[k].l[6] = b.z; twr[k].l[7] = b.w;
+                twr[k].l[8] = c8;
+            }
+        }
+        __syncthreads();
+        // ---- read-out
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            Fr29 v = lds[lidx[k]].v;
+            if (!LAST) v = f29_mul(v, twr[k]);
+            if (LAST && MUL) v = f29_mul(v, scale_s[oidx[k] % 3u].v);
+            if (LAST && !MUL) v = f29_weak_reduce(v);   // weak bound (<= 21 r) -> < 2 r before packing, no multiply
+            const Fr o = f29_pack_canonical<FrP>(v);
+            v4u *yp = reinterpret_cast<v4u *>(y + oidx[k]);
+            v4u lo, hi;
+            lo.x = o.l[0]; lo.y = o.l[1]; lo.z = o.l[2]; lo.w = o.l[3];
+            hi.x = o.l[4]; hi.y = o.l[5]; hi.z = o.l[6]; hi.w = o.l[7];
+            yp[0] = lo;
+            yp[1] = hi;
+        }
+        if (!has_next) break;
+        tile = next;
+        __syncthreads();   // LDS is overwritten by the next tile
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- radix-8 pass (r03)
 // The same pass (same tile -> output index map, same fused scalings, same tables) with THREE butterfly stages per LDS round trip: every lane
 // holds 8 elements in registers and runs a radix-8 decimation-in-time group on them (12 twiddle products), so a 7-stage sub-transform is
@@ -586,6 +749,34 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
                 hipLaunchKernelGGL(ntt_pass8_kernel<TB8>, dim3(grid8, gc), dim3(1u << (TB8 - 3)), sizeof(Fr29P) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0))), ctx->stream, cols, log_n, m, log_s, cb,
                                    (const Fr29L *)tw->t1, (const Fr29L *)tw->t2, tw->lo_bits, tdirect, tstage, first ? in_len : N,
                                    (first && in_scale3) ? 1 : 0, (last && out_scale3) ? 1 : 0, sc);
+                prof_end(ctx);
+                H2_HIPCHK(hipGetLastError());
+                in_scratch = to_scratch;
+                log_s += m;
+                continue;
+            }
+            // the specialised full-tile kernel: every pass of a transform of 2^11 points or more at the default tile size
+            if (ctx->ntt_tile_kernel && P >= 2 && m + cb == 10 && m >= 2 && (last || tdirect) && N <= (1ull << 28)) {
+                const size_t shmem_t = sizeof(Fr29L) * (1024 + ((size_t)1 << (m - 1)) + 8);
+                // equal shares: every workgroup walks `rounds` tiles (the last few one less) instead of some walking one more than the others
+                const uint32_t slots = (uint32_t)ctx->num_cus * 3, rounds = (tiles + slots - 1) / slots;
+                const uint32_t grid_t = (tiles + rounds - 1) / rounds;
+                const bool mul = first ? in_scale3 != nullptr : (last && out_scale3 != nullptr);
+                const uint32_t in_len32 = (uint32_t)(first ? in_len : N);
+                prof_begin(ctx, "ntt_pass_kernel");
+#define H2_NTT_TILE(KIND, MUL)                                                                                                                      \
+    hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL>), dim3(grid_t, gc), dim3(256), shmem_t, ctx->stream, cols, log_n, m, log_s, cb, (const Fr29L *)tw->t1, \
+                       (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc)
+                if (first) {
+                    if (mul) H2_NTT_TILE(0, true);
+                    else H2_NTT_TILE(0, false);
+                } else if (!last) {
+                    H2_NTT_TILE(1, false);
+                } else {
+                    if (mul) H2_NTT_TILE(2, true);
+                    else H2_NTT_TILE(2, false);
+                }
+#undef H2_NTT_TILE
                 prof_end(ctx);
                 H2_HIPCHK(hipGetLastError());
                 in_scratch = to_scratch;

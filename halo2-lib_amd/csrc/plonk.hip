@@ -1013,10 +1013,18 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     }
     G1Affine random_commitment;
     {
-        const Fr *vals = draw(n);
-        H2_HIPCHK(hipMemcpyAsync(random_poly, vals, sizeof(Fr) * n, hipMemcpyHostToDevice, pk->copy_stream));
-        H2_HIPCHK(hipEventRecord(pk->copy_ev, pk->copy_stream));
-        H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));
+        if (rng == h2hip_chacha_rng_fill) {
+            // libh2hip's own seeded ChaCha generator: counter mode, so the n elements are generated where they are needed — on the
+            // device, straight into the polynomial — and the host only advances the stream position (same values as the host callback)
+            h2hip_chacha_rng *cr = (h2hip_chacha_rng *)rng_user;
+            H2_CHK(rng_chacha_fill_dev(ctx, random_poly, n, cr->seed, cr->rounds, cr->pos, st));
+            cr->pos += n;
+        } else {
+            const Fr *vals = draw(n);
+            H2_HIPCHK(hipMemcpyAsync(random_poly, vals, sizeof(Fr) * n, hipMemcpyHostToDevice, pk->copy_stream));
+            H2_HIPCHK(hipEventRecord(pk->copy_ev, pk->copy_stream));
+            H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));
+        }
         draw(1);   // random_blind
         std::vector<const void *> cols(perm_z.begin(), perm_z.end());
         std::vector<const h2hip_bases *> bases(cols.size(), pk->g_lagrange);

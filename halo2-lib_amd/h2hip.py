@@ -94,6 +94,11 @@ _PROTOS = {
     "h2hip_permutation_product_terms_sets_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
     "h2hip_lookup_permute_presorted_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _sz]),
     "h2hip_array_rng_fill": (None, [_vp, _vp, _sz]),
+    "h2hip_rng_seed_from_u64": (None, [C.c_uint64, _vp]),
+    "h2hip_chacha_rng_init": (None, [_vp, _vp, _int]),
+    "h2hip_chacha_block": (None, [_vp, C.c_uint64, C.c_uint64, _int, _vp]),
+    "h2hip_chacha_rng_fill": (None, [_vp, _vp, _sz]),
+    "h2hip_rng_chacha_fill_dev": (_int, [_vp, _vp, _sz, _vp, _int, C.c_uint64]),
     "h2hip_ifft_batch_dev": (_int, [_vp, _vp, _sz, _vp, _u32, _vp]),
     "h2hip_coeff_to_extended_batch_dev": (_int, [_vp, _vp, _u32, _vp, _u32, _sz, _vp, _vp]),
     "h2hip_fr_linear_combination_dev": (_int, [_vp, _vp, _vp, _vp, _sz, _sz]),

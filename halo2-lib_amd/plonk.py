@@ -91,6 +91,41 @@ class ArrayRng:
         self.pos += n
 
 
+class _ChaChaRngState(C.Structure):   # h2hip_chacha_rng
+    _fields_ = [("seed", C.c_uint8 * 32), ("rounds", C.c_int32), ("pos", C.c_uint64)]
+
+
+class ChaChaRng:
+    """The `Fr::random(&mut rng)` stream of a seeded rand_chacha generator — what the reference hands to create_proof
+    (halo2-base/src/utils/testing.rs:38: `StdRng::seed_from_u64(0)`, rand 0.8's StdRng = ChaCha12).  libh2hip's own generator
+    (csrc/rng.hip): create_proof produces its large draws ON THE DEVICE from (seed, position); `device=False` forces every draw through the
+    one-thread host generator behind a Python callback (same values, same bytes: the A/B the bench line and the tests use).
+    seed: 32 bytes, or an int for `seed_from_u64`."""
+
+    def __init__(self, lib, seed=0, rounds: int = 12, device: bool = True):
+        self.lib, self.device = lib, device
+        if isinstance(seed, int):
+            buf = (C.c_uint8 * 32)()
+            lib.h2hip_rng_seed_from_u64(C.c_uint64(seed), buf)
+            seed = bytes(buf)
+        if len(seed) != 32:
+            raise ValueError("ChaChaRng: the seed has 32 bytes")
+        self.state = _ChaChaRngState()
+        lib.h2hip_chacha_rng_init(C.byref(self.state), (C.c_uint8 * 32)(*seed), rounds)
+
+    @property
+    def pos(self) -> int:
+        return int(self.state.pos)
+
+    def fill_into(self, dst: int, n: int):
+        self.lib.h2hip_chacha_rng_fill(C.byref(self.state), _vp(dst), n)
+
+    def fill(self, n: int) -> np.ndarray:
+        out = np.empty((n, 4), dtype=np.uint64)
+        self.fill_into(out.ctypes.data, n)
+        return out
+
+
 class CallbackRng:
     """adapts any object with fill(n) -> (n, 4) uint64 Montgomery array"""
 
@@ -161,7 +196,7 @@ def keygen(kzg: ParamsKZG, params: BaseCircuitParams, fixed: Sequence[np.ndarray
 def create_proof(pk: ProvingKey, advice: Sequence, instances: Sequence[np.ndarray], rng, timings: Optional[dict] = None,
                  advice_on_device: bool = False) -> bytes:
     """create_proof for one circuit: advice columns (host (n,4) arrays, or device pointers with advice_on_device), instance columns
-    ((m,4) arrays), rng = ArrayRng / CallbackRng.  Returns the proof bytes (Blake2bWrite::finalize)."""
+    ((m,4) arrays), rng = ArrayRng / ChaChaRng / CallbackRng.  Returns the proof bytes (Blake2bWrite::finalize)."""
     ctx, sh = pk.ctx, pk.shape
     n = 1 << pk.params.k
     if len(advice) != sh.num_advice_total:
@@ -199,6 +234,10 @@ def create_proof(pk: ProvingKey, advice: Sequence, instances: Sequence[np.ndarra
         rng.pos += st.pos
         if st.exhausted:
             raise RuntimeError("ArrayRng exhausted")
+    elif isinstance(rng, ChaChaRng) and rng.device:   # libh2hip's seeded generator: the prover's device path for the large draws
+        rc = ctx.lib.h2hip_plonk_create_proof(ctx.handle, pk.handle, adv, 1 if advice_on_device else 0, ip, il,
+                                              C.cast(ctx.lib.h2hip_chacha_rng_fill, _vp), C.cast(C.pointer(rng.state), _vp), _ptr(proof), proof.nbytes,
+                                              C.byref(plen), stage)
     else:
         cb = _RNG_FN(_fill)
         rc = ctx.lib.h2hip_plonk_create_proof(ctx.handle, pk.handle, adv, 1 if advice_on_device else 0, ip, il, C.cast(cb, _vp), None, _ptr(proof),

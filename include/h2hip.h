@@ -437,6 +437,24 @@ typedef struct {
     int exhausted;
 } h2hip_array_rng;
 void h2hip_array_rng_fill(void *user, void *out_fr, size_t n);
+/* The `Fr::random(&mut rng)` stream of a seeded rand_chacha generator (the reference's prover RNG, halo2-base/src/utils/testing.rs:38
+ * `StdRng::seed_from_u64(0)` = ChaCha12; gen_srs's `ChaCha20Rng::from_seed([0; 32])`, halo2-base/src/utils/mod.rs:441): element j of the
+ * stream = keystream block j (counter mode) reduced mod r as Fr::from_u512 does.  `pos` = the number of elements drawn so far.
+ * h2hip_chacha_rng_fill is a ready-made h2hip_rng_fill_fn, `user` = the h2hip_chacha_rng, that generates on ONE host thread; when it is the
+ * function handed to h2hip_plonk_create_proof the prover generates its large draws (the n scalars of the random polynomial) ON THE DEVICE
+ * with h2hip_rng_chacha_fill_dev instead — same values, same final `pos`, no host generation and no upload.  The block function is pinned
+ * to RFC 8439's vectors; the stream layout is [UPSTREAM-RECALL]. */
+typedef struct {
+    uint8_t seed[32];
+    int32_t rounds;   /* 12: rand 0.8's StdRng; 20: ChaCha20Rng; 8: ChaCha8Rng */
+    uint64_t pos;
+} h2hip_chacha_rng;
+void h2hip_rng_seed_from_u64(uint64_t state, uint8_t *seed_out32);   /* rand_core's SeedableRng::seed_from_u64 (PCG32 expansion) */
+void h2hip_chacha_rng_init(h2hip_chacha_rng *rng, const uint8_t *seed32, int rounds);
+void h2hip_chacha_block(const uint8_t *seed32, uint64_t counter, uint64_t stream, int rounds, uint8_t *out64);
+void h2hip_chacha_rng_fill(void *user, void *out_fr, size_t n);
+/* out_dev[i] = stream element first_block + i, i < n (Montgomery Fr), on the context's stream */
+int h2hip_rng_chacha_fill_dev(h2hip_ctx *ctx, void *out_dev, size_t n, const uint8_t *seed32, int rounds, uint64_t first_block);
 #define H2HIP_PLONK_STAGES 12
 const char *h2hip_plonk_stage_name(int stage);
 /* advice: num_advice_total columns of 2^k Montgomery Fr (host pointers, or device pointers when advice_on_device != 0); rows >=

@@ -119,6 +119,9 @@ def _c_protos():
 
 def _rs_class(t):
     t = t.strip()
+    arr = re.fullmatch(r"\[\s*(\w+)\s*;\s*(\d+)\s*\]", t)   # [u8; 32]
+    if arr:
+        return "%sx%s" % (_rs_class(arr.group(1)), arr.group(2))
     if t.startswith("*") or t.startswith("Option<") or t.endswith("_fn"):
         return "ptr"
     return {"c_int": "i32", "i32": "i32", "c_uint": "u32", "u32": "u32", "u64": "u64", "i64": "i64", "usize": "usize", "f64": "f64", "u8": "u8"}[t]
@@ -137,6 +140,8 @@ def _rs_protos():
 def _py_class(t):
     if t is None:
         return "void"
+    if isinstance(t, type) and issubclass(t, ctypes.Array):
+        return "%sx%d" % (_py_class(t._type_), t._length_)
     if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or issubclass(t, ctypes._Pointer) or issubclass(t, ctypes._CFuncPtr):
         return "ptr"
     return {ctypes.c_int: "i32", ctypes.c_uint: "u32", ctypes.c_uint32: "u32", ctypes.c_int32: "i32", ctypes.c_uint64: "u64", ctypes.c_int64: "i64",
@@ -190,7 +195,11 @@ def _c_structs():
             names = [first[1]] + [n.strip() for n in decl.split(",")[1:]]
             for nm in names:
                 ptr = "*" in ty or nm.startswith("*")
-                fields.append((nm.lstrip("*"), "ptr" if ptr else _c_class(ty + " x")))
+                arr = re.fullmatch(r"(\w+)\[(\d+)\]", nm)   # a fixed-size array member (uint8_t seed[32])
+                if arr and not ptr:
+                    fields.append((arr.group(1), "%sx%s" % (_c_class(ty + " x"), arr.group(2))))
+                else:
+                    fields.append((nm.lstrip("*"), "ptr" if ptr else _c_class(ty + " x")))
         out[m.group(2)] = fields
     return out
 
@@ -210,8 +219,9 @@ def test_struct_layouts_agree():
     import halo2_lib_amd.plonk as PL
 
     c, rs = _c_structs(), _rs_structs()
-    assert set(c) == {"h2hip_base_circuit_params", "h2hip_plonk_shape", "h2hip_array_rng"}, sorted(c)
-    py = {"h2hip_base_circuit_params": PL.BaseCircuitParams, "h2hip_plonk_shape": PL.ConstraintSystemShape, "h2hip_array_rng": PL._ArrayRngState}
+    assert set(c) == {"h2hip_base_circuit_params", "h2hip_plonk_shape", "h2hip_array_rng", "h2hip_chacha_rng"}, sorted(c)
+    py = {"h2hip_base_circuit_params": PL.BaseCircuitParams, "h2hip_plonk_shape": PL.ConstraintSystemShape, "h2hip_array_rng": PL._ArrayRngState,
+          "h2hip_chacha_rng": PL._ChaChaRngState}
     for name, fields in c.items():
         assert [(n, "u64" if t == "usize" else t) for n, t in rs[name]] == [(n, "u64" if t == "usize" else t) for n, t in fields], name
         pf = [(n, _py_class(t)) for n, t in py[name]._fields_]
