@@ -193,13 +193,6 @@ int h2hip_init(int device, void *hip_stream, h2hip_ctx **out) {
     return H2HIP_OK;
 }
 
-static void destroy_split_streams(h2hip_ctx *ctx) {
-    for (hipEvent_t e : ctx->split_ev) hipEventDestroy(e);
-    ctx->split_ev.clear();
-    if (ctx->split_acc) hipStreamDestroy(ctx->split_acc);
-    if (ctx->split_aux) hipStreamDestroy(ctx->split_aux);
-    ctx->split_acc = ctx->split_aux = nullptr;
-}
 }  // extern "C"
 namespace h2 {
 // Small host tables (job descriptors) -> device without a synchronisation: the bytes are copied into a pinned ring first, so the caller's
@@ -245,7 +238,6 @@ void h2hip_destroy(h2hip_ctx *ctx) {
         hipFree(t.t2);
         for (int k = 0; k < 4; ++k) {
             if (t.direct[k]) hipFree(t.direct[k]);
-            if (t.stage[k]) hipFree(t.stage[k]);
         }
     }
     for (auto &p : ctx->pending) {
@@ -260,7 +252,6 @@ void h2hip_destroy(h2hip_ctx *ctx) {
             hipEventDestroy(ctx->lane_ev[l]);
         }
     if (ctx->fork_ev) hipEventDestroy(ctx->fork_ev);
-    destroy_split_streams(ctx);
     for (auto e : ctx->timer_ev)
         if (e) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -279,23 +270,16 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_chunk")) return &ctx->msm_chunk;
     if (!strcmp(name, "msm_seg")) return &ctx->msm_seg;
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
-    if (!strcmp(name, "msm_accum_variant")) return &ctx->msm_accum_variant;
-    if (!strcmp(name, "msm_table_nontemporal")) return &ctx->msm_table_nontemporal;
-    if (!strcmp(name, "msm_fold_windows")) return &ctx->msm_fold_windows;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_tile_kernel")) return &ctx->ntt_tile_kernel;
-    if (!strcmp(name, "msm_debug_reorder")) return &ctx->msm_debug_reorder;
-    if (!strcmp(name, "msm_split_windows")) return &ctx->msm_split_windows;
-    if (!strcmp(name, "ntt_wave_local")) return &ctx->ntt_wave_local;
-    if (!strcmp(name, "ntt_radix8")) return &ctx->ntt_radix8;
-    if (!strcmp(name, "ntt_tile_bits8")) return &ctx->ntt_tile_bits8;
+    if (!strcmp(name, "ntt_stagger")) return &ctx->ntt_stagger;
+    if (!strcmp(name, "ntt_stagger_mode")) return &ctx->ntt_stagger_mode;
+    if (!strcmp(name, "ntt_grid_full")) return &ctx->ntt_grid_full;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
-    if (!strcmp(name, "msm_split_streams")) return &ctx->msm_split_streams;
     if (!strcmp(name, "msm_quad_tails")) return &ctx->msm_quad_tails;
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
-    if (!strcmp(name, "msm_sort_mode")) return &ctx->msm_sort_mode;
     if (!strcmp(name, "msm_scatter_full_lds")) return &ctx->msm_scatter_full_lds;
     if (!strcmp(name, "msm_sort_threads")) return &ctx->msm_sort_threads;
     if (!strcmp(name, "msm_fuse_cols")) return &ctx->msm_fuse_cols;
@@ -311,7 +295,6 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     int *p = param_slot(ctx, name);
     H2_REQUIRE(p, "unknown parameter name");
     if (p == &ctx->msm_window_bits) H2_REQUIRE(value == 0 || (value >= 4 && value <= 16), "msm_window_bits must be 0 (auto) or 4..16 (a window's histogram lives in LDS; at most 64 windows)");
-    if (p == &ctx->msm_fold_windows) H2_REQUIRE(value >= 0 && value <= 64, "msm_fold_windows must be 0..64");
     if (p == &ctx->msm_chunk) H2_REQUIRE(value == 0 || (value >= 2 && value <= 4096), "msm_chunk must be 0 (auto) or 2..4096");
     if (p == &ctx->msm_seg) H2_REQUIRE(value >= 1 && value <= 1024 && (value & (value - 1)) == 0, "msm_seg must be a power of two <= 1024");
     if (p == &ctx->msm_fuse_cols) H2_REQUIRE(value >= 0 && value <= (int)MSM_MAX_COLS, "msm_fuse_cols must be 0 (auto) or 1..32");
@@ -320,12 +303,8 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_sort_threads) H2_REQUIRE(value == 256 || value == 512 || value == 1024, "msm_sort_threads must be 256, 512 or 1024");
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
     if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 0 && value <= 4, "msm_lanes must be 0 (auto) or 1..4");
-    if (p == &ctx->msm_split_windows) H2_REQUIRE(value >= 0 && value <= 2, "msm_split_windows must be 0, 1 (from 2^18 points on) or 2 (every size: tests)");
-    if (p == &ctx->msm_sort_mode) H2_REQUIRE(value >= 0 && value <= 2, "msm_sort_mode must be 0 or 1 (one-pass sort) or 2 (two-level sort)");
-    if (p == &ctx->msm_accum_variant) H2_REQUIRE(value >= 2 && value <= 7, "msm_accum_variant must be 2..7");
     if (p == &ctx->ntt_min_col_bits) H2_REQUIRE(value >= 0 && value <= 5, "ntt_min_col_bits must be 0..5");
-    if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
-    if (p == &ctx->ntt_tile_bits8) H2_REQUIRE(value >= 4 && value <= 11, "ntt_tile_bits8 must be 4..11");
+    if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 11, "ntt_tile_bits must be 4..11 (11: only the full-tile kernel exists at that size)");
     *p = value;
     return H2HIP_OK;
 }
@@ -571,8 +550,6 @@ int h2hip_msm_g1_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scala
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && bases && out_host && (n == 0 || scalars_dev), "NULL argument");
     H2_REQUIRE(point_format == H2HIP_POINT_JACOBIAN || point_format == H2HIP_POINT_AFFINE, "unknown point_format");
-    if (ctx->msm_split_windows && bases->tables > 1 && n >= (ctx->msm_split_windows >= 2 ? (size_t)1 : (size_t)1 << 18) && n <= bases->n)   // one MSM as two half jobs on two lanes
-        return msm_batch_impl(ctx, bases, nullptr, &scalars_dev, false, n, 1, point_format, out_host);
     char *outbuf = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, 1024, (void **)&outbuf));
     H2_CHK(msm_run(ctx, bases, (const Fr *)scalars_dev, n, (XYZZ *)outbuf));
@@ -630,12 +607,6 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     int NL = ctx->msm_lanes;
     if (NL <= 0) NL = n >= ((size_t)1 << 20) ? 1 : 3;   // (2^18 / 2^19 were on 2 lanes until the window model moved them to c = 15: 3 lanes now win by 2 %, k = 18 / 19 proofs)
     if (NL > 4) NL = 4;
-    // msm_split_windows: a column's windows are dealt to two lanes (half jobs that add into the column's one bucket array) — the first sort
-    // and the last merge of a round are half as long, and a single MSM overlaps with itself
-    const bool want_split_w = ctx->msm_split_windows && bases->tables > 1 && !scalars_on_host && n >= (ctx->msm_split_windows >= 2 ? (size_t)1 : (size_t)1 << 18) && ctx->msm_fold_windows <= 1 &&
-                              ctx->msm_fuse_cols <= 1 && !ctx->msm_split_streams && count <= 64;
-    if (want_split_w && NL < 2) NL = 2;
-    if (NL < 2 && ctx->msm_split_streams && !scalars_on_host && count >= 2 && n > ((size_t)1 << 17)) NL = 2;   // the split-stream schedule alternates two scratch sets
     for (int l = 0; l < NL; ++l) {
         if (!ctx->lane[l]) {
             h2hip_ctx *c = nullptr;
@@ -647,12 +618,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         h2hip_ctx *c = ctx->lane[l];
         c->msm_chunk = ctx->msm_chunk;
         c->msm_seg = ctx->msm_seg;
-        c->msm_accum_variant = ctx->msm_accum_variant;
-        c->msm_table_nontemporal = ctx->msm_table_nontemporal;
-        c->msm_fold_windows = ctx->msm_fold_windows;
         c->msm_scatter_split = ctx->msm_scatter_split;
-        c->msm_sort_mode = ctx->msm_sort_mode;
-        c->msm_debug_reorder = ctx->msm_debug_reorder;
         c->msm_scatter_full_lds = ctx->msm_scatter_full_lds;
         c->msm_sort_threads = ctx->msm_sort_threads;
         c->msm_quad_tails = ctx->msm_quad_tails;
@@ -701,13 +667,10 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     if (precomp) {
         const uint32_t cw = bases->window_bits;
         const uint32_t wcol = (255 + cw - 1) / cw;
-        uint32_t sets = wcol;
-        if (ctx->msm_fold_windows > 1) sets = (wcol + std::min<uint32_t>((uint32_t)ctx->msm_fold_windows, wcol) - 1) / std::min<uint32_t>((uint32_t)ctx->msm_fold_windows, wcol);
-        keys_per_col = (size_t)sets << (cw - 1);
+        keys_per_col = (size_t)wcol << (cw - 1);   // one bucket set per window
     }
-    const bool split_w = want_split_w && fuse == 1 && sizeof(XYZZ29) * keys_per_col * count <= ((size_t)2 << 30);
-    const bool deferred = split_w || (precomp && ctx->msm_defer_reduce && count >= 2 && n > 0 && (fuse == 1 ? count <= 64 : true) &&
-                                      sizeof(XYZZ29) * keys_per_col * count <= ((size_t)2 << 30));
+    const bool deferred = precomp && ctx->msm_defer_reduce && count >= 2 && n > 0 && (fuse == 1 ? count <= 64 : true) &&
+                          sizeof(XYZZ29) * keys_per_col * count <= ((size_t)2 << 30);
     XYZZ29 *all_buckets = nullptr;
     if (deferred) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH_BUCKETS, sizeof(XYZZ29) * keys_per_col * count, (void **)&all_buckets));
     // the shared bucket array was zero-filled behind the previous batch's reduction (side stream): the lanes wait for that instead of filling
@@ -724,80 +687,10 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         for (size_t j = 0; j < count; ++j) staged[j] = stage + sizeof(Fr) * n * j;
         scalars_dev = staged.data();
     }
-    // Split-stream schedule (deferred reduction, device-resident columns): the multiplier-bound accumulations of all MSMs run back to back on
-    // ONE stream and never compete with each other, while every latency-bound sort and merge is issued on a second, higher-priority
-    // stream — MSM i+1 is sorted and MSM i-1 merged while MSM i accumulates.  Two scratch sets (lane contexts 0 / 1) alternate.
-    const bool split = deferred && ctx->msm_split_streams && !scalars_on_host && count >= 2 && NL >= 2;
-    if (split) {
-        if (!ctx->split_acc) {
-            int lo = 0, hi = 0;   // numerically lower = higher priority
-            hipDeviceGetStreamPriorityRange(&lo, &hi);
-            H2_HIPCHK(hipStreamCreateWithPriority(&ctx->split_acc, hipStreamNonBlocking, lo));
-            H2_HIPCHK(hipStreamCreateWithPriority(&ctx->split_aux, hipStreamNonBlocking, hi));
-        }
-        while (ctx->split_ev.size() < 2 * count + 2) {
-            hipEvent_t e = nullptr;
-            H2_HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->split_ev.push_back(e);
-        }
-        hipStream_t A = ctx->split_acc, Bx = ctx->split_aux;
-        H2_HIPCHK(hipStreamWaitEvent(A, ctx->fork_ev, 0));
-        H2_HIPCHK(hipStreamWaitEvent(Bx, ctx->fork_ev, 0));
-        if (buckets_zeroed) H2_HIPCHK(hipStreamWaitEvent(Bx, ctx->clean_ev, 0));   // the sorts (on Bx) precede everything that touches the buckets
-        hipStream_t saved[2] = {ctx->lane[0]->stream, ctx->lane[1]->stream};
-        int rc = H2HIP_OK;
-        auto phase = [&](size_t j, hipStream_t stream, uint32_t mask) {
-            if (rc != H2HIP_OK) return;
-            h2hip_ctx *c = ctx->lane[j & 1];
-            c->stream = stream;
-            const Fr *col = (const Fr *)scalars_dev[j];
-            rc = msm_run_cols(c, bases_of(j), &col, 1, n, nullptr, all_buckets + keys_per_col * j, mask, buckets_zeroed);
-        };
-        auto sort = [&](size_t j) {
-            phase(j, Bx, MSM_PHASE_SORT);
-            if (rc == H2HIP_OK && hipEventRecord(ctx->split_ev[2 * j], Bx) != hipSuccess) rc = H2HIP_ERR_HIP;
-        };
-        auto accumulate = [&](size_t j) {
-            if (rc == H2HIP_OK && hipStreamWaitEvent(A, ctx->split_ev[2 * j], 0) != hipSuccess) rc = H2HIP_ERR_HIP;
-            phase(j, A, MSM_PHASE_ACCUM);
-            if (rc == H2HIP_OK && hipEventRecord(ctx->split_ev[2 * j + 1], A) != hipSuccess) rc = H2HIP_ERR_HIP;
-        };
-        auto merge = [&](size_t j) {
-            if (rc == H2HIP_OK && hipStreamWaitEvent(Bx, ctx->split_ev[2 * j + 1], 0) != hipSuccess) rc = H2HIP_ERR_HIP;
-            phase(j, Bx, MSM_PHASE_MERGE);
-        };
-        sort(0);
-        accumulate(0);
-        for (size_t j = 1; j < count; ++j) {
-            sort(j);       // scratch set j & 1 was last used by MSM j - 2, whose merge precedes this on the same in-order stream
-            accumulate(j);
-            merge(j - 1);
-        }
-        merge(count - 1);
-        ctx->lane[0]->stream = saved[0];
-        ctx->lane[1]->stream = saved[1];
-        if (rc == H2HIP_OK && hipEventRecord(ctx->split_ev[2 * count], Bx) != hipSuccess) rc = H2HIP_ERR_HIP;
-        if (rc == H2HIP_OK && hipStreamWaitEvent(ctx->stream, ctx->split_ev[2 * count], 0) != hipSuccess) rc = H2HIP_ERR_HIP;
-        if (rc != H2HIP_OK) {
-            hipStreamSynchronize(A);
-            hipStreamSynchronize(Bx);
-            if (rc == H2HIP_ERR_HIP) set_error("split-stream MSM batch: a HIP stream / event call failed");
-            return rc;
-        }
-    }
-    if (split_w) {   // two half jobs per column, dealt over the lanes in issue order
-        const uint32_t cw = bases->window_bits, wcol = (255 + cw - 1) / cw, half = (wcol + 1) / 2, B = 1u << (cw - 1);
-        size_t t = 0;
-        for (size_t j = 0; j < count; ++j)
-            for (int h = 0; h < 2; ++h, ++t) {
-                h2hip_ctx *c = ctx->lane[t % NL];
-                const Fr *col = (const Fr *)scalars_dev[j];
-                const uint32_t w_lo = h ? half : 0u, w_cnt = h ? wcol - half : half;
-                H2_LANES_RC(msm_run_cols(c, bases_of(j), &col, 1, n, nullptr, all_buckets + keys_per_col * j + (size_t)w_lo * B, MSM_PHASE_ALL, buckets_zeroed,
-                                         w_lo, w_cnt));
-            }
-    }
-    const size_t ngroups = (split || split_w) ? 0 : groups.size();
+    // (two other schedules were built, measured slower and removed in r04: every accumulation on one stream with all sorts / merges on a
+    // second, higher-priority one — 2^19 1.00 vs 0.95 ms per MSM, tools/batch_ab.py in r02 — and a column's windows dealt to two lanes —
+    // the k = 19 proof 15.7-15.8 vs 14.7 ms, profiles/r03_msm_split_windows_ab.log)
+    const size_t ngroups = groups.size();
     for (size_t g = 0; g < ngroups; ++g) {
         const size_t j0 = groups[g].first, gsize = groups[g].second;
         h2hip_ctx *c = ctx->lane[g % NL];
@@ -808,7 +701,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         char *outbuf = nullptr;
         H2_LANES_RC(ws_reserve(c, h2hip_ctx::WS_OUT, sizeof(XYZZ) * MSM_MAX_COLS, (void **)&outbuf));
         H2_LANES_RC(msm_run_cols(c, gb, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
-                                 deferred ? all_buckets + keys_per_col * j0 : nullptr, MSM_PHASE_ALL, buckets_zeroed));
+                                 deferred ? all_buckets + keys_per_col * j0 : nullptr, buckets_zeroed));
         if (!deferred) {   // the group's results, one lane each, into their slots of the batch's result array
             prof_begin(c, "point_finish_kernel");
             hipLaunchKernelGGL(point_finish_slot_kernel, dim3((uint32_t)gsize), dim3(64), 0, c->stream, (const XYZZ *)outbuf,

@@ -52,8 +52,6 @@ struct TwiddleSet {   // omega^i tables for one (log_n, omega)
     void *t2 = nullptr;   // omega^(i<<lo_bits), i < 2^(log_n-lo_bits)
     void *direct[4] = {nullptr, nullptr, nullptr, nullptr};   // per-stride direct tables omega^(t << log_s) for later passes
     uint32_t direct_log_s[4] = {0, 0, 0, 0};
-    void *stage[4] = {nullptr, nullptr, nullptr, nullptr};    // stage-twiddle tables omega_R^k, k < R/2, per sub-transform size R = 2^m (radix-8 passes)
-    uint32_t stage_m[4] = {0, 0, 0, 0};
 };
 
 struct KernelStat {
@@ -81,32 +79,13 @@ struct h2hip_ctx {
     int ntt_tile_bits = 10;
     int ntt_min_col_bits = 2;    // log2 of the minimum number of adjacent columns per tile (coalescing vs number of passes)
     int ntt_full_table = 1;      // first pass reads a full omega^e table instead of composing two table entries
-    int ntt_wave_local = 0;      // 1: full tiles with >= 4 columns are stored column-major, every wave owns whole columns and the stage pairs are separated by
-                                 // wave-level ordering points instead of block barriers.  Bit-exact, measured neutral (tools/ntt_ab.py: 2^22 0.518 vs 0.527 ms,
-                                 // coset 2^19->2^21 0.267 vs 0.257 ms): the barriers are not what the pass kernel waits for.  Off by default.
-    int ntt_radix8 = 0;          // 1: passes on the radix-8 kernel (ntt_pass8_kernel: three stages per LDS round trip, 8 elements per lane, 2048-element tiles of
-                                 // bare 36-byte elements, two workgroups per CU); 0 (default): the radix-4 kernel.  Bit-exact, measured SLOWER (tools/ntt_r03.py,
-                                 // profiles/r03_ntt_radix8_ab.log: 2^22 0.81 vs 0.65 ms, 2^19 0.109 vs 0.083, coset 2^19->2^21 0.39 vs 0.30): the third stage per
-                                 // round trip does not pay for what it takes — 8 waves per CU instead of 12 (175 registers per lane), nine 4-byte LDS accesses per
-                                 // element instead of three 16-byte ones, and the 8-element prefetch array in scratch.
-    int ntt_tile_bits8 = 11;     // log2 of the radix-8 kernel's tile (<= 11; smaller values only to force many passes in tests)
-    int msm_split_windows = 0;   // batch API, large precomputed MSMs: 1 = every column's windows are dealt to two lanes (two half jobs adding into the column's one bucket array)
-    int msm_debug_reorder = 0;   // diagnostics only: reorder the entries inside every bucket after the sort (1 ascending point index, 2 hashed); results unchanged
     int ntt_tile_kernel = 1;     // 1 (default): full 1024-element tiles go through ntt_tile_kernel (r04: no exposed global-memory latency); 0: the generic pass kernel
+    int ntt_stagger = 3, ntt_stagger_mode = 0, ntt_grid_full = 0;   // EXPERIMENT (r04): start delay per workgroup class (units of s_sleep 127), class = f(blockIdx) by mode 1..3; 1: grid = all slots
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
-    int msm_sort_mode = 0;       // 0 / 1: the one-pass LDS-histogram counting sort (default); 2: the two-level sort with coalesced writes (msm_csort_*; measured level or behind inside proofs)
     int msm_scatter_split = 0;   // bucket sub-ranges per window in the scatter (0 = auto, power of two)
     int msm_scatter_full_lds = 1;   // 1: the scatter declares the full 128 KiB of LDS (one workgroup per CU: one segment per XCD at a time); 0: only its cursors
-    int msm_fold_windows = 0;    // precomputed bases: windows per shared bucket set (0 / 1 = one set per window: the default).  The sort is bucket-major inside a group of this many windows, so the
-                                 // accumulation sums the group's entries of a bucket index into one bucket ([col][groups][B] instead of [col][windows][B]);
-                                 // >= the window count: one bucket set per column and no per-index presum in the reduction.  Bit-exact, measured SLOWER
-                                 // (tools/fold_ab.py, same run: 2^19 1.29-1.40 vs 1.17 ms synchronous, 1.06-1.10 vs 0.94 per MSM in batches of 4; groups of 2..8 in
-                                 // between; create_proof k=19 16.9 vs 16.2 ms): runs 16x longer make the segmented merge of the partial sums run ~5 doubling
-                                 // steps instead of ~2.5, which costs more than the presum it removes.
-    int msm_table_nontemporal = 1;   // accumulation: gather the base-table entries with non-temporal loads (no reuse; keeps the reused lines in L2)
-    int msm_accum_variant = 3;   // accumulate kernel build: 6 / 7 = the next table entry requested before the current addition, at 2 / 3 waves per SIMD (measured 5 % slower), 5 = two waves per SIMD by launch bounds (no spills in the wave-level merge; measured 2 % slower than 3), 3 / 4 = min waves per SIMD it is compiled for, 2 = registers padded to two waves per SIMD
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]
     // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled
     bool profiling = false;
@@ -124,16 +103,10 @@ struct h2hip_ctx {
     // batch lanes (h2hip_msm_g1_batch_dev): child contexts with their own stream + scratch
     h2hip_ctx *lane[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int msm_split_streams = 0;   // 1: batch API, deferred reduction: all accumulations back to back on one stream, every sort / merge on a second,
-                                 // higher-priority one (MSM i+1 sorted and MSM i-1 merged while MSM i accumulates).  Measured SLOWER (tools/batch_ab.py, same run:
-                                 // 2^19 1.00 vs 0.95 ms per MSM in batches of 4, 2^20 1.75-1.82 vs 1.69): kernels that share the chip with an accumulation
-                                 // stretch more than the overlap hides, and stretch the accumulation.  Off by default.
     // pinned ring for small job tables (kernel argument tables too large for the kernarg segment): staged there, they are uploaded
     // asynchronously without a stream synchronisation per call (upload_jobs in capi.hip)
     char *job_ring = nullptr;
     size_t job_ring_off = 0;
-    hipStream_t split_acc = nullptr, split_aux = nullptr;
-    std::vector<hipEvent_t> split_ev;
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
     int fr_invert_run = 0;           // elements per lane (= per inversion) in h2hip_fr_batch_invert_dev; 0 = auto (n / 2^16 in 4..32)
     int lookup_big_tile_bits = 19;   // lookup sort: 4096-key LDS tiles from 2^bits padded keys (12..28), 1024-key tiles below
@@ -200,10 +173,9 @@ int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_
 int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *bases, bool precompute);
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
 constexpr uint32_t MSM_MAX_COLS = 32;   // columns one fused multi-column MSM handles
-// ext_buckets != nullptr: stop after the merge and leave the column's buckets ([sets][B], sets = window groups of msm_fold_windows; zeroed here) there for msm_reduce_cols
-enum { MSM_PHASE_SORT = 1u, MSM_PHASE_ACCUM = 2u, MSM_PHASE_MERGE = 4u, MSM_PHASE_REDUCE = 8u, MSM_PHASE_ALL = 15u };
+// ext_buckets != nullptr: stop after the merge and leave the columns' buckets ([col][windows][B]; zeroed here unless ext_buckets_zeroed) there for msm_reduce_cols
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev,
-                 XYZZ29 *ext_buckets, uint32_t phases = MSM_PHASE_ALL, bool ext_buckets_zeroed = false, uint32_t w_lo = 0, uint32_t w_cnt = 0);   // w_cnt != 0: only the column's windows [w_lo, w_lo + w_cnt)
+                 XYZZ29 *ext_buckets, bool ext_buckets_zeroed = false);
 // zero-fill-after-use of the bucket arrays (see h2hip_ctx::clean_*): is the buffer's head already (scheduled to be) zero?  (a true answer
 // CONSUMES the state: the caller dirties the array) / schedule the fill
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);

@@ -56,18 +56,15 @@ constexpr uint32_t MAX_LDS_BUCKETS = 1u << 15;   // 128 KiB of u32 counters
 struct DigitCols {
     const Fr *scalars[MSM_MAX_COLS];
 };
-// (the first workgroup also writes the sort's two sentinels — counts[nsort] = 0 and offsets[nsort + 1 .. nsort + ks] = ~0, read by the scan and by
-// the accumulation's boundary walk — which were two tiny memset launches per MSM on the lane's critical path)
-// (w_lo: only the windows [w_lo, w_lo + W) are written — a column whose windows are dealt to two lanes; the signed-digit carry still runs
-// through the windows below)
+// (the first workgroup also writes the sort's two sentinels — counts[nsort] = 0 and offsets[nsort + 1] = ~0, read by the scan and by the
+// accumulation's boundary walk — which were two tiny memset launches per MSM on the lane's critical path)
 __global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_t n, uint32_t c, uint32_t W, uint32_t *__restrict__ digits,
-                                                         uint32_t *__restrict__ counts_tail, uint32_t *__restrict__ offsets_tail, uint32_t ks,
-                                                         uint32_t w_lo) {
+                                                         uint32_t *__restrict__ counts_tail, uint32_t *__restrict__ offsets_tail) {
     H2_SORT_PRIORITY();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        if (threadIdx.x == 0) counts_tail[0] = 0;
-        if (threadIdx.x < ks) offsets_tail[threadIdx.x] = 0xFFFFFFFFu;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        counts_tail[0] = 0;
+        offsets_tail[0] = 0xFFFFFFFFu;
     }
     if (i >= n) return;
     digits += (size_t)blockIdx.y * W * n;
@@ -75,7 +72,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_
     const uint32_t B = 1u << (c - 1);
     const uint64_t mask = (1ull << c) - 1;
     uint32_t carry = 0;
-    for (uint32_t w = 0; w < w_lo + W; ++w) {
+    for (uint32_t w = 0; w < W; ++w) {
         uint32_t bit = w * c, limb = bit >> 5, off = bit & 31;
         uint64_t lo = 0, hi = 0;
         // static selection keeps s in registers (a runtime-indexed array would live in scratch)
@@ -88,7 +85,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_
         uint32_t neg = v > B ? 1u : 0u;
         uint32_t d = neg ? (1u << c) - v : v;
         carry = neg;
-        if (w >= w_lo) digits[(size_t)(w - w_lo) * n + i] = d | (neg << 31);
+        digits[(size_t)w * n + i] = d | (neg << 31);
     }
 }
 
@@ -141,20 +138,7 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t *__restri
 }
 
 // ------------------------------------------------------------------ 3. prefix over chunks per (window, bucket)
-// Precomputed bases: every window of a column carries weight 1, so groups of `fg` windows can share a bucket set.  The counting sort then
-// lays its keys out BUCKET-major inside a group — key = ((col*NG + grp)*B + b)*fg + r for window grp*fg + r of column col (NG = groups per
-// column; keys of windows past the last one stay empty) — so the sorted list holds the group's entries of one bucket index next to each
-// other and the accumulation sums them into ONE bucket: the bucket array is [col][NG][B] instead of [col][Wcol][B].
-struct FoldKeys {
-    uint32_t fg, ng, wcol;   // fg == 0: plain window-major keys w*B + b
-};
-__device__ __forceinline__ uint32_t sort_key(uint32_t w, uint32_t b, uint32_t B, const FoldKeys &f) {
-    if (!f.fg) return w * B + b;
-    const uint32_t col = w / f.wcol, wc = w - col * f.wcol, grp = wc / f.fg, r = wc - grp * f.fg;
-    return ((col * f.ng + grp) * B + b) * f.fg + r;
-}
-__global__ __launch_bounds__(256) void msm_hist_scan_kernel(uint32_t *__restrict__ bhist, uint32_t W, uint32_t B, uint32_t G, FoldKeys fold_w,
-                                                            uint32_t *__restrict__ counts) {
+__global__ __launch_bounds__(256) void msm_hist_scan_kernel(uint32_t *__restrict__ bhist, uint32_t W, uint32_t B, uint32_t G, uint32_t *__restrict__ counts) {
     H2_SORT_PRIORITY();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W * B) return;
@@ -170,7 +154,7 @@ __global__ __launch_bounds__(256) void msm_hist_scan_kernel(uint32_t *__restrict
             run += v[k];
         }
     }
-    counts[sort_key(w, b, B, fold_w)] = run;
+    counts[t] = run;   // key = w * B + b
 }
 
 // exclusive scan of u32 (3 kernels)
@@ -259,7 +243,7 @@ int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32
 // segment's slice of the sorted array (n*4/S bytes) fits that XCD's 4 MiB L2, so the 4-byte writes combine there
 // instead of each costing a 64-byte HBM write.
 __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
-                                                           uint32_t G, uint32_t chunk, uint32_t S, uint32_t table_stride, uint32_t Wcol, FoldKeys fold_w,
+                                                           uint32_t G, uint32_t chunk, uint32_t S, uint32_t table_stride, uint32_t Wcol,
                                                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ bhist,
                                                            uint32_t *__restrict__ sval) {
     H2_SORT_PRIORITY();
@@ -270,7 +254,7 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     const uint32_t w = seg / S, h = seg - w * S;
     const uint32_t Bs = B / S, b0 = h * Bs;   // this workgroup's bucket range [b0, b0 + Bs)
     const uint32_t *bh = bhist + ((size_t)w * G + g) * B + b0;
-    for (uint32_t b = threadIdx.x; b < Bs; b += blockDim.x) cursor[b] = offsets[sort_key(w, b0 + b, B, fold_w)] + bh[b];
+    for (uint32_t b = threadIdx.x; b < Bs; b += blockDim.x) cursor[b] = offsets[w * B + b0 + b] + bh[b];
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t *dw = digits + (size_t)w * n;
@@ -293,184 +277,13 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     }
 }
 
-// ------------------------------------------------------------------ 4b. two-level sort with coalesced writes (r03; selectable, not the default — see msm_run_cols)
-// The one-pass counting sort above writes every entry on its own (a 4-byte store to its final position): 8.9 M scattered write transactions
-// per 2^19-point MSM, which is what its 76 us are made of (the L2 retires them per transaction, not per byte), plus W*G full-window
-// histograms (35 MB) written, prefixed in place and read back.  Here every write is a coalesced run:
-//   A  msm_csort_hist      (window, chunk) workgroups count their entries per COARSE bucket (key >> LB: 128 per window)
-//      exclusive scan over (window, coarse bucket, chunk)
-//   B  msm_csort_scatter   the workgroup sorts its chunk by coarse bucket IN LDS and copies the runs out: a run of ~64 entries per
-//                          (chunk, coarse bucket) is contiguous in the coarse array; entries carry (point index, sign, fine key)
-//   C  msm_csort_fine      one workgroup per coarse bucket (~4Ki entries): histogram of the fine keys -> the window's bucket offsets (written
-//                          directly: no global scan over W * 2^(c-1) counts), counting sort in LDS, one contiguous copy-out.  Buckets that
-//                          do not fit the LDS buffer (0/1-heavy circuit columns put a quarter of a window into one key) are placed directly.
-// Traffic: the digits are read twice, the entries written twice and read once — all of it coalesced.
-constexpr uint32_t CS_THREADS = 512, CS_CHUNK = 8192, CS_MAX_NC = 128, CS_MAX_NF = 256, CS_BUF = 8192;
-struct CSortGeom {
-    uint32_t LB, NC, NF;   // fine bits, coarse buckets per window, fine keys per coarse bucket (NC * NF = B)
-};
-__global__ __launch_bounds__(CS_THREADS) void msm_csort_hist_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t G, CSortGeom cg,
-                                                                    uint32_t *__restrict__ chist) {
-    H2_SORT_PRIORITY();
-    __shared__ uint32_t hist[CS_THREADS / 64][CS_MAX_NC];   // one sub-histogram per wave: no cross-wave contention on 128 counters
-    const uint32_t w = blockIdx.x / G, g = blockIdx.x - w * G, tid = threadIdx.x, wave = tid >> 6;
-    for (uint32_t k = tid; k < (CS_THREADS / 64) * CS_MAX_NC; k += CS_THREADS) (&hist[0][0])[k] = 0;
-    __syncthreads();
-    const uint32_t lo = g * CS_CHUNK, hi = lo + CS_CHUNK < n ? lo + CS_CHUNK : n;
-    const uint32_t *dw = digits + (size_t)w * n;
-    for (uint32_t i = lo + tid; i < hi; i += 8 * CS_THREADS) {
-        uint32_t d[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) d[k] = i + k * CS_THREADS < hi ? dw[i + k * CS_THREADS] & 0x7fffffffu : 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k)
-            if (d[k]) atomicAdd(&hist[wave][(d[k] - 1) >> cg.LB], 1u);
-    }
-    __syncthreads();
-    for (uint32_t cb = tid; cb < cg.NC; cb += CS_THREADS) {
-        uint32_t sum = 0;
-#pragma unroll
-        for (uint32_t v = 0; v < CS_THREADS / 64; ++v) sum += hist[v][cb];
-        chist[((size_t)w * cg.NC + cb) * G + g] = sum;
-    }
-}
-__global__ __launch_bounds__(CS_THREADS) void msm_csort_scatter_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t G, CSortGeom cg,
-                                                                       const uint32_t *__restrict__ cscan, uint32_t *__restrict__ centries) {
-    H2_SORT_PRIORITY();
-    __shared__ uint32_t lbase[CS_MAX_NC + 1], cursor[CS_MAX_NC], gbase[CS_MAX_NC];
-    __shared__ uint32_t sorted[CS_CHUNK];
-    const uint32_t w = blockIdx.x / G, g = blockIdx.x - w * G, tid = threadIdx.x;
-    // this chunk's count per coarse bucket = the difference of neighbouring entries of the scanned array; local exclusive prefix by one wave
-    if (tid < 64) {
-        uint32_t run = 0;
-        for (uint32_t c0 = 0; c0 < cg.NC; c0 += 64) {
-            const uint32_t cb = c0 + tid;
-            uint32_t cnt = 0, gb = 0;
-            if (cb < cg.NC) {
-                const size_t idx = ((size_t)w * cg.NC + cb) * G + g;
-                gb = cscan[idx];
-                cnt = cscan[idx + 1] - gb;
-            }
-            uint32_t incl = cnt;   // inclusive scan over the wave by shuffles
-            for (uint32_t d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl(incl, (int)(tid >= d ? tid - d : tid));
-                if (tid >= d) incl += up;
-            }
-            if (cb < cg.NC) {
-                lbase[cb] = run + incl - cnt;
-                cursor[cb] = run + incl - cnt;
-                gbase[cb] = gb;
-            }
-            run += __shfl(incl, 63);
-        }
-        if (tid == 0) lbase[cg.NC] = run;
-    }
-    __syncthreads();
-    const uint32_t lo = g * CS_CHUNK, hi = lo + CS_CHUNK < n ? lo + CS_CHUNK : n;
-    const uint32_t *dw = digits + (size_t)w * n;
-    const uint32_t fmask = cg.NF - 1;
-    for (uint32_t i = lo + tid; i < hi; i += 8 * CS_THREADS) {
-        uint32_t dv[8], pos[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) dv[k] = i + k * CS_THREADS < hi ? dw[i + k * CS_THREADS] : 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t d = dv[k] & 0x7fffffffu;
-            pos[k] = d ? atomicAdd(&cursor[(d - 1) >> cg.LB], 1u) : KEY_INVALID;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k)
-            if (pos[k] != KEY_INVALID)
-                sorted[pos[k]] = ((i + k * CS_THREADS) << cg.LB) | (((dv[k] & 0x7fffffffu) - 1) & fmask) | (dv[k] & 0x80000000u);
-    }
-    __syncthreads();
-    const uint32_t total = lbase[cg.NC];
-    for (uint32_t p = tid; p < total; p += CS_THREADS) {
-        uint32_t a = 0, b = cg.NC;   // largest cb with lbase[cb] <= p
-        while (b - a > 1) {
-            const uint32_t mid = (a + b) >> 1;
-            if (lbase[mid] <= p) a = mid;
-            else b = mid;
-        }
-        centries[gbase[a] + (p - lbase[a])] = sorted[p];
-    }
-}
-__global__ __launch_bounds__(CS_THREADS) void msm_csort_fine_kernel(const uint32_t *__restrict__ centries, const uint32_t *__restrict__ cscan, uint32_t G,
-                                                                    CSortGeom cg, uint32_t B, uint32_t Wcol, uint32_t table_stride, uint32_t nsort,
-                                                                    uint32_t *__restrict__ sval, uint32_t *__restrict__ offsets) {
-    H2_SORT_PRIORITY();
-    __shared__ uint32_t fh[CS_MAX_NF], cur[CS_MAX_NF], buf[CS_BUF];
-    const uint32_t tid = threadIdx.x, cbi = blockIdx.x, w = cbi / cg.NC, cb = cbi - w * cg.NC;
-    const uint32_t cstart = cscan[(size_t)cbi * G], cend = cscan[(size_t)(cbi + 1) * G], size = cend - cstart;
-    const uint32_t fmask = cg.NF - 1;
-    for (uint32_t f = tid; f < cg.NF; f += CS_THREADS) fh[f] = 0;
-    __syncthreads();
-    for (uint32_t e = tid; e < size; e += CS_THREADS) atomicAdd(&fh[centries[cstart + e] & fmask], 1u);
-    __syncthreads();
-    // exclusive prefix over the NF <= 256 fine counts (Hillis-Steele over the first NF lanes)
-    uint32_t mine = tid < cg.NF ? fh[tid] : 0u, incl = mine;
-    if (tid < CS_MAX_NF) cur[tid] = incl;
-    __syncthreads();
-    for (uint32_t d = 1; d < cg.NF; d <<= 1) {
-        uint32_t up = 0;
-        if (tid < cg.NF && tid >= d) up = cur[tid - d];
-        __syncthreads();
-        if (tid < cg.NF) {
-            incl += up;
-            cur[tid] = incl;
-        }
-        __syncthreads();
-    }
-    if (tid < cg.NF) {
-        const uint32_t excl = incl - mine;
-        offsets[(size_t)w * B + cb * cg.NF + tid] = cstart + excl;   // the bucket boundaries the accumulation walks
-        cur[tid] = excl;
-    }
-    if (cbi + 1 == gridDim.x && tid == 0) offsets[nsort] = cend;      // total number of entries
-    __syncthreads();
-    const uint32_t idx_base = (w % Wcol) * table_stride;   // precomputed bases: window w of a column reads table level w
-    const bool fits = size <= CS_BUF;
-    for (uint32_t e = tid; e < size; e += CS_THREADS) {
-        const uint32_t v = centries[cstart + e];
-        const uint32_t pos = atomicAdd(&cur[v & fmask], 1u);
-        const uint32_t out = (idx_base + ((v & 0x7fffffffu) >> cg.LB)) | (v & 0x80000000u);
-        if (fits) buf[pos] = out;
-        else sval[cstart + pos] = out;
-    }
-    if (!fits) return;
-    __syncthreads();
-    for (uint32_t p = tid; p < size; p += CS_THREADS) sval[cstart + p] = buf[p];
-}
-
-// diagnostics (msm_debug_reorder): reorder the entries INSIDE every bucket — 1: ascending point index, 2: hashed (no order at all).  The
-// sum of a bucket does not depend on it; the accumulation's table gather does (tools/msm_r03.py measures how much).  One thread per
-// bucket, insertion sort in place; buckets above 1024 entries are left alone.
-__global__ __launch_bounds__(256) void msm_debug_reorder_kernel(uint32_t *__restrict__ sval, const uint32_t *__restrict__ offsets, uint32_t nkeys, int mode) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= nkeys) return;
-    const uint32_t lo = offsets[k], hi = offsets[k + 1];
-    if (hi - lo > 1024) return;
-    for (uint32_t i = lo + 1; i < hi; ++i) {
-        const uint32_t v = sval[i], kv = mode == 1 ? (v & 0x7fffffffu) : (v & 0x7fffffffu) * 2654435761u;
-        uint32_t j = i;
-        while (j > lo) {
-            const uint32_t u = sval[j - 1], ku = mode == 1 ? (u & 0x7fffffffu) : (u & 0x7fffffffu) * 2654435761u;
-            if (ku <= kv) break;
-            sval[j] = u;
-            --j;
-        }
-        sval[j] = v;
-    }
-}
-
 // ------------------------------------------------------------------ 5. chunked bucket accumulation
 // largest k in [lo, nkeys) with offsets[k] <= e   (offsets has nkeys+1 entries, e < offsets[nkeys])
-// (ks = stride between consecutive run keys in `offsets`: 1, or the number of windows folded into one bucket)
-__device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offsets, uint32_t ks, uint32_t lo, uint32_t nkeys, uint32_t e) {
+__device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offsets, uint32_t lo, uint32_t nkeys, uint32_t e) {
     uint32_t hi = nkeys;
     while (hi - lo > 1) {
         uint32_t mid = lo + ((hi - lo) >> 1);
-        if (offsets[(size_t)mid * ks] <= e) lo = mid;
+        if (offsets[mid] <= e) lo = mid;
         else hi = mid;
     }
     return lo;
@@ -480,12 +293,10 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offset
 // the L2 instead of evicting the lines the kernel does reuse — each lane's slice of the sorted entry list (32 entries per 128-byte line,
 // touched over ~32 additions) and the bucket offsets.  rocprofv3 PMC (profiles/r02_hbm_counter_calibration.md): with plain loads the
 // kernel issued 2.0 memory-side line requests per addition, one of them a re-fetch of such an evicted line.
-template <bool NT>
 __device__ __forceinline__ G1Affine load_table_entry(const G1Affine *__restrict__ p) {
 #ifdef H2_HIPEMU
     return *p;
 #else
-    if (!NT) return *p;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     const v4u *q = reinterpret_cast<const v4u *>(p);
     v4u a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1), c = __builtin_nontemporal_load(q + 2),
@@ -527,13 +338,12 @@ __device__ __forceinline__ XYZZ29 xyzz29_shfl(const XYZZ29 &v, uint32_t src) {
 // boundaries leave as (key, XYZZ) partials — slot 2*wave (left) and 2*wave + 1 (right) of a sorted, hole-free list that msm_merge_kernel
 // finishes: 2 slots per 64 lanes instead of 2 per lane (r02: 0.5 M partials of 144 B per 2^19-point MSM through HBM and a first merge level
 // of 2048 workgroups).  No lane leaves early: lanes without entries take part in the shuffles with empty sums.
-template <bool NT, bool PF = false>
 __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
-                                               const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t ks, uint32_t K,
+                                               const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
                                                XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals,
                                                uint32_t nthreads) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, wave = t >> 6;
-    const uint32_t total = offsets[(size_t)nkeys * ks];
+    const uint32_t total = offsets[nkeys];
     const uint64_t start64 = (uint64_t)t * K;
     const bool valid = t < nthreads && start64 < total;
     uint32_t start = 0, end = 0, cur = 0, next = 0, hk = KEY_INVALID;
@@ -543,39 +353,19 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
     if (valid) {
         start = (uint32_t)start64;
         end = (start64 + K > total) ? total : start + K;
-        cur = find_key(offsets, ks, 0, nkeys, start);
-        next = offsets[(size_t)(cur + 1) * ks];
+        cur = find_key(offsets, 0, nkeys, start);
+        next = offsets[cur + 1];
     }
     const uint32_t first_key = valid ? cur : KEY_INVALID;   // key of the lane's first entry
     bool l_open = false;                                     // the lane's first run began before `start`
-    if (valid) l_open = offsets[(size_t)cur * ks] < start;
+    if (valid) l_open = offsets[cur] < start;
     uint4 sv4 = {0u, 0u, 0u, 0u};
-    auto entry = [&](uint32_t e) -> uint32_t {   // sorted entry e (called for consecutive e)
-        if (NT) {   // the lane's entries 16 bytes at a time: a quarter of the loads (and of the chances to find the line evicted)
-            if ((e & 3u) == 0 || e == start) sv4 = reinterpret_cast<const uint4 *>(sval)[e >> 2];
-            const uint32_t sel = e & 3u;
-            return sel == 0 ? sv4.x : sel == 1 ? sv4.y : sel == 2 ? sv4.z : sv4.w;
-        }
-        return sval[e];
+    auto entry = [&](uint32_t e) -> uint32_t {   // sorted entry e (called for consecutive e): 16 bytes at a time — a quarter of the loads
+        if ((e & 3u) == 0 || e == start) sv4 = reinterpret_cast<const uint4 *>(sval)[e >> 2];
+        const uint32_t sel = e & 3u;
+        return sel == 0 ? sv4.x : sel == 1 ? sv4.y : sel == 2 ? sv4.z : sv4.w;
     };
-    // PF: the table entry of the NEXT addition is requested before this one is computed (the gather's ~2 us then overlap ~2400 instructions)
-    uint32_t v_nxt = 0;
-    G1Affine p_nxt;
-    if (PF && start < end) {
-        v_nxt = entry(start);
-        p_nxt = load_table_entry<NT>(bases + (v_nxt & 0x7fffffffu));
-    }
     for (uint32_t e = start; e < end; ++e) {
-        uint32_t v;
-        G1Affine p;
-        if (PF) {
-            v = v_nxt;
-            p = p_nxt;
-            if (e + 1 < end) {
-                v_nxt = entry(e + 1);
-                p_nxt = load_table_entry<NT>(bases + (v_nxt & 0x7fffffffu));
-            }
-        }
         if (e >= next) {   // bucket boundary: close the run
             if (first) {
                 lsave[threadIdx.x] = acc;
@@ -585,13 +375,11 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
                 buckets[cur] = acc;
             }
             acc = XYZZ29::identity();
-            cur = (offsets[(size_t)(cur + 2) * ks] > e) ? cur + 1 : find_key(offsets, ks, cur + 1, nkeys, e);
-            next = offsets[(size_t)(cur + 1) * ks];
+            cur = (offsets[cur + 2] > e) ? cur + 1 : find_key(offsets, cur + 1, nkeys, e);
+            next = offsets[cur + 1];
         }
-        if (!PF) {
-            v = entry(e);
-            p = load_table_entry<NT>(bases + (v & 0x7fffffffu));   // packed R'-domain point, one aligned 64-byte gather
-        }
+        const uint32_t v = entry(e);
+        const G1Affine p = load_table_entry(bases + (v & 0x7fffffffu));   // packed R'-domain point, one aligned 64-byte gather
         if (!p.is_identity()) xyzz29_add_affine(acc, f29_split<Q29P>(p.x), f29_split<Q29P>(p.y), (v >> 31) != 0);
     }
     // ---- close the shared runs inside the wave
@@ -670,24 +458,14 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
     }
 }
 
-template <int MINW, bool NT, bool PF = false>
-__global__ __launch_bounds__(256, MINW) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
-                                                        const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t ks, uint32_t K,
-                                                        XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
-                                                        XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
-    msm_accum_body<NT, PF>(sval, bases, offsets, nkeys, ks, K, buckets, out_keys, out_vals, nthreads);
-}
-// Same body with the register allocation padded to 176 per lane: two waves per SIMD instead of three, which leaves a
-// third of every SIMD's register file free at all times for the tail / sort kernels of the neighbouring pipelined MSMs
-// (msm_accum_variant = 2).
-__global__ __launch_bounds__(256) void msm_accum_w2_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
-                                                           const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t ks, uint32_t K,
-                                                           XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
-                                                           XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
-#ifndef H2_HIPEMU
-    asm volatile("" ::: "v119");
-#endif
-    msm_accum_body<false>(sval, bases, offsets, nkeys, ks, K, buckets, out_keys, out_vals, nthreads);
+// three waves per SIMD (168 registers per lane); measured and left behind (profiles/r03_msm_tune_*.log, r03_knob_ab.log): two waves per
+// SIMD by launch bounds or by register padding (2 % slower / equal in isolation, nothing end to end), four (spills), the next table entry
+// requested one addition ahead (5 % slower: the gather is not what the kernel waits for), plain instead of non-temporal table loads
+__global__ __launch_bounds__(256, 3) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
+                                                          const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
+                                                          XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
+                                                          XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
+    msm_accum_body(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
 }
 
 // ------------------------------------------------------------------ 6. segmented merge of the partial list
@@ -1094,12 +872,6 @@ __global__ __launch_bounds__(64) void msm_cols_out_kernel(const XYZZ29 *__restri
     if (col < ncols) out[col] = xyzz29_to_sat(win[col]);
 }
 
-// windows per shared bucket set (0: none) for a context's msm_fold_windows setting
-static uint32_t fold_group(const h2hip_ctx *ctx, bool precomp, uint32_t Wcol) {
-    if (!precomp || ctx->msm_fold_windows <= 1) return 0;
-    return (uint32_t)ctx->msm_fold_windows < Wcol ? (uint32_t)ctx->msm_fold_windows : Wcol;
-}
-
 // Bucket reduction for ncols bucket sets laid out [col][Wcol][B] (plain bases: one column, Wcol weighted windows):
 // per-index presum over a column's windows (precomputed tables), sum_b (b+1)*bucket[b] per set, conversion / fold.
 // All columns go through the same launches: the dependent chains are as long as for one column.
@@ -1115,8 +887,7 @@ int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t c, const 
     XYZZ29 *seg, *win, *presum = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SEG, sizeof(XYZZ29) * nseg, (void **)&seg));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_WIN, sizeof(XYZZ29) * 64, (void **)&win));
-    const uint32_t fg = fold_group(ctx, precomp, Wcol);
-    const uint32_t rows = precomp ? (fg ? (Wcol + fg - 1) / fg : Wcol) : 1;   // bucket sets per column the accumulation left: [col][rows][B]
+    const uint32_t rows = precomp ? Wcol : 1;   // bucket sets per column the accumulation left: [col][rows][B]
     const uint32_t pre_rows = (rows + 3) / 4;
     if (precomp && rows > 1) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(XYZZ29) * B * (size_t)ncols * (pre_rows + 1), (void **)&presum));
     const XYZZ29 *red_in = buckets;
@@ -1197,7 +968,7 @@ int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes) 
 }
 
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out, XYZZ29 *ext_buckets,
-                 uint32_t phases, bool ext_buckets_zeroed, uint32_t w_lo, uint32_t w_cnt) {
+                 bool ext_buckets_zeroed) {
     H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..32 columns per fused MSM");
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
@@ -1212,23 +983,13 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     H2_REQUIRE(ncols == 1 || precomp, "a fused multi-column MSM needs precomputed bases");
     const uint32_t c = precomp ? bases->window_bits : (ctx->msm_window_bits ? (uint32_t)ctx->msm_window_bits : pick_window(n));
     H2_REQUIRE(c >= 2 && c <= 16, "window bits must be 2..16 (a window's bucket histogram lives in LDS)");
-    const uint32_t Wfull = (255 + c - 1) / c;   // windows of one column
-    H2_REQUIRE(Wfull <= 64, "too many windows");
-    H2_REQUIRE(!precomp || bases->tables >= Wfull, "precomputed table has too few windows");
-    // w_cnt != 0: only the windows [w_lo, w_lo + w_cnt) of the one column, their buckets into ext_buckets (= the column's array + w_lo * B):
-    // table level w_lo + w is reached by handing the kernels the table from that level on
-    H2_REQUIRE(w_cnt == 0 || (ncols == 1 && precomp && ext_buckets && w_lo + w_cnt <= Wfull), "a window sub-range needs one column, precomputed bases and a shared bucket array");
-    const uint32_t Wcol = w_cnt ? w_cnt : Wfull;
+    const uint32_t Wcol = (255 + c - 1) / c;   // windows of one column
+    H2_REQUIRE(Wcol <= 64, "too many windows");
+    H2_REQUIRE(!precomp || bases->tables >= Wcol, "precomputed table has too few windows");
     const uint32_t W = Wcol * ncols;           // windows the sort / accumulation see
-    const G1Affine *table = (const G1Affine *)bases->pts29 + (w_cnt ? (size_t)w_lo * bases->n : 0);
+    const G1Affine *table = (const G1Affine *)bases->pts29;
     const uint32_t B = 1u << (c - 1);
-    FoldKeys fold_w;
-    fold_w.fg = w_cnt ? 0u : fold_group(ctx, precomp, Wcol);
-    fold_w.ng = fold_w.fg ? (Wcol + fold_w.fg - 1) / fold_w.fg : 0u;
-    fold_w.wcol = Wcol;
-    const uint32_t ks = fold_w.fg ? fold_w.fg : 1u;
-    const uint32_t nsort = fold_w.fg ? ncols * fold_w.ng * fold_w.fg * B : W * B;   // keys of the counting sort (>= W*B: a short last group is padded)
-    const uint32_t nkeys = nsort / ks;     // run keys of the accumulation = bucket slots
+    const uint32_t nkeys = W * B;              // keys of the counting sort = run keys of the accumulation = bucket slots
     const uint64_t emax = (uint64_t)n * W;
     H2_REQUIRE(emax < 0xFFFFFFF0ull, "n*W overflows 32 bits");
     uint32_t K1 = (uint32_t)ctx->msm_chunk;
@@ -1249,34 +1010,17 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     const uint32_t G = (uint32_t)((n + chunk - 1) / chunk);
     const uint32_t sort_grid = sort_grid_size(W, G);
 
+    // The one-pass LDS-histogram counting sort is the only sort.  r03 also built a two-level sort with only coalesced writes (0.124 -> 0.087 ms
+    // at 2^19 on uniform scalars) that lost inside the proofs — 5-9 % slower accumulation on its entry order, 15-20 % behind on 0/1-heavy columns
+    // at k >= 20 — a bucket-major sort with one bucket set per column (msm_fold_windows: the wave-level merge of its 16x longer runs cost more
+    // than the presum it saved) and a column's windows dealt to two lanes; all three were removed in r04, their A/B logs are
+    // profiles/r03_msm_sort_ab.log, r03_msm_reorder.log, r02_msm_fold_windows_ab.log, r03_msm_split_windows_ab.log.
     uint32_t *digits, *bhist, *counts, *offsets, *sval, *pkey[2];
     XYZZ29 *buckets, *pval[2];
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_DIGITS, sizeof(uint32_t) * emax, (void **)&digits));
-    // two-level sort (r03, the default): coarse buckets of a window = the top 7 bits of the key (fewer for small windows), fine keys below
-    CSortGeom cg;
-    cg.LB = c - 1 > 7 ? c - 1 - 7 : (c - 1) / 2;
-    cg.NF = 1u << cg.LB;
-    cg.NC = B >> cg.LB;
-    const uint32_t Gc = (uint32_t)((n + CS_CHUNK - 1) / CS_CHUNK);
-    const size_t ncoarse = (size_t)W * cg.NC * Gc;
-    // measured (profiles/r03_msm_sort_ab.log, r03_msm_reorder.log): on uniform scalars the sort itself is ahead from 2^18 points on (2^19:
-    // 0.124 -> 0.087 ms per MSM, 2^20: 0.24 -> 0.18; 2^16: many tiny coarse buckets, 0.03 -> 0.10 ms), but at 2^19 the accumulation that
-    // follows runs 5-9 % slower on its output (the entry order inside a bucket moves the gather by that much: ascending 0.70, hashed 0.74 ms)
-    // and the k = 19 proof does not gain (15.4 -> 15.5-15.7 ms); on a circuit's 0/1-heavy columns ONE workgroup walks the coarse bucket that
-    // holds a quarter of a window (0.5 M entries at 2^21) and the proofs at k >= 20 lose 15-20 % (k = 21: 62 -> 76 ms).  So the one-pass sort
-    // stays the default at every size; msm_sort_mode 2 selects this one (it would need heavy coarse buckets dealt over several workgroups).
-    const bool two_level = ctx->msm_sort_mode == 2 && !fold_w.fg && n <= ((size_t)1 << (31 - cg.LB)) && cg.NC <= CS_MAX_NC && cg.NF <= CS_MAX_NF &&
-                           ncoarse + 1 <= (size_t)nsort + 1 + (1u << 20);
-    uint32_t *centries = nullptr, *cscan = nullptr;
-    if (two_level) {
-        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (ncoarse + 2), (void **)&cscan));
-        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SKEY, sizeof(uint32_t) * (emax + 4), (void **)&centries));
-        bhist = nullptr;
-    } else {
-        H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
-    }
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * ((size_t)nsort + 1 + (1u << 20)), (void **)&counts));   // (+ room for the two-level sort's coarse counts)
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * ((size_t)nsort + ks + 1), (void **)&offsets));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * ((size_t)nkeys + 1), (void **)&counts));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * ((size_t)nkeys + 2), (void **)&offsets));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_SVAL, sizeof(uint32_t) * (emax + 4), (void **)&sval));   // + 4: the accumulation reads aligned 16-byte groups
     if (ext_buckets) buckets = ext_buckets;
     else H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BUCKETS, sizeof(XYZZ29) * nkeys, (void **)&buckets));
@@ -1288,10 +1032,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PKEY1, sizeof(uint32_t) * 2 * (size_t)blocks1, (void **)&pkey[1]));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ29) * 2 * (size_t)blocks1, (void **)&pval[1]));
 
-    // `phases` lets a caller issue the latency-bound sort and merge of one MSM and its multiplier-bound accumulation on different
-    // streams (all derived sizes and scratch pointers are recomputed identically on every call for the same arguments)
-    if (phases & MSM_PHASE_SORT) {
-    if (nsort != W * B) H2_HIPCHK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nsort, st));   // padded keys: no window writes their counts
+    // ---- sort
     if (ext_buckets) {   // a batch's shared array: zeroed by the batch (after its previous use) or here
         if (!ext_buckets_zeroed) H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
     } else if (buckets_prezeroed(ctx, 0, buckets, sizeof(XYZZ29) * nkeys)) {
@@ -1299,31 +1040,15 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     } else {
         H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
     }
-
     DigitCols dcols;
     for (uint32_t col = 0; col < MSM_MAX_COLS; ++col) {
         H2_REQUIRE(col >= ncols || scalars[col], "NULL scalar column");
         dcols.scalars[col] = col < ncols ? scalars[col] : nullptr;
     }
     prof_begin(ctx, "msm_digits_kernel");
-    H2_REQUIRE(ks <= 256, "fold group too large");
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), ncols), dim3(256), 0, st, dcols, (uint32_t)n, c, Wcol, digits,
-                       two_level ? counts + ncoarse : counts + nsort, offsets + nsort + 1, ks, w_lo);   // + the sentinels counts[last], offsets[(nkeys + 1) * ks]
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), ncols), dim3(256), 0, st, dcols, (uint32_t)n, c, Wcol, digits, counts + nkeys,
+                       offsets + nkeys + 1);   // + the sentinels counts[nkeys], offsets[nkeys + 1]
     prof_end(ctx);
-    if (two_level) {
-        prof_begin(ctx, "msm_hist_kernel");
-        hipLaunchKernelGGL(msm_csort_hist_kernel, dim3(W * Gc), dim3(CS_THREADS), 0, st, (const uint32_t *)digits, (uint32_t)n, Gc, cg, counts);
-        prof_end(ctx);
-        H2_HIPCHK(hipGetLastError());
-        H2_CHK(exclusive_scan_u32(ctx, counts, cscan, (uint32_t)(ncoarse + 1)));   // (window, coarse bucket, chunk) order; the last entry is the total
-        prof_begin(ctx, "msm_scatter_kernel");
-        hipLaunchKernelGGL(msm_csort_scatter_kernel, dim3(W * Gc), dim3(CS_THREADS), 0, st, (const uint32_t *)digits, (uint32_t)n, Gc, cg, (const uint32_t *)cscan,
-                           centries);
-        hipLaunchKernelGGL(msm_csort_fine_kernel, dim3(W * cg.NC), dim3(CS_THREADS), 0, st, (const uint32_t *)centries, (const uint32_t *)cscan, Gc, cg, B, Wcol,
-                           precomp ? (uint32_t)bases->n : 0u, nsort, sval, offsets);
-        prof_end(ctx);
-        H2_HIPCHK(hipGetLastError());
-    } else {
     const uint32_t sort_threads = (uint32_t)ctx->msm_sort_threads;
     if (!ctx->msm_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
         H2_HIPCHK(hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
@@ -1334,10 +1059,10 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * B, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
     prof_end(ctx);
     prof_begin(ctx, "msm_hist_scan_kernel");
-    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nsort + 255) / 256), dim3(256), 0, st, bhist, W, B, G, fold_w, counts);
+    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, bhist, W, B, G, counts);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    H2_CHK(exclusive_scan_u32(ctx, counts, offsets, nsort + 1));
+    H2_CHK(exclusive_scan_u32(ctx, counts, offsets, nkeys + 1));
     prof_begin(ctx, "msm_scatter_kernel");
     uint32_t S = (uint32_t)ctx->msm_scatter_split;   // sub-ranges per window: keep a segment's output slice (n*4/S bytes) within ~2 MiB
     if (S == 0) {
@@ -1347,46 +1072,17 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     if (S > B) S = B;
     const uint32_t scatter_grid = sort_grid_size(W * S, G);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(sort_threads), ctx->msm_scatter_full_lds ? sizeof(uint32_t) * MAX_LDS_BUCKETS : sizeof(uint32_t) * (B / S), st,   // full 128 KiB: one workgroup per CU keeps a segment's writes on one XCD
-                       (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S,
-                       precomp ? (uint32_t)bases->n : 0u, Wcol, fold_w, (const uint32_t *)offsets, (const uint32_t *)bhist, sval);
+                       (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S, precomp ? (uint32_t)bases->n : 0u, Wcol, (const uint32_t *)offsets,
+                       (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    }   // one-pass sort
-    if (ctx->msm_debug_reorder && ks == 1) {
-        prof_begin(ctx, "msm_debug_reorder_kernel");
-        hipLaunchKernelGGL(msm_debug_reorder_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, sval, (const uint32_t *)offsets, nkeys, ctx->msm_debug_reorder);
-        prof_end(ctx);
-    }
-    }   // MSM_PHASE_SORT
 
-    if (phases & MSM_PHASE_ACCUM) {
+    // ---- accumulate (+ wave-level merge), then the block-level merge of the wave-boundary partials
     prof_begin(ctx, "msm_accum_kernel");
-    if (ctx->msm_accum_variant == 6 || ctx->msm_accum_variant == 7) {   // software-prefetched table gather at 2 / 3 waves per SIMD
-        if (ctx->msm_accum_variant == 6)
-            hipLaunchKernelGGL((msm_accum_kernel<2, true, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
-                               (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
-        else
-            hipLaunchKernelGGL((msm_accum_kernel<3, true, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
-                               (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
-    } else if (ctx->msm_accum_variant == 5)   // two waves per SIMD by launch bounds (256 registers: the wave-level merge's epilogue then spills nothing)
-        hipLaunchKernelGGL((msm_accum_kernel<2, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
-                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
-    else if (ctx->msm_accum_variant == 2)
-        hipLaunchKernelGGL(msm_accum_w2_kernel, dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
-                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
-    else if (ctx->msm_accum_variant == 4)
-        hipLaunchKernelGGL((msm_accum_kernel<4, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
-                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
-    else if (ctx->msm_table_nontemporal)
-        hipLaunchKernelGGL((msm_accum_kernel<3, true>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
-                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
-    else
-        hipLaunchKernelGGL((msm_accum_kernel<3, false>), dim3((T1 + 255) / 256), dim3(256), 0, st, (const uint32_t *)sval, table,
-                           (const uint32_t *)offsets, nkeys, ks, K1, buckets, pkey[0], pval[0], T1);
+    hipLaunchKernelGGL(msm_accum_kernel, dim3(accum_blocks), dim3(256), 0, st, (const uint32_t *)sval, table, (const uint32_t *)offsets, nkeys, K1, buckets,
+                       pkey[0], pval[0], T1);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    }   // MSM_PHASE_ACCUM
-    if (phases & MSM_PHASE_MERGE) {
     uint32_t len = len1;
     int src = 0;
     for (;;) {
@@ -1401,15 +1097,14 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         len = 2 * blocks;
         src ^= 1;
     }
-    }   // MSM_PHASE_MERGE
 
-    if (ext_buckets || !(phases & MSM_PHASE_REDUCE)) return H2HIP_OK;   // the caller reduces several MSMs' buckets together
+    if (ext_buckets) return H2HIP_OK;   // the caller reduces several MSMs' buckets together
     H2_CHK(msm_reduce_cols(ctx, bases, c, buckets, ncols, out));
     return buckets_clean_after_use(ctx, 0, buckets, sizeof(XYZZ29) * nkeys);
 }
 
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
-    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr, MSM_PHASE_ALL, false, 0, 0);
+    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr, false);
 }
 
 }  // namespace h2

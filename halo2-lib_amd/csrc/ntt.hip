@@ -78,18 +78,14 @@ struct NttCols {
 __global__ __launch_bounds__(256) void ntt_pass_kernel(NttCols cols, uint32_t log_n, uint32_t m,
                                                        uint32_t log_s, uint32_t cb, const Fr29L *__restrict__ t1,
                                                        const Fr29L *__restrict__ t2, uint32_t lo_bits, const Fr29L *__restrict__ tdirect,
-                                                       uint64_t in_len, int in_mul, int out_mul, NttScale sc, int debug_skip, int wave_local) {
+                                                       uint64_t in_len, int in_mul, int out_mul, NttScale sc, int debug_skip) {
     HIP_DYNAMIC_SHARED(Fr29L, lds)
     const Fr *__restrict__ x = cols.x[blockIdx.y];
     Fr *__restrict__ y = cols.y[blockIdx.y];
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << m, C = 1u << cb;
     const uint32_t elems = R << cb;
-    // wave_local (full 1024-element tiles with >= 4 columns): the tile is stored column-major (column c at c*(R+1): the odd stride keeps
-    // the fill / read-out conflict-free) and every wave owns C/4 whole columns, so all butterfly stages of a tile stay inside one wave —
-    // the block barriers between the stage pairs (four waves waiting for each other every two stages) become wave-level ordering points
-    const uint32_t col_stride = wave_local ? R + 1 : 0;
-    Fr29L *tw_s = lds + (wave_local ? C * (R + 1) : elems);   // omega_R^k, k < R/2
+    Fr29L *tw_s = lds + elems;   // omega_R^k, k < R/2
     Fr29L *scale_s = tw_s + (R >> 1) + 1;               // [0..3) input scales, [3..6) output scales (R' form)
     const uint64_t rows_stride = 1ull << (log_n - m);   // N/R
     const uint32_t ntiles = 1u << (log_n - m - cb);
@@ -126,52 +122,13 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(NttCols cols, uint32_t lo
                     uint64_t idx = j0 + c + (uint64_t)t * rows_stride;
                     v = f29_mul(v, scale_s[idx % 3].v);   // zero padding stays zero
                 }
-                lds[wave_local ? c * col_stride + bitrev_m(t, m) : (bitrev_m(t, m) << cb) + c].v = v;   // DIT: bit-reversed rows in, natural rows out
+                lds[(bitrev_m(t, m) << cb) + c].v = v;   // DIT: bit-reversed rows in, natural rows out
             }
         }
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);   // next tile's loads overlap this tile's arithmetic
 
         uint32_t st = (debug_skip & 1) ? m : 0;
-        if (wave_local && !(debug_skip & 1)) {
-            const uint32_t wave = tid >> 6, lane = tid & 63u;
-            const uint32_t cwb = cb - 2;                       // log2(columns per wave)
-            __syncthreads();                                   // the cooperative fill is complete
-            if (m & 1) {   // one radix-2 stage (twiddle 1): C/4 * R/2 = 128 butterflies per wave
-#pragma unroll
-                for (uint32_t it = 0; it < 2; ++it) {
-                    const uint32_t idx = lane + 64 * it;
-                    const uint32_t cc = idx & ((1u << cwb) - 1), p = idx >> cwb;
-                    const uint32_t e0 = ((wave << cwb) + cc) * col_stride + (p << 1), e1 = e0 + 1;
-                    Fr29 a = lds[e0].v, t = lds[e1].v;
-                    lds[e0].v = f29_norm(f29_add(a, t));
-                    lds[e1].v = f29_sub<2>(a, t);
-                }
-                st = 1;
-            }
-            const uint32_t cc = lane & ((1u << cwb) - 1), p = lane >> cwb;   // C/4 * R/4 = 64 radix-4 groups per wave: one per lane
-            const uint32_t cbase = ((wave << cwb) + cc) * col_stride;
-            for (; st < m; st += 2) {
-                const uint32_t h = 1u << st;
-                H2_WAVE_SYNC();
-                const uint32_t i = p & (h - 1), blk = p >> st;
-                const uint32_t e0 = cbase + (blk << (st + 2)) + i, stride = h;
-                Fr29 x0 = lds[e0].v, x1 = lds[e0 + stride].v, x2 = lds[e0 + 2 * stride].v, x3 = lds[e0 + 3 * stride].v;
-                if (st) {
-                    Fr29 w1 = tw_s[i << (m - 1 - st)].v;
-                    x1 = f29_mul(x1, w1);
-                    x3 = f29_mul(x3, w1);
-                }
-                Fr29 y0 = f29_add(x0, x1), y1 = f29_sub_lazy<2>(x0, x1);
-                Fr29 y2 = f29_mul_wide(f29_add(x2, x3), tw_s[i << (m - 2 - st)].v);
-                Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), tw_s[(i + h) << (m - 2 - st)].v);
-                lds[e0].v = f29_norm(f29_add(y0, y2));
-                lds[e0 + 2 * stride].v = f29_sub<2>(y0, y2);
-                lds[e0 + stride].v = f29_norm(f29_add(y1, y3));
-                lds[e0 + 3 * stride].v = f29_sub<2>(y1, y3);
-            }
-            st = m;
-        }
-        if (!wave_local && (m & 1) && !(debug_skip & 1)) {   // odd number of stages: one radix-2 stage (twiddle 1), then radix-4 rounds
+        if ((m & 1) && !(debug_skip & 1)) {   // odd number of stages: one radix-2 stage (twiddle 1), then radix-4 rounds
             __syncthreads();
             for (uint32_t b = tid; b < (elems >> 1); b += 256) {
                 uint32_t c = b & (C - 1), p = b >> cb;
@@ -219,7 +176,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(NttCols cols, uint32_t lo
                 c = e & (C - 1);
             }
             uint64_t j = j0 + c, q = j & smask, jq = j - q;
-            Fr29 v = lds[wave_local ? c * col_stride + u : (u << cb) + c].v;
+            Fr29 v = lds[(u << cb) + c].v;
             uint64_t oidx = (jq << m) + q + ((uint64_t)u << log_s);
             if (has_tw && !(debug_skip & 2)) {
                 // omega^(jq*u): jq is a multiple of s, so a direct table of omega^(s*t), t < N/s, serves later passes
@@ -248,23 +205,53 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(NttCols cols, uint32_t lo
 // four compile-time iterations.  Same LDS layout, same arithmetic, bit-identical results.
 // KIND: 0 = first pass (log_s = 0; IN_MUL: fused coset scaling with implicit zero padding), 1 = middle pass, 2 = last pass (no
 // inter-pass twiddles; OUT_MUL: fused ifft divisor / zeta^-i scaling).
-template <int KIND, bool MUL>
-__global__ __launch_bounds__(256) void ntt_tile_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
-                                                       const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
-                                                       const Fr29L *__restrict__ tdirect, uint32_t in_len, NttScale sc) {
-    HIP_DYNAMIC_SHARED(Fr29L, lds)
-    constexpr bool FIRST = KIND == 0, LAST = KIND == 2;
+// TB = log2 of the tile (10: 256 lanes, 48-byte LDS elements, the next tile prefetched into registers, three workgroups per CU;
+// 11: 512 lanes, bare 36-byte LDS elements (9-word stride: conflict-free 4-byte accesses), no register prefetch and at most 128 registers per
+// lane, so that TWO workgroups = 16 waves = four per SIMD share a CU: a third more waves to issue from while others wait).
+struct Fr29P {   // packed LDS element
+    uint32_t l[9];
+};
+template <bool PACKED>
+struct TileElem {
+    typedef Fr29L type;
+    static __device__ __forceinline__ Fr29 ld(const type *p) { return p->v; }
+    static __device__ __forceinline__ void st(type *p, const Fr29 &v) { p->v = v; }
+};
+template <>
+struct TileElem<true> {
+    typedef Fr29P type;
+    static __device__ __forceinline__ Fr29 ld(const type *p) {
+        Fr29 r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r.l[i] = p->l[i];
+        return r;
+    }
+    static __device__ __forceinline__ void st(type *p, const Fr29 &v) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) p->l[i] = v.l[i];
+    }
+};
+template <int KIND, bool MUL, int TB>
+__global__ __launch_bounds__(1 << (TB - 2), TB == 11 ? 4 : 3) void ntt_tile_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
+                                                                                 const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
+                                                                                 const Fr29L *__restrict__ tdirect, uint32_t in_len, NttScale sc, uint32_t stagger, uint32_t stagger_mode) {
+    constexpr bool FIRST = KIND == 0, LAST = KIND == 2, PACKED = TB == 11, PREFETCH = TB == 10;
+    constexpr uint32_t TILE = 1u << TB, T = TILE / 4;
+    typedef TileElem<PACKED> E;
+    typedef typename E::type Elem;
+    HIP_DYNAMIC_SHARED(uint4, lds_tile_raw)
+    Elem *lds = reinterpret_cast<Elem *>(lds_tile_raw);
     const Fr *__restrict__ x = cols.x[blockIdx.y];
     Fr *__restrict__ y = cols.y[blockIdx.y];
     const uint32_t tid = threadIdx.x;
-    const uint32_t R = 1u << m, C = 1u << cb;   // R * C = 1024
-    Fr29L *tw_s = lds + 1024;                   // omega_R^k, k < R/2
-    Fr29L *scale_s = tw_s + (R >> 1) + 1;       // [0..3) the three scales (R' form)
+    const uint32_t R = 1u << m, C = 1u << cb;   // R * C = TILE
+    Elem *tw_s = lds + TILE;                    // omega_R^k, k < R/2
+    Elem *scale_s = tw_s + (R >> 1) + 1;        // [0..3) the three scales (R' form)
     const uint32_t rows_stride = 1u << (log_n - m);
-    const uint32_t ntiles = 1u << (log_n - 10);
+    const uint32_t ntiles = 1u << (log_n - TB);
     const uint32_t smask = (1u << log_s) - 1;
-    for (uint32_t k = tid; k < (R >> 1); k += 256) tw_s[k].v = tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m));
-    if (MUL && tid < 3) scale_s[tid].v = fr29_from_sat(FIRST ? sc.in3[tid] : sc.out3[tid]);
+    for (uint32_t k = tid; k < (R >> 1); k += T) E::st(&tw_s[k], tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m)));
+    if (MUL && tid < 3) E::st(&scale_s[tid], fr29_from_sat(FIRST ? sc.in3[tid] : sc.out3[tid]));
 
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     v4u pre[4][2];
@@ -272,7 +259,7 @@ __global__ __launch_bounds__(256) void ntt_tile_kernel(NttCols cols, uint32_t lo
         const uint32_t j0 = tile << cb;
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t e = tid + 256 * k;
+            const uint32_t e = tid + T * k;
             uint32_t idx = j0 + (e & (C - 1)) + (e >> cb) * rows_stride;
             if (FIRST) idx = idx < in_len ? idx : 0u;   // implicit zero padding: a harmless in-range address, the zero is selected at the fill
             const v4u *q = reinterpret_cast<const v4u *>(x + idx);
@@ -282,7 +269,17 @@ __global__ __launch_bounds__(256) void ntt_tile_kernel(NttCols cols, uint32_t lo
     };
     uint32_t tile = blockIdx.x;
     if (tile >= ntiles) return;
-    fetch(tile);
+#ifndef H2_HIPEMU
+    // EXPERIMENT (r04): all workgroups start together and run identical phases (fill / butterflies / read-out), so the whole chip loads,
+    // computes and stores in lock step; a one-time start delay per workgroup class puts a CU's co-resident workgroups out of phase
+    if (stagger_mode) {
+        constexpr uint32_t PH = TB == 11 ? 2 : 3;
+        const uint32_t b = blockIdx.x;
+        const uint32_t ph = stagger_mode == 1 ? (b >> 8) % PH : stagger_mode == 2 ? (b >> 3) % PH : b % PH;
+        for (uint32_t i = 0; i < ph * stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    if (PREFETCH) fetch(tile);
     __syncthreads();   // tw_s / scale_s visible
 
     // one radix-4 group per lane and round
@@ -291,28 +288,29 @@ __global__ __launch_bounds__(256) void ntt_tile_kernel(NttCols cols, uint32_t lo
         const uint32_t h = 1u << st;
         const uint32_t i = gp & (h - 1), blk = gp >> st;
         const uint32_t e0 = (((blk << (st + 2)) + i) << cb) + gc, stride = h << cb;
-        Fr29 x0 = lds[e0].v, x1 = lds[e0 + stride].v, x2 = lds[e0 + 2 * stride].v, x3 = lds[e0 + 3 * stride].v;
+        Fr29 x0 = E::ld(&lds[e0]), x1 = E::ld(&lds[e0 + stride]), x2 = E::ld(&lds[e0 + 2 * stride]), x3 = E::ld(&lds[e0 + 3 * stride]);
         if (st) {   // stage st: omega_{2h}^i (for st == 0 it is 1)
-            const Fr29 w1 = tw_s[i << (m - 1 - st)].v;
+            const Fr29 w1 = E::ld(&tw_s[i << (m - 1 - st)]);
             x1 = f29_mul(x1, w1);
             x3 = f29_mul(x3, w1);
         }
         const Fr29 y0 = f29_add(x0, x1), y1 = f29_sub_lazy<2>(x0, x1);
         // stage st+1 (half = 2h): omega_{4h}^i and omega_{4h}^(i+h)
-        const Fr29 y2 = f29_mul_wide(f29_add(x2, x3), tw_s[i << (m - 2 - st)].v);
-        const Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), tw_s[(i + h) << (m - 2 - st)].v);
-        lds[e0].v = f29_norm(f29_add(y0, y2));
-        lds[e0 + 2 * stride].v = f29_sub<2>(y0, y2);
-        lds[e0 + stride].v = f29_norm(f29_add(y1, y3));
-        lds[e0 + 3 * stride].v = f29_sub<2>(y1, y3);
+        const Fr29 y2 = f29_mul_wide(f29_add(x2, x3), E::ld(&tw_s[i << (m - 2 - st)]));
+        const Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), E::ld(&tw_s[(i + h) << (m - 2 - st)]));
+        E::st(&lds[e0], f29_norm(f29_add(y0, y2)));
+        E::st(&lds[e0 + 2 * stride], f29_sub<2>(y0, y2));
+        E::st(&lds[e0 + stride], f29_norm(f29_add(y1, y3)));
+        E::st(&lds[e0 + 3 * stride], f29_sub<2>(y1, y3));
     };
 
     for (;;) {
         const uint32_t j0 = tile << cb;
-        // ---- fill: the prefetched rows go to LDS bit-reversed (DIT: bit-reversed rows in, natural rows out)
+        if (!PREFETCH) fetch(tile);
+        // ---- fill: the rows go to LDS bit-reversed (DIT: bit-reversed rows in, natural rows out)
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t e = tid + 256 * k;
+            const uint32_t e = tid + T * k;
             const uint32_t t = e >> cb, c = e & (C - 1);
             Fr s;
             s.l[0] = pre[k][0].x; s.l[1] = pre[k][0].y; s.l[2] = pre[k][0].z; s.l[3] = pre[k][0].w;
@@ -320,25 +318,25 @@ __global__ __launch_bounds__(256) void ntt_tile_kernel(NttCols cols, uint32_t lo
             Fr29 v = f29_split<R29P>(s);
             if (FIRST) {
                 const uint32_t idx = j0 + c + t * rows_stride;
-                if (MUL) v = f29_mul(v, scale_s[idx % 3u].v);
+                if (MUL) v = f29_mul(v, E::ld(&scale_s[idx % 3u]));
                 if (idx >= in_len) v = Fr29::zero();
             }
-            lds[(bitrev_m(t, m) << cb) + c].v = v;
+            E::st(&lds[(bitrev_m(t, m) << cb) + c], v);
         }
         const uint32_t next = tile + gridDim.x;
-        const bool has_next = next < ntiles;   // wave-uniform
-        if (has_next) fetch(next);             // in flight during the whole transform of this tile
+        const bool has_next = next < ntiles;       // wave-uniform
+        if (PREFETCH && has_next) fetch(next);     // in flight during the whole transform of this tile
         __syncthreads();
         uint32_t st = 0;
         if (m & 1) {   // odd number of stages: one radix-2 stage (twiddle 1) first
 #pragma unroll
             for (uint32_t k = 0; k < 2; ++k) {
-                const uint32_t b = tid + 256 * k;
+                const uint32_t b = tid + T * k;
                 const uint32_t c = b & (C - 1), p = b >> cb;
                 const uint32_t e0 = ((p << 1) << cb) + c, e1 = e0 + C;
-                const Fr29 a = lds[e0].v, t = lds[e1].v;
-                lds[e0].v = f29_norm(f29_add(a, t));
-                lds[e1].v = f29_sub<2>(a, t);
+                const Fr29 a = E::ld(&lds[e0]), t = E::ld(&lds[e1]);
+                E::st(&lds[e0], f29_norm(f29_add(a, t)));
+                E::st(&lds[e1], f29_sub<2>(a, t));
             }
             st = 1;
             __syncthreads();
@@ -354,7 +352,7 @@ __global__ __launch_bounds__(256) void ntt_tile_kernel(NttCols cols, uint32_t lo
         Fr29 twr[4];
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t e = tid + 256 * k;
+            const uint32_t e = tid + T * k;
             uint32_t u, c;
             if (FIRST) {   // first pass: output (j0 + c) * R + u is contiguous in u
                 c = e >> m;
@@ -379,9 +377,9 @@ __global__ __launch_bounds__(256) void ntt_tile_kernel(NttCols cols, uint32_t lo
         // ---- read-out
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
-            Fr29 v = lds[lidx[k]].v;
+            Fr29 v = E::ld(&lds[lidx[k]]);
             if (!LAST) v = f29_mul(v, twr[k]);
-            if (LAST && MUL) v = f29_mul(v, scale_s[oidx[k] % 3u].v);
+            if (LAST && MUL) v = f29_mul(v, E::ld(&scale_s[oidx[k] % 3u]));
             if (LAST && !MUL) v = f29_weak_reduce(v);   // weak bound (<= 21 r) -> < 2 r before packing, no multiply
             const Fr o = f29_pack_canonical<FrP>(v);
             v4u *yp = reinterpret_cast<v4u *>(y + oidx[k]);
@@ -395,193 +393,6 @@ __global__ __launch_bounds__(256) void ntt_tile_kernel(NttCols cols, uint32_t lo
         tile = next;
         __syncthreads();   // LDS is overwritten by the next tile
     }
-}
-
-// ---------------------------------------------------------------------------------------------- radix-8 pass (r03)
-// The same pass (same tile -> output index map, same fused scalings, same tables) with THREE butterfly stages per LDS round trip: every lane
-// holds 8 elements in registers and runs a radix-8 decimation-in-time group on them (12 twiddle products), so a 7-stage sub-transform is
-// 3 + 3 + 1 stages in three round trips instead of 1 + 2 + 2 + 2 in four, and an element crosses the LDS 1.33 times per stage pair instead
-// of twice.  Tile = 2^TB elements stored as bare 9-limb elements (36 B: odd word stride), T = 2^(TB-3) lanes; TB = 11: 256 lanes, 72 KiB:
-// two workgroups per CU.  The stage twiddles omega_R^k are read from a global table (t_stage, 2^(m-1) entries, L2-resident) instead of a
-// per-workgroup LDS copy.  Leftover stages (m mod 3) run as radix-2 / radix-4 groups on the same 8 registers per lane.
-struct Fr29P {   // packed LDS element
-    uint32_t l[9];
-};
-__device__ __forceinline__ Fr29 ld29(const Fr29P *p) {
-    Fr29 r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = p->l[i];
-    return r;
-}
-__device__ __forceinline__ void st29(Fr29P *p, const Fr29 &v) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) p->l[i] = v.l[i];
-}
-// limb-wise a + (2r - b): no carries, no range assertions (a: limbs < 2^31 + 2^30, b normalised and < 2r)
-__device__ __forceinline__ Fr29 f29_sub2_lazy_wide(const Fr29 &a, const Fr29 &b) {
-    Fr29 r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + (R29P::sub2p(i) - b.l[i]);
-    return r;
-}
-// G butterfly stages (G = 1, 2, 3) starting at stage st on the 2^G elements x[0], x[D], ..., positions i + j*h of their block (h = 2^st).
-// tws = omega_R^k table; exponent of the pair (j, j + 2^s) at stage st + s: (i + (j mod 2^s) * h) << (m - 1 - st - s).
-template <int G>
-__device__ __forceinline__ void radix_group(Fr29 (&x)[8], const int base, const Fr29P *tws, uint32_t i, uint32_t h, uint32_t m, uint32_t st) {
-    constexpr int N = 1 << G;
-#pragma unroll
-    for (int s = 0; s < G; ++s) {
-        const int d = 1 << s;
-        if (s == 2) {   // the upper operands of the third stage carry two lazy stages: bring their limbs back below 2^31
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-                if (j & d) x[base + j] = f29_norm(x[base + j]);
-        }
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (j & d) continue;
-            Fr29 &a = x[base + j], &b = x[base + j + d];
-            Fr29 t;
-            if (st == 0 && s == 0) {
-                t = b;   // omega^0
-            } else {
-                const uint32_t e = (i + (uint32_t)(j & (d - 1)) * h) << (m - 1 - st - s);
-                t = f29_mul_wide(b, ld29(&tws[e]));
-            }
-            const Fr29 lo = f29_add(a, t);
-            b = f29_sub2_lazy_wide(a, t);
-            a = lo;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < N; ++j) x[base + j] = f29_norm(x[base + j]);
-}
-
-// one LDS round trip: G stages on the lane's 8 / 2^G groups of 2^G elements (all register indices are compile-time constants)
-template <int G, uint32_t T>
-__device__ __forceinline__ void ntt8_round(Fr29P *lds8, const Fr29P *tstage, uint32_t tid, uint32_t elems, uint32_t cb, uint32_t m, uint32_t st) {
-    constexpr int N = 1 << G, PER = 8 >> G;   // elements per group, groups per lane
-    const uint32_t h = 1u << st, C = 1u << cb, ngroups = elems >> G;
-    Fr29 xr[8];
-    uint32_t e0s[PER], is[PER];
-#pragma unroll
-    for (int r = 0; r < PER; ++r) {
-        const uint32_t gi = tid + T * (uint32_t)r;
-        const uint32_t c = gi & (C - 1), p = gi >> cb;
-        const uint32_t i = p & (h - 1), blk = p >> st;
-        is[r] = i;
-        e0s[r] = gi < ngroups ? (((blk << (st + G)) + i) << cb) + c : 0xFFFFFFFFu;
-        if (e0s[r] != 0xFFFFFFFFu) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) xr[r * N + k] = ld29(&lds8[e0s[r] + (((uint32_t)k * h) << cb)]);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < PER; ++r)
-        if (e0s[r] != 0xFFFFFFFFu) radix_group<G>(xr, r * N, tstage, is[r], h, m, st);
-#pragma unroll
-    for (int r = 0; r < PER; ++r)
-        if (e0s[r] != 0xFFFFFFFFu) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) st29(&lds8[e0s[r] + (((uint32_t)k * h) << cb)], xr[r * N + k]);
-        }
-}
-
-template <int TB>
-__global__ __launch_bounds__(1 << (TB - 3)) void ntt_pass8_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
-                                                                const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
-                                                                const Fr29L *__restrict__ tdirect, const Fr29L *__restrict__ tstage, uint64_t in_len,
-                                                                int in_mul, int out_mul, NttScale sc) {
-    HIP_DYNAMIC_SHARED(Fr29P, lds8)
-    constexpr uint32_t T = 1u << (TB - 3);
-    const Fr *__restrict__ x = cols.x[blockIdx.y];
-    Fr *__restrict__ y = cols.y[blockIdx.y];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t R = 1u << m, C = 1u << cb;
-    const uint32_t elems = R << cb;                     // <= 2^TB
-    const uint64_t rows_stride = 1ull << (log_n - m);   // N/R
-    const uint32_t ntiles = 1u << (log_n - m - cb);
-    const bool has_tw = (log_s + m) < log_n;            // the last pass has j - q == 0 everywhere
-    const uint64_t smask = (1ull << log_s) - 1;
-    __shared__ Fr29L scale_s[6];
-    if (tid < 3 && in_mul) scale_s[tid].v = fr29_from_sat(sc.in3[tid]);
-    if (tid >= 3 && tid < 6 && out_mul) scale_s[tid].v = fr29_from_sat(sc.out3[tid - 3]);
-    // the sub-transform's stage twiddles omega_R^k, k < R/2, behind the tile (R <= 256: 4.5 KiB)
-    Fr29P *tw8 = lds8 + elems;
-    for (uint32_t k = tid; k < (R >> 1); k += T) st29(&tw8[k], tstage[k].v);
-
-    Fr pre[8];
-    auto fetch = [&](uint32_t tile) {
-        const uint64_t j0 = (uint64_t)tile << cb;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t e = tid + T * k;
-            const uint64_t idx = j0 + (e & (C - 1)) + (uint64_t)(e >> cb) * rows_stride;
-            pre[k] = (e < elems && idx < in_len) ? x[idx] : Fr::zero();
-        }
-    };
-    uint32_t tile = blockIdx.x;
-    if (tile < ntiles) fetch(tile);
-    __syncthreads();   // scale_s visible
-
-    for (; tile < ntiles; tile += gridDim.x) {
-        const uint64_t j0 = (uint64_t)tile << cb;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t e = tid + T * k;
-            if (e < elems) {
-                const uint32_t t = e >> cb, c = e & (C - 1);
-                Fr29 v = f29_split<R29P>(pre[k]);
-                if (in_mul) {
-                    const uint64_t idx = j0 + c + (uint64_t)t * rows_stride;
-                    v = f29_mul(v, scale_s[idx % 3].v);   // zero padding stays zero
-                }
-                st29(&lds8[(bitrev_m(t, m) << cb) + c], v);   // DIT: bit-reversed rows in, natural rows out
-            }
-        }
-        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);   // next tile's loads overlap this tile's arithmetic
-
-        for (uint32_t st = 0; st < m;) {
-            const uint32_t g = m - st >= 3 ? 3u : m - st;   // stages of this round
-            __syncthreads();
-            if (g == 3) ntt8_round<3, T>(lds8, tw8, tid, elems, cb, m, st);
-            else if (g == 2) ntt8_round<2, T>(lds8, tw8, tid, elems, cb, m, st);
-            else ntt8_round<1, T>(lds8, tw8, tid, elems, cb, m, st);
-            st += g;
-        }
-        __syncthreads();
-
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t e = tid + T * k;
-            if (e >= elems) continue;
-            uint32_t u, c;
-            if (log_s == 0) {   // first pass: output (j0+c)*R + u is contiguous in u
-                c = e >> m;
-                u = e & (R - 1);
-            } else {            // later passes: contiguous in q (i.e. in c)
-                u = e >> cb;
-                c = e & (C - 1);
-            }
-            const uint64_t j = j0 + c, q = j & smask, jq = j - q;
-            Fr29 v = ld29(&lds8[(u << cb) + c]);
-            const uint64_t oidx = (jq << m) + q + ((uint64_t)u << log_s);
-            if (has_tw) {
-                const Fr29 w = tdirect ? tdirect[(jq >> log_s) * u].v : tw_lookup(t1, t2, lo_bits, jq * u);   // log_s = 0: jq = j
-                v = f29_mul(v, w);
-            }
-            if (out_mul) v = f29_mul(v, scale_s[3 + oidx % 3].v);
-            if (!has_tw && !out_mul) v = f29_weak_reduce(v);   // weak bound -> < 2 r before packing, no multiply
-            y[oidx] = f29_pack_canonical<FrP>(v);
-        }
-        __syncthreads();   // LDS is overwritten by the next tile
-    }
-}
-
-// stage-twiddle table of a pass: out[k] = omega^(k << (log_n - m)) = omega_R^k, k < 2^(m-1)
-__global__ void ntt_stage_twiddle_kernel(Fr29L *out, Fr omega, uint32_t shift, uint32_t count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i].v = fr29_from_sat(fe_pow_u64(omega, (uint64_t)i << shift));
 }
 
 // direct inter-pass twiddle table for a pass with stride 2^log_s: out[t] = omega^(t << log_s), t < count
@@ -614,7 +425,6 @@ static int get_twiddles(h2hip_ctx *ctx, uint32_t log_n, const Fr &omega, Twiddle
         hipFree(ctx->twiddles.front().t2);
         for (int k = 0; k < 4; ++k) {
             if (ctx->twiddles.front().direct[k]) hipFree(ctx->twiddles.front().direct[k]);
-            if (ctx->twiddles.front().stage[k]) hipFree(ctx->twiddles.front().stage[k]);
         }
         ctx->twiddles.erase(ctx->twiddles.begin());
     }
@@ -651,36 +461,6 @@ static int get_direct_table(h2hip_ctx *ctx, TwiddleSet *tw, uint32_t log_s, cons
     return H2HIP_OK;   // all slots taken: fall back to the composed lookup
 }
 
-// stage-twiddle table omega_R^k, k < R/2, for sub-transforms of size R = 2^m (one per distinct m of a transform's passes)
-static int get_stage_table(h2hip_ctx *ctx, TwiddleSet *tw, uint32_t m, const Fr29L **out) {
-    for (int k = 0; k < 4; ++k)
-        if (tw->stage[k] && tw->stage_m[k] == m) {
-            *out = (const Fr29L *)tw->stage[k];
-            return H2HIP_OK;
-        }
-    for (int k = 0; k < 4; ++k)
-        if (!tw->stage[k]) {
-            const uint32_t count = m ? 1u << (m - 1) : 1u;
-            H2_HIPCHK(hipMalloc(&tw->stage[k], sizeof(Fr29L) * count));
-            tw->stage_m[k] = m;
-            prof_begin(ctx, "ntt_twiddle_kernel");
-            hipLaunchKernelGGL(ntt_stage_twiddle_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, (Fr29L *)tw->stage[k], tw->omega, tw->log_n - m, count);
-            prof_end(ctx);
-            H2_HIPCHK(hipGetLastError());
-            *out = (const Fr29L *)tw->stage[k];
-            return H2HIP_OK;
-        }
-    // all four slots hold other sizes (only when the tile size changes between calls: tuning sweeps, tests): replace the first one
-    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(tw->stage[0]);
-    for (int k = 0; k < 3; ++k) {
-        tw->stage[k] = tw->stage[k + 1];
-        tw->stage_m[k] = tw->stage_m[k + 1];
-    }
-    tw->stage[3] = nullptr;
-    return get_stage_table(ctx, tw, m, out);
-}
-
 // a[j]: N = 2^log_n device elements each (results land there), ncols equal-size columns transformed together.  in_override (optional):
 // column j reads its input from in_override[j] (in_len valid elements, implicit zeros beyond).  in_scale3 / out_scale3 (optional, host
 // pointers to 3 Fr): multiply input / output element i by scale[i mod 3].
@@ -696,18 +476,34 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
         sc.in3[i] = in_scale3 ? in_scale3[i] : Fr::one();
         sc.out3[i] = out_scale3 ? out_scale3[i] : Fr::one();
     }
-    constexpr uint32_t TB8 = 11;   // radix-8 passes: 2048-element tiles (72 KiB of LDS: two 256-lane workgroups per CU)
-    const bool radix8 = ctx->ntt_radix8 != 0;
-    const uint32_t LT = radix8 ? (uint32_t)ctx->ntt_tile_bits8 : (uint32_t)ctx->ntt_tile_bits;
+    uint32_t LT = (uint32_t)ctx->ntt_tile_bits;
     uint32_t mlist[8], P;
-    if (log_n <= LT) {
-        P = 1;
-        mlist[0] = log_n;
-    } else {
-        uint32_t maxm = LT - (uint32_t)ctx->ntt_min_col_bits;   // at least 2^min_col_bits adjacent columns per tile (row segments of 32 B each)
-        if (radix8 && maxm > 8) maxm = 8;                       // the radix-8 kernel keeps omega_R^k, k < R/2, in LDS behind its 72 KiB tile
-        P = (log_n + maxm - 1) / maxm;
-        for (uint32_t i = 0; i < P; ++i) mlist[i] = log_n / P + (i < log_n % P ? 1 : 0);
+    auto plan = [&](uint32_t lt) {
+        if (log_n <= lt) {
+            P = 1;
+            mlist[0] = log_n;
+        } else {
+            uint32_t maxm = lt - (uint32_t)ctx->ntt_min_col_bits;   // at least 2^min_col_bits adjacent columns per tile (row segments of 32 B each)
+            P = (log_n + maxm - 1) / maxm;
+            for (uint32_t i = 0; i < P; ++i) mlist[i] = log_n / P + (i < log_n % P ? 1 : 0);
+        }
+    };
+    plan(LT);
+    if (LT == 11) {
+        // 2048-element tiles exist only in the full-tile kernel: every pass has to qualify for it (full tiles, direct twiddle tables), or the
+        // whole transform runs on 1024-element tiles
+        bool ok = ctx->ntt_tile_kernel && P >= 2 && N <= (1ull << 28);
+        for (uint32_t i = 0, ls = 0; ok && i < P; ls += mlist[i], ++i) {
+            uint32_t cbi = LT - mlist[i];
+            if (cbi > log_n - mlist[i]) cbi = log_n - mlist[i];
+            if (i > 0 && cbi > ls) cbi = ls;
+            ok = mlist[i] >= 2 && mlist[i] + cbi == LT;
+            if (ok && i + 1 < P) ok = ls ? log_n - ls <= 16 : (log_n <= 23 && ctx->ntt_full_table);
+        }
+        if (!ok) {
+            LT = 10;
+            plan(LT);
+        }
     }
     TwiddleSet *tw = nullptr;
     H2_CHK(get_twiddles(ctx, log_n, omega, &tw));
@@ -737,36 +533,34 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
             const uint32_t grid = tiles < (uint32_t)ctx->num_cus * 3 ? tiles : (uint32_t)ctx->num_cus * 3;
             const Fr29L *tdirect = nullptr;
             if (i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
-            if (radix8) {
-                const Fr29L *tstage = nullptr;
-                H2_CHK(get_stage_table(ctx, tw, m, &tstage));
-                if (!ctx->ntt_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
-                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_pass8_kernel<TB8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(Fr29P) * ((1u << TB8) + 1024u))));
-                    ctx->ntt_lds_attr_set = true;
-                }
-                const uint32_t grid8 = tiles < (uint32_t)ctx->num_cus * 2 ? tiles : (uint32_t)ctx->num_cus * 2;
-                prof_begin(ctx, "ntt_pass_kernel");
-                hipLaunchKernelGGL(ntt_pass8_kernel<TB8>, dim3(grid8, gc), dim3(1u << (TB8 - 3)), sizeof(Fr29P) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0))), ctx->stream, cols, log_n, m, log_s, cb,
-                                   (const Fr29L *)tw->t1, (const Fr29L *)tw->t2, tw->lo_bits, tdirect, tstage, first ? in_len : N,
-                                   (first && in_scale3) ? 1 : 0, (last && out_scale3) ? 1 : 0, sc);
-                prof_end(ctx);
-                H2_HIPCHK(hipGetLastError());
-                in_scratch = to_scratch;
-                log_s += m;
-                continue;
-            }
-            // the specialised full-tile kernel: every pass of a transform of 2^11 points or more at the default tile size
-            if (ctx->ntt_tile_kernel && P >= 2 && m + cb == 10 && m >= 2 && (last || tdirect) && N <= (1ull << 28)) {
-                const size_t shmem_t = sizeof(Fr29L) * (1024 + ((size_t)1 << (m - 1)) + 8);
+            // the specialised full-tile kernels: every pass of a transform larger than the tile
+            if (ctx->ntt_tile_kernel && P >= 2 && m + cb == LT && (LT == 10 || LT == 11) && m >= 2 && (last || tdirect) && N <= (1ull << 28)) {
+                const bool big = LT == 11;
+                const size_t shmem_t = (big ? sizeof(Fr29P) : sizeof(Fr29L)) * (((size_t)1 << LT) + ((size_t)1 << (m - 1)) + 8);
                 // equal shares: every workgroup walks `rounds` tiles (the last few one less) instead of some walking one more than the others
-                const uint32_t slots = (uint32_t)ctx->num_cus * 3, rounds = (tiles + slots - 1) / slots;
-                const uint32_t grid_t = (tiles + rounds - 1) / rounds;
+                const uint32_t slots = (uint32_t)ctx->num_cus * (big ? 2 : 3), rounds = (tiles + slots - 1) / slots;
+                const uint32_t grid_t = ctx->ntt_grid_full ? (tiles < slots ? tiles : slots) : (tiles + rounds - 1) / rounds;
                 const bool mul = first ? in_scale3 != nullptr : (last && out_scale3 != nullptr);
                 const uint32_t in_len32 = (uint32_t)(first ? in_len : N);
+                if (big && !ctx->ntt_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
+                    const int cap = (int)(sizeof(Fr29P) * (2048 + 1024 + 8));
+                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<0, true, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<0, false, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<1, false, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<2, true, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<2, false, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                    ctx->ntt_lds_attr_set = true;
+                }
                 prof_begin(ctx, "ntt_pass_kernel");
-#define H2_NTT_TILE(KIND, MUL)                                                                                                                      \
-    hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL>), dim3(grid_t, gc), dim3(256), shmem_t, ctx->stream, cols, log_n, m, log_s, cb, (const Fr29L *)tw->t1, \
-                       (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc)
+#define H2_NTT_TILE(KIND, MUL)                                                                                                                          \
+    do {                                                                                                                                                \
+        if (big)                                                                                                                                        \
+            hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL, 11>), dim3(grid_t, gc), dim3(512), shmem_t, ctx->stream, cols, log_n, m, log_s, cb,          \
+                               (const Fr29L *)tw->t1, (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc, (uint32_t)ctx->ntt_stagger, (uint32_t)ctx->ntt_stagger_mode); \
+        else                                                                                                                                            \
+            hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL, 10>), dim3(grid_t, gc), dim3(256), shmem_t, ctx->stream, cols, log_n, m, log_s, cb,          \
+                               (const Fr29L *)tw->t1, (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc, (uint32_t)ctx->ntt_stagger, (uint32_t)ctx->ntt_stagger_mode); \
+    } while (0)
                 if (first) {
                     if (mul) H2_NTT_TILE(0, true);
                     else H2_NTT_TILE(0, false);
@@ -783,12 +577,11 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
                 log_s += m;
                 continue;
             }
-            const int wave_local = (ctx->ntt_wave_local && cb >= 2 && m + cb == 10 && m >= 2) ? 1 : 0;
-            const size_t shmem = sizeof(Fr29L) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)) + 8 + (wave_local ? ((size_t)1 << cb) : 0));
+            const size_t shmem = sizeof(Fr29L) * (((size_t)1 << (m + cb)) + ((size_t)1 << (m ? m - 1 : 0)) + 8);
             prof_begin(ctx, "ntt_pass_kernel");
             hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid, gc), dim3(256), shmem, ctx->stream, cols, log_n, m, log_s, cb, (const Fr29L *)tw->t1,
                                (const Fr29L *)tw->t2, tw->lo_bits, tdirect, first ? in_len : N, (first && in_scale3) ? 1 : 0,
-                               (last && out_scale3) ? 1 : 0, sc, ctx->ntt_debug_skip, wave_local);
+                               (last && out_scale3) ? 1 : 0, sc, ctx->ntt_debug_skip);
             prof_end(ctx);
             H2_HIPCHK(hipGetLastError());
             in_scratch = to_scratch;

@@ -57,10 +57,11 @@ int h2hip_init(int device, void *hip_stream, h2hip_ctx **out);
 void h2hip_destroy(h2hip_ctx *ctx);
 int h2hip_sync(h2hip_ctx *ctx);
 /* tuning knobs (defaults are the tuned values): "msm_window_bits" (0 = auto), "msm_chunk" (0 = auto), "msm_seg",
- * "msm_scatter_split" (0 = auto), "msm_lanes", "msm_quad_tails", "msm_accum_variant", "msm_sort_mode" (0 / 1 = the one-pass counting sort,
- * 2 = the two-level sort with coalesced writes: ahead on uniform scalars from 2^18 points on, behind on a circuit's 0/1-heavy columns), "ntt_tile_bits", "ntt_min_col_bits", "ntt_full_table";
- * profiling aids: "ntt_debug_skip" (produces wrong results), "msm_debug_reorder" (reorders the entries inside the buckets, results unchanged);
- * "msm_split_windows" (1: large precomputed MSMs run as two half jobs, a column's windows dealt to two lanes — measured slower, off) */
+ * "msm_scatter_split" (0 = auto), "msm_lanes", "msm_quad_tails", "msm_fuse_cols", "msm_defer_reduce", "ntt_tile_bits" (10; 11 = 2048-element
+ * tiles), "ntt_tile_kernel" (1 = the specialised full-tile pass kernel, 0 = the generic one), "ntt_min_col_bits", "ntt_full_table";
+ * profiling aid: "ntt_debug_skip" (produces wrong results).  The variants r01-r03 measured slower (two-level sort, bucket-major sort,
+ * split streams, split windows, accumulation builds 2/5/6/7, radix-8 and wave-local NTT passes) were removed in r04; their A/B logs stay
+ * under profiles/. */
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value);
 int h2hip_get_param(h2hip_ctx *ctx, const char *name, int *value);
 

@@ -27,31 +27,11 @@ def test_ntt_matches_oracle(ctx, log_n):
     assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
 
 
-def test_ntt_wave_local_variant(ctx):
-    """ntt_wave_local = 1: column-major tiles, stage pairs inside one wave (bit-exact with the default pass kernel)"""
-    ctx.set_param("ntt_wave_local", 1)
-    try:
-        for log_n in (11, 13, 15):
-            a = rand_fr(1 << log_n, 40 + log_n)
-            w, winv, div = domain_consts(log_n)
-            got = ctx.best_fft(a, w, log_n)
-            assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=4))
-            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
-        a = rand_fr(1 << 12, 7)
-        we, weinv, ediv = domain_consts(14)
-        z = fr([O.ZETA])
-        assert np.array_equal(ctx.coeff_to_extended(a, 12, 14, we, z), CO.coeff_to_extended(a, 12, 14, we, z, threads=4))
-    finally:
-        ctx.set_param("ntt_wave_local", 0)
-
-
-@pytest.mark.parametrize("radix8", [1, 0])
 @pytest.mark.parametrize("tile", [4, 6, 8])
-def test_ntt_small_tiles_force_many_passes(ctx, tile, radix8):
-    """both pass kernels — radix-8 (three stages per LDS round trip, the default) and radix-4 — with tiles small enough that a 2^12 transform
-    takes up to six passes: every (stages per pass, columns per tile, leftover-stage) combination, the fused coset scalings included"""
-    ctx.set_param("ntt_radix8", radix8)
-    ctx.set_param("ntt_tile_bits8" if radix8 else "ntt_tile_bits", tile)
+def test_ntt_small_tiles_force_many_passes(ctx, tile):
+    """the generic pass kernel with tiles small enough that a 2^12 transform takes up to six passes: every (stages per pass, columns per
+    tile, leftover-stage) combination, the fused coset scalings included"""
+    ctx.set_param("ntt_tile_bits", tile)
     try:
         for log_n in (7, 12):
             a = rand_fr(1 << log_n, 3)
@@ -66,24 +46,7 @@ def test_ntt_small_tiles_force_many_passes(ctx, tile, radix8):
         assert np.array_equal(ext, CO.coeff_to_extended(a, 9, 11, we, z, threads=4))
         assert np.array_equal(ctx.extended_to_coeff(ext, 11, weinv, ediv, zinv)[: 1 << 9], a)
     finally:
-        ctx.set_param("ntt_tile_bits8", 11)
         ctx.set_param("ntt_tile_bits", 10)
-        ctx.set_param("ntt_radix8", 0)
-
-
-def test_ntt_radix8_kernel_matches(ctx):
-    """ntt_radix8 = 1: the radix-8 pass kernel (selectable; measured slower than the default radix-4 kernel on MI355X) against the oracle at the
-    sizes of the default test, with its 2048-element tiles"""
-    ctx.set_param("ntt_radix8", 1)
-    try:
-        for log_n in (0, 1, 5, 10, 11, 13, 15):
-            a = rand_fr(1 << log_n, log_n)
-            w, winv, div = domain_consts(log_n)
-            got = ctx.best_fft(a, w, log_n)
-            assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=4))
-            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
-    finally:
-        ctx.set_param("ntt_radix8", 0)
 
 
 @pytest.mark.parametrize("k,ek", [(0, 2), (3, 5), (9, 11), (12, 14)])
@@ -193,18 +156,13 @@ def test_msm_precomputed_bases(ctx, c):
     try:
         b = ctx.bases_upload(bases, BASES_PRECOMPUTE)
         for s in (rand_fr(n, c), circuit_like_fr(n, c + 1)):
-            want = CO.best_multiexp(s, bases, threads=4)
-            for fold in (64, 4, 0):   # windows per shared bucket set: all (no presum) / groups of 4 (ragged last group) / one set per window
-                ctx.set_param("msm_fold_windows", fold)
-                assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), want), fold
-        ctx.set_param("msm_fold_windows", 0)
+            assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=4))
         # a prefix of the table still works (n < table size)
         s = rand_fr(100, 3)
         assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases[:100], threads=2))
         b.free()
     finally:
         ctx.set_param("msm_window_bits", 0)
-        ctx.set_param("msm_fold_windows", 0)
 
 
 @pytest.mark.parametrize("n", [1, 2, 31, 257, 5000])
@@ -429,16 +387,14 @@ def test_msm_randomized_shapes_emulated(ctx):
         b = ctx.bases_upload(bases_all[:n], flags)
         want = [CO.best_multiexp(s, bases_all[:n], threads=4) for s in cols]
         dptrs = [ctx.to_device(s) for s in cols]
-        for fuse, defer, fold in ((0, 1, 64), (1, 1, 64), (1, 0, 64), (0, 1, 0), (1, 1, 3)):
+        for fuse, defer in ((0, 1), (1, 1), (1, 0), (3, 1), (3, 0)):
             ctx.set_param("msm_fuse_cols", fuse)
             ctx.set_param("msm_defer_reduce", defer)
-            ctx.set_param("msm_fold_windows", fold)
             got = ctx.msm_batch_dev(b, dptrs, n, H.POINT_AFFINE)
             for j in range(len(cols)):
-                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, fold, j)
+                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, j)
         ctx.set_param("msm_fuse_cols", 0)
         ctx.set_param("msm_defer_reduce", 1)
-        ctx.set_param("msm_fold_windows", 0)
         for d in dptrs:
             ctx.free(d)
         b.free()
@@ -515,9 +471,9 @@ def test_msm_g2_emulated(ctx):
     _g2_msm_checks(ctx, [1, 2, 37, 300])
 
 
-def test_msm_batch_split_streams_and_mixed_bases(ctx):
-    """the batch schedule with all accumulations on one stream and every sort / merge on another (msm_split_streams, deferred reduction),
-    on and off, for 2..5 columns incl. an all-zero one; and h2hip_msm_g1_multi_dev: columns over two different base sets in one call"""
+def test_msm_batch_pipelined_and_mixed_bases(ctx):
+    """the per-column lane pipeline with the deferred joint reduction for 2..5 columns incl. an all-zero one; and h2hip_msm_g1_multi_dev:
+    columns over two different base sets in one call"""
     from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
 
     n = 700
@@ -532,18 +488,15 @@ def test_msm_batch_split_streams_and_mixed_bases(ctx):
     want_b = [CO.best_multiexp(c, bases_b, threads=2) for c in cols]
     ctx.set_param("msm_fuse_cols", 1)          # per-column pipeline + deferred joint reduction (what large sizes use)
     try:
-        for split in (1, 0):
-            ctx.set_param("msm_split_streams", split)
-            for count in (2, 3, 5):
-                got = ctx.msm_batch_dev(ba, dptrs[:count], n, H.POINT_AFFINE)
-                assert all(np.array_equal(got[j:j + 1], want_a[j]) for j in range(count)), (split, count)
-            sets = [ba, bb, bb, ba, bb]
-            got = ctx.msm_multi_dev(sets, dptrs, n, H.POINT_AFFINE)
-            for j, s in enumerate(sets):
-                assert np.array_equal(got[j:j + 1], (want_a if s is ba else want_b)[j]), (split, j)
+        for count in (2, 3, 5):
+            got = ctx.msm_batch_dev(ba, dptrs[:count], n, H.POINT_AFFINE)
+            assert all(np.array_equal(got[j:j + 1], want_a[j]) for j in range(count)), count
+        sets = [ba, bb, bb, ba, bb]
+        got = ctx.msm_multi_dev(sets, dptrs, n, H.POINT_AFFINE)
+        for j, s in enumerate(sets):
+            assert np.array_equal(got[j:j + 1], (want_a if s is ba else want_b)[j]), j
     finally:
         ctx.set_param("msm_fuse_cols", 0)
-        ctx.set_param("msm_split_streams", 0)
     # automatic fusing: runs of columns over the same set become fused multi-column MSMs (a group never spans two sets), reduced together
     many = [ba] * 7 + [bb] * 2 + [ba] * 3
     mptrs = [dptrs[j % 5] for j in range(len(many))]
@@ -559,52 +512,9 @@ def test_msm_batch_split_streams_and_mixed_bases(ctx):
     bb.free()
 
 
-@pytest.mark.parametrize("variant", [6, 7, 5])
-def test_msm_accumulate_variants_agree(ctx, variant):
-    """msm_accum_variant 6 / 7 (the next table entry is requested before the current addition) and 5 (two waves per SIMD) against the oracle"""
-    n = 3000
-    bases = CO.known_dlog_bases(n, fr([11]), fr([7]))
-    b = ctx.bases_upload(bases)
-    ctx.set_param("msm_accum_variant", variant)
-    try:
-        for s in (rand_fr(n, 31), circuit_like_fr(n, 32)):
-            assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=4))
-    finally:
-        ctx.set_param("msm_accum_variant", 3)
-        b.free()
-
-
-def test_msm_split_windows(ctx):
-    """msm_split_windows: a column's windows dealt to two lanes as half jobs that add into the column's one bucket array — the single MSM, a
-    batch of one and a batch of three, against the oracle and against the unsplit path"""
-    from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
-
-    n = 3000
-    bases = CO.known_dlog_bases(n, fr([7]), fr([5]))
-    b = ctx.bases_upload(bases, BASES_PRECOMPUTE)
-    cols = [rand_fr(n, 51), circuit_like_fr(n, 52), np.repeat(fr([R - 1]), n, axis=0)]
-    want = [CO.best_multiexp(s, bases, threads=8) for s in cols]
-    dcols = [ctx.to_device(s) for s in cols]
-    try:
-        for mode in (2, 0):
-            ctx.set_param("msm_split_windows", mode)
-            for s, w in zip(cols, want):
-                assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), w), mode
-            got = ctx.msm_batch_dev(b, dcols, n, H.POINT_AFFINE)
-            assert all(np.array_equal(g, w.reshape(-1)) for g, w in zip(got, want)), mode
-            assert np.array_equal(ctx.msm_batch_dev(b, dcols[:1], n, H.POINT_AFFINE)[0], want[0].reshape(-1)), mode
-            assert np.array_equal(ctx.msm(b, cols[0][:777], H.POINT_AFFINE), CO.best_multiexp(cols[0][:777], bases[:777], threads=4)), mode
-    finally:
-        ctx.set_param("msm_split_windows", 0)
-        for d in dcols:
-            ctx.free(d)
-        b.free()
-
-
-def test_msm_two_level_sort_paths(ctx):
-    """the two-level sort (msm_sort_mode 2; selectable, not the default): several chunks per window, a coarse bucket larger than the LDS buffer (all scalars equal:
-    every entry of a window lands in ONE key, placed directly), windows with no entries at all — and the one-pass sort (msm_sort_mode 1) on
-    the same inputs"""
+def test_msm_sort_degenerate_inputs(ctx):
+    """the counting sort on degenerate inputs: several chunks per window, all scalars equal (every entry of a window lands in ONE key),
+    windows with no entries at all, at the automatic and at a small window size"""
     n = 20000
     bases = CO.known_dlog_bases(n, fr([3]), fr([11]))
     b = ctx.bases_upload(bases)
@@ -612,14 +522,11 @@ def test_msm_two_level_sort_paths(ctx):
     big = np.repeat(fr([R - 5]), n, axis=0)
     mixed = np.concatenate([ones[: n // 2], rand_fr(n - n // 2, 91)])
     try:
-        for mode in (2, 1):
-            ctx.set_param("msm_sort_mode", mode)
-            for c in (0, 12):
-                ctx.set_param("msm_window_bits", c)
-                for s in (ones, big, mixed):
-                    assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=8)), (mode, c)
+        for c in (0, 12):
+            ctx.set_param("msm_window_bits", c)
+            for s in (ones, big, mixed):
+                assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=8)), c
     finally:
-        ctx.set_param("msm_sort_mode", 0)
         ctx.set_param("msm_window_bits", 0)
         b.free()
 
@@ -635,3 +542,30 @@ def test_full_range_field_inputs(ctx):
     F.check_pointwise(ctx, 2000)
     F.check_inverse_and_products(ctx, [1, 37, 3000])
     F.check_eval_and_division(ctx, [1, 9, 2049])
+
+
+@pytest.mark.parametrize("tile_bits,tile_kernel", [(10, 1), (10, 0), (11, 1)])
+def test_ntt_full_tile_kernels(ctx, tile_bits, tile_kernel):
+    """ntt_tile_kernel (r04): the specialised full-tile pass kernel at 1024-element tiles (the default), the generic pass kernel instead
+    (ntt_tile_kernel = 0), and the 2048-element / 36-byte-element build (ntt_tile_bits = 11; sizes whose passes do not all fill such a tile
+    fall back to 1024-element tiles) — forward, inverse with its fused divisor, coset extension with zero padding and back, bit-exact"""
+    ctx.set_param("ntt_tile_bits", tile_bits)
+    ctx.set_param("ntt_tile_kernel", tile_kernel)
+    try:
+        for log_n in (11, 12, 13, 14, 16):
+            a = rand_fr(1 << log_n, 70 + log_n)
+            w, winv, div = domain_consts(log_n)
+            got = ctx.best_fft(a, w, log_n)
+            assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=4)), log_n
+            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a), log_n
+        for k, ek in ((10, 12), (11, 14), (13, 15)):
+            a = rand_fr(1 << k, k)
+            we, weinv, ediv = domain_consts(ek)
+            z, zinv = fr([O.ZETA]), fr([O.ZETA * O.ZETA % R])
+            ext = ctx.coeff_to_extended(a, k, ek, we, z)
+            assert np.array_equal(ext, CO.coeff_to_extended(a, k, ek, we, z, threads=4)), (k, ek)
+            back = ctx.extended_to_coeff(ext, ek, weinv, ediv, zinv)
+            assert np.array_equal(back[: 1 << k], a) and not back[1 << k:].any()
+    finally:
+        ctx.set_param("ntt_tile_bits", 10)
+        ctx.set_param("ntt_tile_kernel", 1)

@@ -119,26 +119,17 @@ def test_msm_many_duplicates_and_single_bucket(ctx):
     b.free()
 
 
-def test_msm_both_sorts_at_every_size(ctx):
-    """msm_sort_mode 2 selects the two-level sort (small windows: few coarse buckets, few fine keys; one
-    chunk; a coarse bucket past the LDS buffer), 1 forces the one-pass sort: both against the oracle on the same inputs"""
+def test_msm_sizes_and_base_kinds(ctx):
+    """a ladder of sizes over plain and precomputed bases (one chunk / several chunks per window, a window whose entries all share one key),
+    three scalar distributions each, against the oracle"""
     from halo2_lib_amd.h2hip import BASES_PRECOMPUTE
 
-    try:
-        for n, flags in ((1, 0), (777, 0), (1 << 10, 0), (20000, 0), (1 << 14, BASES_PRECOMPUTE), (70001, BASES_PRECOMPUTE)):
-            bases = CO.known_dlog_bases(n, fr([5]), fr([13]))
-            b = ctx.bases_upload(bases, flags)
-            cols = [rand_fr(n, n), circuit_like_fr(n, n + 1), np.repeat(fr([1]), n, axis=0)]
-            want = [CO.best_multiexp(s, bases, threads=NT) for s in cols]
-            for mode, split in ((2, 0), (1, 0), (1, 2), (2, 2)):   # split 2: a column's windows as two half jobs on two lanes (precomputed bases only)
-                ctx.set_param("msm_sort_mode", mode)
-                ctx.set_param("msm_split_windows", split)
-                for s, w in zip(cols, want):
-                    assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), w), (n, flags, mode, split)
-            b.free()
-    finally:
-        ctx.set_param("msm_sort_mode", 0)
-        ctx.set_param("msm_split_windows", 0)
+    for n, flags in ((1, 0), (777, 0), (1 << 10, 0), (20000, 0), (1 << 14, BASES_PRECOMPUTE), (70001, BASES_PRECOMPUTE)):
+        bases = CO.known_dlog_bases(n, fr([5]), fr([13]))
+        b = ctx.bases_upload(bases, flags)
+        for s in (rand_fr(n, n), circuit_like_fr(n, n + 1), np.repeat(fr([1]), n, axis=0)):
+            assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), CO.best_multiexp(s, bases, threads=NT)), (n, flags)
+        b.free()
 
 
 def test_fr_batches(ctx):
@@ -316,16 +307,14 @@ def test_msm_randomized_shapes(ctx):
         assert np.array_equal(ctx.msm(b, cols[0], H.POINT_AFFINE), want[0]), (case, n, flags)
         assert np.array_equal(ctx.msm_batch(b, cols, H.POINT_AFFINE), np.concatenate(want)), (case, n, flags, "host columns")
         dptrs = [ctx.to_device(s) for s in cols]
-        for fuse, defer, fold in ((0, 1, 64), (1, 1, 64), (1, 0, 64), (3, 1, 64), (0, 1, 0), (1, 1, 4), (3, 0, 3)):
+        for fuse, defer in ((0, 1), (1, 1), (1, 0), (3, 1), (3, 0)):
             ctx.set_param("msm_fuse_cols", fuse)
             ctx.set_param("msm_defer_reduce", defer)
-            ctx.set_param("msm_fold_windows", fold)   # windows per shared bucket set (64: one set per column, 0: one per window)
             got = ctx.msm_batch_dev(b, dptrs, n, H.POINT_AFFINE)
             for j in range(len(cols)):
-                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, fold, j)
+                assert np.array_equal(got[j:j + 1], want[j]), (case, n, flags, fuse, defer, j)
         ctx.set_param("msm_fuse_cols", 0)
         ctx.set_param("msm_defer_reduce", 1)
-        ctx.set_param("msm_fold_windows", 0)
         for d in dptrs:
             ctx.free(d)
         b.free()

@@ -31,8 +31,8 @@ while time.time() - t0 < budget:
     shape = (k, na, nl, nf, ni, lb)
     knobs = {}
     if os.environ.get("H2HIP_FUZZ_KNOBS"):
-        knobs = {"msm_sort_mode": rnd.choice([0, 2]), "msm_split_windows": rnd.choice([0, 2]), "msm_accum_variant": rnd.choice([3, 3, 2, 5, 6]),
-                 "ntt_radix8": rnd.choice([0, 1]), "msm_fuse_cols": rnd.choice([0, 1, 4]), "msm_lanes": rnd.choice([0, 1, 2])}
+        knobs = {"ntt_tile_kernel": rnd.choice([1, 1, 0]), "ntt_tile_bits": rnd.choice([10, 10, 11, 6]), "msm_fuse_cols": rnd.choice([0, 1, 4]),
+                 "msm_lanes": rnd.choice([0, 1, 2]), "msm_defer_reduce": rnd.choice([1, 1, 0])}
         for name, val in knobs.items():
             ctx.set_param(name, val)
     try:

@@ -24,8 +24,6 @@ if "--msm" in sys.argv:
     s = g.integers(0, 2**63, size=(1 << k, 4), dtype=np.uint64)
     s[:, 3] &= np.uint64((1 << 60) - 1)
     d = ctx.to_device(s)
-    for nt in (0, 1):   # msm_accum_kernel<3, false> = plain loads, <3, true> = non-temporal table gathers + 16-byte entry-list loads
-        ctx.set_param("msm_table_nontemporal", nt)
-        for _ in range(4):
-            ctx.msm_dev(params.g, d, 1 << k)
+    for _ in range(4):   # (r02 compared plain against non-temporal table gathers here: profiles/r02_hbm_counter_calibration.md; only the latter is left)
+        ctx.msm_dev(params.g, d, 1 << k)
     print("msm done")
