@@ -243,7 +243,15 @@ def main():
         t0 = time.perf_counter()
         pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
         keygen_s = time.perf_counter() - t0
-        draws = synthetic_scalars(n + 4096, 4242)
+        # the prover's randomness: the reference hands create_proof `StdRng::seed_from_u64(0)` (halo2-base/src/utils/testing.rs:38) = ChaCha12 in
+        # counter mode.  libh2hip's seeded generator reproduces that Fr::random stream and the prover generates its 2^k blinding scalars ON THE
+        # DEVICE inside the timed call (PL.ChaChaRng, csrc/rng.hip).  `draws` = the same stream as an array (generated by the same kernel, once):
+        # what the pre-drawn-array comparison figure and the CPU baseline consume, so that all of them produce the SAME proof bytes.
+        rng_seed = PL.ChaChaRng(ctx.lib, 0, 12).state.seed
+        d_draws = ctx.malloc(32 * (n + 4096))
+        ctx._chk(ctx.lib.h2hip_rng_chacha_fill_dev(ctx.handle, d_draws, n + 4096, rng_seed, 12, 0))
+        draws = ctx.download(d_draws, (n + 4096, 4))
+        ctx.free(d_draws)
     except Exception as e:
         if world == 1:
             raise
@@ -259,13 +267,25 @@ def main():
         comm = Comm(ctx, rccl=args.dist_backend == "nccl", device=xdev)   # libh2hip's own communicator (RCCL over xGMI / a gloo callback)
         if sharded:
             sk = shard_proving_key(pk, ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange), device=xdev, precompute=True, comm=comm)
+        # what the N-rank run actually ran on: libh2hip's view of its communicator (h2hip_comm_info) and every rank's GPU, gathered for the line
+        import ctypes as _C
+
+        cw, cr, crccl = _C.c_int(), _C.c_int(), _C.c_int()
+        ctx._chk(ctx.lib.h2hip_comm_info(comm.handle, _C.byref(cw), _C.byref(cr), _C.byref(crccl)))
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": cr.value, "world": cw.value, "is_rccl": bool(crccl.value), "cuda_device": local_rank, "gpu_name": props.name,
+                "gpu_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        comm_ranks = [None] * world
+        dist.all_gather_object(comm_ranks, mine)
 
     # the timed proofs take the advice columns RESIDENT IN HBM (advice_on_device: the bench contract times the hot path with its inputs on the
     # device); the same call with the columns in host memory — the Vec the Rust prover fills, staged over PCIe inside the call — is timed
     # next to it (`seconds_per_proof_host_advice`).  The RNG stream is a host callback in both, as it is in the reference.
     adv_dev = [ctx.to_device(np.ascontiguousarray(c)) for c in circ.advice]
-    prove = lambda stages=None: PL.create_proof(pk, adv_dev, circ.instances, PL.ArrayRng(draws), stages, advice_on_device=True)
-    prove_host = lambda: PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))
+    prove = lambda stages=None: PL.create_proof(pk, adv_dev, circ.instances, PL.ChaChaRng(ctx.lib, 0, 12), stages, advice_on_device=True)
+    prove_host = lambda: PL.create_proof(pk, circ.advice, circ.instances, PL.ChaChaRng(ctx.lib, 0, 12))
+    prove_array = lambda: PL.create_proof(pk, adv_dev, circ.instances, PL.ArrayRng(draws), advice_on_device=True)
+    prove_host_rng = lambda: PL.create_proof(pk, adv_dev, circ.instances, PL.ChaChaRng(ctx.lib, 0, 12, device=False), advice_on_device=True)
     t0 = time.perf_counter()
     first = prove()                      # the cold first proof after keygen (allocates the key's buffer pool, builds twiddle tables)
     cold_s = time.perf_counter() - t0
@@ -300,6 +320,18 @@ def main():
         raise SystemExit("bench.py: host-resident and device-resident advice columns gave different proofs")
     if not PL.verify_proof(pk, circ.instances, proof):
         raise SystemExit("bench.py: the timed proof does not verify — refusing to report a number")
+    # the same proof with its randomness prepared OUTSIDE the call (a pre-drawn array: what r03's headline timed) and with the stream generated
+    # by the library's one-thread host generator inside the call (what a host-side rand_chacha would cost the caller): same bytes, both timed
+    prove_array()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof_array = prove_array()
+    array_rng_s = (time.perf_counter() - t0) / args.steps
+    t0 = time.perf_counter()
+    proof_host_rng = prove_host_rng()
+    host_rng_s = time.perf_counter() - t0
+    if proof_array != proof or proof_host_rng != proof:
+        raise SystemExit("bench.py: the device-generated, host-generated and pre-drawn RNG streams gave different proofs")
     if world > 1:
         import hashlib
 
@@ -359,14 +391,20 @@ def main():
             "config": {"workload": "BASELINE configs[3]: h2hip_plonk_create_proof for the k=%d secp256k1-ECDSA configuration (bench_ecdsa.config:1: 1 advice column with the "
                                    "lookup behind q_lookup, 1 constants column, lookup_bits %d, no instances), synthetic circuit-like witness (halo2_lib_amd/testing.py: "
                                    "every gate satisfied, 0/1 / small / full-width cells, range-checked cells, copy constraints); one step = one proof: host wall clock "
-                                   "around the C call with the advice column resident in HBM (advice_on_device), incl. the host RNG callback's blinding scalars (16 MiB "
-                                   "staged over PCIe) and the proof bytes coming back; `seconds_per_proof_host_advice` = the same with the advice column staged from host "
+                                   "around the C call with the advice column resident in HBM (advice_on_device), incl. the generation of the 2^k blinding scalars (ChaCha12 "
+                                   "Fr::random stream of StdRng::seed_from_u64(0), on the device) and the proof bytes coming back; `seconds_per_proof_host_advice` = the same with the advice column staged from host "
                                    "memory inside the call; witness generation (CPU gadgets, Rust) excluded" % (k, k - 1),
                        "constraints_per_proof": cells, "constraints_definition": "assigned advice cells (SURVEY.md §8d)", "msm_count": sh.num_commitments, "msm_size": n,
                        "extended_k": sh.extended_k, "degree": sh.degree, "proof_bytes": len(proof),
                        "sharding": ("ONE proof per step over %d GPUs: commitments point-range sharded (2^%d / %d points per GPU), see DESIGN.md §6" % (world, k, world)) if sharded else
                                    ("none (1 GPU)" if world == 1 else "%d independent proofs per step, one per GPU (replicas, no exchange)" % world)},
-            "seconds_per_proof": seconds, "seconds_per_proof_host_advice": host_advice_s, "seconds_per_proof_all_kernels_profiled": all_profiled_s, "cold_first_proof_seconds": cold_s, "keygen_seconds": keygen_s,
+            "seconds_per_proof": seconds, "seconds_per_proof_host_advice": host_advice_s,
+            "seconds_per_proof_with_rng": {"device_generated_chacha12": seconds, "host_generated_chacha12_one_thread": host_rng_s, "predrawn_array_outside_the_call": array_rng_s,
+                                           "proof_bytes_identical": True,
+                                           "note": "the headline (`value`, seconds_per_proof) draws its blinding from `StdRng::seed_from_u64(0)`'s Fr::random stream (ChaCha12, "
+                                                   "halo2-base/src/utils/testing.rs:38) generated on the device INSIDE the timed call (h2hip_chacha_rng_fill handed to create_proof: "
+                                                   "csrc/rng.hip); host_generated = the same stream from libh2hip's one-thread host generator behind the RNG callback (1 proof); "
+                                                   "predrawn_array = r03's set-up, randomness prepared before the call.  Stream layout [UPSTREAM-RECALL], block function pinned to RFC 8439"}, "seconds_per_proof_all_kernels_profiled": all_profiled_s, "cold_first_proof_seconds": cold_s, "keygen_seconds": keygen_s,
             "proof_verified_by_h2hip_plonk_verify_proof": True, "proof_repeatable": True,
             "stage_ms": {k_: round(v, 3) for k_, v in stages.items()}, "stage_ms_sum": round(sum(stages.values()), 3),
             "kernel_ms_per_proof": account, "gpu_busy_ms_per_proof": busy_all_ms,
@@ -400,9 +438,24 @@ def main():
                 cb = cpu_baseline_create_proof(ctx, kzg, pk, circ, draws, proof, k, s_toxic)
                 out["cpu_baseline"] = {"value": cells / cb["seconds"], "unit": "constraints/s", "cores": cb["cores"], "kind": "port", "sample": cb["sample"], **{
                     k_: v for k_, v in cb.items() if k_ not in ("cores", "kind", "sample")}}
-                out["speedup_vs_cpu_port"] = cb["seconds"] / seconds
+                out["speedup_vs_cpu_port"] = cb["seconds"] / host_advice_s   # like for like: both take the witness from host memory
+                out["speedup_vs_cpu_port_advice_resident_in_hbm"] = cb["seconds"] / seconds
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world > 1:
+            P96 = 96
+            nl_ = sh.num_lookups
+            out["comm"] = {"transport": "RCCL (ncclAllGather on the context's stream; librccl dlopen'ed by libh2hip)" if comm_ranks[0]["is_rccl"] else
+                                        "callback (torch.distributed %s all_gather on host tensors)" % args.dist_backend,
+                           "ranks": comm_ranks, "distinct_gpus": len({r["gpu_uuid"] or r["pci_bus_id"] or r["cuda_device"] for r in comm_ranks}),
+                           "sharded_proof_exchanges": None if not sharded else {
+                               "host_allgather_payload_bytes_per_rank": [72, P96 * (sh.num_advice_total + 2 * nl_), P96 * (sh.num_perm_sets + nl_ + 1), 0,
+                                                                         P96 * sh.quotient_pieces, P96, P96],
+                               "host_allgather_what": ["hello (shape, point range, RNG digest)", "round 1: advice + permuted lookup columns", "round 2: grand products + random polynomial",
+                                                       "go-ahead before the coset all-gather (status only)", "h(X) pieces", "SHPLONK W", "SHPLONK W'"],
+                               "device_allgather_bytes_per_rank": 32 * n * (-(-(1 << (sh.extended_k - k)) // world)),
+                               "device_allgather_what": "this rank's cosets of h(X)'s numerator, [max cosets per rank][2^k] Fr, device to device",
+                               "status_word_bytes": 8}}
         out["reference_published"] = {"total_proof_time_s": 7.6, "source": "/root/reference/README.md:242 (32 vCPU r6a / M2 Max, end to end incl. witness generation; other hardware)"}
     if sk is not None:
         sk.free()

@@ -272,9 +272,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_tile_kernel")) return &ctx->ntt_tile_kernel;
-    if (!strcmp(name, "ntt_stagger")) return &ctx->ntt_stagger;
-    if (!strcmp(name, "ntt_stagger_mode")) return &ctx->ntt_stagger_mode;
-    if (!strcmp(name, "ntt_grid_full")) return &ctx->ntt_grid_full;
+    if (!strcmp(name, "plonk_warm_keygen")) return &ctx->plonk_warm_keygen;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
@@ -304,7 +302,7 @@ int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value) {
     if (p == &ctx->msm_scatter_split) H2_REQUIRE(value >= 0 && value <= 64 && (value & (value - 1)) == 0, "msm_scatter_split must be 0 or a power of two <= 64");
     if (p == &ctx->msm_lanes) H2_REQUIRE(value >= 0 && value <= 4, "msm_lanes must be 0 (auto) or 1..4");
     if (p == &ctx->ntt_min_col_bits) H2_REQUIRE(value >= 0 && value <= 5, "ntt_min_col_bits must be 0..5");
-    if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 11, "ntt_tile_bits must be 4..11 (11: only the full-tile kernel exists at that size)");
+    if (p == &ctx->ntt_tile_bits) H2_REQUIRE(value >= 4 && value <= 10, "ntt_tile_bits must be 4..10");
     *p = value;
     return H2HIP_OK;
 }

@@ -80,7 +80,6 @@ struct h2hip_ctx {
     int ntt_min_col_bits = 2;    // log2 of the minimum number of adjacent columns per tile (coalescing vs number of passes)
     int ntt_full_table = 1;      // first pass reads a full omega^e table instead of composing two table entries
     int ntt_tile_kernel = 1;     // 1 (default): full 1024-element tiles go through ntt_tile_kernel (r04: no exposed global-memory latency); 0: the generic pass kernel
-    int ntt_stagger = 3, ntt_stagger_mode = 0, ntt_grid_full = 0;   // EXPERIMENT (r04): start delay per workgroup class (units of s_sleep 127), class = f(blockIdx) by mode 1..3; 1: grid = all slots
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
@@ -108,6 +107,11 @@ struct h2hip_ctx {
     char *job_ring = nullptr;
     size_t job_ring_off = 0;
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
+#ifdef H2_HIPEMU
+    int plonk_warm_keygen = 0;       // (the CPU-emulated test build does not pay for a second proof per key)
+#else
+    int plonk_warm_keygen = 1;       // h2hip_plonk_keygen ends with one throw-away proof (pool, twiddles, lanes warm when it returns)
+#endif
     int fr_invert_run = 0;           // elements per lane (= per inversion) in h2hip_fr_batch_invert_dev; 0 = auto (n / 2^16 in 4..32)
     int lookup_big_tile_bits = 19;   // lookup sort: 4096-key LDS tiles from 2^bits padded keys (12..28), 1024-key tiles below
     int msm_quad_seg_max = 32768;   // bucket reduction: quad-lane kernels up to this many segments (latency-bound), one-lane kernels above

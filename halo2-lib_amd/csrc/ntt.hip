@@ -205,39 +205,36 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(NttCols cols, uint32_t lo
 // four compile-time iterations.  Same LDS layout, same arithmetic, bit-identical results.
 // KIND: 0 = first pass (log_s = 0; IN_MUL: fused coset scaling with implicit zero padding), 1 = middle pass, 2 = last pass (no
 // inter-pass twiddles; OUT_MUL: fused ifft divisor / zeta^-i scaling).
-// TB = log2 of the tile (10: 256 lanes, 48-byte LDS elements, the next tile prefetched into registers, three workgroups per CU;
-// 11: 512 lanes, bare 36-byte LDS elements (9-word stride: conflict-free 4-byte accesses), no register prefetch and at most 128 registers per
-// lane, so that TWO workgroups = 16 waves = four per SIMD share a CU: a third more waves to issue from while others wait).
+// LDS: the 1024-element tile as 48-byte elements (three 16-byte accesses per element), the stage twiddles and the three scales behind it as
+// bare 36-byte elements, so that a pass with m = 8 (128 twiddles) still fits three workgroups into a CU's 160 KiB (with 48-byte twiddles it
+// took 55.7 KiB and only two fitted).  Measured and left behind in r04 (profiles/r04_ntt_experiments.log): a 2048-element build on 36-byte
+// elements with 512 lanes, at most 128 registers and no register prefetch — four waves per SIMD instead of three — ran at the same speed
+// (2^22 0.60 vs 0.61 ms), as did start delays that put a CU's workgroups out of phase.
 struct Fr29P {   // packed LDS element
     uint32_t l[9];
 };
-template <bool PACKED>
+__device__ __forceinline__ Fr29 ld29(const Fr29P *p) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = p->l[i];
+    return r;
+}
+__device__ __forceinline__ void st29(Fr29P *p, const Fr29 &v) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p->l[i] = v.l[i];
+}
 struct TileElem {
     typedef Fr29L type;
     static __device__ __forceinline__ Fr29 ld(const type *p) { return p->v; }
     static __device__ __forceinline__ void st(type *p, const Fr29 &v) { p->v = v; }
 };
-template <>
-struct TileElem<true> {
-    typedef Fr29P type;
-    static __device__ __forceinline__ Fr29 ld(const type *p) {
-        Fr29 r;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) r.l[i] = p->l[i];
-        return r;
-    }
-    static __device__ __forceinline__ void st(type *p, const Fr29 &v) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) p->l[i] = v.l[i];
-    }
-};
-template <int KIND, bool MUL, int TB>
-__global__ __launch_bounds__(1 << (TB - 2), TB == 11 ? 4 : 3) void ntt_tile_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
-                                                                                 const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
-                                                                                 const Fr29L *__restrict__ tdirect, uint32_t in_len, NttScale sc, uint32_t stagger, uint32_t stagger_mode) {
-    constexpr bool FIRST = KIND == 0, LAST = KIND == 2, PACKED = TB == 11, PREFETCH = TB == 10;
-    constexpr uint32_t TILE = 1u << TB, T = TILE / 4;
-    typedef TileElem<PACKED> E;
+template <int KIND, bool MUL>
+__global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
+                                                          const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
+                                                          const Fr29L *__restrict__ tdirect, uint32_t in_len, NttScale sc) {
+    constexpr bool FIRST = KIND == 0, LAST = KIND == 2, PREFETCH = true;
+    constexpr uint32_t TB = 10, TILE = 1u << TB, T = TILE / 4;
+    typedef TileElem E;
     typedef typename E::type Elem;
     HIP_DYNAMIC_SHARED(uint4, lds_tile_raw)
     Elem *lds = reinterpret_cast<Elem *>(lds_tile_raw);
@@ -245,13 +242,13 @@ __global__ __launch_bounds__(1 << (TB - 2), TB == 11 ? 4 : 3) void ntt_tile_kern
     Fr *__restrict__ y = cols.y[blockIdx.y];
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << m, C = 1u << cb;   // R * C = TILE
-    Elem *tw_s = lds + TILE;                    // omega_R^k, k < R/2
-    Elem *scale_s = tw_s + (R >> 1) + 1;        // [0..3) the three scales (R' form)
+    Fr29P *tw_s = reinterpret_cast<Fr29P *>(lds + TILE);   // omega_R^k, k < R/2
+    Fr29P *scale_s = tw_s + (R >> 1);                      // [0..3) the three scales (R' form)
     const uint32_t rows_stride = 1u << (log_n - m);
     const uint32_t ntiles = 1u << (log_n - TB);
     const uint32_t smask = (1u << log_s) - 1;
-    for (uint32_t k = tid; k < (R >> 1); k += T) E::st(&tw_s[k], tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m)));
-    if (MUL && tid < 3) E::st(&scale_s[tid], fr29_from_sat(FIRST ? sc.in3[tid] : sc.out3[tid]));
+    for (uint32_t k = tid; k < (R >> 1); k += T) st29(&tw_s[k], tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m)));
+    if (MUL && tid < 3) st29(&scale_s[tid], fr29_from_sat(FIRST ? sc.in3[tid] : sc.out3[tid]));
 
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     v4u pre[4][2];
@@ -269,16 +266,6 @@ __global__ __launch_bounds__(1 << (TB - 2), TB == 11 ? 4 : 3) void ntt_tile_kern
     };
     uint32_t tile = blockIdx.x;
     if (tile >= ntiles) return;
-#ifndef H2_HIPEMU
-    // EXPERIMENT (r04): all workgroups start together and run identical phases (fill / butterflies / read-out), so the whole chip loads,
-    // computes and stores in lock step; a one-time start delay per workgroup class puts a CU's co-resident workgroups out of phase
-    if (stagger_mode) {
-        constexpr uint32_t PH = TB == 11 ? 2 : 3;
-        const uint32_t b = blockIdx.x;
-        const uint32_t ph = stagger_mode == 1 ? (b >> 8) % PH : stagger_mode == 2 ? (b >> 3) % PH : b % PH;
-        for (uint32_t i = 0; i < ph * stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     if (PREFETCH) fetch(tile);
     __syncthreads();   // tw_s / scale_s visible
 
@@ -290,14 +277,14 @@ __global__ __launch_bounds__(1 << (TB - 2), TB == 11 ? 4 : 3) void ntt_tile_kern
         const uint32_t e0 = (((blk << (st + 2)) + i) << cb) + gc, stride = h << cb;
         Fr29 x0 = E::ld(&lds[e0]), x1 = E::ld(&lds[e0 + stride]), x2 = E::ld(&lds[e0 + 2 * stride]), x3 = E::ld(&lds[e0 + 3 * stride]);
         if (st) {   // stage st: omega_{2h}^i (for st == 0 it is 1)
-            const Fr29 w1 = E::ld(&tw_s[i << (m - 1 - st)]);
+            const Fr29 w1 = ld29(&tw_s[i << (m - 1 - st)]);
             x1 = f29_mul(x1, w1);
             x3 = f29_mul(x3, w1);
         }
         const Fr29 y0 = f29_add(x0, x1), y1 = f29_sub_lazy<2>(x0, x1);
         // stage st+1 (half = 2h): omega_{4h}^i and omega_{4h}^(i+h)
-        const Fr29 y2 = f29_mul_wide(f29_add(x2, x3), E::ld(&tw_s[i << (m - 2 - st)]));
-        const Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), E::ld(&tw_s[(i + h) << (m - 2 - st)]));
+        const Fr29 y2 = f29_mul_wide(f29_add(x2, x3), ld29(&tw_s[i << (m - 2 - st)]));
+        const Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), ld29(&tw_s[(i + h) << (m - 2 - st)]));
         E::st(&lds[e0], f29_norm(f29_add(y0, y2)));
         E::st(&lds[e0 + 2 * stride], f29_sub<2>(y0, y2));
         E::st(&lds[e0 + stride], f29_norm(f29_add(y1, y3)));
@@ -318,7 +305,7 @@ __global__ __launch_bounds__(1 << (TB - 2), TB == 11 ? 4 : 3) void ntt_tile_kern
             Fr29 v = f29_split<R29P>(s);
             if (FIRST) {
                 const uint32_t idx = j0 + c + t * rows_stride;
-                if (MUL) v = f29_mul(v, E::ld(&scale_s[idx % 3u]));
+                if (MUL) v = f29_mul(v, ld29(&scale_s[idx % 3u]));
                 if (idx >= in_len) v = Fr29::zero();
             }
             E::st(&lds[(bitrev_m(t, m) << cb) + c], v);
@@ -379,7 +366,7 @@ __global__ __launch_bounds__(1 << (TB - 2), TB == 11 ? 4 : 3) void ntt_tile_kern
         for (uint32_t k = 0; k < 4; ++k) {
             Fr29 v = E::ld(&lds[lidx[k]]);
             if (!LAST) v = f29_mul(v, twr[k]);
-            if (LAST && MUL) v = f29_mul(v, E::ld(&scale_s[oidx[k] % 3u]));
+            if (LAST && MUL) v = f29_mul(v, ld29(&scale_s[oidx[k] % 3u]));
             if (LAST && !MUL) v = f29_weak_reduce(v);   // weak bound (<= 21 r) -> < 2 r before packing, no multiply
             const Fr o = f29_pack_canonical<FrP>(v);
             v4u *yp = reinterpret_cast<v4u *>(y + oidx[k]);
@@ -489,22 +476,6 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
         }
     };
     plan(LT);
-    if (LT == 11) {
-        // 2048-element tiles exist only in the full-tile kernel: every pass has to qualify for it (full tiles, direct twiddle tables), or the
-        // whole transform runs on 1024-element tiles
-        bool ok = ctx->ntt_tile_kernel && P >= 2 && N <= (1ull << 28);
-        for (uint32_t i = 0, ls = 0; ok && i < P; ls += mlist[i], ++i) {
-            uint32_t cbi = LT - mlist[i];
-            if (cbi > log_n - mlist[i]) cbi = log_n - mlist[i];
-            if (i > 0 && cbi > ls) cbi = ls;
-            ok = mlist[i] >= 2 && mlist[i] + cbi == LT;
-            if (ok && i + 1 < P) ok = ls ? log_n - ls <= 16 : (log_n <= 23 && ctx->ntt_full_table);
-        }
-        if (!ok) {
-            LT = 10;
-            plan(LT);
-        }
-    }
     TwiddleSet *tw = nullptr;
     H2_CHK(get_twiddles(ctx, log_n, omega, &tw));
     const size_t group = ncols < NTT_BATCH ? ncols : NTT_BATCH;
@@ -533,34 +504,19 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
             const uint32_t grid = tiles < (uint32_t)ctx->num_cus * 3 ? tiles : (uint32_t)ctx->num_cus * 3;
             const Fr29L *tdirect = nullptr;
             if (i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
-            // the specialised full-tile kernels: every pass of a transform larger than the tile
-            if (ctx->ntt_tile_kernel && P >= 2 && m + cb == LT && (LT == 10 || LT == 11) && m >= 2 && (last || tdirect) && N <= (1ull << 28)) {
-                const bool big = LT == 11;
-                const size_t shmem_t = (big ? sizeof(Fr29P) : sizeof(Fr29L)) * (((size_t)1 << LT) + ((size_t)1 << (m - 1)) + 8);
-                // equal shares: every workgroup walks `rounds` tiles (the last few one less) instead of some walking one more than the others
-                const uint32_t slots = (uint32_t)ctx->num_cus * (big ? 2 : 3), rounds = (tiles + slots - 1) / slots;
-                const uint32_t grid_t = ctx->ntt_grid_full ? (tiles < slots ? tiles : slots) : (tiles + rounds - 1) / rounds;
+            // the specialised full-tile kernel: every pass of a transform larger than the tile
+            if (ctx->ntt_tile_kernel && P >= 2 && LT == 10 && m + cb == 10 && m >= 2 && (last || tdirect) && N <= (1ull << 28)) {
+                const size_t shmem_t = sizeof(Fr29L) * 1024 + sizeof(Fr29P) * (((size_t)1 << (m - 1)) + 3);
+                // one persistent workgroup per slot (measured against equal shares — ceil(tiles / rounds) workgroups, every one walking the same number
+                // of tiles: 2^22 0.62 vs 0.575 ms, profiles/r04_ntt_experiments.log: fewer workgroups than slots leave a third of the CUs one short)
+                const uint32_t slots = (uint32_t)ctx->num_cus * 3;
+                const uint32_t grid_t = tiles < slots ? tiles : slots;
                 const bool mul = first ? in_scale3 != nullptr : (last && out_scale3 != nullptr);
                 const uint32_t in_len32 = (uint32_t)(first ? in_len : N);
-                if (big && !ctx->ntt_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
-                    const int cap = (int)(sizeof(Fr29P) * (2048 + 1024 + 8));
-                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<0, true, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<0, false, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<1, false, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<2, true, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                    H2_HIPCHK(hipFuncSetAttribute((const void *)ntt_tile_kernel<2, false, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-                    ctx->ntt_lds_attr_set = true;
-                }
                 prof_begin(ctx, "ntt_pass_kernel");
-#define H2_NTT_TILE(KIND, MUL)                                                                                                                          \
-    do {                                                                                                                                                \
-        if (big)                                                                                                                                        \
-            hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL, 11>), dim3(grid_t, gc), dim3(512), shmem_t, ctx->stream, cols, log_n, m, log_s, cb,          \
-                               (const Fr29L *)tw->t1, (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc, (uint32_t)ctx->ntt_stagger, (uint32_t)ctx->ntt_stagger_mode); \
-        else                                                                                                                                            \
-            hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL, 10>), dim3(grid_t, gc), dim3(256), shmem_t, ctx->stream, cols, log_n, m, log_s, cb,          \
-                               (const Fr29L *)tw->t1, (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc, (uint32_t)ctx->ntt_stagger, (uint32_t)ctx->ntt_stagger_mode); \
-    } while (0)
+#define H2_NTT_TILE(KIND, MUL)                                                                                                                \
+    hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL>), dim3(grid_t, gc), dim3(256), shmem_t, ctx->stream, cols, log_n, m, log_s, cb, (const Fr29L *)tw->t1, \
+                       (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc)
                 if (first) {
                     if (mul) H2_NTT_TILE(0, true);
                     else H2_NTT_TILE(0, false);

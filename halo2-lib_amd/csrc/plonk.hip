@@ -1420,6 +1420,41 @@ int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, 
         h2hip_plonk_pk_free(ctx, pk);
         return rc;
     }
+    // Warm-up (r04): one throw-away proof of the all-zero witness, so that what a FIRST create_proof used to pay for — the key's buffer pool,
+    // the twiddle tables of both domains, the MSM lanes and their scratch, the pinned staging buffer, the LDS attributes — exists when keygen
+    // returns (the first proof after keygen took 22-27 ms against 15 ms warm).  Best effort: a failure here only leaves the first proof cold.
+    if (ctx->plonk_warm_keygen) {
+        std::vector<Fr *> zero_cols(pk->sh.num_advice_total, nullptr);
+        bool ok = true;
+        for (auto &c : zero_cols) {
+            if (hipMalloc((void **)&c, sizeof(Fr) * pk->sh.n) != hipSuccess) {
+                c = nullptr;
+                ok = false;
+                break;
+            }
+            hipMemsetAsync(c, 0, sizeof(Fr) * pk->sh.n, ctx->stream);
+        }
+        if (ok) {
+            std::vector<const void *> adv(zero_cols.begin(), zero_cols.end());
+            std::vector<Fr> inst_zero(1, Fr::zero());
+            std::vector<const void *> inst(pk->sh.p.num_instance, inst_zero.data());
+            std::vector<size_t> inst_len(pk->sh.p.num_instance, 0);
+            h2hip_chacha_rng wr;
+            uint8_t seed[32] = {0};
+            h2hip_chacha_rng_init(&wr, seed, 8);
+            std::vector<uint8_t> throwaway;
+            const Fr saved = pk->transcript_repr;
+            pk->transcript_repr = Fr::zero();
+            const int wrc = create_proof_impl(ctx, pk, adv.data(), true, inst.data(), inst_len.data(), h2hip_chacha_rng_fill, &wr, throwaway, nullptr);
+            pk->transcript_repr = saved;
+            if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
+            hipStreamSynchronize(ctx->stream);
+            if (wrc != H2HIP_OK) set_error("");   // not the caller's error
+        }
+        hipStreamSynchronize(ctx->stream);
+        for (Fr *c : zero_cols)
+            if (c) hipFree(c);
+    }
     *out = pk;
     return H2HIP_OK;
 }

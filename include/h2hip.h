@@ -57,8 +57,8 @@ int h2hip_init(int device, void *hip_stream, h2hip_ctx **out);
 void h2hip_destroy(h2hip_ctx *ctx);
 int h2hip_sync(h2hip_ctx *ctx);
 /* tuning knobs (defaults are the tuned values): "msm_window_bits" (0 = auto), "msm_chunk" (0 = auto), "msm_seg",
- * "msm_scatter_split" (0 = auto), "msm_lanes", "msm_quad_tails", "msm_fuse_cols", "msm_defer_reduce", "ntt_tile_bits" (10; 11 = 2048-element
- * tiles), "ntt_tile_kernel" (1 = the specialised full-tile pass kernel, 0 = the generic one), "ntt_min_col_bits", "ntt_full_table";
+ * "msm_scatter_split" (0 = auto), "msm_lanes", "msm_quad_tails", "msm_fuse_cols", "msm_defer_reduce", "ntt_tile_bits" (10),
+ * "ntt_tile_kernel" (1 = the specialised full-tile pass kernel, 0 = the generic one), "ntt_min_col_bits", "ntt_full_table";
  * profiling aid: "ntt_debug_skip" (produces wrong results).  The variants r01-r03 measured slower (two-level sort, bucket-major sort,
  * split streams, split windows, accumulation builds 2/5/6/7, radix-8 and wave-local NTT passes) were removed in r04; their A/B logs stay
  * under profiles/. */

@@ -544,11 +544,10 @@ def test_full_range_field_inputs(ctx):
     F.check_eval_and_division(ctx, [1, 9, 2049])
 
 
-@pytest.mark.parametrize("tile_bits,tile_kernel", [(10, 1), (10, 0), (11, 1)])
+@pytest.mark.parametrize("tile_bits,tile_kernel", [(10, 1), (10, 0)])
 def test_ntt_full_tile_kernels(ctx, tile_bits, tile_kernel):
-    """ntt_tile_kernel (r04): the specialised full-tile pass kernel at 1024-element tiles (the default), the generic pass kernel instead
-    (ntt_tile_kernel = 0), and the 2048-element / 36-byte-element build (ntt_tile_bits = 11; sizes whose passes do not all fill such a tile
-    fall back to 1024-element tiles) — forward, inverse with its fused divisor, coset extension with zero padding and back, bit-exact"""
+    """ntt_tile_kernel (r04): the specialised full-tile pass kernel (the default) and the generic pass kernel instead (ntt_tile_kernel = 0)
+    — forward, inverse with its fused divisor, coset extension with zero padding and back, bit-exact"""
     ctx.set_param("ntt_tile_bits", tile_bits)
     ctx.set_param("ntt_tile_kernel", tile_kernel)
     try:

@@ -265,3 +265,40 @@ def test_prover_flow_gpu(k):
         _prove_and_verify(ctx, k, seed=k)
     finally:
         ctx.close()
+
+
+def test_keygen_warm_up_proof_emulated():
+    """plonk_warm_keygen = 1 (the GPU build's default): keygen ends with a throw-away proof of the all-zero witness so that the first real
+    proof finds the buffer pool, twiddle tables and lanes in place — the key and the proofs made from it are the same with and without it"""
+    import halo2_lib_amd as H
+    from halo2_lib_amd import halo2_proofs as HP
+    from halo2_lib_amd import plonk as PL
+    from halo2_lib_amd import testing as T
+    from oracle import c_oracle as CO
+    from oracle import plonk as P
+    from tests.emu_util import emu_context
+    from tests.util import PreDrawnRng
+
+    class _B:
+        mul = staticmethod(CO.fr_mul)
+        add = staticmethod(CO.fr_add)
+
+    ctx = emu_context()
+    try:
+        shape = (6, 2, 1, 1, 1, 4)
+        sh = P.Shape(*shape)
+        kzg = HP.ParamsKZG.setup(ctx, 6, 0xBEEF, precompute=False)
+        circ = T.build_circuit(sh, 2, _B)
+        proofs, reprs = [], []
+        for warm in (0, 1):
+            ctx.set_param("plonk_warm_keygen", warm)
+            pk = PL.keygen(kzg, PL.BaseCircuitParams.new(*shape), circ.fixed, circ.copies)
+            reprs.append(pk.transcript_repr)
+            proofs.append(PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(2000, 5)))
+            assert PL.verify_proof(pk, circ.instances, proofs[-1])
+            pk.free()
+        assert proofs[0] == proofs[1] and reprs[0] == reprs[1]
+        kzg.free()
+    finally:
+        ctx.set_param("plonk_warm_keygen", 0)
+        ctx.close()

@@ -31,7 +31,7 @@ while time.time() - t0 < budget:
     shape = (k, na, nl, nf, ni, lb)
     knobs = {}
     if os.environ.get("H2HIP_FUZZ_KNOBS"):
-        knobs = {"ntt_tile_kernel": rnd.choice([1, 1, 0]), "ntt_tile_bits": rnd.choice([10, 10, 11, 6]), "msm_fuse_cols": rnd.choice([0, 1, 4]),
+        knobs = {"ntt_tile_kernel": rnd.choice([1, 1, 0]), "ntt_tile_bits": rnd.choice([10, 10, 8, 6]), "msm_fuse_cols": rnd.choice([0, 1, 4]),
                  "msm_lanes": rnd.choice([0, 1, 2]), "msm_defer_reduce": rnd.choice([1, 1, 0])}
         for name, val in knobs.items():
             ctx.set_param(name, val)
