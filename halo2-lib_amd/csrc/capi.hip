@@ -96,6 +96,17 @@ static void prof_collect(h2hip_ctx *ctx) {
     ctx->pending.clear();
 }
 
+// a child context's (MSM lane, the prover's side stream) kernel timers into the parent's table
+void prof_fold_child(h2hip_ctx *parent, h2hip_ctx *child) {
+    prof_collect(child);
+    for (auto &kv : child->stats) {
+        parent->stats[kv.first].total_ms += kv.second.total_ms;
+        parent->stats[kv.first].launches += kv.second.launches;
+        parent->stats[kv.first].spans.insert(parent->stats[kv.first].spans.end(), kv.second.spans.begin(), kv.second.spans.end());
+    }
+    child->stats.clear();
+}
+
 __global__ void point_finish_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         XYZZ p = in[0];
@@ -228,6 +239,7 @@ void h2hip_destroy(h2hip_ctx *ctx) {
         hipStreamSynchronize(ctx->clean_stream);
         hipStreamDestroy(ctx->clean_stream);
         hipEventDestroy(ctx->clean_ev);
+        if (ctx->tail_ev) hipEventDestroy(ctx->tail_ev);
         hipEventDestroy(ctx->used_ev);
     }
     if (ctx->job_ring) hipHostFree(ctx->job_ring);
@@ -273,6 +285,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_tile_kernel")) return &ctx->ntt_tile_kernel;
     if (!strcmp(name, "plonk_warm_keygen")) return &ctx->plonk_warm_keygen;
+    if (!strcmp(name, "plonk_tail_overlap")) return &ctx->plonk_tail_overlap;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
@@ -712,6 +725,13 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));
         H2_HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
     }
+    if (ctx->msm_tail_hook) {   // the accumulations are queued and joined: what follows on this stream is the reduction's tail
+        std::function<int(hipEvent_t)> hook;
+        hook.swap(ctx->msm_tail_hook);
+        if (!ctx->tail_ev) H2_HIPCHK(hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming));
+        H2_HIPCHK(hipEventRecord(ctx->tail_ev, ctx->stream));
+        H2_CHK(hook(ctx->tail_ev));
+    }
     if (deferred) {   // one bucket reduction per 64 columns, on the caller's stream
         XYZZ *sums = nullptr;
         H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OUT, sizeof(XYZZ) * count, (void **)&sums));
@@ -730,13 +750,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->profiling)   // fold the lanes' kernel timers into the parent's table
         for (int l = 0; l < NL; ++l) {
-            prof_collect(ctx->lane[l]);
-            for (auto &kv : ctx->lane[l]->stats) {
-                ctx->stats[kv.first].total_ms += kv.second.total_ms;
-                ctx->stats[kv.first].launches += kv.second.launches;
-                ctx->stats[kv.first].spans.insert(ctx->stats[kv.first].spans.end(), kv.second.spans.begin(), kv.second.spans.end());
-            }
-            ctx->lane[l]->stats.clear();
+            prof_fold_child(ctx, ctx->lane[l]);
         }
     return H2HIP_OK;
 }

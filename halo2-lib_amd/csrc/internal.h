@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -106,7 +107,14 @@ struct h2hip_ctx {
     // asynchronously without a stream synchronisation per call (upload_jobs in capi.hip)
     char *job_ring = nullptr;
     size_t job_ring_off = 0;
+    // One-shot hook of the batch MSM (set by the prover before a commitment round): called on the host right after the lanes' accumulations and
+    // merges have been joined into `stream` — `ev` is recorded there at that point — and BEFORE the latency-bound bucket reduction is queued, so
+    // that work the caller queues on another stream behind `ev` runs next to the reduction's few waves instead of after them (plonk.hip: the
+    // round's challenge-independent transforms).  Cleared before it is called; left set if the call took a path without lanes.
+    std::function<int(hipEvent_t ev)> msm_tail_hook;
+    hipEvent_t tail_ev = nullptr;
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
+    int plonk_tail_overlap = 1;      // create_proof: the challenge-independent transforms of rounds 1 and 3 run on a side stream next to the commitment MSMs' bucket reduction
 #ifdef H2_HIPEMU
     int plonk_warm_keygen = 0;       // (the CPU-emulated test build does not pay for a second proof per key)
 #else
@@ -184,6 +192,8 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 // CONSUMES the state: the caller dirties the array) / schedule the fill
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);
 int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes);
+// capi.hip: a child context's (MSM lane, the prover's side stream) kernel timers folded into the parent's table
+void prof_fold_child(h2hip_ctx *parent, h2hip_ctx *child);
 // rng.hip: n elements of the ChaCha Fr::random stream from element first_block on, on `stream`
 int rng_chacha_fill_dev(h2hip_ctx *ctx, Fr *out_dev, size_t n, const uint8_t seed[32], int rounds, uint64_t first_block, hipStream_t stream);
 // comm.hip: the fallible preparations of a later h2hip_comm_allgather_dev of `bytes` per rank, done ahead of time

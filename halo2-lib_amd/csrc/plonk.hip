@@ -248,6 +248,8 @@ struct h2hip_plonk_pk {
     size_t exch_next = 0;
     hipStream_t copy_stream = nullptr;   // the RNG-drawn random polynomial is uploaded on its own stream, next to the NTTs
     hipEvent_t copy_ev = nullptr;
+    h2hip_ctx *side = nullptr;           // child context (own stream, NTT scratch and twiddle cache): the transforms that run next to an MSM's tail
+    hipEvent_t side_ev = nullptr;
     Fr *host_stage = nullptr;   // pinned staging for the RNG-drawn scalars (the n coefficients of the random polynomial, the blinding rows)
     size_t host_stage_elems = 0;
 };
@@ -610,6 +612,20 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     }
     // bump allocation over the staging buffer: a draw's values stay where they are until the buffer wraps, so the (asynchronous) uploads
     // that read them need no synchronisation per draw — wide circuits draw hundreds of small tails
+    // the vanishing argument's random polynomial: with libh2hip's counter-mode generator its n scalars are a function of (seed, position),
+    // and the position of that draw follows from the shape — generated NOW, on the copy stream, next to the first rounds
+    Fr *random_poly = nullptr;
+    bool rng_ahead = false;
+    uint64_t rng_ahead_pos = 0;
+    if (rng == h2hip_chacha_rng_fill && rng_user) {
+        const h2hip_chacha_rng *cr = (const h2hip_chacha_rng *)rng_user;
+        const uint64_t L = sh.lookups.size(), S = sh.num_perm_sets, A = sh.num_advice_total;
+        rng_ahead_pos = cr->pos + A * (uint64_t)(n - u) + A + L * (2 * ((uint64_t)bf + 1) + 2) + S * ((uint64_t)bf + 1) + L * ((uint64_t)bf + 1);
+        H2_CHK(sc.take(n, &random_poly));
+        H2_CHK(rng_chacha_fill_dev(ctx, random_poly, n, cr->seed, cr->rounds, rng_ahead_pos, pk->copy_stream));
+        H2_HIPCHK(hipEventRecord(pk->copy_ev, pk->copy_stream));
+        rng_ahead = true;
+    }
     size_t stage_off = 0;
     auto draw = [&](size_t cnt) -> const Fr * {
         if (stage_off + cnt > pk->host_stage_elems) {
@@ -738,6 +754,62 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     };
 
     const bool qshard = sharded_any && pk->shard_quotient;
+    // ---- tail overlap (r04).  A commitment round ends with the MSMs' bucket reduction: ~0.25 ms of dependent point additions on a few waves
+    // while the rest of the chip idles.  Rounds 1 and 3 are followed by transforms that do not depend on the round's challenge (the
+    // coefficient and extended forms of the columns just committed): they are queued on a side stream (a child context: own NTT scratch and
+    // twiddle cache) behind the event the batch MSM records once its accumulations are done, read the Lagrange values the MSM also reads and
+    // write NEW buffers, so they run next to the reduction and to the pointwise kernels that follow.  Single GPU only.
+    const bool overlap = !sharded_any && ctx->plonk_tail_overlap != 0;
+    if (overlap && !pk->side) {
+        H2_CHK(h2hip_init(ctx->device, nullptr, &pk->side));
+        H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
+    }
+    if (overlap) {
+        h2hip_ctx *c = pk->side;
+        c->ntt_tile_bits = ctx->ntt_tile_bits;
+        c->ntt_min_col_bits = ctx->ntt_min_col_bits;
+        c->ntt_full_table = ctx->ntt_full_table;
+        c->ntt_tile_kernel = ctx->ntt_tile_kernel;
+        c->profiling = ctx->profiling;
+        c->prof_filter = ctx->prof_filter;
+        c->prof_ref = ctx->prof_ref;
+    }
+    bool side_busy = false;   // work is queued on the side stream that the main stream has not waited for yet
+    // queues `fn` on the side stream behind the batch MSM's accumulations (or, if the commitment took a path without lanes, behind what
+    // the main stream holds after it) — `arm` before the commitment, `fire_if_pending` after it
+    auto side_arm = [&](std::function<int()> fn) {
+        ctx->msm_tail_hook = [&, fn](hipEvent_t ev) -> int {
+            H2_HIPCHK(hipStreamWaitEvent(pk->side->stream, ev, 0));
+            H2_CHK(fn());
+            H2_HIPCHK(hipEventRecord(pk->side_ev, pk->side->stream));
+            side_busy = true;
+            return H2HIP_OK;
+        };
+    };
+    auto side_fire_if_pending = [&]() -> int {
+        if (!ctx->msm_tail_hook) return H2HIP_OK;
+        std::function<int(hipEvent_t)> hook;
+        hook.swap(ctx->msm_tail_hook);
+        if (!ctx->tail_ev) H2_HIPCHK(hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming));
+        H2_HIPCHK(hipEventRecord(ctx->tail_ev, st));
+        return hook(ctx->tail_ev);
+    };
+    auto side_join = [&]() -> int {   // the main stream continues after everything queued on the side stream
+        if (side_busy) H2_HIPCHK(hipStreamWaitEvent(st, pk->side_ev, 0));
+        side_busy = false;
+        return H2HIP_OK;
+    };
+    // out-of-place lagrange_to_coeff + coeff_to_extended of `src` columns on the side context: coef[i] / cos[i] are taken here
+    auto side_transforms = [&](const std::vector<Fr *> &src, std::vector<Fr *> &coef, std::vector<Fr *> &cos) -> int {
+        coef.assign(src.size(), nullptr);
+        cos.assign(src.size(), nullptr);
+        for (size_t i = 0; i < src.size(); ++i) H2_CHK(sc.take(n, &coef[i]));
+        for (size_t i = 0; i < src.size(); ++i) H2_CHK(sc.take(ne, &cos[i]));
+        const Fr out3[3] = {dom.ifft_divisor, dom.ifft_divisor, dom.ifft_divisor};
+        H2_CHK(ntt_run_batch(pk->side, coef.data(), (const Fr *const *)src.data(), src.size(), k, dom.omega_inv, n, nullptr, out3));
+        return h2hip_coeff_to_extended_batch_dev(pk->side, (const void *const *)coef.data(), k, (void *const *)cos.data(), ek, src.size(), &dom.ext_omega, &dom.zeta);
+    };
+    std::vector<Fr *> r1_src, r1_coef, r1_cos, r3_src, r3_coef, r3_cos;
     const size_t ncm = qshard ? pk->my_cosets.size() : 0;                 // cosets of the extended domain evaluated here
     const size_t ne_loc = qshard ? std::max<size_t>(ncm * (size_t)n, 1) : ne;   // extended-domain evaluations of a column held by this rank
     pk->exch_sizes.clear();
@@ -876,7 +948,17 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         }
         laps.lap(ST_LOOKUP_PERMUTE);
         std::vector<G1Affine> pts;
+        if (overlap) {   // this round's columns -> coefficient and extended form, next to the commitments' reduction and the grand products
+            r1_src.assign(adv.begin(), adv.end());
+            for (Fr *p : inst_values) r1_src.push_back(p);
+            for (LookupState &s : lks) {
+                r1_src.push_back(s.ap);
+                r1_src.push_back(s.sp);
+            }
+            side_arm([&]() -> int { return side_transforms(r1_src, r1_coef, r1_cos); });
+        }
         H2_CHK(commit_points(pk->g_lagrange, cols, n, pts));
+        H2_CHK(side_fire_if_pending());
         for (size_t i = 0; i < adv.size(); ++i) H2_CHK(tr.write_point(pts[i]));
         const Fr theta = tr.squeeze_challenge();
         (void)theta;
@@ -946,8 +1028,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // ---- this round's commitments are the grand products AND the vanishing argument's random polynomial (nothing is squeezed between
     // them): one batched call over two base sets.  Before the host draws the 2^k random scalars, the GPU is given everything that no longer
     // needs the Lagrange values of the first-round columns: their coefficient and extended forms — RNG, upload (own stream) and NTTs overlap.
-    Fr *random_poly = nullptr;
-    H2_CHK(sc.take(n, &random_poly));
+    if (!random_poly) H2_CHK(sc.take(n, &random_poly));
     // all columns of a round go through the transforms together (32 per launch): a wide shape's 2^14-row columns are far too small to fill the chip alone
     auto to_coeff = [&](const std::vector<Fr *> &cols) -> int {
         return h2hip_ifft_batch_dev(ctx, (void *const *)cols.data(), cols.size(), &dom.omega_inv, k, &dom.ifft_divisor);
@@ -979,6 +1060,35 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     };
     std::vector<Fr *> adv_cos(adv.size()), inst_cos(inst_values.size()), perm_cos(sh.num_perm_sets);
     std::vector<LookupCosets> lk_cos(lks.size());
+    std::vector<Fr *> lagrange_done;   // Lagrange-form buffers the side stream may still be reading: released after side_join()
+    if (overlap) {
+        // the side stream holds (or is still producing) the coefficient and extended forms of the first-round columns; the grand products
+        // above were the last readers of their Lagrange values on THIS stream: the names move on to the new buffers
+        size_t i = 0;
+        for (size_t c = 0; c < adv.size(); ++c, ++i) {
+            lagrange_done.push_back(adv[c]);
+            adv[c] = r1_coef[i];
+            adv_cos[c] = r1_cos[i];
+        }
+        for (size_t c = 0; c < inst_values.size(); ++c, ++i) {
+            lagrange_done.push_back(inst_values[c]);
+            inst_values[c] = r1_coef[i];
+            inst_cos[c] = r1_cos[i];
+        }
+        for (size_t li = 0; li < lks.size(); ++li) {
+            LookupState &s = lks[li];
+            if (s.own_inp) {
+                sc.release(s.inp);   // (a product of this stream, never read by the side stream)
+                s.inp = nullptr;
+            }
+            lagrange_done.push_back(s.ap);
+            s.ap = r1_coef[i];
+            lk_cos[li].ap = r1_cos[i++];
+            lagrange_done.push_back(s.sp);
+            s.sp = r1_coef[i];
+            lk_cos[li].sp = r1_cos[i++];
+        }
+    } else
     {
         std::vector<Fr *> round1(adv.begin(), adv.end());
         std::vector<Fr **> round1_cos;
@@ -1001,23 +1111,36 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(to_coeff(round1));
         H2_CHK(to_ext(round1, round1_cos));
     }
-    for (size_t li = 0; li < lks.size(); ++li) {
-        const Lookup &l = sh.lookups[li];
-        LookupCosets &c = lk_cos[li];
+    auto lookup_input_cosets = [&]() -> int {
+        for (size_t li = 0; li < lks.size(); ++li) {
+            const Lookup &l = sh.lookups[li];
+            LookupCosets &c = lk_cos[li];
+            c.inp = nullptr;
+            if (l.q_col >= 0) {   // the product of the cosets is the coset of the product polynomial q_lookup(X) * a(X)
+                H2_CHK(sc.take(ne_loc, &c.inp));
+                H2_CHK(h2hip_fr_mul_batch_dev(ctx, c.inp, fixed_cos(l.q_col), adv_cos[l.advice_col], qshard ? ncm * (size_t)n : ne));
+            }
+        }
+        return H2HIP_OK;
+    };
+    for (LookupCosets &c : lk_cos) {
         c.z = nullptr;
         c.inp = nullptr;
-        if (l.q_col >= 0) {   // the product of the cosets is the coset of the product polynomial q_lookup(X) * a(X)
-            H2_CHK(sc.take(ne_loc, &c.inp));
-            H2_CHK(h2hip_fr_mul_batch_dev(ctx, c.inp, fixed_cos(l.q_col), adv_cos[l.advice_col], qshard ? ncm * (size_t)n : ne));
-        }
     }
+    if (!overlap) H2_CHK(lookup_input_cosets());   // (overlapping: after the side stream's extended forms have been joined, below)
     G1Affine random_commitment;
     {
         if (rng == h2hip_chacha_rng_fill) {
             // libh2hip's own seeded ChaCha generator: counter mode, so the n elements are generated where they are needed — on the
-            // device, straight into the polynomial — and the host only advances the stream position (same values as the host callback)
+            // device, straight into the polynomial — and the host only advances the stream position (same values as the host callback).
+            // Normally they were generated at the start of the proof already (position known from the shape), next to everything else.
             h2hip_chacha_rng *cr = (h2hip_chacha_rng *)rng_user;
-            H2_CHK(rng_chacha_fill_dev(ctx, random_poly, n, cr->seed, cr->rounds, cr->pos, st));
+            if (rng_ahead && cr->pos == rng_ahead_pos) {
+                H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));
+            } else {
+                if (rng_ahead) H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));   // (the buffer is overwritten in stream order)
+                H2_CHK(rng_chacha_fill_dev(ctx, random_poly, n, cr->seed, cr->rounds, cr->pos, st));
+            }
             cr->pos += n;
         } else {
             const Fr *vals = draw(n);
@@ -1035,14 +1158,36 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         cols.push_back(random_poly);
         bases.push_back(pk->g);
         std::vector<G1Affine> pts;
+        if (overlap) {   // the grand products' coefficient and extended forms do not depend on y: next to this round's reduction
+            r3_src.assign(perm_z.begin(), perm_z.end());
+            for (LookupState &s : lks) r3_src.push_back(s.z);
+            side_arm([&]() -> int { return side_transforms(r3_src, r3_coef, r3_cos); });
+        }
         H2_CHK(commit_points_multi(nullptr, bases, cols, n, pts));
+        H2_CHK(side_fire_if_pending());
         for (size_t i = 0; i + 1 < pts.size(); ++i) H2_CHK(tr.write_point(pts[i]));
         random_commitment = pts.back();
         laps.lap(ST_COMMIT_PRODUCTS);
     }
     H2_CHK(tr.write_point(random_commitment));
     const Fr y = tr.squeeze_challenge();
-    {
+    if (overlap) {
+        H2_CHK(side_join());   // both rounds' transforms are complete before anything below reads their results or reuses their inputs
+        for (Fr *p : lagrange_done) sc.release(p);
+        size_t i = 0;
+        for (uint32_t si = 0; si < sh.num_perm_sets; ++si, ++i) {
+            sc.release(perm_z[si]);
+            perm_z[si] = r3_coef[i];
+            perm_cos[si] = r3_cos[i];
+        }
+        for (size_t li = 0; li < lks.size(); ++li, ++i) {
+            sc.release(lks[li].z);
+            lks[li].z = r3_coef[i];
+            lk_cos[li].z = r3_cos[i];
+        }
+        H2_CHK(lookup_input_cosets());
+        if (stage_ms) laps.lap(ST_TO_COEFF);
+    } else {
         std::vector<Fr *> zs(perm_z.begin(), perm_z.end());
         std::vector<Fr **> zs_cos;
         for (uint32_t si = 0; si < sh.num_perm_sets; ++si) zs_cos.push_back(&perm_cos[si]);
@@ -1447,6 +1592,8 @@ int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, 
             pk->transcript_repr = Fr::zero();
             const int wrc = create_proof_impl(ctx, pk, adv.data(), true, inst.data(), inst_len.data(), h2hip_chacha_rng_fill, &wr, throwaway, nullptr);
             pk->transcript_repr = saved;
+            ctx->msm_tail_hook = nullptr;
+            if (pk->side) hipStreamSynchronize(pk->side->stream);
             if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
             hipStreamSynchronize(ctx->stream);
             if (wrc != H2HIP_OK) set_error("");   // not the caller's error
@@ -1468,6 +1615,8 @@ void h2hip_plonk_pk_free(h2hip_ctx *ctx, h2hip_plonk_pk *pk) {
     if (pk->host_stage) hipHostFree(pk->host_stage);
     if (pk->copy_ev) hipEventDestroy(pk->copy_ev);
     if (pk->copy_stream) hipStreamDestroy(pk->copy_stream);
+    if (pk->side_ev) hipEventDestroy(pk->side_ev);
+    if (pk->side) h2hip_destroy(pk->side);
     pk->pool.destroy();
     delete pk;
 }
@@ -1576,8 +1725,11 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     H2_REQUIRE(proof_cap >= need, "proof buffer too small");
     std::vector<uint8_t> proof;
     int rc = create_proof_impl(ctx, pk, advice, advice_on_device != 0, instances_host, instance_lens, rng, rng_user, proof, stage_ms);
+    ctx->msm_tail_hook = nullptr;   // (never leave a hook of this proof behind: it captures the proof's frame)
+    if (pk->side && ctx->profiling) prof_fold_child(ctx, pk->side);
     if (rc != H2HIP_OK) {
         if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
+        if (pk->side) hipStreamSynchronize(pk->side->stream);
         hipStreamSynchronize(ctx->stream);   // nothing of the failed proof may still run on buffers that go back to the pool
         if (rc != H2HIP_ERR_PEER && pk->comm && pk->exch_next < pk->exch_sizes.size()) {
             // a sharded proof failed HERE (a lookup value missing from the table, an identity commitment, an allocation ...): the other

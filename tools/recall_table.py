@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P, V, L, S = "halo2-lib_amd/csrc/plonk.hip", "halo2-lib_amd/csrc/verifier.hip", "halo2-lib_amd/csrc/lookup.hip", "halo2-lib_amd/csrc/srs.hip"
 OP, OT, OB = "oracle/plonk.py", "oracle/transcript.py", "oracle/bn254.py"
 HP, VR, PL = "halo2-lib_amd/halo2_proofs.py", "halo2-lib_amd/virtual_region.py", "halo2-lib_amd/plonk.py"
+RG, OC = "halo2-lib_amd/csrc/rng.hip", "oracle/chacha.py"
 
 # (item, what is assumed about upstream, [(file, anchor)] product, [(file, anchor)] oracle, how to flip)
 ITEMS = [
@@ -55,6 +56,10 @@ ITEMS = [
     ("`Fr::random`", "`Fr::from_u512` of 64 bytes of the RNG's keystream, little-endian; `gen_srs` seeds ChaCha20 with 32 zero bytes",
      [(HP, "the `s` of `ParamsKZG::<Bn256>::setup(k, ChaCha20Rng::from_seed(Default::default()))`")], [],
      "`halo2_proofs.py` only (the prover's own randomness always comes through the callback)"),
+    ("seeded RNG stream (`StdRng::seed_from_u64(0)`, `ChaCha20Rng::from_seed`)", "rand 0.8 `StdRng` = ChaCha12; keystream block b = ChaCha(key = the 32 seed bytes, 64-bit counter b in state words 12 / 13, stream id 0 in 14 / 15); `next_u64` = two consecutive words, low first; `Fr::random` = `from_u512` of eight `next_u64` = ONE 64-byte block per element; `seed_from_u64` = rand_core's PCG32 expansion (MUL 6364136223846793005, INC 11634580027462260723).  The block function itself is pinned to RFC 8439 (tests/test_rng_chacha.py)",
+     [(RG, "H2_HD void chacha_block(const ChaChaKey &key, uint64_t counter, uint64_t stream, int rounds, uint32_t (&out)[16]) {"), (RG, "void h2hip_rng_seed_from_u64(uint64_t state, uint8_t *seed_out) {"), (P, "rng_ahead_pos = cr->pos + A * (uint64_t)(n - u)")],
+     [(OC, "def chacha_blocks(seed: bytes, counters, rounds: int = 20, stream: int = 0) -> np.ndarray:"), (OC, "def seed_from_u64(state: int) -> bytes:")],
+     "`chacha_block`'s state layout / `fr_from_block` (rng.hip) and oracle/chacha.py; a prover that keeps its own generator simply passes its own `h2hip_rng_fill_fn` and none of this is used"),
     ("SRS file layout", "`u32 k` LE, then g[0..n), g_lagrange[0..n), g2, s_g2 in `SerdeFormat::RawBytes` (Montgomery limbs) or `Processed` (compressed) encoding",
      [(HP, "def read(cls, ctx: Context, path: str, precompute: bool = True)")], [],
      "`ParamsKZG.read` / `.write` (host code); the device side validates whatever points it is given"),
