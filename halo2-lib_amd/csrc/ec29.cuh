@@ -101,6 +101,40 @@ H2_HD void xyzz29_add_affine(XYZZ29 &acc, const Fq29 &x2, const Fq29 &y2, bool n
     acc.zzz = f29_mul(acc.zzz, PPP);
 }
 
+// The same addition for an accumulator whose emptiness is carried in a flag instead of being read off ZZ (the MSM's inner loop: one
+// instruction per step instead of nine ORs and a compare, and closing a run costs no 36-register reset).  `empty`: acc holds nothing
+// (its registers are stale); set when a run cancels to the identity, cleared by the first addition.
+H2_HD void xyzz29_add_affine_flag(XYZZ29 &acc, bool &empty, const Fq29 &x2, const Fq29 &y2, bool neg) {
+    if (empty) {
+        acc.x = x2;
+        acc.y = neg ? f29_neg<2>(y2) : y2;   // < 2 q
+        acc.zz = Fq29::one();
+        acc.zzz = Fq29::one();
+        empty = false;
+        return;
+    }
+    Fq29 U2 = f29_mul(x2, acc.zz);                            // < 1.01
+    Fq29 S2 = f29_mul(y2, acc.zzz);                           // < 1.01
+    Fq29 Pd = f29_sub<6>(U2, acc.x);                          // in (0.75, 7.01) q
+    Fq29 Rd = f29_signed_sub4(S2, neg, acc.y);
+    if (f29_is_zero_mod_q<7>(Pd)) {
+        if (f29_is_zero_mod_q<7>(Rd)) acc = xyzz29_double_affine(x2, neg ? f29_neg<2>(y2) : y2);
+        else empty = true;
+        return;
+    }
+    Fq29 PP = f29_sqr(Pd);                                    // 49 -> < 1.29
+    Fq29 PPP = f29_mul(Pd, PP);                               // < 1.054
+    Fq29 Q = f29_mul(acc.x, PP);                              // < 1.04
+    Fq29 R2 = f29_sqr(Rd);                                    // 36 -> < 1.22
+    Fq29 t = f29_norm(f29_add(f29_add(PPP, Q), Q));           // < 3.14
+    Fq29 X3 = f29_sub<4>(R2, t);                              // < 5.22
+    Fq29 Y3 = f29_mul2(Rd, f29_sub_lazy<6>(Q, X3), f29_sub_lazy<4>(Fq29::zero(), acc.y), PPP);   // lazy operands: no carry passes
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = f29_mul(acc.zz, PP);
+    acc.zzz = f29_mul(acc.zzz, PPP);
+}
+
 // acc += b
 H2_HD void xyzz29_add(XYZZ29 &acc, const XYZZ29 &b) {
     if (b.is_identity()) return;

@@ -346,8 +346,9 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
     const uint32_t total = offsets[nkeys];
     const uint64_t start64 = (uint64_t)t * K;
     const bool valid = t < nthreads && start64 < total;
-    uint32_t start = 0, end = 0, cur = 0, next = 0, hk = KEY_INVALID;
+    uint32_t start = 0, end = 0, cur = 0, next = 0, next2 = 0, hk = KEY_INVALID;
     bool first = true;
+    bool empty = true;   // acc holds nothing yet (its registers are stale): emptiness is a flag, not 36 zeroed registers tested every step
     XYZZ29 acc = XYZZ29::identity();
     __shared__ XYZZ29 lsave[256];   // the lane's first-run sum waits here (not in 36 registers) while the lane walks the rest of its entries
     if (valid) {
@@ -355,6 +356,7 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
         end = (start64 + K > total) ? total : start + K;
         cur = find_key(offsets, 0, nkeys, start);
         next = offsets[cur + 1];
+        next2 = offsets[cur + 2];   // (offsets[nkeys + 1] is the ~0 sentinel)
     }
     const uint32_t first_key = valid ? cur : KEY_INVALID;   // key of the lane's first entry
     bool l_open = false;                                     // the lane's first run began before `start`
@@ -367,6 +369,7 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
     };
     for (uint32_t e = start; e < end; ++e) {
         if (e >= next) {   // bucket boundary: close the run
+            if (empty) acc = XYZZ29::identity();   // (a run of identity table entries, or one that cancelled)
             if (first) {
                 lsave[threadIdx.x] = acc;
                 hk = cur;
@@ -374,14 +377,22 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
             } else {
                 buckets[cur] = acc;
             }
-            acc = XYZZ29::identity();
-            cur = (offsets[cur + 2] > e) ? cur + 1 : find_key(offsets, cur + 1, nkeys, e);
-            next = offsets[cur + 1];
+            empty = true;
+            // the next key: the end of the following bucket was requested at the previous boundary (no dependent load here in the common case)
+            if (next2 > e) {
+                cur = cur + 1;
+                next = next2;
+            } else {   // empty buckets in between
+                cur = find_key(offsets, cur + 1, nkeys, e);
+                next = offsets[cur + 1];
+            }
+            next2 = offsets[cur + 2];   // needed at the next boundary only
         }
         const uint32_t v = entry(e);
         const G1Affine p = load_table_entry(bases + (v & 0x7fffffffu));   // packed R'-domain point, one aligned 64-byte gather
-        if (!p.is_identity()) xyzz29_add_affine(acc, f29_split<Q29P>(p.x), f29_split<Q29P>(p.y), (v >> 31) != 0);
+        if (!p.is_identity()) xyzz29_add_affine_flag(acc, empty, f29_split<Q29P>(p.x), f29_split<Q29P>(p.y), (v >> 31) != 0);
     }
+    if (empty) acc = XYZZ29::identity();
     // ---- close the shared runs inside the wave
     const bool multi = valid && !first;               // the lane crossed at least one run boundary: L = (hk, lsave[lane]), R = (cur, acc)
     const bool r_open = valid && next > end;          // R goes on in the next lane
@@ -458,6 +469,9 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
     }
 }
 
+// r04: the accumulator's emptiness is a flag (not 36 zeroed registers tested every step) and the next bucket's end offset is requested one
+// boundary ahead: SQ_INSTS_VALU per 2^20-point launch 6.417e8 -> 6.322e8 (-1.5 %), time within noise (profiles/r04_accum_flag_ab.log) — the
+// loop is VALU-bound at ~2440 instructions per step, 1467 of them multiplies, ~560 the nine reductions' carries and quotient digits.
 // three waves per SIMD (168 registers per lane); measured and left behind (profiles/r03_msm_tune_*.log, r03_knob_ab.log): two waves per
 // SIMD by launch bounds or by register padding (2 % slower / equal in isolation, nothing end to end), four (spills), the next table entry
 // requested one addition ahead (5 % slower: the gather is not what the kernel waits for), plain instead of non-temporal table loads

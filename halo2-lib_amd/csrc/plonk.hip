@@ -819,6 +819,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         pk->exch_sizes = {9 * sizeof(uint64_t), P * (sh.num_advice_total + 2 * sh.lookups.size()), P * (sh.num_perm_sets + sh.lookups.size() + 1)};
         if (qshard) pk->exch_sizes.push_back(0);
         pk->exch_sizes.push_back(P * sh.quotient_pieces);
+        pk->exch_sizes.push_back(sizeof(Fr) * (sh.num_evals() + 1));   // the evaluations: partial sums over this rank's coefficient range
         pk->exch_sizes.push_back(P);
         pk->exch_sizes.push_back(P);
     }
@@ -1355,10 +1356,35 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     const size_t n_written = evq.size();
     const size_t i_h = want(h_poly, x);
     {
-        std::vector<size_t> lens(evq.size(), n);
         std::vector<Fr> points(evq.size()), vals(evq.size());
         for (size_t i = 0; i < evq.size(); ++i) points[i] = evq[i].point;
-        H2_CHK(h2hip_fr_eval_polynomial_batch_dev(ctx, ev_polys.data(), lens.data(), points.data(), evq.size(), vals.data()));
+        if (!sharded_any) {
+            std::vector<size_t> lens(evq.size(), n);
+            H2_CHK(h2hip_fr_eval_polynomial_batch_dev(ctx, ev_polys.data(), lens.data(), points.data(), evq.size(), vals.data()));
+        } else {
+            // sharded (r04): every polynomial is evaluated over this rank's COEFFICIENT range [lo, hi) — the range of its SRS slice —
+            // p(x) = sum_ranks x^lo * sum_j c[lo + j] x^j: the same batched launch on 1/N of the coefficients, one exchange of 32 bytes per
+            // query, N-term sums on the host.  Every rank ends up with every evaluation (the transcripts stay in lock step).
+            H2_REQUIRE(evq.size() == (size_t)sh.num_evals() + 1, "internal: evaluation count differs from the exchange schedule");
+            const size_t lo = std::min<size_t>(pk->shard_offset, n), hi = std::min<size_t>(pk->shard_offset + pk->shard_len, n);
+            std::vector<const void *> part(evq.size());
+            std::vector<size_t> lens(evq.size(), hi - lo);
+            for (size_t i = 0; i < evq.size(); ++i) part[i] = (const Fr *)ev_polys[i] + lo;
+            if (hi > lo) H2_CHK(h2hip_fr_eval_polynomial_batch_dev(ctx, part.data(), lens.data(), points.data(), evq.size(), vals.data()));
+            for (size_t i = 0; i < evq.size(); ++i) vals[i] = hi > lo ? fe_mul(vals[i], fe_pow_u64(points[i], lo)) : Fr::zero();
+            std::vector<uint8_t> all;
+            H2_CHK(exchange_host(vals.data(), sizeof(Fr) * vals.size(), all));
+            const size_t slot = 8 + sizeof(Fr) * vals.size();
+            for (size_t i = 0; i < vals.size(); ++i) {
+                Fr acc = Fr::zero();
+                for (uint32_t r = 0; r < pk->shard_world; ++r) {
+                    Fr v;
+                    memcpy(&v, all.data() + (size_t)r * slot + 8 + sizeof(Fr) * i, sizeof(Fr));
+                    acc = fe_add(acc, v);
+                }
+                vals[i] = acc;
+            }
+        }
         for (size_t i = 0; i < evq.size(); ++i) evq[i].eval = vals[i];
     }
     for (size_t i = 0; i < n_written; ++i) tr.write_scalar(evq[i].eval);

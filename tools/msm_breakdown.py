@@ -7,6 +7,8 @@ from halo2_lib_amd import halo2_proofs as HP
 
 NAMES = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 ctx = H.Context(0)
+for kv in os.environ.get("H2_PARAMS", "").split():   # name=value context parameters
+    ctx.set_param(kv.split("=")[0], int(kv.split("=")[1]))
 for log_n in [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["19", "20"])]:
     n = 1 << log_n
     s = synthetic_scalars(n, 2); ds = ctx.to_device(s)
