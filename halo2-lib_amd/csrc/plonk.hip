@@ -250,6 +250,9 @@ struct h2hip_plonk_pk {
     hipEvent_t copy_ev = nullptr;
     h2hip_ctx *side = nullptr;           // child context (own stream, NTT scratch and twiddle cache): the transforms that run next to an MSM's tail
     hipEvent_t side_ev = nullptr;
+    h2hip_ctx *side_msm = nullptr;       // child context for the one MSM that depends on nothing: the random polynomial's commitment
+    hipEvent_t side_msm_ev = nullptr;
+    G1Jac *side_msm_out = nullptr;       // its result, page-locked host memory
     Fr *host_stage = nullptr;   // pinned staging for the RNG-drawn scalars (the n coefficients of the random polynomial, the blinding rows)
     size_t host_stage_elems = 0;
 };
@@ -764,6 +767,24 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(h2hip_init(ctx->device, nullptr, &pk->side));
         H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
     }
+    // The vanishing argument's random polynomial depends on nothing but the RNG: when its scalars were generated ahead (libh2hip's counter-
+    // mode generator, above) its COMMITMENT is computed ahead too — one MSM on a second side context, queued behind round 1's accumulations,
+    // running next to that round's reduction, the grand products and the side stream's transforms — so that round 3 commits two columns
+    // instead of three.  The transcript takes the point where upstream writes it: same bytes.
+    const bool random_ahead = overlap && rng_ahead && ctx->plonk_tail_overlap >= 2;
+    bool random_commit_queued = false;
+    if (random_ahead && !pk->side_msm) {
+        H2_CHK(h2hip_init(ctx->device, nullptr, &pk->side_msm));
+        H2_HIPCHK(hipEventCreateWithFlags(&pk->side_msm_ev, hipEventDisableTiming));
+        H2_HIPCHK(hipHostMalloc((void **)&pk->side_msm_out, sizeof(G1Jac), 0));
+    }
+    if (random_ahead) {
+        pk->side_msm->msm_chunk = ctx->msm_chunk;
+        pk->side_msm->msm_seg = ctx->msm_seg;
+        pk->side_msm->profiling = ctx->profiling;
+        pk->side_msm->prof_filter = ctx->prof_filter;
+        pk->side_msm->prof_ref = ctx->prof_ref;
+    }
     if (overlap) {
         h2hip_ctx *c = pk->side;
         c->ntt_tile_bits = ctx->ntt_tile_bits;
@@ -956,7 +977,17 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                 r1_src.push_back(s.ap);
                 r1_src.push_back(s.sp);
             }
-            side_arm([&]() -> int { return side_transforms(r1_src, r1_coef, r1_cos); });
+            side_arm([&]() -> int {
+                H2_CHK(side_transforms(r1_src, r1_coef, r1_cos));
+                if (random_ahead) {   // behind the same event (the hook made pk->side wait for it; this context waits for it and for the generator)
+                    H2_HIPCHK(hipStreamWaitEvent(pk->side_msm->stream, ctx->tail_ev, 0));
+                    H2_HIPCHK(hipStreamWaitEvent(pk->side_msm->stream, pk->copy_ev, 0));
+                    H2_CHK(msm_single_async(pk->side_msm, pk->g, random_poly, n, pk->side_msm_out));
+                    H2_HIPCHK(hipEventRecord(pk->side_msm_ev, pk->side_msm->stream));
+                    random_commit_queued = true;
+                }
+                return H2HIP_OK;
+            });
         }
         H2_CHK(commit_points(pk->g_lagrange, cols, n, pts));
         H2_CHK(side_fire_if_pending());
@@ -1140,6 +1171,10 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                 H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));
             } else {
                 if (rng_ahead) H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));   // (the buffer is overwritten in stream order)
+                if (random_commit_queued) {   // a commitment of the wrong scalars is in flight: let it finish, then forget it
+                    H2_HIPCHK(hipEventSynchronize(pk->side_msm_ev));
+                    random_commit_queued = false;
+                }
                 H2_CHK(rng_chacha_fill_dev(ctx, random_poly, n, cr->seed, cr->rounds, cr->pos, st));
             }
             cr->pos += n;
@@ -1156,8 +1191,10 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             cols.push_back(s.z);
             bases.push_back(pk->g_lagrange);
         }
-        cols.push_back(random_poly);
-        bases.push_back(pk->g);
+        if (!random_commit_queued) {
+            cols.push_back(random_poly);
+            bases.push_back(pk->g);
+        }
         std::vector<G1Affine> pts;
         if (overlap) {   // the grand products' coefficient and extended forms do not depend on y: next to this round's reduction
             r3_src.assign(perm_z.begin(), perm_z.end());
@@ -1166,6 +1203,10 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         }
         H2_CHK(commit_points_multi(nullptr, bases, cols, n, pts));
         H2_CHK(side_fire_if_pending());
+        if (random_commit_queued) {
+            H2_HIPCHK(hipEventSynchronize(pk->side_msm_ev));
+            pts.push_back(jacobian_to_affine(*pk->side_msm_out));
+        }
         for (size_t i = 0; i + 1 < pts.size(); ++i) H2_CHK(tr.write_point(pts[i]));
         random_commitment = pts.back();
         laps.lap(ST_COMMIT_PRODUCTS);
@@ -1620,6 +1661,7 @@ int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, 
             pk->transcript_repr = saved;
             ctx->msm_tail_hook = nullptr;
             if (pk->side) hipStreamSynchronize(pk->side->stream);
+            if (pk->side_msm) hipStreamSynchronize(pk->side_msm->stream);
             if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
             hipStreamSynchronize(ctx->stream);
             if (wrc != H2HIP_OK) set_error("");   // not the caller's error
@@ -1643,6 +1685,9 @@ void h2hip_plonk_pk_free(h2hip_ctx *ctx, h2hip_plonk_pk *pk) {
     if (pk->copy_stream) hipStreamDestroy(pk->copy_stream);
     if (pk->side_ev) hipEventDestroy(pk->side_ev);
     if (pk->side) h2hip_destroy(pk->side);
+    if (pk->side_msm_ev) hipEventDestroy(pk->side_msm_ev);
+    if (pk->side_msm) h2hip_destroy(pk->side_msm);
+    if (pk->side_msm_out) hipHostFree(pk->side_msm_out);
     pk->pool.destroy();
     delete pk;
 }
@@ -1753,9 +1798,11 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     int rc = create_proof_impl(ctx, pk, advice, advice_on_device != 0, instances_host, instance_lens, rng, rng_user, proof, stage_ms);
     ctx->msm_tail_hook = nullptr;   // (never leave a hook of this proof behind: it captures the proof's frame)
     if (pk->side && ctx->profiling) prof_fold_child(ctx, pk->side);
+    if (pk->side_msm && ctx->profiling) prof_fold_child(ctx, pk->side_msm);
     if (rc != H2HIP_OK) {
         if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
         if (pk->side) hipStreamSynchronize(pk->side->stream);
+        if (pk->side_msm) hipStreamSynchronize(pk->side_msm->stream);
         hipStreamSynchronize(ctx->stream);   // nothing of the failed proof may still run on buffers that go back to the pool
         if (rc != H2HIP_ERR_PEER && pk->comm && pk->exch_next < pk->exch_sizes.size()) {
             // a sharded proof failed HERE (a lookup value missing from the table, an identity commitment, an allocation ...): the other
