@@ -163,6 +163,49 @@ def proof_algorithmic_work(ctx, bp, sh):
             "bytes": 96.0 * n * msms + 64.0 * (cols * n + cols * (1 << ext) + (1 << ext))}
 
 
+def measure_hbm_traffic(k, kernel="msm_accum_kernel"):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md's HBM / rocprofv3
+    section prescribes — two SEPARATE `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE, WRITE_SIZE) over a child run of this file's
+    timed workload only (`--pmc-child`), bytes = (2 x FETCH_SIZE_KB + WRITE_SIZE_KB) x 1024: on gfx950 FETCH_SIZE tallies 128-byte requests as
+    64 B (the guide's correction; calibration in profiles/r02_hbm_counter_calibration.md).  Returns None (with the reason) if rocprofv3 is missing."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="h2pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--k", str(k),
+                   "--steps", "4", "--warmup", "1"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "%s pass failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:])
+            db = sqlite3.connect(dbs[0])
+            rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? and kernel_name like ? group by kernel_name",
+                              (counter, "%" + kernel + "%")).fetchall()
+            if not rows:
+                return None, "no %s samples for %s" % (counter, kernel)
+            vals[counter] = (sum(r_[1] * r_[2] for r_ in rows) / sum(r_[1] for r_ in rows), sum(r_[1] for r_ in rows))
+        traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+        return {"bytes_per_launch": traffic, "fetch_size_kb_raw": vals["FETCH_SIZE"][0], "write_size_kb": vals["WRITE_SIZE"][0], "launches_sampled": vals["FETCH_SIZE"][1],
+                "how": "two separate `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE` child runs of `bench.py --pmc-child --steps 4` inside this run; "
+                       "bytes = (2 x FETCH_SIZE_KB + WRITE_SIZE_KB) x 1024 (gfx950: FETCH_SIZE counts a 128-byte request as 64 B); mean over the child's launches of the "
+                       "kernel (keygen's and the proofs' MSMs of 2^k points)"}, None
+    except Exception as e:   # never let the optional measurement break the contract line
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,6 +224,8 @@ def main():
     ap.add_argument("--param", action="append", default=[], help="name=value tuning knob passed to h2hip_set_param (repeatable)")
     ap.add_argument("--lanes", type=int, default=0, help="override msm_lanes (streams used by the batch API)")
     ap.add_argument("--no-replay", action="store_true", help="skip the MSM 2^20, NTT 2^22, K8 and k=21 blocks (extra fields)")
+    ap.add_argument("--no-pmc-traffic", action="store_true", help="skip the two rocprofv3 PMC child runs (FETCH_SIZE / WRITE_SIZE) that fill roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # set on the child runs: only the timed workload, no blocks, no children
     ap.add_argument("--no-sweep", action="store_true", help="skip create_proof over the reference's 18 benchmark shapes (an extra field, ~25 s)")
     ap.add_argument("--precompute", type=int, default=1, help="1: bases carry precomputed 2^(c*w) window tables (fixed-base SRS, H2HIP_BASES_PRECOMPUTE)")
     ap.add_argument("--batch", type=int, default=4, help="MSM block: MSMs issued per h2hip_msm_g1_batch_dev call (a prover commits several columns per round); 1 = synchronous")
@@ -310,6 +355,11 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     seconds = elapsed / args.steps
+    if args.pmc_child:   # a rocprofv3 PMC pass of the parent: the timed workload is all it wants
+        pk.free()
+        kzg.free()
+        ctx.close()
+        return
     if proof != first:
         raise SystemExit("bench.py: create_proof is not repeatable for a fixed RNG stream — refusing to report a number")
     t0 = time.perf_counter()
@@ -372,9 +422,17 @@ def main():
         proofs_per_step = 1 if (world == 1 or sharded) else world
         alg_bytes = 96.0 * msm_n
         traffic_prof = None
-        pmc_path = os.path.join(ROOT, "profiles", "r03_create_proof_k19_pmc_hbm.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r04_create_proof_k19_pmc_hbm.json")
         if os.path.exists(pmc_path) and k == 19 and world == 1:
-            traffic_prof = {"source": os.path.relpath(pmc_path, ROOT), **json.load(open(pmc_path))}
+            import hashlib
+            import subprocess
+
+            raw = open(pmc_path, "rb").read()
+            blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()   # = `git hash-object`: ties the quoted figure to the committed file
+            traffic_prof = {"source": os.path.relpath(pmc_path, ROOT), "git_blob_sha1": blob, **json.loads(raw)}
+        traffic_live, traffic_err = (None, "skipped (--no-pmc-traffic)")
+        if world == 1 and not args.no_pmc_traffic:
+            traffic_live, traffic_err = measure_hbm_traffic(k)
         out = {
             "metric": "create_proof constraints/sec (k=%d ECDSA configuration, halo2-ecc/configs/secp256k1/bench_ecdsa.config:1); MSM G1-adds/sec in `msm_2_%d`" % (k, args.log_n),
             "value": proofs_per_step * cells / seconds,
@@ -412,8 +470,10 @@ def main():
                                    "~200 launches add ~1 ms per proof); ms = sum of launch durations (launches of concurrent MSM lanes overlap), busy_ms = union of their spans" % acct_proofs,
             "roofline": {"bound": "hbm", "kernel": "msm_accum_kernel (2^%d points per launch, %d launches per proof)" % (int(np.log2(msm_n)), round(k_cnt / args.steps)),
                          "achieved": alg_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
-                         "frac": alg_bytes / k_avg_s / 8e12 if k_avg_s > 0 else 0.0, "traffic": None,
-                         "traffic_note": "not measured in this run (PMC counters need rocprofv3); the separately collected figure is under `traffic_from_profiles`",
+                         "frac": alg_bytes / k_avg_s / 8e12 if k_avg_s > 0 else 0.0, "traffic": traffic_live["bytes_per_launch"] if traffic_live else None,
+                         "traffic_measurement": traffic_live if traffic_live else {"error": traffic_err},
+                         "traffic_note": "HBM bytes per launch from the PMC counters of two rocprofv3 child runs inside this run (null if rocprofv3 is unavailable: the "
+                                         "separately collected, committed figure is under `traffic_from_profiles` with the file's git blob hash)",
                          "traffic_from_profiles": traffic_prof,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_avg_s * 1e3, "launches": int(k_cnt),
                          "busy_ms_per_launch": k_busy_ms / max(k_cnt, 1),

@@ -286,6 +286,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_tile_kernel")) return &ctx->ntt_tile_kernel;
     if (!strcmp(name, "plonk_warm_keygen")) return &ctx->plonk_warm_keygen;
     if (!strcmp(name, "plonk_tail_overlap")) return &ctx->plonk_tail_overlap;
+    if (!strcmp(name, "plonk_side_on_lanes")) return &ctx->plonk_side_on_lanes;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
@@ -725,12 +726,13 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));
         H2_HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
     }
-    if (ctx->msm_tail_hook) {   // the accumulations are queued and joined: what follows on this stream is the reduction's tail
-        std::function<int(hipEvent_t)> hook;
-        hook.swap(ctx->msm_tail_hook);
+    // the accumulations are queued and joined: what follows on this stream is the reduction's tail.  The event is recorded HERE; the hook
+    // itself runs after the tail has been queued (its own launches take host time that must not delay the reduction)
+    std::function<int(hipEvent_t)> tail_hook;
+    if (ctx->msm_tail_hook) {
+        tail_hook.swap(ctx->msm_tail_hook);
         if (!ctx->tail_ev) H2_HIPCHK(hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming));
         H2_HIPCHK(hipEventRecord(ctx->tail_ev, ctx->stream));
-        H2_CHK(hook(ctx->tail_ev));
     }
     if (deferred) {   // one bucket reduction per 64 columns, on the caller's stream
         XYZZ *sums = nullptr;
@@ -747,7 +749,10 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         H2_HIPCHK(hipGetLastError());
     }
     H2_HIPCHK(hipMemcpyAsync(out_host, results, psz * count, hipMemcpyDeviceToHost, ctx->stream));
+    int hook_rc = H2HIP_OK;
+    if (tail_hook) hook_rc = tail_hook(ctx->tail_ev);
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    H2_CHK(hook_rc);
     if (ctx->profiling)   // fold the lanes' kernel timers into the parent's table
         for (int l = 0; l < NL; ++l) {
             prof_fold_child(ctx, ctx->lane[l]);

@@ -115,6 +115,7 @@ struct h2hip_ctx {
     hipEvent_t tail_ev = nullptr;
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
     int plonk_tail_overlap = 2;      // create_proof: >= 1: the challenge-independent transforms of rounds 1 and 3 run on a side stream next to the commitment MSMs' bucket reduction; 2: the random polynomial's commitment is computed ahead as well (libh2hip's seeded RNG only)
+    int plonk_side_on_lanes = 1;     // the side work of plonk_tail_overlap runs on two of the batch MSM's (idle) lane contexts instead of contexts of its own
 #ifdef H2_HIPEMU
     int plonk_warm_keygen = 0;       // (the CPU-emulated test build does not pay for a second proof per key)
 #else

@@ -763,9 +763,10 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // twiddle cache) behind the event the batch MSM records once its accumulations are done, read the Lagrange values the MSM also reads and
     // write NEW buffers, so they run next to the reduction and to the pointwise kernels that follow.  Single GPU only.
     const bool overlap = !sharded_any && ctx->plonk_tail_overlap != 0;
-    if (overlap && !pk->side) {
-        H2_CHK(h2hip_init(ctx->device, nullptr, &pk->side));
+    if (overlap && !pk->side_ev) {
         H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
+        H2_HIPCHK(hipEventCreateWithFlags(&pk->side_msm_ev, hipEventDisableTiming));
+        H2_HIPCHK(hipHostMalloc((void **)&pk->side_msm_out, sizeof(G1Jac), 0));
     }
     // The vanishing argument's random polynomial depends on nothing but the RNG: when its scalars were generated ahead (libh2hip's counter-
     // mode generator, above) its COMMITMENT is computed ahead too — one MSM on a second side context, queued behind round 1's accumulations,
@@ -773,36 +774,39 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // instead of three.  The transcript takes the point where upstream writes it: same bytes.
     const bool random_ahead = overlap && rng_ahead && ctx->plonk_tail_overlap >= 2;
     bool random_commit_queued = false;
-    if (random_ahead && !pk->side_msm) {
-        H2_CHK(h2hip_init(ctx->device, nullptr, &pk->side_msm));
-        H2_HIPCHK(hipEventCreateWithFlags(&pk->side_msm_ev, hipEventDisableTiming));
-        H2_HIPCHK(hipHostMalloc((void **)&pk->side_msm_out, sizeof(G1Jac), 0));
-    }
-    if (random_ahead) {
-        pk->side_msm->msm_chunk = ctx->msm_chunk;
-        pk->side_msm->msm_seg = ctx->msm_seg;
-        pk->side_msm->profiling = ctx->profiling;
-        pk->side_msm->prof_filter = ctx->prof_filter;
-        pk->side_msm->prof_ref = ctx->prof_ref;
-    }
-    if (overlap) {
-        h2hip_ctx *c = pk->side;
+    // Which contexts run the side work.  The device serves its streams through a handful of hardware queues (4 by default: with more,
+    // measured, everything gets slower), and the batch MSM's lanes already hold as many: a further stream shares a queue with one of them.
+    // After a round's accumulations the lanes idle until the next round, so by default the side work runs ON two of the lanes' contexts
+    // (each a full context: own stream, NTT scratch, twiddle cache, MSM scratch); separate contexts only where those lanes do not exist
+    // (one lane from 2^20 points on) or with plonk_side_on_lanes = 0.
+    h2hip_ctx *side_c = nullptr, *side_msm_c = nullptr;
+    auto pick_side = [&](h2hip_ctx *lane, h2hip_ctx **own) -> h2hip_ctx * {
+        h2hip_ctx *c = (ctx->plonk_side_on_lanes && lane) ? lane : *own;
+        if (!c) {
+            if (h2hip_init(ctx->device, nullptr, own) != H2HIP_OK) return nullptr;
+            c = *own;
+        }
         c->ntt_tile_bits = ctx->ntt_tile_bits;
         c->ntt_min_col_bits = ctx->ntt_min_col_bits;
         c->ntt_full_table = ctx->ntt_full_table;
         c->ntt_tile_kernel = ctx->ntt_tile_kernel;
+        c->msm_chunk = ctx->msm_chunk;
+        c->msm_seg = ctx->msm_seg;
         c->profiling = ctx->profiling;
         c->prof_filter = ctx->prof_filter;
         c->prof_ref = ctx->prof_ref;
-    }
+        return c;
+    };
     bool side_busy = false;   // work is queued on the side stream that the main stream has not waited for yet
     // queues `fn` on the side stream behind the batch MSM's accumulations (or, if the commitment took a path without lanes, behind what
     // the main stream holds after it) — `arm` before the commitment, `fire_if_pending` after it
     auto side_arm = [&](std::function<int()> fn) {
         ctx->msm_tail_hook = [&, fn](hipEvent_t ev) -> int {
-            H2_HIPCHK(hipStreamWaitEvent(pk->side->stream, ev, 0));
+            side_c = pick_side(ctx->lane[2], &pk->side);
+            H2_REQUIRE(side_c, "create_proof: no side context");
+            H2_HIPCHK(hipStreamWaitEvent(side_c->stream, ev, 0));
             H2_CHK(fn());
-            H2_HIPCHK(hipEventRecord(pk->side_ev, pk->side->stream));
+            H2_HIPCHK(hipEventRecord(pk->side_ev, side_c->stream));
             side_busy = true;
             return H2HIP_OK;
         };
@@ -827,8 +831,8 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         for (size_t i = 0; i < src.size(); ++i) H2_CHK(sc.take(n, &coef[i]));
         for (size_t i = 0; i < src.size(); ++i) H2_CHK(sc.take(ne, &cos[i]));
         const Fr out3[3] = {dom.ifft_divisor, dom.ifft_divisor, dom.ifft_divisor};
-        H2_CHK(ntt_run_batch(pk->side, coef.data(), (const Fr *const *)src.data(), src.size(), k, dom.omega_inv, n, nullptr, out3));
-        return h2hip_coeff_to_extended_batch_dev(pk->side, (const void *const *)coef.data(), k, (void *const *)cos.data(), ek, src.size(), &dom.ext_omega, &dom.zeta);
+        H2_CHK(ntt_run_batch(side_c, coef.data(), (const Fr *const *)src.data(), src.size(), k, dom.omega_inv, n, nullptr, out3));
+        return h2hip_coeff_to_extended_batch_dev(side_c, (const void *const *)coef.data(), k, (void *const *)cos.data(), ek, src.size(), &dom.ext_omega, &dom.zeta);
     };
     std::vector<Fr *> r1_src, r1_coef, r1_cos, r3_src, r3_coef, r3_cos;
     const size_t ncm = qshard ? pk->my_cosets.size() : 0;                 // cosets of the extended domain evaluated here
@@ -979,11 +983,13 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             }
             side_arm([&]() -> int {
                 H2_CHK(side_transforms(r1_src, r1_coef, r1_cos));
-                if (random_ahead) {   // behind the same event (the hook made pk->side wait for it; this context waits for it and for the generator)
-                    H2_HIPCHK(hipStreamWaitEvent(pk->side_msm->stream, ctx->tail_ev, 0));
-                    H2_HIPCHK(hipStreamWaitEvent(pk->side_msm->stream, pk->copy_ev, 0));
-                    H2_CHK(msm_single_async(pk->side_msm, pk->g, random_poly, n, pk->side_msm_out));
-                    H2_HIPCHK(hipEventRecord(pk->side_msm_ev, pk->side_msm->stream));
+                if (random_ahead) {   // behind the same event (the hook made the side context wait for it; this one waits for it and for the generator)
+                    side_msm_c = pick_side(ctx->lane[1], &pk->side_msm);
+                    H2_REQUIRE(side_msm_c, "create_proof: no side context");
+                    H2_HIPCHK(hipStreamWaitEvent(side_msm_c->stream, ctx->tail_ev, 0));
+                    H2_HIPCHK(hipStreamWaitEvent(side_msm_c->stream, pk->copy_ev, 0));
+                    H2_CHK(msm_single_async(side_msm_c, pk->g, random_poly, n, pk->side_msm_out));
+                    H2_HIPCHK(hipEventRecord(pk->side_msm_ev, side_msm_c->stream));
                     random_commit_queued = true;
                 }
                 return H2HIP_OK;
@@ -1662,6 +1668,8 @@ int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, 
             ctx->msm_tail_hook = nullptr;
             if (pk->side) hipStreamSynchronize(pk->side->stream);
             if (pk->side_msm) hipStreamSynchronize(pk->side_msm->stream);
+            for (h2hip_ctx *l : ctx->lane)
+                if (l) hipStreamSynchronize(l->stream);
             if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
             hipStreamSynchronize(ctx->stream);
             if (wrc != H2HIP_OK) set_error("");   // not the caller's error
@@ -1799,10 +1807,15 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     ctx->msm_tail_hook = nullptr;   // (never leave a hook of this proof behind: it captures the proof's frame)
     if (pk->side && ctx->profiling) prof_fold_child(ctx, pk->side);
     if (pk->side_msm && ctx->profiling) prof_fold_child(ctx, pk->side_msm);
+    if (ctx->profiling)
+        for (h2hip_ctx *l : ctx->lane)
+            if (l) prof_fold_child(ctx, l);
     if (rc != H2HIP_OK) {
         if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
         if (pk->side) hipStreamSynchronize(pk->side->stream);
         if (pk->side_msm) hipStreamSynchronize(pk->side_msm->stream);
+        for (h2hip_ctx *l : ctx->lane)
+            if (l) hipStreamSynchronize(l->stream);
         hipStreamSynchronize(ctx->stream);   // nothing of the failed proof may still run on buffers that go back to the pool
         if (rc != H2HIP_ERR_PEER && pk->comm && pk->exch_next < pk->exch_sizes.size()) {
             // a sharded proof failed HERE (a lookup value missing from the table, an identity commitment, an allocation ...): the other

@@ -109,6 +109,18 @@ static bool g2_on_curve(const G2A &Q) {
     F2 b = f2_mul({fq_small(3), Fq::zero()}, f2_inv({fq_small(9), Fq::one()}));   // 3 / (9 + u): the D-twist's constant
     return f2_eq(f2_sqr(Q.y), f2_add(f2_mul(f2_sqr(Q.x), Q.x), b));
 }
+// Q in the order-r subgroup G2 of the twist?  The twist's group has a large cofactor (2q - r), so "on the twist" is not enough: EIP-197
+// rejects such points, and the pairing of one is not what the protocol's equations mean.  [r]Q by double-and-add over the
+// affine formulas above — ~380 additions with a field inversion each, a few milliseconds on the host, paid once per G2 input.
+static bool g2_in_subgroup(const G2A &Q) {
+    if (Q.inf) return true;
+    G2A acc = {f2_zero(), f2_zero(), true};
+    for (int bit = 253; bit >= 0; --bit) {
+        acc = g2_add(acc, acc);
+        if ((FrP::m(bit >> 5) >> (bit & 31)) & 1u) acc = g2_add(acc, Q);
+    }
+    return acc.inf;
+}
 // line through T with twist-slope lam, evaluated at the G1 point (xP, yP) after untwisting: yP - lam*xP*w + (lam*xT - yT)*w^3
 static F12 line_eval(const G2A &T, const F2 &lam, const Fq &xP, const Fq &yP) {
     F12 l;
@@ -658,7 +670,9 @@ int h2hip_pairing_check(const void *g1_points, const void *g2_points, size_t n, 
         G2A Q = {load_f2(q), load_f2(q + 64), false};
         Q.inf = f2_is_zero(Q.x) && f2_is_zero(Q.y);
         H2_REQUIRE(canonical(P.x) && canonical(P.y) && (P.is_identity() || g1_on_curve_host(P)), "a G1 point is not on the curve");
+        H2_REQUIRE(canonical(Q.x.c0) && canonical(Q.x.c1) && canonical(Q.y.c0) && canonical(Q.y.c1), "a G2 coordinate is not a canonical field element");
         H2_REQUIRE(g2_on_curve(Q), "a G2 point is not on the twist");
+        H2_REQUIRE(g2_in_subgroup(Q), "a G2 point is not in the order-r subgroup");
         f = f12_mul(f, miller_loop(P, Q));
     }
     *is_one = f12_is_one(final_exponentiation(f)) ? 1 : 0;

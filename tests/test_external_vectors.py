@@ -113,6 +113,46 @@ def _g2_bytes(Qp):
     return O.ints_to_limbs([x0, x1, y0, y1], Q).tobytes()    # SerdeFormat::RawBytes: x.c0, x.c1, y.c0, y.c1 (Montgomery limbs)
 
 
+def _f2_pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = OP.f2_mul(r, a)
+        a = OP.f2_sqr(a)
+        e >>= 1
+    return r
+
+
+def _f2_sqrt(a):
+    """square root in Fq2 = Fq[u]/(u^2 + 1), q = 3 mod 4, by the norm: (x0 + x1 u)^2 = a0 + a1 u with x0^2 = (a0 +- sqrt(a0^2 + a1^2)) / 2,
+    x1 = a1 / (2 x0); None if a is not a square"""
+    a0, a1 = a
+    fq_sqrt = lambda v: (lambda r: r if r * r % Q == v % Q else None)(pow(v, (Q + 1) // 4, Q))
+    s_ = fq_sqrt((a0 * a0 + a1 * a1) % Q)
+    if s_ is None:
+        return None
+    inv2 = pow(2, -1, Q)
+    for cand in ((a0 + s_) * inv2 % Q, (a0 - s_) * inv2 % Q):
+        x0 = fq_sqrt(cand)
+        if x0:
+            x = (x0, a1 * pow(2 * x0, -1, Q) % Q)
+            if OP.f2_sqr(x) == (a0 % Q, a1 % Q):
+                return x
+    return None
+
+
+def _twist_point_outside_g2():
+    """the first twist point with x = (t, 1), t = 1, 2, ...: on E'(Fq2) but (with overwhelming probability) not of order r"""
+    for t in range(1, 50):
+        x = (t, 1)
+        y = _f2_sqrt(OP.f2_add(OP.f2_mul(OP.f2_sqr(x), x), OP.TWIST_B))
+        if y is not None and OP.f2_sqr(y) == OP.f2_add(OP.f2_mul(OP.f2_sqr(x), x), OP.TWIST_B):
+            T = (x, y)
+            if OP.g2_mul(T, O.R_MOD) is not None:
+                return T
+    raise AssertionError("no twist point found")
+
+
 def _pairing_check(lib, pairs):
     g1 = b"".join(_g1_bytes(P) for P, _ in pairs)
     g2 = b"".join(_g2_bytes(Qp) for _, Qp in pairs)
@@ -132,6 +172,20 @@ def _lib_checks(lib):
     assert rc < 0
     rc, _ = _pairing_check(lib, [(O.G1_GEN, ((1, 2), (3, 4)))])
     assert rc < 0
+    # EIP-197 also rejects twist points OUTSIDE the order-r subgroup (the twist has a large cofactor) and non-canonical coordinates
+    T = _twist_point_outside_g2()
+    assert OP.g2_is_on_curve(T) and OP.g2_mul(T, O.R_MOD) is not None
+    rc, _ = _pairing_check(lib, [(O.G1_GEN, T)])
+    assert rc < 0 and b"subgroup" in lib.h2hip_last_error()
+    cofactor_cleared = OP.g2_mul(T, 2 * Q - O.R_MOD)          # |E'(Fq2)| = r (2q - r): this multiple lands in G2
+    assert OP.g2_mul(cofactor_cleared, O.R_MOD) is None
+    assert _pairing_check(lib, [(O.G1_GEN, cofactor_cleared), (O.g1_neg(O.G1_GEN), cofactor_cleared)]) == (0, 1)
+    (gx0, gx1), (gy0, gy1) = OP.G2_GEN
+    raw = lambda vals: b"".join(int(v).to_bytes(32, "little") for v in vals)
+    mont = lambda v: v * (1 << 256) % Q
+    non_canonical = raw([mont(gx0) + Q, mont(gx1), mont(gy0), mont(gy1)])    # the same residue, written as value + q (still < 2^256)
+    ok = ctypes.c_int(-1)
+    assert lib.h2hip_pairing_check(_g1_bytes(O.G1_GEN), non_canonical, 1, ctypes.byref(ok)) < 0 and b"canonical" in lib.h2hip_last_error()
     # Blake2b: RFC 7693 vectors, then hashlib with halo2's personalisation over every block-boundary length and several digest sizes
     out = ctypes.create_string_buffer(64)
     assert lib.h2hip_blake2b(None, 64, b"abc", 3, out) == 0 and out.raw == RFC7693_ABC
