@@ -787,26 +787,6 @@ int h2hip_msm_g1(h2hip_ctx *ctx, const h2hip_bases *bases, const void *scalars_h
     return h2hip_msm_g1_dev(ctx, bases, stage, n, point_format, out_host);
 }
 
-}   // extern "C"
-namespace h2 {
-// One MSM queued on `c`'s stream WITHOUT waiting for it: the Jacobian result lands in `out_host_pinned` (page-locked memory) once the
-// stream gets there; the caller orders itself behind an event it records on c->stream.  (plonk.hip: the commitment of the vanishing
-// argument's random polynomial, computed on a side context while the main stream runs the grand products.)
-int msm_single_async(h2hip_ctx *c, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, G1Jac *out_host_pinned) {
-    char *outbuf = nullptr;
-    H2_CHK(ws_reserve(c, h2hip_ctx::WS_OUT, 1024, (void **)&outbuf));
-    H2_CHK(msm_run(c, bases, scalars_dev, n, (XYZZ *)outbuf));
-    G1Jac *jac = (G1Jac *)(outbuf + 256);
-    prof_begin(c, "point_finish_kernel");
-    hipLaunchKernelGGL(point_finish_kernel, dim3(1), dim3(64), 0, c->stream, (const XYZZ *)outbuf, jac, (G1Affine *)nullptr);
-    prof_end(c);
-    H2_HIPCHK(hipGetLastError());
-    H2_HIPCHK(hipMemcpyAsync(out_host_pinned, jac, sizeof(G1Jac), hipMemcpyDeviceToHost, c->stream));
-    return H2HIP_OK;
-}
-}   // namespace h2
-extern "C" {
-
 static int finish_point(h2hip_ctx *ctx, char *outbuf, int point_format, void *out_host) {
     XYZZ *acc = (XYZZ *)outbuf;
     G1Jac *jac = (G1Jac *)(outbuf + 256);

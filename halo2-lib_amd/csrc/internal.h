@@ -114,8 +114,8 @@ struct h2hip_ctx {
     std::function<int(hipEvent_t ev)> msm_tail_hook;
     hipEvent_t tail_ev = nullptr;
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
-    int plonk_tail_overlap = 2;      // create_proof: >= 1: the challenge-independent transforms of rounds 1 and 3 run on a side stream next to the commitment MSMs' bucket reduction; 2: the random polynomial's commitment is computed ahead as well (libh2hip's seeded RNG only)
-    int plonk_side_on_lanes = 1;     // the side work of plonk_tail_overlap runs on two of the batch MSM's (idle) lane contexts instead of contexts of its own
+    int plonk_tail_overlap = 1;      // create_proof: the challenge-independent transforms of rounds 1 and 3 run on a side stream next to the commitment MSMs' bucket reduction
+    int plonk_side_on_lanes = 1;     // the side work of plonk_tail_overlap runs on the batch MSM's last (idle) lane context instead of a context of its own
 #ifdef H2_HIPEMU
     int plonk_warm_keygen = 0;       // (the CPU-emulated test build does not pay for a second proof per key)
 #else
@@ -193,8 +193,6 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 // CONSUMES the state: the caller dirties the array) / schedule the fill
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);
 int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes);
-// capi.hip: one MSM queued on c->stream without a synchronisation; the Jacobian result is copied to page-locked host memory in stream order
-int msm_single_async(h2hip_ctx *c, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, G1Jac *out_host_pinned);
 // capi.hip: a child context's (MSM lane, the prover's side stream) kernel timers folded into the parent's table
 void prof_fold_child(h2hip_ctx *parent, h2hip_ctx *child);
 // rng.hip: n elements of the ChaCha Fr::random stream from element first_block on, on `stream`

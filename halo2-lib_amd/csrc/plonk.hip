@@ -250,9 +250,6 @@ struct h2hip_plonk_pk {
     hipEvent_t copy_ev = nullptr;
     h2hip_ctx *side = nullptr;           // child context (own stream, NTT scratch and twiddle cache): the transforms that run next to an MSM's tail
     hipEvent_t side_ev = nullptr;
-    h2hip_ctx *side_msm = nullptr;       // child context for the one MSM that depends on nothing: the random polynomial's commitment
-    hipEvent_t side_msm_ev = nullptr;
-    G1Jac *side_msm_out = nullptr;       // its result, page-locked host memory
     Fr *host_stage = nullptr;   // pinned staging for the RNG-drawn scalars (the n coefficients of the random polynomial, the blinding rows)
     size_t host_stage_elems = 0;
 };
@@ -763,23 +760,16 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // twiddle cache) behind the event the batch MSM records once its accumulations are done, read the Lagrange values the MSM also reads and
     // write NEW buffers, so they run next to the reduction and to the pointwise kernels that follow.  Single GPU only.
     const bool overlap = !sharded_any && ctx->plonk_tail_overlap != 0;
-    if (overlap && !pk->side_ev) {
-        H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
-        H2_HIPCHK(hipEventCreateWithFlags(&pk->side_msm_ev, hipEventDisableTiming));
-        H2_HIPCHK(hipHostMalloc((void **)&pk->side_msm_out, sizeof(G1Jac), 0));
-    }
-    // The vanishing argument's random polynomial depends on nothing but the RNG: when its scalars were generated ahead (libh2hip's counter-
-    // mode generator, above) its COMMITMENT is computed ahead too — one MSM on a second side context, queued behind round 1's accumulations,
-    // running next to that round's reduction, the grand products and the side stream's transforms — so that round 3 commits two columns
-    // instead of three.  The transcript takes the point where upstream writes it: same bytes.
-    const bool random_ahead = overlap && rng_ahead && ctx->plonk_tail_overlap >= 2;
-    bool random_commit_queued = false;
+    if (overlap && !pk->side_ev) H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
+    // (r04 also computed the random polynomial's COMMITMENT ahead — its scalars depend on nothing once the generator is counter-mode — as one
+    // MSM on a second side context behind round 1's accumulations: 14.72-14.99 vs 14.71-14.98 ms, profiles/r04_tail_overlap_ab.log.  The
+    // chip is busy with something ~97 % of the time; only work moved into LOW-occupancy stretches gains, and that MSM is not such work.  Removed.)
     // Which contexts run the side work.  The device serves its streams through a handful of hardware queues (4 by default: with more,
     // measured, everything gets slower), and the batch MSM's lanes already hold as many: a further stream shares a queue with one of them.
-    // After a round's accumulations the lanes idle until the next round, so by default the side work runs ON two of the lanes' contexts
-    // (each a full context: own stream, NTT scratch, twiddle cache, MSM scratch); separate contexts only where those lanes do not exist
-    // (one lane from 2^20 points on) or with plonk_side_on_lanes = 0.
-    h2hip_ctx *side_c = nullptr, *side_msm_c = nullptr;
+    // After a round's accumulations the lanes idle until the next round, so by default the side work runs ON the last lane's context
+    // (a full context: own stream, NTT scratch, twiddle cache); a separate context only where that lane does not exist (one lane from 2^20
+    // points on) or with plonk_side_on_lanes = 0.
+    h2hip_ctx *side_c = nullptr;
     auto pick_side = [&](h2hip_ctx *lane, h2hip_ctx **own) -> h2hip_ctx * {
         h2hip_ctx *c = (ctx->plonk_side_on_lanes && lane) ? lane : *own;
         if (!c) {
@@ -981,19 +971,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                 r1_src.push_back(s.ap);
                 r1_src.push_back(s.sp);
             }
-            side_arm([&]() -> int {
-                H2_CHK(side_transforms(r1_src, r1_coef, r1_cos));
-                if (random_ahead) {   // behind the same event (the hook made the side context wait for it; this one waits for it and for the generator)
-                    side_msm_c = pick_side(ctx->lane[1], &pk->side_msm);
-                    H2_REQUIRE(side_msm_c, "create_proof: no side context");
-                    H2_HIPCHK(hipStreamWaitEvent(side_msm_c->stream, ctx->tail_ev, 0));
-                    H2_HIPCHK(hipStreamWaitEvent(side_msm_c->stream, pk->copy_ev, 0));
-                    H2_CHK(msm_single_async(side_msm_c, pk->g, random_poly, n, pk->side_msm_out));
-                    H2_HIPCHK(hipEventRecord(pk->side_msm_ev, side_msm_c->stream));
-                    random_commit_queued = true;
-                }
-                return H2HIP_OK;
-            });
+            side_arm([&]() -> int { return side_transforms(r1_src, r1_coef, r1_cos); });
         }
         H2_CHK(commit_points(pk->g_lagrange, cols, n, pts));
         H2_CHK(side_fire_if_pending());
@@ -1177,10 +1155,6 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                 H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));
             } else {
                 if (rng_ahead) H2_HIPCHK(hipStreamWaitEvent(st, pk->copy_ev, 0));   // (the buffer is overwritten in stream order)
-                if (random_commit_queued) {   // a commitment of the wrong scalars is in flight: let it finish, then forget it
-                    H2_HIPCHK(hipEventSynchronize(pk->side_msm_ev));
-                    random_commit_queued = false;
-                }
                 H2_CHK(rng_chacha_fill_dev(ctx, random_poly, n, cr->seed, cr->rounds, cr->pos, st));
             }
             cr->pos += n;
@@ -1197,10 +1171,8 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             cols.push_back(s.z);
             bases.push_back(pk->g_lagrange);
         }
-        if (!random_commit_queued) {
-            cols.push_back(random_poly);
-            bases.push_back(pk->g);
-        }
+        cols.push_back(random_poly);
+        bases.push_back(pk->g);
         std::vector<G1Affine> pts;
         if (overlap) {   // the grand products' coefficient and extended forms do not depend on y: next to this round's reduction
             r3_src.assign(perm_z.begin(), perm_z.end());
@@ -1209,10 +1181,6 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         }
         H2_CHK(commit_points_multi(nullptr, bases, cols, n, pts));
         H2_CHK(side_fire_if_pending());
-        if (random_commit_queued) {
-            H2_HIPCHK(hipEventSynchronize(pk->side_msm_ev));
-            pts.push_back(jacobian_to_affine(*pk->side_msm_out));
-        }
         for (size_t i = 0; i + 1 < pts.size(); ++i) H2_CHK(tr.write_point(pts[i]));
         random_commitment = pts.back();
         laps.lap(ST_COMMIT_PRODUCTS);
@@ -1667,7 +1635,6 @@ int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, 
             pk->transcript_repr = saved;
             ctx->msm_tail_hook = nullptr;
             if (pk->side) hipStreamSynchronize(pk->side->stream);
-            if (pk->side_msm) hipStreamSynchronize(pk->side_msm->stream);
             for (h2hip_ctx *l : ctx->lane)
                 if (l) hipStreamSynchronize(l->stream);
             if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
@@ -1693,9 +1660,6 @@ void h2hip_plonk_pk_free(h2hip_ctx *ctx, h2hip_plonk_pk *pk) {
     if (pk->copy_stream) hipStreamDestroy(pk->copy_stream);
     if (pk->side_ev) hipEventDestroy(pk->side_ev);
     if (pk->side) h2hip_destroy(pk->side);
-    if (pk->side_msm_ev) hipEventDestroy(pk->side_msm_ev);
-    if (pk->side_msm) h2hip_destroy(pk->side_msm);
-    if (pk->side_msm_out) hipHostFree(pk->side_msm_out);
     pk->pool.destroy();
     delete pk;
 }
@@ -1806,14 +1770,12 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     int rc = create_proof_impl(ctx, pk, advice, advice_on_device != 0, instances_host, instance_lens, rng, rng_user, proof, stage_ms);
     ctx->msm_tail_hook = nullptr;   // (never leave a hook of this proof behind: it captures the proof's frame)
     if (pk->side && ctx->profiling) prof_fold_child(ctx, pk->side);
-    if (pk->side_msm && ctx->profiling) prof_fold_child(ctx, pk->side_msm);
     if (ctx->profiling)
         for (h2hip_ctx *l : ctx->lane)
             if (l) prof_fold_child(ctx, l);
     if (rc != H2HIP_OK) {
         if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
         if (pk->side) hipStreamSynchronize(pk->side->stream);
-        if (pk->side_msm) hipStreamSynchronize(pk->side_msm->stream);
         for (h2hip_ctx *l : ctx->lane)
             if (l) hipStreamSynchronize(l->stream);
         hipStreamSynchronize(ctx->stream);   // nothing of the failed proof may still run on buffers that go back to the pool

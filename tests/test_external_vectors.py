@@ -141,6 +141,16 @@ def _f2_sqrt(a):
     return None
 
 
+def _g2_mul_raw(T, k):
+    """k * T WITHOUT reducing k mod r (oracle/pairing.py:g2_mul reduces: it is meant for points of G2)"""
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = OP.g2_add(acc, acc)
+        if bit == "1":
+            acc = OP.g2_add(acc, T)
+    return acc
+
+
 def _twist_point_outside_g2():
     """the first twist point with x = (t, 1), t = 1, 2, ...: on E'(Fq2) but (with overwhelming probability) not of order r"""
     for t in range(1, 50):
@@ -148,7 +158,7 @@ def _twist_point_outside_g2():
         y = _f2_sqrt(OP.f2_add(OP.f2_mul(OP.f2_sqr(x), x), OP.TWIST_B))
         if y is not None and OP.f2_sqr(y) == OP.f2_add(OP.f2_mul(OP.f2_sqr(x), x), OP.TWIST_B):
             T = (x, y)
-            if OP.g2_mul(T, O.R_MOD) is not None:
+            if _g2_mul_raw(T, O.R_MOD) is not None:
                 return T
     raise AssertionError("no twist point found")
 
@@ -174,11 +184,11 @@ def _lib_checks(lib):
     assert rc < 0
     # EIP-197 also rejects twist points OUTSIDE the order-r subgroup (the twist has a large cofactor) and non-canonical coordinates
     T = _twist_point_outside_g2()
-    assert OP.g2_is_on_curve(T) and OP.g2_mul(T, O.R_MOD) is not None
+    assert OP.g2_is_on_curve(T) and _g2_mul_raw(T, O.R_MOD) is not None
     rc, _ = _pairing_check(lib, [(O.G1_GEN, T)])
     assert rc < 0 and b"subgroup" in lib.h2hip_last_error()
-    cofactor_cleared = OP.g2_mul(T, 2 * Q - O.R_MOD)          # |E'(Fq2)| = r (2q - r): this multiple lands in G2
-    assert OP.g2_mul(cofactor_cleared, O.R_MOD) is None
+    cofactor_cleared = _g2_mul_raw(T, 2 * Q - O.R_MOD)        # |E'(Fq2)| = r (2q - r): this multiple lands in G2
+    assert cofactor_cleared is not None and _g2_mul_raw(cofactor_cleared, O.R_MOD) is None
     assert _pairing_check(lib, [(O.G1_GEN, cofactor_cleared), (O.g1_neg(O.G1_GEN), cofactor_cleared)]) == (0, 1)
     (gx0, gx1), (gy0, gy1) = OP.G2_GEN
     raw = lambda vals: b"".join(int(v).to_bytes(32, "little") for v in vals)
