@@ -110,6 +110,80 @@ __global__ __launch_bounds__(256) void modmul29_bench_kernel(Fr *__restrict__ io
     io[i] = f29_pack_canonical<FrP>(f29_mul(acc, Fr29::one()));
 }
 
+// r04 probe: ONE radix-4 round of the NTT pass kernel (ntt.hip: two stages, four products per lane, the lazy adds / subs / norms between
+// them) in a loop, with the parts of the real kernel switched on one at a time — MODE 0: registers only; 1: the four elements and three
+// twiddles come from LDS and go back to it every iteration (48-byte elements, conflict-free addresses of a later round); 2: + a block
+// barrier per iteration; 3: like 2 with the first round's 4-way conflicting addresses.  Modes >= 1 declare the real kernel's LDS footprint
+// (three workgroups per CU).  Reported as products/s (4 per lane and iteration): against h2hip_bench_modmul29's rate it says what the
+// round's own instruction stream, its LDS round trip and its barrier each cost (tools/issue_probe.py).
+struct alignas(16) ProbeElem {
+    Fr29 v;
+    uint32_t pad[3];
+};
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void ntt_round_probe_kernel(Fr *__restrict__ io, uint32_t iters) {
+    HIP_DYNAMIC_SHARED(ProbeElem, plds)
+    const uint32_t tid = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + tid;
+    Fr y0 = io[i];
+    y0.l[7] &= 0x0fffffffu;
+    const Fr29 y = f29_split<R29P>(y0);
+    Fr29 x0 = y, x1 = y, x2 = y, x3 = y;
+    x1.l[0] ^= 1u;
+    x2.l[0] ^= 2u;
+    x3.l[0] ^= 3u;
+    // addresses of a radix-4 group in a 1024-element tile with 4 columns: a later round (st = 2: conflict-free) or the first (st = 0)
+    const uint32_t c = tid & 3u, p = tid >> 2;
+    const uint32_t st = MODE == 3 ? 0u : 2u, h = 1u << st;
+    const uint32_t e0 = ((((p >> st) << (st + 2)) + (p & (h - 1))) << 2) + c, stride = h << 2;
+    ProbeElem *tw = plds + 1024;
+    if (MODE >= 1) {
+        plds[e0].v = x0;
+        plds[e0 + stride].v = x1;
+        plds[e0 + 2 * stride].v = x2;
+        plds[e0 + 3 * stride].v = x3;
+        if (tid < 128) tw[tid].v = y;
+        __syncthreads();
+    }
+    Fr29 w1 = y, w2 = y, w3 = y;
+    w2.l[1] ^= 5u;
+    w3.l[1] ^= 9u;
+    for (uint32_t it = 0; it < iters; ++it) {
+        if (MODE >= 1) {
+            x0 = plds[e0].v;
+            x1 = plds[e0 + stride].v;
+            x2 = plds[e0 + 2 * stride].v;
+            x3 = plds[e0 + 3 * stride].v;
+            w1 = tw[(tid + it) & 127u].v;
+            w2 = tw[(tid + 2 * it + 1) & 127u].v;
+            w3 = tw[(tid + 3 * it + 2) & 127u].v;
+        }
+        x1 = f29_mul(x1, w1);
+        x3 = f29_mul(x3, w1);
+        const Fr29 a0 = f29_add(x0, x1), a1 = f29_sub_lazy<2>(x0, x1);
+        const Fr29 a2 = f29_mul_wide(f29_add(x2, x3), w2);
+        const Fr29 a3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), w3);
+        x0 = f29_norm(f29_add(a0, a2));
+        x2 = f29_sub<2>(a0, a2);
+        x1 = f29_norm(f29_add(a1, a3));
+        x3 = f29_sub<2>(a1, a3);
+        // keep the values inside the products' input bounds over many iterations (the real kernel runs <= 5 rounds per tile)
+        x0 = f29_weak_reduce(x0);
+        x1 = f29_weak_reduce(x1);
+        x2 = f29_weak_reduce(x2);
+        x3 = f29_weak_reduce(x3);
+        if (MODE >= 1) {
+            plds[e0].v = x0;
+            plds[e0 + stride].v = x1;
+            plds[e0 + 2 * stride].v = x2;
+            plds[e0 + 3 * stride].v = x3;
+        }
+        if (MODE >= 2) __syncthreads();
+    }
+    const Fr29 acc = f29_norm(f29_add(f29_norm(f29_add(x0, x1)), f29_norm(f29_add(x2, x3))));
+    io[i] = f29_pack_canonical<FrP>(f29_mul(acc, Fr29::one()));
+}
+
 // the THIRD multiplier representation — 5 x 52-bit limbs held as doubles, products by v_fma_f64.  With the FP64
 // unit rounding toward zero, hi = fma(a, b, 2^104) carries floor(a*b / 2^52) in its mantissa and lo = fma(a, b, 2^104 + 2^52 - hi) the low 52
 // bits (both exact); column sums are integer additions of the raw bit patterns (the exponent fields are cancelled by the initial column
@@ -1574,19 +1648,24 @@ int h2hip_quotient_permutation_sets_dev(h2hip_ctx *ctx, void *acc, const void *c
 int h2hip_bench_modmul29(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && elapsed_ms && modmuls && blocks && iters, "bad argument");
-    H2_REQUIRE(chains == 1 || chains == 2, "chains must be 1 or 2");
+    H2_REQUIRE(chains == 1 || chains == 2 || (chains >= 16 && chains <= 19), "chains must be 1 or 2 (16..19: the NTT round probe, mode = chains - 16)");
     Fr *buf = nullptr;
     size_t lanes = (size_t)blocks * 256;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(Fr) * lanes, (void **)&buf));
     H2_HIPCHK(hipMemsetAsync(buf, 0x5a, sizeof(Fr) * lanes, ctx->stream));
+    const size_t probe_lds = sizeof(ProbeElem) * (1024 + 128 + 8);
     for (int rep = 0; rep < 2; ++rep) {   // rep 0 = warm-up
         H2_CHK(h2hip_timer_start(ctx));
         if (chains == 1) hipLaunchKernelGGL(modmul29_bench_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, buf, iters);
         if (chains == 2) hipLaunchKernelGGL(modmul29_bench_kernel<2>, dim3(blocks), dim3(256), 0, ctx->stream, buf, iters);
+        if (chains == 16) hipLaunchKernelGGL(ntt_round_probe_kernel<0>, dim3(blocks), dim3(256), 0, ctx->stream, buf, iters);
+        if (chains == 17) hipLaunchKernelGGL(ntt_round_probe_kernel<1>, dim3(blocks), dim3(256), probe_lds, ctx->stream, buf, iters);
+        if (chains == 18) hipLaunchKernelGGL(ntt_round_probe_kernel<2>, dim3(blocks), dim3(256), probe_lds, ctx->stream, buf, iters);
+        if (chains == 19) hipLaunchKernelGGL(ntt_round_probe_kernel<3>, dim3(blocks), dim3(256), probe_lds, ctx->stream, buf, iters);
         H2_HIPCHK(hipGetLastError());
         H2_CHK(h2hip_timer_stop(ctx, elapsed_ms));
     }
-    *modmuls = (double)lanes * iters * chains;
+    *modmuls = (double)lanes * iters * (chains >= 16 ? 4 : chains);
     return H2HIP_OK;
 }
 
