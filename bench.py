@@ -185,7 +185,7 @@ def measure_hbm_traffic(k, kernel="msm_accum_kernel"):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--k", str(k),
                    "--steps", "4", "--warmup", "1"]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 return None, "%s pass failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:])
