@@ -792,7 +792,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // the main stream holds after it) — `arm` before the commitment, `fire_if_pending` after it
     auto side_arm = [&](std::function<int()> fn) {
         ctx->msm_tail_hook = [&, fn](hipEvent_t ev) -> int {
-            side_c = pick_side(ctx->lane[2], &pk->side);
+            if (!side_c) side_c = pick_side(ctx->lane[2], &pk->side);   // chosen once per proof: side_join() waits for ONE stream's event
             H2_REQUIRE(side_c, "create_proof: no side context");
             H2_HIPCHK(hipStreamWaitEvent(side_c->stream, ev, 0));
             H2_CHK(fn());
