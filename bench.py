@@ -127,7 +127,7 @@ def synthetic_scalars(n: int, seed: int) -> np.ndarray:
 
 def window_for(ctx, n):
     c = ctx.get_param("msm_window_bits")
-    if c == 0:   # mirror of pick_window() in msm.hip
+    if c == 0:   # mirror of pick_window() in msm_tables.hip
         best, best_cost = 4, float("inf")
         for cc in range(4, 21):
             W = (255 + cc - 1) // cc

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libh2hip.so")
-SOURCES = ["capi.hip", "ntt.hip", "msm.hip", "fr_ops.hip", "srs.hip", "lookup.hip", "prover_ops.hip", "plonk.hip", "verifier.hip", "g2.hip", "comm.hip", "rng.hip"]
+SOURCES = ["capi.hip", "ntt.hip", "msm.hip", "msm_tables.hip", "fr_ops.hip", "srs.hip", "lookup.hip", "prover_ops.hip", "plonk.hip", "verifier.hip", "g2.hip", "comm.hip", "rng.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".cuh", ".h", ".inc"))) + [os.path.join("..", "..", "include", "h2hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -182,7 +182,8 @@ int upload_jobs(h2hip_ctx *ctx, void *dst_dev, const void *src_host, size_t byte
 int exclusive_scan_u32_segments(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t segments, size_t in_stride,
                                 size_t out_stride);   // `segments` independent scans of n elements, in_stride / out_stride elements apart
 int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32_t n);   // out[i] = sum_{j<i} in[j]; in != out
-int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_t n);
+int batch_normalize_jac(h2hip_ctx *ctx, const G1Jac *tmp, G1Affine *out, uint32_t n);   // msm_tables.hip
+uint32_t pick_window(size_t n, bool precomp = false);   // Pippenger window width for n points (msm_tables.hip)
 int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *bases, bool precompute);
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, size_t n, XYZZ *out_dev);
 constexpr uint32_t MSM_MAX_COLS = 32;   // columns one fused multi-column MSM handles
