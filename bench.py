@@ -503,19 +503,29 @@ def main():
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
         if world > 1:
-            P96 = 96
-            nl_ = sh.num_lookups
+            sharded_exchanges = None
+            if sharded:
+                # the schedule of the last sharded proof as libh2hip ran it (h2hip_plonk_pk_last_exchanges), labelled in the order plonk.hip builds it
+                cnt = _C.c_size_t(0)
+                sizes = (_C.c_size_t * 32)()
+                ctx._chk(ctx.lib.h2hip_plonk_pk_last_exchanges(pk.handle, sizes, 32, _C.byref(cnt)))
+                what = ["hello (shape, point range, stages sharded, RNG digest)", "round 1: advice + permuted lookup columns",
+                        "grand products: the row ranges' total products (and the go-ahead of their all-gather)",
+                        "round 2: grand products + random polynomial", "go-ahead before the coset all-gather (status only)", "h(X) pieces",
+                        "evaluations: partial sums over the coefficient ranges", "SHPLONK: the ranges' partial evaluations at the rotation sets' points (carries)",
+                        "SHPLONK W", "SHPLONK: the linearisation's partial evaluation at u (carry)", "SHPLONK W'"]
+                nprod = sh.num_perm_sets + sh.num_lookups
+                rows = -(-n // world)
+                sharded_exchanges = {"host_allgather_payload_bytes_per_rank": [int(sizes[i]) for i in range(cnt.value)],
+                                     "host_allgather_what": what if cnt.value == len(what) else "(%d exchanges: stages switched off)" % cnt.value,
+                                     "device_allgathers_bytes_per_rank": {
+                                         "grand product columns, this rank's rows (device to device)": 32 * nprod * (rows + 1),
+                                         "h(X)'s numerator, this rank's cosets (device to device)": 32 * n * (-(-(1 << (sh.extended_k - k)) // world))},
+                                     "status_word_bytes": 8}
             out["comm"] = {"transport": "RCCL (ncclAllGather on the context's stream; librccl dlopen'ed by libh2hip)" if comm_ranks[0]["is_rccl"] else
                                         "callback (torch.distributed %s all_gather on host tensors)" % args.dist_backend,
                            "ranks": comm_ranks, "distinct_gpus": len({r["gpu_uuid"] or r["pci_bus_id"] or r["cuda_device"] for r in comm_ranks}),
-                           "sharded_proof_exchanges": None if not sharded else {
-                               "host_allgather_payload_bytes_per_rank": [72, P96 * (sh.num_advice_total + 2 * nl_), P96 * (sh.num_perm_sets + nl_ + 1), 0,
-                                                                         P96 * sh.quotient_pieces, P96, P96],
-                               "host_allgather_what": ["hello (shape, point range, RNG digest)", "round 1: advice + permuted lookup columns", "round 2: grand products + random polynomial",
-                                                       "go-ahead before the coset all-gather (status only)", "h(X) pieces", "SHPLONK W", "SHPLONK W'"],
-                               "device_allgather_bytes_per_rank": 32 * n * (-(-(1 << (sh.extended_k - k)) // world)),
-                               "device_allgather_what": "this rank's cosets of h(X)'s numerator, [max cosets per rank][2^k] Fr, device to device",
-                               "status_word_bytes": 8}}
+                           "sharded_proof_exchanges": None if not sharded else sharded_exchanges}
         out["reference_published"] = {"total_proof_time_s": 7.6, "source": "/root/reference/README.md:242 (32 vCPU r6a / M2 Max, end to end incl. witness generation; other hardware)"}
     if sk is not None:
         sk.free()

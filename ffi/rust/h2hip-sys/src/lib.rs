@@ -76,6 +76,7 @@ pub struct h2hip_comm {
 }
 pub const H2HIP_SHARD_QUOTIENT: u32 = 1;
 pub const H2HIP_SHARD_FORCE: u32 = 2;
+pub const H2HIP_SHARD_PRODUCTS: u32 = 4;
 pub const H2HIP_ERR_PEER: c_int = -5;
 pub const H2HIP_OK: c_int = 0;
 pub const H2HIP_ERR_INVALID: c_int = -1;
@@ -145,6 +146,7 @@ extern "C" {
     pub fn h2hip_fr_eval_polynomial_dev(ctx: *mut h2hip_ctx, coeffs_dev: *const c_void, n: usize, x: *const c_void, out_host: *mut c_void) -> c_int;
     pub fn h2hip_fr_kate_division_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, b: *const c_void) -> c_int;
     pub fn h2hip_fr_kate_division_multi_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, points: *const c_void, weights: *const c_void, m: u32) -> c_int;
+    pub fn h2hip_fr_kate_division_range_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, points: *const c_void, weights: *const c_void, carries: *const c_void, m: u32) -> c_int;
     pub fn h2hip_quotient_flex_gate_dev(ctx: *mut h2hip_ctx, acc_dev: *mut c_void, q_dev: *const c_void, a_dev: *const c_void, ext_k: u32, k: u32, y: *const c_void) -> c_int;
     pub fn h2hip_fr_add_batch_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, n: usize) -> c_int;
     pub fn h2hip_fr_sub_batch_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, n: usize) -> c_int;
@@ -194,6 +196,9 @@ extern "C" {
     pub fn h2hip_permutation_product_terms_sets_dev(ctx: *mut h2hip_ctx, num_dev: *mut c_void, den_dev: *mut c_void, cols_dev: *const *const c_void,
                                                     sigmas_dev: *const *const c_void, num_columns: u32, chunk_len: u32, rows: usize,
                                                     beta: *const c_void, gamma: *const c_void, delta: *const c_void, omega: *const c_void) -> c_int;
+    pub fn h2hip_permutation_product_terms_rows_dev(ctx: *mut h2hip_ctx, num_dev: *mut c_void, den_dev: *mut c_void, cols_dev: *const *const c_void,
+                                                    sigmas_dev: *const *const c_void, num_columns: u32, chunk_len: u32, row0: usize, rows: usize,
+                                                    beta: *const c_void, gamma: *const c_void, delta: *const c_void, omega: *const c_void) -> c_int;
     pub fn h2hip_permutation_product_terms_dev(ctx: *mut h2hip_ctx, num_dev: *mut c_void, den_dev: *mut c_void, cols_dev: *const *const c_void,
                                                sigmas_dev: *const *const c_void, ncols: u32, first_col_index: u32, rows: usize, beta: *const c_void,
                                                gamma: *const c_void, delta: *const c_void, omega: *const c_void) -> c_int;
@@ -211,6 +216,7 @@ extern "C" {
     pub fn h2hip_plonk_pk_set_transcript_repr(pk: *mut h2hip_plonk_pk, fr: *const c_void) -> c_int;
     pub fn h2hip_plonk_pk_set_sharding(pk: *mut h2hip_plonk_pk, comm: *mut h2hip_comm, g_shard: *const h2hip_bases, g_lagrange_shard: *const h2hip_bases,
                                        offset: usize, len: usize, flags: u32) -> c_int;
+    pub fn h2hip_plonk_pk_last_exchanges(pk: *const h2hip_plonk_pk, sizes: *mut usize, cap: usize, count: *mut usize) -> c_int;
     pub fn h2hip_comm_rccl_unique_id(out128: *mut c_void) -> c_int;
     pub fn h2hip_comm_init_rccl(ctx: *mut h2hip_ctx, unique_id128: *const c_void, world: c_int, rank: c_int, out: *mut *mut h2hip_comm) -> c_int;
     pub fn h2hip_comm_init_callback(world: c_int, rank: c_int, allgather: h2hip_allgather_fn, user: *mut c_void, out: *mut *mut h2hip_comm) -> c_int;

@@ -3,6 +3,7 @@
 // sub / mul / mul_add on column values) plus the diagnostic multiplier micro-benchmark that defines the
 // integer roofline quoted by bench.py.
 #include "internal.h"
+#include <utility>
 #include "fq29.cuh"
 
 namespace h2 {
@@ -508,14 +509,16 @@ __global__ __launch_bounds__(256) void fr_eval_final_batch_kernel(const EvalJob 
 constexpr uint32_t KATE_J = 8, KATE_TILE = 256 * KATE_J;
 template <uint32_t J>
 __device__ __forceinline__ Fr kate_tile_scan(const Fr *__restrict__ c, size_t n, size_t lo, Fr b, const PowTable &pw, Fr *sh, Fr carry_in,
-                                             Fr *__restrict__ q) {
-    // returns the tile head; when q != nullptr also writes the quotient coefficients of this tile (256 * J coefficients, J per lane)
+                                             Fr *__restrict__ q, const Fr *top = nullptr) {
+    // returns the tile head; when q != nullptr also writes the quotient coefficients of this tile (256 * J coefficients, J per lane).
+    // `top`: a virtual coefficient of index n (range division: what the coefficients above this range contribute, see KateJob::top)
     const uint32_t tid = threadIdx.x;
     const size_t base = lo + (size_t)tid * J;
     Fr h = Fr::zero();
     for (int k = (int)J - 1; k >= 0; --k) {
         h = fe_mul(h, b);
         if (base + k < n) h = fe_add(h, c[base + k]);
+        else if (top && base + k == n) h = fe_add(h, *top);
     }
     sh[tid] = h;
     __syncthreads();
@@ -591,6 +594,8 @@ __global__ __launch_bounds__(256) void fr_kate_apply_kernel(const Fr *__restrict
 // heads-carry-apply triple per root on a shrinking intermediate).
 struct KateJob {
     Fr b, w;
+    Fr top;   // range division (h2hip_fr_kate_division_range_dev): sum_{i >= n} f_i b^(i - n) over the coefficients ABOVE the range held here,
+              // which enters the suffix Horner as one more coefficient of index n; zero otherwise
     PowTable pw;
 };
 // (J = coefficients per lane: a tile is 256 * J coefficients.  The multi-point kernels pick J by the polynomial's length — when there are fewer
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(256) void fr_kate_heads_multi_kernel(const Fr *__re
                                                                   Fr *__restrict__ heads) {
     __shared__ Fr sh[256];
     const KateJob &job = jobs[blockIdx.y];
-    Fr h = kate_tile_scan<J>(c, n, (size_t)blockIdx.x * (256 * J), job.b, job.pw, sh, Fr::zero(), nullptr);
+    Fr h = kate_tile_scan<J>(c, n, (size_t)blockIdx.x * (256 * J), job.b, job.pw, sh, Fr::zero(), nullptr, &job.top);
     if (threadIdx.x == 0) heads[(size_t)blockIdx.y * (ntiles + 1) + blockIdx.x] = h;
 }
 __global__ __launch_bounds__(256) void fr_kate_carry_multi_kernel(const Fr *__restrict__ heads, Fr *__restrict__ carry, uint32_t ntiles,
@@ -639,64 +644,80 @@ __global__ __launch_bounds__(256) void fr_kate_carry_multi_kernel(const Fr *__re
 // All M points of the set advance together through one pass over the tile: their Horner values, their suffix scans (one pair of barriers
 // per doubling step for all points) and their quotient chains; the tile's incoming carry sits in an extra scan slot (index 256), which the scan
 // multiplies by the right power of b^J on its own.  Points beyond m (padding up to the compiled M) carry weight 0.
-template <int M, uint32_t J>
+// (compile-time loop over the points: with `for (j < M)` + `#pragma unroll` the compiler leaves the loops around two field multiplications per
+// point rolled and the per-point arrays in scratch memory; a pack expansion leaves it no choice)
+template <class F, int... Js>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Js...>) {
+    (f(std::integral_constant<int, Js>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+template <int M, uint32_t J, bool TOP>
 __global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__restrict__ c, size_t n, const KateJob *__restrict__ jobs, uint32_t m,
                                                                   uint32_t ntiles, const Fr *__restrict__ carry, Fr *__restrict__ q, int accumulate) {
     __shared__ Fr sh[M][257];
     const uint32_t tid = threadIdx.x;
     const size_t lo = (size_t)blockIdx.x * (256 * J), base = lo + (size_t)tid * J;
-    Fr cv[J], acc[J];
-#pragma unroll
-    for (uint32_t k = 0; k < J; ++k) {
-        cv[k] = base + k < n ? c[base + k] : Fr::zero();
-        acc[k] = Fr::zero();
-    }
+    const int ktop = TOP && n >= base && n < base + J ? (int)(n - base) : -1;   // the lane (one in the grid) that holds the virtual coefficient n
+    const size_t n_out = n + (TOP ? 1 : 0);
+    // (no per-lane arrays over k either: the k loops stay rolled, the coefficients are read again in the second pass — the tile was just read,
+    // they come from the caches.  The job list is padded with zero jobs up to M: b, w are wave-uniform loads, no select)
     Fr b[M], h[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        b[j] = (uint32_t)j < m ? jobs[j].b : Fr::zero();
+    static_for<M>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        b[j] = jobs[j].b;
         h[j] = Fr::zero();
-    }
-#pragma unroll
+    });
+#pragma unroll 1
     for (int k = (int)J - 1; k >= 0; --k) {
-#pragma unroll
-        for (int j = 0; j < M; ++j) h[j] = fe_add(fe_mul(h[j], b[j]), cv[k]);   // coefficients past n are zero
+        const Fr cvk = base + k < n ? c[base + k] : Fr::zero();   // coefficients past n are zero
+        static_for<M>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            h[j] = fe_add(fe_mul(h[j], b[j]), cvk);
+            if (TOP && k == ktop) h[j] = fe_add(h[j], jobs[j].top);
+        });
     }
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
+    static_for<M>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         sh[j][tid] = h[j];
         if (tid == 0) sh[j][256] = (uint32_t)j < m ? carry[(size_t)j * (ntiles + 1) + blockIdx.x] : Fr::zero();
-    }
+    });
     __syncthreads();
     for (uint32_t d = 1, l = 0; d <= 256; d <<= 1, ++l) {   // inclusive suffix scan over 257 slots: I_t = h_t + b^J * I_{t+1}, I_256 = carry
         Fr o[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) o[j] = tid + d <= 256 ? sh[j][tid + d] : Fr::zero();
+        static_for<M>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            o[j] = tid + d <= 256 ? sh[j][tid + d] : Fr::zero();
+        });
         __syncthreads();
         if (tid + d <= 256) {
-#pragma unroll
-            for (int j = 0; j < M; ++j)
+            static_for<M>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
                 if ((uint32_t)j < m) sh[j][tid] = fe_add(sh[j][tid], fe_mul(o[j], jobs[j].pw.p[l]));
+            });
         }
         __syncthreads();
     }
     Fr tmp[M], w[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
+    static_for<M>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         tmp[j] = sh[j][tid + 1];
-        w[j] = (uint32_t)j < m ? jobs[j].w : Fr::zero();
-    }
-#pragma unroll
+        w[j] = jobs[j].w;
+    });
+#pragma unroll 1
     for (int k = (int)J - 1; k >= 0; --k) {
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            tmp[j] = fe_add(cv[k], fe_mul(tmp[j], b[j]));             // = quotient coefficient of index base + k - 1 for point j
-            acc[k] = fe_add(acc[k], fe_mul(w[j], tmp[j]));
-        }
+        const Fr cvk = base + k < n ? c[base + k] : Fr::zero();
+        Fr acc = Fr::zero();
+        static_for<M>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            tmp[j] = fe_add(cvk, fe_mul(tmp[j], b[j]));             // = quotient coefficient of index base + k - 1 for point j
+            if (TOP && k == ktop) tmp[j] = fe_add(tmp[j], jobs[j].top);
+            acc = fe_add(acc, fe_mul(w[j], tmp[j]));
+        });
+        if (base + k < n_out && base + k >= 1) q[base + k - 1] = accumulate ? fe_add(q[base + k - 1], acc) : acc;
     }
-#pragma unroll
-    for (uint32_t k = 0; k < J; ++k)
-        if (base + k < n && base + k >= 1) q[base + k - 1] = accumulate ? fe_add(q[base + k - 1], acc[k]) : acc[k];
 }
 
 // ------------------------------------------------------------------ K8: Poseidon permutation batches
@@ -1288,21 +1309,27 @@ int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size
 }  // extern "C"
 // q[0..n-1) = sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j]),  m <= 8 points; q_dev must not alias coeffs_dev
 template <uint32_t J>
-static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m) {
+static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m,
+                                   const void *tops = nullptr) {
     const uint32_t tile = 256 * J;
-    const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
-    std::vector<KateJob> jobs(m);
+    const int with_top = tops != nullptr;
+    const uint32_t ntiles = (uint32_t)((n + (with_top ? 1 : 0) + tile - 1) / tile);   // the virtual coefficient n may open a tile of its own
+    const uint32_t m_pad = (m + 3) / 4 * 4;   // a pass handles up to four points and reads that many jobs: zero jobs (b = w = top = 0) behind the last
+    std::vector<KateJob> jobs(m_pad);
+    memset((void *)jobs.data(), 0, sizeof(KateJob) * m_pad);
     for (uint32_t j = 0; j < m; ++j) {
         memcpy(&jobs[j].b, (const char *)points + sizeof(Fr) * j, sizeof(Fr));
         memcpy(&jobs[j].w, (const char *)weights + sizeof(Fr) * j, sizeof(Fr));
+        if (with_top) memcpy(&jobs[j].top, (const char *)tops + sizeof(Fr) * j, sizeof(Fr));
+        else jobs[j].top = Fr::zero();
         pow_table(jobs[j].b, J, jobs[j].pw);   // p[l] = b^(J * 2^l): p[8] = b^tile
     }
     char *buf = nullptr;
-    const size_t jobs_bytes = (sizeof(KateJob) * m + 255) / 256 * 256;
+    const size_t jobs_bytes = (sizeof(KateJob) * m_pad + 255) / 256 * 256;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, jobs_bytes + sizeof(Fr) * 2 * (size_t)m * (ntiles + 1), (void **)&buf));
     KateJob *djobs = (KateJob *)buf;
     Fr *heads = (Fr *)(buf + jobs_bytes), *carry = heads + (size_t)m * (ntiles + 1);
-    H2_CHK(upload_jobs(ctx, djobs, jobs.data(), sizeof(KateJob) * m));   // through the pinned ring: no synchronisation per call
+    H2_CHK(upload_jobs(ctx, djobs, jobs.data(), sizeof(KateJob) * m_pad));   // through the pinned ring: no synchronisation per call
     prof_begin(ctx, "fr_kate_kernels");
     hipLaunchKernelGGL(fr_kate_heads_multi_kernel<J>, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, ntiles, heads);
     hipLaunchKernelGGL(fr_kate_carry_multi_kernel, dim3(m), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles, (const KateJob *)djobs);
@@ -1311,16 +1338,29 @@ static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, 
         const KateJob *jb = djobs + j0;
         const Fr *cr = carry + (size_t)j0 * (ntiles + 1);
         const int accumulate = j0 ? 1 : 0;
-        if (mm == 1)
-            hipLaunchKernelGGL((fr_kate_apply_multi_kernel<1, J>), dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
-        else if (mm == 2)
-            hipLaunchKernelGGL((fr_kate_apply_multi_kernel<2, J>), dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
-        else
-            hipLaunchKernelGGL((fr_kate_apply_multi_kernel<4, J>), dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate);
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate); };
+        if (with_top) {
+            if (mm == 1) go(fr_kate_apply_multi_kernel<1, J, true>);
+            else if (mm == 2) go(fr_kate_apply_multi_kernel<2, J, true>);
+            else go(fr_kate_apply_multi_kernel<4, J, true>);
+        } else {
+            if (mm == 1) go(fr_kate_apply_multi_kernel<1, J, false>);
+            else if (mm == 2) go(fr_kate_apply_multi_kernel<2, J, false>);
+            else go(fr_kate_apply_multi_kernel<4, J, false>);
+        }
     }
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
+}
+// coefficients per lane: a tile is 256 * J coefficients; about one wave per SIMD or more (ctx->kate_coeffs_per_lane overrides: 1, 2, 4, 8)
+static int kate_division_multi_pick(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m, const void *tops) {
+    uint32_t j = ctx->kate_coeffs_per_lane;
+    if (j != 1 && j != 2 && j != 4 && j != 8) j = n >= ((size_t)1 << 19) ? 8 : n >= ((size_t)1 << 18) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;
+    if (j == 8) return kate_division_multi_run<8>(ctx, q, coeffs, n, points, weights, m, tops);
+    if (j == 4) return kate_division_multi_run<4>(ctx, q, coeffs, n, points, weights, m, tops);
+    if (j == 2) return kate_division_multi_run<2>(ctx, q, coeffs, n, points, weights, m, tops);
+    return kate_division_multi_run<1>(ctx, q, coeffs, n, points, weights, m, tops);
 }
 extern "C" {
 int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m) {
@@ -1328,11 +1368,18 @@ int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs
     H2_REQUIRE(ctx && points && weights && n >= 1 && coeffs && (n == 1 || q) && m >= 1 && m <= 8, "bad argument (1..8 points)");
     H2_REQUIRE(q != coeffs, "q must not alias coeffs");
     if (n == 1) return H2HIP_OK;
-    // coefficients per lane: about one wave per SIMD or more (2^19 coefficients: 8 per lane -> 256 tiles of 4 waves)
-    if (n >= ((size_t)1 << 19)) return kate_division_multi_run<8>(ctx, q, coeffs, n, points, weights, m);
-    if (n >= ((size_t)1 << 18)) return kate_division_multi_run<4>(ctx, q, coeffs, n, points, weights, m);
-    if (n >= ((size_t)1 << 17)) return kate_division_multi_run<2>(ctx, q, coeffs, n, points, weights, m);
-    return kate_division_multi_run<1>(ctx, q, coeffs, n, points, weights, m);
+    return kate_division_multi_pick(ctx, q, coeffs, n, points, weights, m, nullptr);
+}
+// The same division for ONE COEFFICIENT RANGE [lo, lo + n) of f (the multi-GPU prover: a rank holds the range of its SRS slice): coeffs_dev = that
+// range, carries[j] = sum_{i >= lo + n} f_i points[j]^(i - lo - n) — what the ranges above contribute, assembled by the caller from the ranks'
+// partial evaluations (zero for the top range) — and q_dev[0..n) = the quotient's coefficients lo .. lo + n - 1 (n values, one more than the
+// whole-polynomial call writes: the quotient coefficient lo + n - 1 is the carry itself).
+int h2hip_fr_kate_division_range_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, const void *carries,
+                                     uint32_t m) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && points && weights && carries && n >= 1 && coeffs && q && m >= 1 && m <= 8, "bad argument (1..8 points)");
+    H2_REQUIRE(q != coeffs, "q must not alias coeffs");
+    return kate_division_multi_pick(ctx, q, coeffs, n, points, weights, m, carries);
 }
 
 // ------------------------------------------------------------------ K8 Poseidon

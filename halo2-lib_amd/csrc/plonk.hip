@@ -236,7 +236,7 @@ struct h2hip_plonk_pk {
     size_t shard_offset = 0, shard_len = 0;
     uint32_t shard_world = 1, shard_rank = 0;
     h2hip_comm *comm = nullptr;
-    bool shard_quotient = false;
+    bool shard_quotient = false, shard_products = false;
     std::vector<uint32_t> my_cosets;          // cosets of the extended domain (rows = coset mod 2^(ek-k)) this rank evaluates h(X) on
     uint32_t max_cosets = 1;                  // cosets of the busiest rank (the all-gather's uniform slot count)
     std::vector<Fr *> fixed_cosets_sh, sigma_cosets_sh;   // [my_cosets][n] slices of the key's extended-domain arrays
@@ -454,6 +454,7 @@ static int keygen_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *const *fi
 }
 
 // ---------------------------------------------------------------------------------------------- SHPLONK bookkeeping
+constexpr size_t SHPLONK_MAX_OPENINGS = 64;   // (rotation set, point) pairs of one proof: the slots of the sharded prover's carry exchange
 struct Query {
     int poly;   // index into the prover's polynomial list
     Fr point, eval;
@@ -831,11 +832,15 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     pk->exch_next = 0;
     if (sharded_any) {   // the proof's host exchanges in order (payload bytes): hello, the five commitment rounds, the quotient's go-ahead
         const size_t P = sizeof(G1Jac);
-        pk->exch_sizes = {9 * sizeof(uint64_t), P * (sh.num_advice_total + 2 * sh.lookups.size()), P * (sh.num_perm_sets + sh.lookups.size() + 1)};
+        pk->exch_sizes = {9 * sizeof(uint64_t), P * (sh.num_advice_total + 2 * sh.lookups.size())};
+        if (pk->shard_products) pk->exch_sizes.push_back(sizeof(Fr) * (sh.num_perm_sets + sh.lookups.size()));   // the row ranges' total products
+        pk->exch_sizes.push_back(P * (sh.num_perm_sets + sh.lookups.size() + 1));
         if (qshard) pk->exch_sizes.push_back(0);
         pk->exch_sizes.push_back(P * sh.quotient_pieces);
         pk->exch_sizes.push_back(sizeof(Fr) * (sh.num_evals() + 1));   // the evaluations: partial sums over this rank's coefficient range
+        pk->exch_sizes.push_back(sizeof(Fr) * SHPLONK_MAX_OPENINGS);   // SHPLONK by coefficient range: the rotation sets' partial evaluations (carries)
         pk->exch_sizes.push_back(P);
+        pk->exch_sizes.push_back(sizeof(Fr));                          // ... and the linearisation's
         pk->exch_sizes.push_back(P);
     }
     tr.common_scalar(pk->transcript_repr);   // vk.hash_into(transcript)
@@ -867,6 +872,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(tails_flush(tails));
     }
     draw(sh.num_advice_total);   // Blind(Fr::random) per column: drawn, unused by KZG
+    std::vector<std::pair<uint64_t, uint64_t>> rank_ranges;   // sharded: (offset, len) of every rank's coefficient / point range
     if (sharded_any) {
         // every rank must run the same proof: same shape, same RNG stream (a digest of the first column's blinding rows), and point ranges
         // that tile [0, n) — otherwise the ranks would emit a proof that fails to verify without any of them noticing
@@ -877,7 +883,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         me.len = pk->shard_len;
         me.rank = pk->shard_rank;
         me.k = k;
-        me.ncols = sh.num_advice_total;
+        me.ncols = (uint64_t)sh.num_advice_total | (uint64_t)(pk->shard_quotient ? 1 : 0) << 32 | (uint64_t)(pk->shard_products ? 1 : 0) << 33;   // + the stages sharded: the exchange schedule depends on them
         {
             Blake2b h(32, "h2hip-shard-rng");
             h.update(pk->host_stage, sizeof(Fr) * (size_t)(n - u));   // the first draw of this proof sits at the start of the staging buffer
@@ -888,6 +894,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         std::vector<uint8_t> all;
         H2_CHK(exchange_host(&me, sizeof(me), all));
         std::vector<std::pair<uint64_t, uint64_t>> ranges;
+        rank_ranges.clear();
         for (uint32_t r = 0; r < pk->shard_world; ++r) {
             Hello o;
             memcpy(&o, all.data() + (size_t)r * (8 + sizeof(Hello)) + 8, sizeof(Hello));
@@ -897,6 +904,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             }
             ranges.push_back({o.offset, o.len});
         }
+        rank_ranges = ranges;   // by rank, for the carries of the range divisions
         std::sort(ranges.begin(), ranges.end());
         uint64_t pos = 0;
         for (auto &rg : ranges) {
@@ -990,7 +998,103 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         return c.kind == 0 ? pk->fixed_values[c.index] : c.kind == 1 ? adv[c.index] : inst_values[c.index];
     };
     std::vector<Fr *> perm_z(sh.num_perm_sets);
-    {
+    const bool pshard = sharded_any && pk->shard_products;
+    if (pshard) {
+        // Sharded by ROW RANGE (r04): a product column is a prefix product over the rows, so rank r forms the factors of its rows [a, b) — the
+        // rows of its point range below the blinding rows — inverts and multiplies them up locally (1/N of the single-GPU work), the ranks
+        // exchange their ranges' total products (32 bytes per product), every rank scales its rows by the product of everything before them (for
+        // the permutation argument that includes the earlier sets: z_i(0) = z_{i-1}(last usable row)), and ONE device-to-device all-gather
+        // completes the columns on every rank (their coefficient forms are needed everywhere).  This rank's commitment partials only read its
+        // own rows.  The blinding rows come from the (replicated) RNG stream.
+        const size_t S = sh.num_perm_sets, nseg = S + lks.size();
+        const size_t a = std::min<size_t>(pk->shard_offset, u), b = std::min<size_t>(pk->shard_offset + pk->shard_len, u), m = b - a;
+        size_t max_m = 0;
+        for (auto &rg : rank_ranges) max_m = std::max<size_t>(max_m, std::min<size_t>(rg.first + rg.second, u) - std::min<size_t>(rg.first, u));
+        const size_t row_stride = max_m + 1, slot_elems = nseg * row_stride;
+        Fr *num = nullptr, *den = nullptr, *sendb = nullptr, *recvb = nullptr;
+        std::vector<Fr *> zcol(nseg);
+        if (nseg) {
+            H2_CHK(sc.take(nseg * std::max<size_t>(m, 1), &num));
+            H2_CHK(sc.take(nseg * std::max<size_t>(m, 1), &den));
+            H2_CHK(sc.take(slot_elems, &sendb));
+            H2_CHK(sc.take(slot_elems * pk->shard_world, &recvb));
+            H2_CHK(comm_reserve_allgather_dev(pk->comm, sizeof(Fr) * slot_elems));
+        }
+        for (uint32_t si = 0; si < S; ++si) {
+            H2_CHK(sc.take(n, &perm_z[si]));
+            zcol[si] = perm_z[si];
+        }
+        for (size_t li = 0; li < lks.size(); ++li) {
+            H2_CHK(sc.take(n, &lks[li].z));
+            zcol[S + li] = lks[li].z;
+        }
+        if (S && m) {
+            std::vector<const void *> pcols(sh.perm_columns.size()), psig(sh.perm_columns.size());
+            for (size_t c = 0; c < sh.perm_columns.size(); ++c) {
+                pcols[c] = column_values(sh.perm_columns[c]);
+                psig[c] = pk->sigma_values[c];
+            }
+            H2_CHK(h2hip_permutation_product_terms_rows_dev(ctx, num, den, pcols.data(), psig.data(), (uint32_t)pcols.size(), sh.chunk_len, a, m, &beta, &gamma,
+                                                            &dom.delta, &dom.omega));
+        }
+        for (size_t li = 0; li < lks.size() && m; ++li) {
+            LookupState &s = lks[li];
+            H2_CHK(h2hip_lookup_product_terms_dev(ctx, num + (S + li) * m, den + (S + li) * m, s.inp + a, pk->fixed_values[sh.lookups[li].table_col] + a, s.ap + a,
+                                                  s.sp + a, m, &beta, &gamma));
+        }
+        std::vector<Fr> totals(nseg, Fr::one());
+        if (nseg) {
+            // local prefix products, each starting at 1: column s gets rows [a, b] (m + 1 values; the last one = this range's total)
+            std::vector<void *> zloc(nseg);
+            for (size_t j = 0; j < nseg; ++j) zloc[j] = zcol[j] + a;
+            H2_CHK(h2hip_fr_grand_products_dev(ctx, zloc.data(), num, den, nseg, m, 0));
+            for (size_t j = 0; j < nseg; ++j) H2_HIPCHK(hipMemcpyAsync(&totals[j], zcol[j] + b, sizeof(Fr), hipMemcpyDeviceToHost, st));
+            H2_HIPCHK(hipStreamSynchronize(st));
+        }
+        std::vector<uint8_t> all;
+        H2_CHK(exchange_host(totals.data(), sizeof(Fr) * nseg, all));   // (also the go-ahead of the all-gather below: nothing after it can fail on one rank alone)
+        if (nseg) {
+            const size_t slot = 8 + sizeof(Fr) * nseg;
+            Fr chain = Fr::one();   // the permutation sets run on from one another
+            for (size_t j = 0; j < nseg; ++j) {
+                Fr before = Fr::one(), whole = Fr::one();
+                for (uint32_t r = 0; r < pk->shard_world; ++r) {
+                    Fr t;
+                    memcpy(&t, all.data() + (size_t)r * slot + 8 + sizeof(Fr) * j, sizeof(Fr));
+                    whole = fe_mul(whole, t);
+                    if (rank_ranges[r].first < pk->shard_offset) before = fe_mul(before, t);
+                }
+                const Fr start = j < S ? fe_mul(chain, before) : before;
+                if (j < S) chain = fe_mul(chain, whole);
+                H2_CHK(h2hip_fr_scale_dev(ctx, zcol[j] + a, &start, m + 1));
+                H2_HIPCHK(hipMemcpyAsync(sendb + j * row_stride, zcol[j] + a, sizeof(Fr) * (m + 1), hipMemcpyDeviceToDevice, st));
+            }
+            H2_CHK(h2hip_comm_allgather_dev(pk->comm, ctx, sendb, sizeof(Fr) * slot_elems, recvb));
+            for (uint32_t r = 0; r < pk->shard_world; ++r) {
+                if (r == pk->shard_rank) continue;
+                const size_t ar = std::min<size_t>(rank_ranges[r].first, u), br = std::min<size_t>(rank_ranges[r].first + rank_ranges[r].second, u);
+                if (rank_ranges[r].second == 0) continue;
+                std::vector<Fr *> dst(nseg);
+                for (size_t j = 0; j < nseg; ++j) dst[j] = zcol[j] + ar;
+                H2_CHK(fr_scatter_rows(ctx, dst.data(), nseg, recvb + (size_t)r * slot_elems, row_stride, br - ar + 1));
+            }
+        }
+        {
+            TailRun tz;
+            tails_reserve(tz, nseg, (size_t)bf + 1, bf);
+            for (size_t j = 0; j < nseg; ++j) {
+                const Fr *tail = draw(bf);
+                H2_CHK(tails_add(tz, zcol[j] + (n - bf), tail));
+                draw(1);   // blind
+            }
+            H2_CHK(tails_flush(tz));
+        }
+        if (recvb) sc.release(recvb);
+        if (sendb) sc.release(sendb);
+        if (den) sc.release(den);
+        if (num) sc.release(num);
+        if (stage_ms) laps.lap(ST_PRODUCTS);
+    } else {
         const size_t segs = std::max<size_t>(sh.num_perm_sets, lks.size());
         Fr *num = nullptr, *den = nullptr;
         if (segs) {
@@ -1437,6 +1541,12 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     ask(i_random);
     laps.lap(ST_EVALS);
     // ---- ProverSHPLONK::create_proof [UPSTREAM-RECALL poly/kzg/multiopen/shplonk/prover.rs]
+    // Sharded (r04): every step between the evaluations and the two commitments is pointwise in the coefficient index — S_i = sum_j y^j P_ij,
+    // the v-weighted sum of the sets' quotients, the linearisation — except the divisions by (X - root), whose suffix Horner needs ONE value per
+    // (range boundary, root): what the coefficients above the range evaluate to.  With the commitments sharded by point range = coefficient
+    // range a rank only ever needs ITS range [lo, hi) of these polynomials: it forms S_i on its range, the ranks exchange the ranges' partial
+    // evaluations at the roots (32 bytes per (set, root) pair), and each divides its range with the carry assembled from the ranges above
+    // (h2hip_fr_kate_division_range_dev).  The same for the final division of the linearisation by (X - u).
     {
         const Fr yq = tr.squeeze_challenge();
         std::vector<RotationSet> sets;
@@ -1444,40 +1554,79 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         construct_intermediate_sets(queries, sets, super_points);
         H2_REQUIRE(!sets.empty(), "more than 64 distinct opening points");
         const Fr v = tr.squeeze_challenge();
+        const size_t lo = sharded_any ? std::min<size_t>(pk->shard_offset, n) : 0, hi = sharded_any ? std::min<size_t>(pk->shard_offset + pk->shard_len, n) : n;
+        const size_t L = hi - lo;   // coefficients held here (everything on one GPU)
+        // carry of this rank's range for root p: sum over the ranges above of E_s(p) * p^(lo_s - hi), E_s = rank s's partial evaluation relative to lo_s
+        auto carry_from = [&](const std::vector<uint8_t> &all, size_t slot_bytes, size_t idx, const Fr &p) -> Fr {
+            Fr c = Fr::zero();
+            for (uint32_t r = 0; r < pk->shard_world; ++r) {
+                if (rank_ranges[r].second == 0 || rank_ranges[r].first < hi) continue;
+                Fr e;
+                memcpy(&e, all.data() + (size_t)r * slot_bytes + 8 + sizeof(Fr) * idx, sizeof(Fr));
+                c = fe_add(c, fe_mul(e, fe_pow_u64(p, rank_ranges[r].first - hi)));
+            }
+            return c;
+        };
         // S_i(X) = sum_j y^j P_ij(X) (kept for the linearisation), r_i(X) = sum_j y^j * interpolant of P_ij on the set's points
         std::vector<Fr *> S(sets.size());
-        std::vector<std::vector<Fr>> low(sets.size());
+        std::vector<std::vector<Fr>> low(sets.size()), pf_weights(sets.size());
         Fr *buf_a = nullptr, *buf_b = nullptr, *h_x = nullptr;
         H2_CHK(sc.take(n, &buf_a));
         H2_CHK(sc.take(n, &buf_b));
         H2_CHK(sc.take(n, &h_x));
         H2_HIPCHK(hipMemsetAsync(h_x, 0, sizeof(Fr) * n, st));
-        Fr vpow = Fr::one();
+        size_t n_open = 0;
         for (size_t i = 0; i < sets.size(); ++i) {
             const RotationSet &rs = sets[i];
             H2_REQUIRE(rs.points.size() <= 8, "more than 8 rotations in one opening set");
+            n_open += rs.points.size();
             H2_CHK(sc.take(n, &S[i]));
             low[i].assign(rs.points.size(), Fr::zero());
             Fr ypow = Fr::one();
-            std::vector<Fr> pf_weights;
-            const std::vector<std::vector<Fr>> basis = lagrange_basis(rs.points, pf_weights);
+            const std::vector<std::vector<Fr>> basis = lagrange_basis(rs.points, pf_weights[i]);
             std::vector<const void *> terms(rs.polys.size());
             std::vector<Fr> ypows(rs.polys.size());
             for (size_t j = 0; j < rs.polys.size(); ++j) {
-                terms[j] = polys[rs.polys[j]];
+                terms[j] = polys[rs.polys[j]] + lo;
                 ypows[j] = ypow;
                 std::vector<Fr> r = lagrange_interpolate(basis, rs.evals[j]);
                 for (size_t t = 0; t < r.size(); ++t) low[i][t] = fe_add(low[i][t], fe_mul(ypow, r[t]));
                 ypow = fe_mul(ypow, yq);
             }
-            H2_CHK(h2hip_fr_linear_combination_dev(ctx, S[i], terms.data(), ypows.data(), terms.size(), n));   // every P_j read once
-
+            if (L) H2_CHK(h2hip_fr_linear_combination_dev(ctx, S[i] + lo, terms.data(), ypows.data(), terms.size(), L));   // every P_j read once
+        }
+        std::vector<std::vector<Fr>> carries(sets.size());
+        if (sharded_any) {
+            H2_REQUIRE(n_open <= SHPLONK_MAX_OPENINGS, "sharded create_proof: more (rotation set, point) pairs than the exchange holds");
+            std::vector<const void *> part;
+            std::vector<size_t> lens;
+            std::vector<Fr> at, vals(SHPLONK_MAX_OPENINGS, Fr::zero());
+            for (size_t i = 0; i < sets.size(); ++i)
+                for (const Fr &pt : sets[i].points) {
+                    part.push_back(S[i] + lo);
+                    lens.push_back(L);
+                    at.push_back(pt);
+                }
+            if (L) H2_CHK(h2hip_fr_eval_polynomial_batch_dev(ctx, part.data(), lens.data(), at.data(), part.size(), vals.data()));
+            std::vector<uint8_t> all;
+            H2_CHK(exchange_host(vals.data(), sizeof(Fr) * SHPLONK_MAX_OPENINGS, all));
+            size_t idx = 0;
+            for (size_t i = 0; i < sets.size(); ++i)
+                for (const Fr &pt : sets[i].points) carries[i].push_back(carry_from(all, 8 + sizeof(Fr) * SHPLONK_MAX_OPENINGS, idx++, pt));
+        }
+        Fr vpow = Fr::one();
+        for (size_t i = 0; i < sets.size(); ++i) {
+            const RotationSet &rs = sets[i];
             // (S_i - r_i) / prod_j (X - point_j) = sum_j w_j (S_i(X) - S_i(point_j)) / (X - point_j) (partial fractions; r_i interpolates S_i
             // on the points by construction): all roots in ONE pass over S_i, no copy and no explicit subtraction of r_i
-            H2_CHK(h2hip_fr_kate_division_multi_dev(ctx, buf_b, S[i], n, rs.points.data(), pf_weights.data(), (uint32_t)rs.points.size()));
-            Fr *cur = buf_b;
-            const size_t len = (size_t)n - 1;   // the coefficients above degree n - 1 - #points come out as zeros
-            H2_CHK(h2hip_fr_axpy_dev(ctx, h_x, &vpow, cur, len));
+            if (!sharded_any) {
+                H2_CHK(h2hip_fr_kate_division_multi_dev(ctx, buf_b, S[i], n, rs.points.data(), pf_weights[i].data(), (uint32_t)rs.points.size()));
+                H2_CHK(h2hip_fr_axpy_dev(ctx, h_x, &vpow, buf_b, (size_t)n - 1));   // the coefficients above degree n - 1 - #points come out as zeros
+            } else if (L) {
+                H2_CHK(h2hip_fr_kate_division_range_dev(ctx, buf_b + lo, S[i] + lo, L, rs.points.data(), pf_weights[i].data(), carries[i].data(),
+                                                        (uint32_t)rs.points.size()));
+                H2_CHK(h2hip_fr_axpy_dev(ctx, h_x + lo, &vpow, buf_b + lo, L));
+            }
             vpow = fe_mul(vpow, v);
         }
         {
@@ -1500,20 +1649,33 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             }
             if (i == 0) z_diff_0 = z_i;
             const Fr c_i = fe_mul(vpow, z_i);
-            lin_terms.push_back(S[i]);
+            lin_terms.push_back(S[i] + lo);
             lin_coeffs.push_back(c_i);
             const0 = fe_add(const0, fe_mul(c_i, eval_small(low[i], uq)));
             vpow = fe_mul(vpow, v);
         }
         Fr zt = Fr::one();
         for (const Fr &p : super_points) zt = fe_mul(zt, fe_sub(uq, p));
-        lin_terms.push_back(h_x);
+        lin_terms.push_back(h_x + lo);
         lin_coeffs.push_back(fe_neg(zt));
-        H2_CHK(h2hip_fr_linear_combination_dev(ctx, l_x, lin_terms.data(), lin_coeffs.data(), lin_terms.size(), n));
-        H2_CHK(h2hip_fr_sub_low_dev(ctx, l_x, &const0, 1));
-        H2_CHK(h2hip_fr_kate_division_dev(ctx, buf_b, l_x, n, &uq));
+        if (L) H2_CHK(h2hip_fr_linear_combination_dev(ctx, l_x + lo, lin_terms.data(), lin_coeffs.data(), lin_terms.size(), L));
+        if (L && lo == 0) H2_CHK(h2hip_fr_sub_low_dev(ctx, l_x, &const0, 1));
         const Fr inv0 = fe_inv(z_diff_0);
-        H2_CHK(h2hip_fr_scale_dev(ctx, buf_b, &inv0, (size_t)n - 1));
+        if (!sharded_any) {
+            H2_CHK(h2hip_fr_kate_division_dev(ctx, buf_b, l_x, n, &uq));
+            H2_CHK(h2hip_fr_scale_dev(ctx, buf_b, &inv0, (size_t)n - 1));
+        } else {
+            Fr e = Fr::zero();
+            const void *part = l_x + lo;
+            if (L) H2_CHK(h2hip_fr_eval_polynomial_batch_dev(ctx, &part, &L, &uq, 1, &e));
+            std::vector<uint8_t> all;
+            H2_CHK(exchange_host(&e, sizeof(Fr), all));
+            const Fr carry = carry_from(all, 8 + sizeof(Fr), 0, uq), one = Fr::one();
+            if (L) {
+                H2_CHK(h2hip_fr_kate_division_range_dev(ctx, buf_b + lo, l_x + lo, L, &uq, &one, &carry, 1));
+                H2_CHK(h2hip_fr_scale_dev(ctx, buf_b + lo, &inv0, L));
+            }
+        }
         std::vector<const void *> cols(1, buf_b);
         H2_CHK(commit_batch(pk->g, cols, (size_t)n - 1));
     }
@@ -1692,6 +1854,16 @@ static void shard_release(h2hip_plonk_pk *pk) {
     pk->g_shard = pk->g_lagrange_shard = nullptr;
     pk->comm = nullptr;
     pk->shard_quotient = false;
+    pk->shard_products = false;
+}
+
+// the host exchanges of the key's last sharded proof, in order: payload bytes per rank (each travels with an 8-byte status word); what a
+// multi-GPU run reports about itself (bench.py --gpus N).  count: the number of exchanges; sizes: the first min(count, cap) of them
+int h2hip_plonk_pk_last_exchanges(const h2hip_plonk_pk *pk, size_t *sizes, size_t cap, size_t *count) {
+    H2_REQUIRE(pk && count && (cap == 0 || sizes), "NULL argument");
+    *count = pk->exch_sizes.size();
+    for (size_t i = 0; i < pk->exch_sizes.size() && i < cap; ++i) sizes[i] = pk->exch_sizes[i];
+    return H2HIP_OK;
 }
 
 int h2hip_plonk_pk_set_sharding(h2hip_plonk_pk *pk, h2hip_comm *comm, const h2hip_bases *g_shard, const h2hip_bases *g_lagrange_shard, size_t offset,
@@ -1712,6 +1884,7 @@ int h2hip_plonk_pk_set_sharding(h2hip_plonk_pk *pk, h2hip_comm *comm, const h2hi
     pk->shard_rank = (uint32_t)rank;
     pk->comm = comm;
     pk->shard_quotient = (flags & H2HIP_SHARD_QUOTIENT) != 0;
+    pk->shard_products = (flags & H2HIP_SHARD_PRODUCTS) != 0;
     if (!pk->shard_quotient) return H2HIP_OK;
     // this rank's cosets of the extended domain: c = rank, rank + world, ... < 2^(ek - k), and the [coset][n] slices of the key's arrays
     const uint32_t log_c = pk->sh.extended_k - pk->sh.k, ncos = 1u << log_c, n = pk->sh.n;

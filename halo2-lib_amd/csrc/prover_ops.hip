@@ -181,6 +181,13 @@ int h2hip_permutation_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den
 int h2hip_permutation_product_terms_sets_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
                                              uint32_t num_columns, uint32_t chunk_len, size_t rows, const void *beta, const void *gamma,
                                              const void *delta, const void *omega) {
+    return h2hip_permutation_product_terms_rows_dev(ctx, num_dev, den_dev, cols_dev, sigmas_dev, num_columns, chunk_len, 0, rows, beta, gamma, delta, omega);
+}
+// the same for the ROW RANGE [row0, row0 + rows) of the columns (the multi-GPU prover: a rank forms the factors of its rows only); num / den: set s
+// at [s * rows, (s + 1) * rows)
+int h2hip_permutation_product_terms_rows_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
+                                             uint32_t num_columns, uint32_t chunk_len, size_t row0, size_t rows, const void *beta, const void *gamma,
+                                             const void *delta, const void *omega) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && beta && gamma && delta && omega && (num_columns == 0 || (cols_dev && sigmas_dev)) && (rows == 0 || num_columns == 0 || (num_dev && den_dev)),
                "NULL argument");
@@ -194,13 +201,13 @@ int h2hip_permutation_product_terms_sets_dev(h2hip_ctx *ctx, void *num_dev, void
     const uint32_t grid = grid_rows(ctx, rows, rows >= ((size_t)1 << 16) ? 4 : 1);   // long columns: four rows per lane amortise the omega^i start-up
     g.xstep = fe_pow_u64(g.omega, (uint64_t)grid * 256);
     const uint32_t per_launch = PP_BATCH_COLS / chunk_len * chunk_len;   // whole sets
-    Fr x0 = g.beta;
+    Fr x0 = fe_mul(g.beta, fe_pow_u64(g.omega, (uint64_t)row0));
     for (uint32_t c0 = 0; c0 < num_columns; c0 += per_launch) {
         g.ncols = num_columns - c0 < per_launch ? num_columns - c0 : per_launch;
         g.x0 = x0;
         for (uint32_t j = 0; j < g.ncols; ++j) {
-            g.cols[j] = (const Fr *)cols_dev[c0 + j];
-            g.sigmas[j] = (const Fr *)sigmas_dev[c0 + j];
+            g.cols[j] = (const Fr *)cols_dev[c0 + j] + row0;
+            g.sigmas[j] = (const Fr *)sigmas_dev[c0 + j] + row0;
             x0 = fe_mul(x0, g.delta);
         }
         const size_t first_set = c0 / chunk_len;

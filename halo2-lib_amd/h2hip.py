@@ -81,6 +81,7 @@ _PROTOS = {
     "h2hip_fr_eval_polynomial_batch_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, _vp]),
     "h2hip_fr_kate_division_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_fr_kate_division_multi_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _u32]),
+    "h2hip_fr_kate_division_range_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _u32]),
     "h2hip_quotient_flex_gate_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),
     "h2hip_quotient_permutation_set_dev": (_int, [_vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32, _u32, _vp, _vp, _vp, _u32, _u32, _u32,
@@ -92,6 +93,7 @@ _PROTOS = {
     "h2hip_quotient_lookups_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "h2hip_quotient_permutation_sets_dev": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "h2hip_permutation_product_terms_sets_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
+    "h2hip_permutation_product_terms_rows_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _sz, _sz, _vp, _vp, _vp, _vp]),
     "h2hip_lookup_permute_presorted_batch_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _sz]),
     "h2hip_array_rng_fill": (None, [_vp, _vp, _sz]),
     "h2hip_rng_seed_from_u64": (None, [C.c_uint64, _vp]),
@@ -112,6 +114,7 @@ _PROTOS = {
     "h2hip_plonk_pk_commitments": (_int, [_vp, _vp, _vp]),
     "h2hip_plonk_pk_set_transcript_repr": (_int, [_vp, _vp]),
     "h2hip_plonk_pk_set_sharding": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _u32]),
+    "h2hip_plonk_pk_last_exchanges": (_int, [_vp, _vp, _sz, _vp]),
     "h2hip_comm_rccl_unique_id": (_int, [_vp]),
     "h2hip_comm_init_rccl": (_int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
     "h2hip_comm_init_callback": (_int, [_int, _int, _vp, _vp, C.POINTER(_vp)]),
@@ -712,6 +715,18 @@ class Context:
             for p in d + [dn, dd]:
                 self.free(p)
 
+    def fr_kate_division_range(self, coeffs: np.ndarray, points: np.ndarray, weights: np.ndarray, carries: np.ndarray) -> np.ndarray:
+        """the quotient coefficients lo .. lo + n - 1 of sum_j weights[j] * f(X) / (X - points[j]) from f's coefficient range [lo, lo + n) and the
+        carries of the ranges above (h2hip.h)"""
+        c, pts, w, cr = _fe(coeffs), _fe(points), _fe(weights), _fe(carries)
+        d, q = self.to_device(c), self.malloc(32 * len(c))
+        try:
+            self._chk(self.lib.h2hip_fr_kate_division_range_dev(self.handle, _vp(q), _vp(d), len(c), _ptr(pts), _ptr(w), _ptr(cr), len(pts)))
+            return self.download(q, (len(c), 4))
+        finally:
+            self.free(d)
+            self.free(q)
+
     def fr_kate_division_multi(self, coeffs: np.ndarray, points: np.ndarray, weights: np.ndarray) -> np.ndarray:
         """sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j])"""
         c, pts, w = _fe(coeffs), _fe(points), _fe(weights)
@@ -795,16 +810,23 @@ class Context:
             for p in [d_acc, d_z] + ([d_zp] if d_zp else []) + d_cols + d_sig + d_l:
                 self.free(p)
 
-    def permutation_product_terms_sets(self, cols, sigmas, chunk_len, beta, gamma, delta, omega):
-        """(num, den) factor columns of every permutation set: two lists of (rows, 4) arrays"""
-        rows = len(_fe(cols[0]))
+    def permutation_product_terms_sets(self, cols, sigmas, chunk_len, beta, gamma, delta, omega, row0=None, rows=None):
+        """(num, den) factor columns of every permutation set: two lists of (rows, 4) arrays; row0 / rows: only that row range
+        (h2hip_permutation_product_terms_rows_dev)"""
+        by_rows = row0 is not None
+        row0 = row0 or 0
+        rows = len(_fe(cols[0])) - row0 if rows is None else rows
         sets = (len(cols) + chunk_len - 1) // chunk_len
         dc, pc = self._ptr_table(cols)
         ds, ps = self._ptr_table(sigmas)
-        dn, dd = self.malloc(32 * rows * sets), self.malloc(32 * rows * sets)
+        dn, dd = self.malloc(32 * max(rows * sets, 1)), self.malloc(32 * max(rows * sets, 1))
         try:
-            self._chk(self.lib.h2hip_permutation_product_terms_sets_dev(self.handle, _vp(dn), _vp(dd), pc, ps, len(dc), chunk_len, rows, _ptr(_fe(beta)),
-                                                                        _ptr(_fe(gamma)), _ptr(_fe(delta)), _ptr(_fe(omega))))
+            if by_rows:
+                self._chk(self.lib.h2hip_permutation_product_terms_rows_dev(self.handle, _vp(dn), _vp(dd), pc, ps, len(dc), chunk_len, row0, rows,
+                                                                            _ptr(_fe(beta)), _ptr(_fe(gamma)), _ptr(_fe(delta)), _ptr(_fe(omega))))
+            else:
+                self._chk(self.lib.h2hip_permutation_product_terms_sets_dev(self.handle, _vp(dn), _vp(dd), pc, ps, len(dc), chunk_len, rows, _ptr(_fe(beta)),
+                                                                            _ptr(_fe(gamma)), _ptr(_fe(delta)), _ptr(_fe(omega))))
             num, den = self.download(dn, (sets * rows, 4)), self.download(dd, (sets * rows, 4))
             return [num[s * rows:(s + 1) * rows] for s in range(sets)], [den[s * rows:(s + 1) * rows] for s in range(sets)]
         finally:

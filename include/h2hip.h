@@ -237,6 +237,11 @@ int h2hip_permutation_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den
 int h2hip_permutation_product_terms_sets_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
                                              uint32_t num_columns, uint32_t chunk_len, size_t rows, const void *beta, const void *gamma,
                                              const void *delta, const void *omega);
+/* ... restricted to the rows [row0, row0 + rows) of the (full-length) columns: num / den hold `rows` factors per set (the sharded prover's rank
+ * forms the factors of its row range only) */
+int h2hip_permutation_product_terms_rows_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
+                                             uint32_t num_columns, uint32_t chunk_len, size_t row0, size_t rows, const void *beta, const void *gamma,
+                                             const void *delta, const void *omega);
 /* factors of a lookup's grand product: num[i] = (a[i]+beta)(s[i]+gamma), den[i] = (a'[i]+beta)(s'[i]+gamma) */
 int h2hip_lookup_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *a_dev, const void *s_dev, const void *a_perm_dev,
                                    const void *s_perm_dev, size_t rows, const void *beta, const void *gamma);
@@ -254,6 +259,11 @@ int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_d
  * 1 / prod_{i != j} (points[j] - points[i]) this is (f(X) - r(X)) / prod_j (X - points[j]), r the interpolant of f on the points: the
  * quotient of one SHPLONK rotation set in a single pass over f. */
 int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_dev, size_t n, const void *points, const void *weights, uint32_t m);
+/* The same quotient for ONE COEFFICIENT RANGE [lo, lo + n) of f (the multi-GPU prover, where a rank holds the coefficient range of its SRS
+ * slice): coeffs_dev = that range; carries[j] = sum_{i >= lo + n} f_i points[j]^(i - lo - n), i.e. what the ranges above contribute (the caller
+ * assembles it from the other ranks' partial evaluations; zeros for the top range); q_dev[0..n) = the quotient's coefficients lo .. lo + n - 1. */
+int h2hip_fr_kate_division_range_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_dev, size_t n, const void *points, const void *weights,
+                                     const void *carries, uint32_t m);
 
 /* ---- K6: the halo2-base custom gate's term of the quotient numerator on the extended domain:
  *      acc[i] = acc[i]*y + q[i]*(a[i] + a[i+s]*a[i+2s] - a[i+3s]), s = 2^(ext_k-k)
@@ -418,9 +428,14 @@ int h2hip_comm_allgather_host(h2hip_comm *comm, h2hip_ctx *ctx, const void *send
  * exchange with an error status, so that all ranks return (H2HIP_ERR_PEER on the others) instead of waiting in a collective.
  * comm == NULL or world 1 switches sharding off.  The bases and the communicator must outlive the key (or the next set_sharding call). */
 #define H2HIP_SHARD_QUOTIENT 1u
+#define H2HIP_SHARD_PRODUCTS 4u /* the grand products (permutation and lookup arguments) by row range: local prefix products, one 32-byte exchange per
+                                 product, one device-to-device all-gather of the columns */
 #define H2HIP_SHARD_FORCE 2u /* run the sharded code path even with a one-rank communicator (tests: a 1-GPU box exercises RCCL and the coset kernels) */
 int h2hip_plonk_pk_set_sharding(h2hip_plonk_pk *pk, h2hip_comm *comm, const h2hip_bases *g_shard, const h2hip_bases *g_lagrange_shard, size_t offset,
                                 size_t len, uint32_t flags);
+/* the host exchanges of the key's last sharded proof in order — payload bytes per rank, each sent with an 8-byte status word (count: how many;
+ * sizes: the first min(count, cap)): hello, the commitment rounds, the products' totals, the go-ahead, evaluations, SHPLONK's carries ... */
+int h2hip_plonk_pk_last_exchanges(const h2hip_plonk_pk *pk, size_t *sizes, size_t cap, size_t *count);
 /* coefficient / extended-domain helpers of the sharded prover: f(X) -> f(s X) for `count` columns of n coefficients; the listed cosets
  * (count <= 16) of an (n << log_cosets)-point array one after the other; and the inverse with slots[c] = position of coset c in `in` */
 int h2hip_fr_coset_scale_batch_dev(h2hip_ctx *ctx, void *const *outs_dev, const void *const *ins_dev, size_t count, size_t n, const void *s);

@@ -131,6 +131,12 @@ def check_prover_steps(ctx, n, seed=5):
             c0, c1 = si * chunk, min((si + 1) * chunk, len(many_c))
             wn1, wd1 = ctx.permutation_product_terms(many_c[c0:c1], many_s[c0:c1], c0, fr([beta]), fr([gamma]), fr([O.DELTA]), fr([omega]))
             assert np.array_equal(nums[si], wn1) and np.array_equal(dens[si], wd1), (chunk, si)
+        # a row range of the same columns (the sharded prover's form) = those rows of the whole-column factors
+        if n >= 5:
+            r0, rn = n // 3, n - n // 3 - 1
+            pn, pd = ctx.permutation_product_terms_sets(many_c, many_s, chunk, fr([beta]), fr([gamma]), fr([O.DELTA]), fr([omega]), row0=r0, rows=rn)
+            for si in range(len(nums)):
+                assert np.array_equal(pn[si], nums[si][r0:r0 + rn]) and np.array_equal(pd[si], dens[si][r0:r0 + rn]), (chunk, si)
     # lookup factors
     a_, s_, ap, sp = (rand_fr(n, seed + 30 + j) for j in range(4))
     gn, gd = ctx.lookup_product_terms(a_, s_, ap, sp, fr([beta]), fr([gamma]))
@@ -206,6 +212,14 @@ def check_prover_steps(ctx, n, seed=5):
             assert got == want
             if m > 1:                                # ... and it IS the quotient by the product of the roots: top m-1 coefficients vanish
                 assert got[len(got) - (m - 1):] == [0] * (m - 1)
+            # the same quotient by COEFFICIENT RANGES (the multi-GPU prover's form): each range divided on its own with the carries of the
+            # ranges above it (big-int Horner), concatenated = the whole-polynomial quotient followed by a zero
+            cuts = sorted({0, 1, n // 3, n - 2, n})
+            pieces = []
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                carries = [horner(f[hi:], b) for b in bs]
+                pieces += to_i(ctx.fr_kate_division_range(a_[lo:hi], fr(bs), fr(ws), fr(carries)))
+            assert pieces == want + [0], (m, cuts)
 
 
 def check_ntt_batches(ctx, ks=(3, 11), ncols=35):

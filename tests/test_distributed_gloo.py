@@ -213,9 +213,16 @@ def _worker_scenarios(rank, world, port, q):
                 out["after_rng"] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
             sk.free()
             if name == "multi" and not full:
+                # a very uneven tiling: the last rank's rows are blinding rows only (no factor of any grand product), the first holds 5 rows
+                n_ = 1 << shape[0]
+                cuts = [0, 5, n_ - 3, n_]
+                sk = shard_proving_key(pk, g, gl, precompute=False, point_range=(cuts[rank], cuts[rank + 1]))
+                out["ragged"] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
+                sk.free()
+            if name == "multi" and not full:
                 out["msm_only"] = out["single"] = out["single_unsharded_again"] = True
             if name == "multi" and full:   # commitments only (h(X) replicated)
-                sk = shard_proving_key(pk, g, gl, precompute=False, shard_quotient=False)
+                sk = shard_proving_key(pk, g, gl, precompute=False, shard_quotient=False, shard_products=False)
                 out["msm_only"] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
                 sk.free()
             out[name + "_unsharded_again"] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
@@ -245,6 +252,6 @@ def test_sharded_create_proof_scenarios(world):
     for r in range(world):
         o = res[r]
         assert o["multi"] and o["single"] and o["msm_only"] and o["multi_unsharded_again"] and o["single_unsharded_again"], (r, o)
-        assert o["after_fail"] and o["after_rng"], (r, o)
+        assert o["after_fail"] and o["after_rng"] and o.get("ragged", True), (r, o)
         assert o["fail"] == (-1 if r == world - 1 else -5), (r, o)     # H2HIP_ERR_INVALID where the witness is wrong, H2HIP_ERR_PEER elsewhere
         assert o["rng"] == -1, (r, o)                                   # every rank sees the mismatch in the hello exchange

@@ -346,6 +346,30 @@ def test_msm_batch_many_small_columns(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [(1 << 18) + 5, 1 << 20, 1 << 21])
+def test_kate_division_by_coefficient_ranges(ctx, n):
+    """h2hip_fr_kate_division_range_dev at the sharded prover's sizes (ranges of 2^16 .. 2^20 coefficients: every tile variant, ranges that end
+    on a tile boundary so that the carry opens a tile of its own): the ranges' quotients, with carries assembled from partial evaluations the
+    way create_proof does, concatenate to the whole-polynomial quotient"""
+    f = rand_fr(n, 51)
+    for m, world in ((1, 2), (4, 3), (5, 8)):
+        pts, ws = rand_fr(m, 52 + m), rand_fr(m, 60 + m)
+        want = ctx.fr_kate_division_multi(f, pts, ws)
+        cuts = [n * r // world for r in range(world + 1)]
+        if world == 3:
+            cuts[1] += 7   # uneven, not tile aligned
+        # partial evaluations E_r(p) = sum_j f[lo_r + j] p^j, then carry of rank r = sum_{s > r} E_s(p) * p^(lo_s - hi_r)  (big-int on the host)
+        E = [[O.limbs_to_ints(ctx.fr_eval_polynomial(f[cuts[r]:cuts[r + 1]], pts[j:j + 1]), R)[0] for j in range(m)] for r in range(world)]
+        pi = O.limbs_to_ints(pts, R)
+        got = []
+        for r in range(world):
+            carries = [sum(E[s][j] * pow(pi[j], cuts[s] - cuts[r + 1], R) for s in range(r + 1, world)) % R for j in range(m)]
+            got.append(ctx.fr_kate_division_range(f[cuts[r]:cuts[r + 1]], pts, ws, fr(carries)))
+        got = np.concatenate(got)
+        assert np.array_equal(got[:-1], want) and not got[-1].any(), (n, m, world)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [(1 << 17) + 3, 1 << 18, (1 << 19) - 1, 1 << 20])
 def test_kate_division_multi_tile_lengths(ctx, n):
     """the multi-point division picks its tile (1 / 2 / 4 / 8 coefficients per lane) by the polynomial's length: every variant against the
