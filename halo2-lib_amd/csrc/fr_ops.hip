@@ -1356,7 +1356,7 @@ static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, 
 // coefficients per lane: a tile is 256 * J coefficients; about one wave per SIMD or more (ctx->kate_coeffs_per_lane overrides: 1, 2, 4, 8)
 static int kate_division_multi_pick(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m, const void *tops) {
     uint32_t j = ctx->kate_coeffs_per_lane;
-    if (j != 1 && j != 2 && j != 4 && j != 8) j = n >= ((size_t)1 << 19) ? 8 : n >= ((size_t)1 << 18) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;
+    if (j != 1 && j != 2 && j != 4 && j != 8) j = n >= ((size_t)1 << 20) ? 8 : n >= ((size_t)1 << 18) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;   // (2^19: 4 and 8 within noise, 4 ahead by 0.04 ms per proof; 2^21: 8 ahead by 0.4 ms — profiles/r04_kate_tile_ab.log)
     if (j == 8) return kate_division_multi_run<8>(ctx, q, coeffs, n, points, weights, m, tops);
     if (j == 4) return kate_division_multi_run<4>(ctx, q, coeffs, n, points, weights, m, tops);
     if (j == 2) return kate_division_multi_run<2>(ctx, q, coeffs, n, points, weights, m, tops);

@@ -422,7 +422,13 @@ int h2hip_comm_allgather_host(h2hip_comm *comm, h2hip_ctx *ctx, const void *send
  *     dealt round-robin to the ranks (coset c to rank c mod N), each rank runs coeff_to_extended and the quotient identities for its
  *     cosets only (identities are pointwise up to rotations, which stay inside a coset), ONE device-to-device all-gather (2^ek x 32 B in
  *     total) precedes extended_to_coeff.  Ranks >= 2^(ek-k) take no part in this stage.
- *   - replicated on every rank: uploads, lookup permutation, grand products, lagrange_to_coeff, evaluations, SHPLONK's pointwise work.
+ *   - evaluations and SHPLONK's polynomial work run on the rank's COEFFICIENT range (= its point range): partial evaluations x^lo * sum_j c[lo + j] x^j
+ *     are exchanged and summed (32 bytes per query); the divisions by (X - root) take the ranges above as a carry assembled from one exchange of
+ *     partial evaluations (h2hip_fr_kate_division_range_dev);
+ *   - with H2HIP_SHARD_PRODUCTS the grand products of the permutation and lookup arguments are formed by ROW range: local factors, inversion
+ *     and prefix products, one 32-byte exchange per product, a scaling by everything before the range, ONE device-to-device all-gather of
+ *     the rows (every rank needs the complete columns for their coefficient forms);
+ *   - replicated on every rank: uploads, lookup permutation, lagrange_to_coeff, extended_to_coeff.
  * Safety: at its first exchange a proof checks that all ranks agree on the shape and the RNG stream and that the point ranges tile
  * [0, 2^k) (H2HIP_ERR_INVALID otherwise); every host exchange carries a status word, and a rank that fails takes part in the next
  * exchange with an error status, so that all ranks return (H2HIP_ERR_PEER on the others) instead of waiting in a collective.
