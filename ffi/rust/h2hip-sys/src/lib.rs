@@ -229,6 +229,7 @@ extern "C" {
     pub fn h2hip_fr_coset_gather_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, in_dev: *const c_void, cosets: *const u32, count: u32, log_cosets: u32,
                                      n: usize) -> c_int;
     pub fn h2hip_fr_coset_interleave_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, in_dev: *const c_void, slots: *const u32, log_cosets: u32, n: usize) -> c_int;
+    pub fn h2hip_fr_coset_combine_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, in_dev: *const c_void, slots: *const u32, log_cosets: u32, n: usize, rho_inv: *const c_void, zeta_n_inv: *const c_void) -> c_int;
     pub fn h2hip_array_rng_fill(user: *mut c_void, out_fr: *mut c_void, n: usize);
     pub fn h2hip_rng_seed_from_u64(state: u64, seed_out32: *mut u8);
     pub fn h2hip_chacha_rng_init(rng: *mut h2hip_chacha_rng, seed32: *const u8, rounds: c_int);

@@ -7,6 +7,7 @@
 // The multiplier is integer, not MFMA: one Montgomery product = 128 v_mad_u64_u32 + 8 v_mul_lo_u32
 // (quarter-rate VALU) plus carry chains; rows are "lazy-carry" so the 8 MADs of a row are independent.
 #pragma once
+#include <utility>
 #include <stdint.h>
 
 #ifndef H2_HD
@@ -259,6 +260,18 @@ H2_HD Fe<P> fe_inv(const Fe<P> &a) {
     Fe<P> r;
     modinv_limbs32<P>(a.l, r.l);
     return fe_mul(r, fe_mul(Fe<P>::r2(), Fe<P>::r2()));
+}
+
+// A compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}).  `#pragma unroll` is a request the
+// compiler turns down when the unrolled body exceeds its size threshold (a few field multiplications per iteration do) — the loop then stays
+// rolled and every array indexed by its counter moves to scratch memory; a pack expansion leaves it no choice.
+template <class F, int... Js>
+H2_HD void static_for_impl(F &&f, std::integer_sequence<int, Js...>) {
+    (f(std::integral_constant<int, Js>{}), ...);
+}
+template <int N, class F>
+H2_HD void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 }  // namespace h2

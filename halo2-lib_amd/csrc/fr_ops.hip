@@ -3,7 +3,6 @@
 // sub / mul / mul_add on column values) plus the diagnostic multiplier micro-benchmark that defines the
 // integer roofline quoted by bench.py.
 #include "internal.h"
-#include <utility>
 #include "fq29.cuh"
 
 namespace h2 {
@@ -644,16 +643,8 @@ __global__ __launch_bounds__(256) void fr_kate_carry_multi_kernel(const Fr *__re
 // All M points of the set advance together through one pass over the tile: their Horner values, their suffix scans (one pair of barriers
 // per doubling step for all points) and their quotient chains; the tile's incoming carry sits in an extra scan slot (index 256), which the scan
 // multiplies by the right power of b^J on its own.  Points beyond m (padding up to the compiled M) carry weight 0.
-// (compile-time loop over the points: with `for (j < M)` + `#pragma unroll` the compiler leaves the loops around two field multiplications per
-// point rolled and the per-point arrays in scratch memory; a pack expansion leaves it no choice)
-template <class F, int... Js>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Js...>) {
-    (f(std::integral_constant<int, Js>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
+// (static_for, field.cuh: with `for (j < M)` + `#pragma unroll` the compiler leaves the loops around two field multiplications per point rolled
+// and the per-point arrays in scratch memory)
 template <int M, uint32_t J, bool TOP>
 __global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__restrict__ c, size_t n, const KateJob *__restrict__ jobs, uint32_t m,
                                                                   uint32_t ntiles, const Fr *__restrict__ carry, Fr *__restrict__ q, int accumulate) {

@@ -1384,11 +1384,22 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(comm_reserve_allgather_dev(pk->comm, sizeof(Fr) * slot_elems));
         std::vector<uint8_t> all;
         H2_CHK(exchange_host(nullptr, 0, all));
+        // r04: extended_to_coeff by cosets as well.  The inverse transform of the whole extended domain factors into the size-n inverse coset
+        // transform of every coset (iNTT, then s_c^-t: done HERE, where the coset's values are — 1 / 2^(ek-k) of the whole transform's work per
+        // coset) and a 2^(ek-k)-point inverse DFT across the cosets for every t, which is pointwise: it runs on every rank after the all-gather
+        // (h2hip_fr_coset_combine_dev) and leaves h(X)'s coefficients where extended_to_coeff would
+        for (size_t m = 0; m < ncm; ++m) {
+            const Fr s_c_inv = fe_inv(coset_shift(pk->my_cosets[m]));
+            Fr *col = acc_loc + m * (size_t)n;
+            H2_CHK(h2hip_ifft_dev(ctx, col, &dom.omega_inv, k, &dom.ifft_divisor));
+            H2_CHK(h2hip_fr_coset_scale_batch_dev(ctx, (void *const *)&col, (const void *const *)&col, 1, n, &s_c_inv));
+        }
         H2_CHK(h2hip_comm_allgather_dev(pk->comm, ctx, acc_loc, sizeof(Fr) * slot_elems, gathered));
         const uint32_t log_c = ek - k;
         uint32_t slots[16] = {0};
         for (uint32_t c = 0; c < (1u << log_c); ++c) slots[c] = (c % pk->shard_world) * pk->max_cosets + c / pk->shard_world;
-        H2_CHK(h2hip_fr_coset_interleave_dev(ctx, acc, gathered, slots, log_c, n));
+        const Fr rho_inv = fe_inv(fe_pow_u64(dom.ext_omega, (uint64_t)n)), zeta_n_inv = fe_inv(fe_pow_u64(dom.zeta, (uint64_t)n));
+        H2_CHK(h2hip_fr_coset_combine_dev(ctx, acc, gathered, slots, log_c, n, &rho_inv, &zeta_n_inv));
         sc.release(gathered);
         sc.release(acc_loc);
     }
@@ -1403,7 +1414,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     for (Fr *p : adv_cos) sc.release(p);
     for (Fr *p : inst_cos) sc.release(p);
     // ---- back to coefficients, split into pieces, commit
-    H2_CHK(h2hip_extended_to_coeff_dev(ctx, acc, ek, &dom.ext_omega_inv, &dom.ext_ifft_divisor, &dom.zeta_inv));
+    if (!qshard) H2_CHK(h2hip_extended_to_coeff_dev(ctx, acc, ek, &dom.ext_omega_inv, &dom.ext_ifft_divisor, &dom.zeta_inv));   // (sharded: done by cosets above)
     laps.lap(ST_H_COEFF);
     draw(sh.quotient_pieces);   // h_blinds
     {

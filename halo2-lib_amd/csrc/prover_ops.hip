@@ -149,6 +149,45 @@ __global__ __launch_bounds__(256) void coset_interleave_kernel(Fr *__restrict__ 
     for (uint32_t c = 0; c < nc; ++c) out[(j << log_c) + c] = in[(size_t)sl.slot[c] * n + j];
 }
 
+// Coefficients of a polynomial of degree < C * n (C = 2^LOGC) from its PER-COSET inverse transforms: coset c of the extended domain is s_c * <omega>,
+// s_c = zeta * omega_e^c, and the inverse coset transform of its n evaluations (iNTT of size n, then the scaling by s_c^-t) is
+//     P_c[t] = sum_q h[q n + t] * (s_c^n)^q = sum_q (h[q n + t] * zeta^(n q)) * rho^(c q),     rho = omega_e^n (a primitive C-th root of unity)
+// — a C-point DFT over q for every t.  So  h[q n + t] = zeta^(-n q) / C * sum_c P_c[t] * rho^(-c q):  one lane per t, a decimation-in-frequency
+// network in registers (results in bit-reversed order), C scalings.  The sharded prover runs the size-n transforms where the cosets are (1 / C of
+// extended_to_coeff's work each) and only this pointwise step on every rank after the all-gather.
+struct CosetCombineArgs {
+    uint32_t slot[16];
+    Fr tw[8];       // rho^-j, j < C / 2
+    Fr scale[16];   // zeta^(-n q) / C
+};
+template <int LOGC>
+__global__ __launch_bounds__(256) void coset_combine_kernel(Fr *__restrict__ out, const Fr *__restrict__ in, CosetCombineArgs a, size_t n) {
+    constexpr int C = 1 << LOGC;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Fr x[C];
+    static_for<C>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        x[c] = in[(size_t)a.slot[c] * n + t];
+    });
+    static_for<LOGC>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, len = (C / 2) >> st;
+        static_for<C / 2>([&](auto pc) {   // pair pr of the stage: block pr / len, offset pr % len
+            constexpr int pr = decltype(pc)::value, j = pr % len, lo = (pr / len) * 2 * len + j;
+            const Fr u = x[lo], v = x[lo + len];
+            x[lo] = fe_add(u, v);
+            const Fr d = fe_sub(u, v);
+            x[lo + len] = j == 0 ? d : fe_mul(d, a.tw[j << st]);
+        });
+    });
+    static_for<C>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        int rev = 0;
+        for (int bit = 0; bit < LOGC; ++bit) rev |= ((q >> bit) & 1) << (LOGC - 1 - bit);
+        out[(size_t)q * n + t] = fe_mul(x[rev], a.scale[q]);
+    });
+}
+
 extern "C" {
 
 int h2hip_permutation_product_terms_dev(h2hip_ctx *ctx, void *num_dev, void *den_dev, const void *const *cols_dev, const void *const *sigmas_dev,
@@ -308,6 +347,41 @@ int h2hip_fr_coset_interleave_dev(h2hip_ctx *ctx, void *out_dev, const void *in_
     for (uint32_t c = 0; c < 16; ++c) sl.slot[c] = c < (1u << log_cosets) ? slots[c] : 0;
     prof_begin(ctx, "coset_interleave_kernel");
     hipLaunchKernelGGL(coset_interleave_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (Fr *)out_dev, (const Fr *)in_dev, sl, log_cosets, n);
+    prof_end(ctx);
+    H2_HIPCHK(hipGetLastError());
+    return H2HIP_OK;
+}
+
+// out[q * n + t] = zeta_n_inv^q / C * sum_c in[slots[c] * n + t] * rho_inv^(c q),  C = 2^log_cosets (1 <= log_cosets <= 4): the coefficients of the
+// degree < C * n polynomial whose per-coset inverse transforms P_c sit at in[slots[c] * n ...] (see coset_combine_kernel); out must not alias in
+int h2hip_fr_coset_combine_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, const uint32_t *slots, uint32_t log_cosets, size_t n, const void *rho_inv,
+                               const void *zeta_n_inv) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && out_dev && in_dev && slots && rho_inv && zeta_n_inv && log_cosets >= 1 && log_cosets <= 4 && out_dev != in_dev, "bad argument");
+    if (!n) return H2HIP_OK;
+    const uint32_t C = 1u << log_cosets;
+    CosetCombineArgs a;
+    memset((void *)&a, 0, sizeof(a));
+    for (uint32_t c = 0; c < C; ++c) a.slot[c] = slots[c];
+    const Fr r = ld(rho_inv), zn = ld(zeta_n_inv);
+    Fr p = Fr::one();
+    for (uint32_t j = 0; j < C / 2; ++j) {
+        a.tw[j] = p;
+        p = fe_mul(p, r);
+    }
+    Fr cf = Fr::zero();
+    for (uint32_t i = 0; i < C; ++i) cf = fe_add(cf, Fr::one());
+    Fr sc = fe_inv(cf);
+    for (uint32_t q = 0; q < C; ++q) {
+        a.scale[q] = sc;
+        sc = fe_mul(sc, zn);
+    }
+    const dim3 grid((uint32_t)((n + 255) / 256)), blk(256);
+    prof_begin(ctx, "coset_combine_kernel");
+    if (log_cosets == 1) hipLaunchKernelGGL(coset_combine_kernel<1>, grid, blk, 0, ctx->stream, (Fr *)out_dev, (const Fr *)in_dev, a, n);
+    if (log_cosets == 2) hipLaunchKernelGGL(coset_combine_kernel<2>, grid, blk, 0, ctx->stream, (Fr *)out_dev, (const Fr *)in_dev, a, n);
+    if (log_cosets == 3) hipLaunchKernelGGL(coset_combine_kernel<3>, grid, blk, 0, ctx->stream, (Fr *)out_dev, (const Fr *)in_dev, a, n);
+    if (log_cosets == 4) hipLaunchKernelGGL(coset_combine_kernel<4>, grid, blk, 0, ctx->stream, (Fr *)out_dev, (const Fr *)in_dev, a, n);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;

@@ -125,6 +125,7 @@ _PROTOS = {
     "h2hip_fr_coset_scale_batch_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _sz, _sz, _vp]),
     "h2hip_fr_coset_gather_dev": (_int, [_vp, _vp, _vp, C.POINTER(_u32), _u32, _u32, _sz]),
     "h2hip_fr_coset_interleave_dev": (_int, [_vp, _vp, _vp, C.POINTER(_u32), _u32, _sz]),
+    "h2hip_fr_coset_combine_dev": (_int, [_vp, _vp, _vp, C.POINTER(_u32), _u32, _sz, _vp, _vp]),
     "h2hip_plonk_stage_name": (C.c_char_p, [_int]),
     "h2hip_plonk_create_proof": (_int, [_vp, _vp, C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_sz), _vp, _vp, _vp, _sz, C.POINTER(_sz),
                                         C.POINTER(C.c_double)]),

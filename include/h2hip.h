@@ -447,6 +447,11 @@ int h2hip_plonk_pk_last_exchanges(const h2hip_plonk_pk *pk, size_t *sizes, size_
 int h2hip_fr_coset_scale_batch_dev(h2hip_ctx *ctx, void *const *outs_dev, const void *const *ins_dev, size_t count, size_t n, const void *s);
 int h2hip_fr_coset_gather_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, const uint32_t *cosets, uint32_t count, uint32_t log_cosets, size_t n);
 int h2hip_fr_coset_interleave_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, const uint32_t *slots, uint32_t log_cosets, size_t n);
+/* ... and the coefficients of a polynomial of degree < n << log_cosets from its PER-COSET inverse transforms P_c (iNTT of size n of coset c's
+ * evaluations, then the scaling by s_c^-t; at in[slots[c] * n ...]): out[q n + t] = zeta_n_inv^q / C * sum_c P_c[t] * rho_inv^(c q), C = 2^log_cosets,
+ * rho = ext_omega^n, zeta_n_inv = zeta^-n — extended_to_coeff with the size-n transforms done where the cosets are */
+int h2hip_fr_coset_combine_dev(h2hip_ctx *ctx, void *out_dev, const void *in_dev, const uint32_t *slots, uint32_t log_cosets, size_t n, const void *rho_inv,
+                               const void *zeta_n_inv);
 
 /* `Fr::random(rng)` x n into out (Montgomery limbs); called in upstream's draw order */
 typedef void (*h2hip_rng_fill_fn)(void *user, void *out_fr, size_t n);

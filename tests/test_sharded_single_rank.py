@@ -100,6 +100,30 @@ def _coset_helpers(ctx):
     assert np.array_equal(ctx.download(d_back, (n << log_c, 4)), full)
     for d in d_in + d_out + [d_full, d_g, d_all, d_back]:
         ctx.free(d)
+    # extended_to_coeff by cosets: the size-n inverse transform of every coset (iNTT, then s_c^-t) + h2hip_fr_coset_combine_dev = the whole-domain
+    # extended_to_coeff of the same evaluations, for 2, 4 and 8 cosets
+    k = 6
+    for log_c in (1, 2, 3):
+        ek, nc = k + log_c, 1 << log_c
+        omega, omega_e, zeta = O.omega_for(k), O.omega_for(ek), O.ZETA
+        evals = rand_fr(n << log_c, 20 + log_c)
+        want = ctx.extended_to_coeff(evals, ek, O.ints_to_limbs([O.inv_mod(omega_e, R)], R), O.ints_to_limbs([O.inv_mod(1 << ek, R)], R),
+                                     O.ints_to_limbs([O.inv_mod(zeta, R)], R))
+        order = list(range(nc))[::-1]                                  # coset c sits at position slots[c] of the gathered buffer
+        parts = [None] * nc
+        for c in range(nc):
+            s_c = zeta * pow(omega_e, c, R) % R
+            p_c = ctx.ifft(evals[c::nc], O.ints_to_limbs([O.inv_mod(omega, R)], R), k, O.ints_to_limbs([O.inv_mod(n, R)], R))
+            parts[order[c]] = CO.fr_mul(p_c, O.ints_to_limbs([pow(O.inv_mod(s_c, R), t, R) for t in range(n)], R))
+        d_p = ctx.to_device(np.concatenate(parts))
+        d_h = ctx.malloc(32 * (n << log_c))
+        slots = (C.c_uint32 * nc)(*order)
+        rho_inv = O.ints_to_limbs([O.inv_mod(pow(omega_e, n, R), R)], R)
+        zeta_n_inv = O.ints_to_limbs([O.inv_mod(pow(zeta, n, R), R)], R)
+        ctx._chk(ctx.lib.h2hip_fr_coset_combine_dev(ctx.handle, d_h, d_p, slots, log_c, n, rho_inv.ctypes.data, zeta_n_inv.ctypes.data))
+        assert np.array_equal(ctx.download(d_h, (n << log_c, 4)), want), log_c
+        ctx.free(d_p)
+        ctx.free(d_h)
 
 
 @pytest.mark.parametrize("shape", [(6, 2, 1, 1, 1, 4), (6, 1, 1, 1, 0, 4)])
