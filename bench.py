@@ -511,7 +511,10 @@ def main():
                 ctx._chk(ctx.lib.h2hip_plonk_pk_last_exchanges(pk.handle, sizes, 32, _C.byref(cnt)))
                 what = ["hello (shape, point range, stages sharded, RNG digest)", "round 1: advice + permuted lookup columns",
                         "grand products: the row ranges' total products (and the go-ahead of their all-gather)",
-                        "round 2: grand products + random polynomial", "go-ahead before the coset all-gather (status only)", "h(X) pieces",
+                        ] + (["go-ahead before the all-gather of the first-round columns' coefficient forms (status only)"] if world >= 8 else []) + [
+                        "round 2: grand products + random polynomial",
+                        ] + (["go-ahead before the all-gather of the product columns' coefficient forms (status only)"] if world >= 8 else []) + [
+                        "go-ahead before the coset all-gather (status only)", "h(X) pieces",
                         "evaluations: partial sums over the coefficient ranges", "SHPLONK: the ranges' partial evaluations at the rotation sets' points (carries)",
                         "SHPLONK W", "SHPLONK: the linearisation's partial evaluation at u (carry)", "SHPLONK W'"]
                 nprod = sh.num_perm_sets + sh.num_lookups

@@ -77,6 +77,7 @@ pub struct h2hip_comm {
 pub const H2HIP_SHARD_QUOTIENT: u32 = 1;
 pub const H2HIP_SHARD_FORCE: u32 = 2;
 pub const H2HIP_SHARD_PRODUCTS: u32 = 4;
+pub const H2HIP_SHARD_NTT_COLUMNS: u32 = 8;
 pub const H2HIP_ERR_PEER: c_int = -5;
 pub const H2HIP_OK: c_int = 0;
 pub const H2HIP_ERR_INVALID: c_int = -1;

@@ -236,7 +236,7 @@ struct h2hip_plonk_pk {
     size_t shard_offset = 0, shard_len = 0;
     uint32_t shard_world = 1, shard_rank = 0;
     h2hip_comm *comm = nullptr;
-    bool shard_quotient = false, shard_products = false;
+    bool shard_quotient = false, shard_products = false, shard_ntt = false;
     std::vector<uint32_t> my_cosets;          // cosets of the extended domain (rows = coset mod 2^(ek-k)) this rank evaluates h(X) on
     uint32_t max_cosets = 1;                  // cosets of the busiest rank (the all-gather's uniform slot count)
     std::vector<Fr *> fixed_cosets_sh, sigma_cosets_sh;   // [my_cosets][n] slices of the key's extended-domain arrays
@@ -834,7 +834,9 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         const size_t P = sizeof(G1Jac);
         pk->exch_sizes = {9 * sizeof(uint64_t), P * (sh.num_advice_total + 2 * sh.lookups.size())};
         if (pk->shard_products) pk->exch_sizes.push_back(sizeof(Fr) * (sh.num_perm_sets + sh.lookups.size()));   // the row ranges' total products
+        if (pk->shard_ntt) pk->exch_sizes.push_back(0);   // go-ahead of the column-dealt lagrange_to_coeff of the first-round columns (queued before round 2's commitments) ...
         pk->exch_sizes.push_back(P * (sh.num_perm_sets + sh.lookups.size() + 1));
+        if (pk->shard_ntt) pk->exch_sizes.push_back(0);   // ... and of the product columns
         if (qshard) pk->exch_sizes.push_back(0);
         pk->exch_sizes.push_back(P * sh.quotient_pieces);
         pk->exch_sizes.push_back(sizeof(Fr) * (sh.num_evals() + 1));   // the evaluations: partial sums over this rank's coefficient range
@@ -883,7 +885,8 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         me.len = pk->shard_len;
         me.rank = pk->shard_rank;
         me.k = k;
-        me.ncols = (uint64_t)sh.num_advice_total | (uint64_t)(pk->shard_quotient ? 1 : 0) << 32 | (uint64_t)(pk->shard_products ? 1 : 0) << 33;   // + the stages sharded: the exchange schedule depends on them
+        me.ncols = (uint64_t)sh.num_advice_total | (uint64_t)(pk->shard_quotient ? 1 : 0) << 32 | (uint64_t)(pk->shard_products ? 1 : 0) << 33 |
+                   (uint64_t)(pk->shard_ntt ? 1 : 0) << 34;   // + the stages sharded: the exchange schedule depends on them
         {
             Blake2b h(32, "h2hip-shard-rng");
             h.update(pk->host_stage, sizeof(Fr) * (size_t)(n - u));   // the first draw of this proof sits at the start of the staging buffer
@@ -1151,7 +1154,38 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     if (!random_poly) H2_CHK(sc.take(n, &random_poly));
     // all columns of a round go through the transforms together (32 per launch): a wide shape's 2^14-row columns are far too small to fill the chip alone
     auto to_coeff = [&](const std::vector<Fr *> &cols) -> int {
-        return h2hip_ifft_batch_dev(ctx, (void *const *)cols.data(), cols.size(), &dom.omega_inv, k, &dom.ifft_divisor);
+        if (!(sharded_any && pk->shard_ntt))
+            return h2hip_ifft_batch_dev(ctx, (void *const *)cols.data(), cols.size(), &dom.omega_inv, k, &dom.ifft_divisor);
+        // Sharded by COLUMN (H2HIP_SHARD_NTT_COLUMNS; north_star: "independent NTT columns shard across the GPUs"): column j is transformed by rank
+        // j mod N — in the all-gather's send buffer — and ONE device-to-device all-gather hands every rank every coefficient form (each needs
+        // them all: its cosets read whole polynomials).  Pays when a transform takes longer than moving one column between GPUs (k = 21: 0.3 ms
+        // against 64 MiB over the links a rank receives on: eight fully connected GPUs, not two).  Everything that can fail on this rank alone
+        // comes before the go-ahead exchange.
+        const uint32_t N = pk->shard_world, me_ = pk->shard_rank;
+        const size_t slot_cols = (cols.size() + N - 1) / N, slot_elems = slot_cols * (size_t)n;
+        if (cols.empty()) {
+            std::vector<uint8_t> all;
+            return exchange_host(nullptr, 0, all);
+        }
+        Fr *sendb = nullptr, *recvb = nullptr;
+        H2_CHK(sc.take(slot_elems, &sendb));
+        H2_CHK(sc.take(slot_elems * N, &recvb));
+        std::vector<Fr *> mine;
+        for (size_t j = me_; j < cols.size(); j += N) {
+            Fr *dst = sendb + (j / N) * (size_t)n;
+            H2_HIPCHK(hipMemcpyAsync(dst, cols[j], sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
+            mine.push_back(dst);
+        }
+        if (!mine.empty()) H2_CHK(h2hip_ifft_batch_dev(ctx, (void *const *)mine.data(), mine.size(), &dom.omega_inv, k, &dom.ifft_divisor));
+        H2_CHK(comm_reserve_allgather_dev(pk->comm, sizeof(Fr) * slot_elems));
+        std::vector<uint8_t> all;
+        H2_CHK(exchange_host(nullptr, 0, all));
+        H2_CHK(h2hip_comm_allgather_dev(pk->comm, ctx, sendb, sizeof(Fr) * slot_elems, recvb));
+        for (size_t j = 0; j < cols.size(); ++j)
+            H2_HIPCHK(hipMemcpyAsync(cols[j], recvb + (j % N) * slot_elems + (j / N) * (size_t)n, sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
+        sc.release(recvb);
+        sc.release(sendb);
+        return H2HIP_OK;
     };
     // the shift of coset c of the extended domain: s_c = zeta * omega_e^c (rows i = (j << (ek - k)) + c are the points s_c * omega^j)
     auto coset_shift = [&](uint32_t c) -> Fr { return fe_mul(dom.zeta, fe_pow_u64(dom.ext_omega, c)); };
@@ -1866,6 +1900,7 @@ static void shard_release(h2hip_plonk_pk *pk) {
     pk->comm = nullptr;
     pk->shard_quotient = false;
     pk->shard_products = false;
+    pk->shard_ntt = false;
 }
 
 // the host exchanges of the key's last sharded proof, in order: payload bytes per rank (each travels with an 8-byte status word); what a
@@ -1896,6 +1931,7 @@ int h2hip_plonk_pk_set_sharding(h2hip_plonk_pk *pk, h2hip_comm *comm, const h2hi
     pk->comm = comm;
     pk->shard_quotient = (flags & H2HIP_SHARD_QUOTIENT) != 0;
     pk->shard_products = (flags & H2HIP_SHARD_PRODUCTS) != 0;
+    pk->shard_ntt = (flags & H2HIP_SHARD_NTT_COLUMNS) != 0;
     if (!pk->shard_quotient) return H2HIP_OK;
     // this rank's cosets of the extended domain: c = rank, rank + world, ... < 2^(ek - k), and the [coset][n] slices of the key's arrays
     const uint32_t log_c = pk->sh.extended_k - pk->sh.k, ncos = 1u << log_c, n = pk->sh.n;

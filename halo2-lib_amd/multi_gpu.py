@@ -214,7 +214,7 @@ class Comm:
             self.handle = None
 
 
-SHARD_QUOTIENT, SHARD_FORCE, SHARD_PRODUCTS = 1, 2, 4
+SHARD_QUOTIENT, SHARD_FORCE, SHARD_PRODUCTS, SHARD_NTT_COLUMNS = 1, 2, 4, 8
 
 
 class ShardedKey:
@@ -232,12 +232,13 @@ class ShardedKey:
 
 
 def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, group=None, device=None, precompute: bool = True,
-                      rccl: bool = None, shard_quotient: bool = True, comm=None, shard_products: bool = True, point_range=None) -> ShardedKey:
+                      rccl: bool = None, shard_quotient: bool = True, comm=None, shard_products: bool = True, point_range=None, shard_ntt_columns: bool = None) -> ShardedKey:
     """Shards a proving key's create_proof over the process group (h2hip_plonk_pk_set_sharding): this rank uploads ONLY its point range of
     the SRS (g_points / g_lagrange_points: the full (n, 8) affine arrays or anything sliceable that yields them) as base sets with their own
     window tables; h(X)'s numerator is evaluated by cosets of the extended domain (shard_quotient), the grand products by row range
     (shard_products); evaluations and SHPLONK's polynomial work always run on the rank's coefficient range.  point_range: this rank's (lo, hi) instead
-    of the even split.  The exchange runs inside libh2hip:
+    of the even split.  shard_ntt_columns: lagrange_to_coeff dealt by column with an all-gather of the coefficient forms (None: from 8 ranks, where a
+    rank receives on seven links at once — with fewer, moving a column costs more than transforming it).  The exchange runs inside libh2hip:
     over its own RCCL communicator when the process group's backend is nccl (rccl=None: decided from the backend), else over a
     torch.distributed callback (gloo on the CPU)."""
     import torch.distributed as dist
@@ -247,6 +248,8 @@ def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, g
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = 1 << pk.params.k
+    if shard_ntt_columns is None:
+        shard_ntt_columns = world >= 8
     lo, hi = point_range if point_range is not None else shard_range(n, rank, world)   # (the ranks' ranges must tile [0, n): checked by the proof's first exchange)
     ctx = pk.ctx
     own_comm = comm is None
@@ -258,5 +261,6 @@ def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, g
     gs = ctx.bases_upload(np.ascontiguousarray(g_points[lo:hi]), flags)
     gls = ctx.bases_upload(np.ascontiguousarray(g_lagrange_points[lo:hi]), flags)
     ctx._chk(ctx.lib.h2hip_plonk_pk_set_sharding(pk.handle, comm.handle, gs.handle, gls.handle, lo, hi - lo,
-                                                 (SHARD_QUOTIENT if shard_quotient else 0) | (SHARD_PRODUCTS if shard_products else 0)))
+                                                 (SHARD_QUOTIENT if shard_quotient else 0) | (SHARD_PRODUCTS if shard_products else 0) |
+                                                 (SHARD_NTT_COLUMNS if shard_ntt_columns else 0)))
     return ShardedKey(pk, gs, gls, comm, own_comm)

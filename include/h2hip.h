@@ -428,7 +428,9 @@ int h2hip_comm_allgather_host(h2hip_comm *comm, h2hip_ctx *ctx, const void *send
  *   - with H2HIP_SHARD_PRODUCTS the grand products of the permutation and lookup arguments are formed by ROW range: local factors, inversion
  *     and prefix products, one 32-byte exchange per product, a scaling by everything before the range, ONE device-to-device all-gather of
  *     the rows (every rank needs the complete columns for their coefficient forms);
- *   - replicated on every rank: uploads, lookup permutation, lagrange_to_coeff, extended_to_coeff.
+ *   - with H2HIP_SHARD_QUOTIENT extended_to_coeff runs by cosets too (the size-n inverse transform of a coset where the coset is, a pointwise
+ *     combine on every rank after the all-gather); with H2HIP_SHARD_NTT_COLUMNS lagrange_to_coeff is dealt by column;
+ *   - replicated on every rank: uploads, the lookup permutation (and lagrange_to_coeff without H2HIP_SHARD_NTT_COLUMNS).
  * Safety: at its first exchange a proof checks that all ranks agree on the shape and the RNG stream and that the point ranges tile
  * [0, 2^k) (H2HIP_ERR_INVALID otherwise); every host exchange carries a status word, and a rank that fails takes part in the next
  * exchange with an error status, so that all ranks return (H2HIP_ERR_PEER on the others) instead of waiting in a collective.
@@ -436,6 +438,8 @@ int h2hip_comm_allgather_host(h2hip_comm *comm, h2hip_ctx *ctx, const void *send
 #define H2HIP_SHARD_QUOTIENT 1u
 #define H2HIP_SHARD_PRODUCTS 4u /* the grand products (permutation and lookup arguments) by row range: local prefix products, one 32-byte exchange per
                                  product, one device-to-device all-gather of the columns */
+#define H2HIP_SHARD_NTT_COLUMNS 8u /* lagrange_to_coeff by column: column j on rank j mod N, one device-to-device all-gather of the coefficient forms per
+                                    batch (first-round columns, product columns); pays when a transform outlasts moving a column between GPUs */
 #define H2HIP_SHARD_FORCE 2u /* run the sharded code path even with a one-rank communicator (tests: a 1-GPU box exercises RCCL and the coset kernels) */
 int h2hip_plonk_pk_set_sharding(h2hip_plonk_pk *pk, h2hip_comm *comm, const h2hip_bases *g_shard, const h2hip_bases *g_lagrange_shard, size_t offset,
                                 size_t len, uint32_t flags);

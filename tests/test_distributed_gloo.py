@@ -186,7 +186,7 @@ def _worker_scenarios(rank, world, port, q):
             budget = _rng_budget(sh)
             single = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9))
             g, gl = ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange)
-            sk = shard_proving_key(pk, g, gl, precompute=False)
+            sk = shard_proving_key(pk, g, gl, precompute=False, shard_ntt_columns=True)   # every stage that can be sharded
             out[name] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
             if name == "multi":
                 # a witness outside the lookup table on ONE rank: that rank reports the cause, the others H2HIP_ERR_PEER; nobody hangs

@@ -84,7 +84,7 @@ class _GpuBackend:
         self.mul, self.add = ctx.fr_mul, ctx.fr_add
 
 
-SHARD_QUOTIENT, SHARD_FORCE, SHARD_PRODUCTS = 1, 2, 4
+SHARD_QUOTIENT, SHARD_FORCE, SHARD_PRODUCTS, SHARD_NTT_COLUMNS = 1, 2, 4, 8
 
 
 def _comm(ctx, kind):
@@ -136,7 +136,7 @@ def test_proof_bytes_equal_oracle_prover_at_reference_shape(name):
             n = 1 << k
             for kind in ("rccl", "callback"):
                 comm, keep = _comm(ctx, kind)
-                for flags in (SHARD_QUOTIENT | SHARD_PRODUCTS | SHARD_FORCE, SHARD_FORCE):   # every sharded stage / commitments, evaluations and SHPLONK only
+                for flags in (SHARD_QUOTIENT | SHARD_PRODUCTS | SHARD_NTT_COLUMNS | SHARD_FORCE, SHARD_FORCE):   # every sharded stage / commitments, evaluations and SHPLONK only
                     ctx._chk(ctx.lib.h2hip_plonk_pk_set_sharding(pk.handle, comm, kzg.g.handle, kzg.g_lagrange.handle, 0, n, flags))
                     got = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, M.RNG_SEED + k))
                     assert _sha(got) == e["proof_sha256"], (kind, flags)

@@ -21,7 +21,7 @@ from oracle import c_oracle as CO
 from oracle import plonk as P
 from tests.util import PreDrawnRng, R, rand_fr
 
-SHARD_QUOTIENT, SHARD_FORCE, SHARD_PRODUCTS = 1, 2, 4
+SHARD_QUOTIENT, SHARD_FORCE, SHARD_PRODUCTS, SHARD_NTT_COLUMNS = 1, 2, 4, 8
 
 
 class _OracleBackend:
@@ -59,7 +59,7 @@ def _prove_both_ways(ctx, shape, make_comm, precompute, seed=4):
     single = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9))
     comm, keep = make_comm(ctx)
     n = 1 << shape[0]
-    for flags in (SHARD_QUOTIENT | SHARD_PRODUCTS | SHARD_FORCE, SHARD_FORCE):   # every sharded stage / commitments, evaluations and SHPLONK only
+    for flags in (SHARD_QUOTIENT | SHARD_PRODUCTS | SHARD_NTT_COLUMNS | SHARD_FORCE, SHARD_FORCE):   # every sharded stage / commitments, evaluations and SHPLONK only
         ctx._chk(ctx.lib.h2hip_plonk_pk_set_sharding(pk.handle, comm, kzg.g.handle, kzg.g_lagrange.handle, 0, n, flags))
         assert PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single, flags
     ctx._chk(ctx.lib.h2hip_plonk_pk_set_sharding(pk.handle, None, None, None, 0, 0, 0))
