@@ -220,6 +220,8 @@ def main():
                          "proves its own circuit (independent replicas, no exchange).  The MSM block follows the same choice.")
     ap.add_argument("--sharded-proof", action="store_true", help="accepted for compatibility: with --gpus N > 1 the top-level line already IS the sharded k=19 proof (--scaling strong)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (exchange staged through the host; testing)")
+    ap.add_argument("--shard-ntt-columns", choices=["auto", "on", "off"], default="auto",
+                    help="sharded proof: lagrange_to_coeff dealt by column (H2HIP_SHARD_NTT_COLUMNS); auto = from 8 ranks")
     ap.add_argument("--share-device", action="store_true", help="testing on a 1-GPU box: every rank uses GPU 0 (requires --dist-backend gloo)")
     ap.add_argument("--param", action="append", default=[], help="name=value tuning knob passed to h2hip_set_param (repeatable)")
     ap.add_argument("--lanes", type=int, default=0, help="override msm_lanes (streams used by the batch API)")
@@ -311,7 +313,8 @@ def main():
 
         comm = Comm(ctx, rccl=args.dist_backend == "nccl", device=xdev)   # libh2hip's own communicator (RCCL over xGMI / a gloo callback)
         if sharded:
-            sk = shard_proving_key(pk, ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange), device=xdev, precompute=True, comm=comm)
+            sk = shard_proving_key(pk, ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange), device=xdev, precompute=True, comm=comm,
+                                   shard_ntt_columns={"auto": None, "on": True, "off": False}[args.shard_ntt_columns])
         # what the N-rank run actually ran on: libh2hip's view of its communicator (h2hip_comm_info) and every rank's GPU, gathered for the line
         import ctypes as _C
 
@@ -509,11 +512,12 @@ def main():
                 cnt = _C.c_size_t(0)
                 sizes = (_C.c_size_t * 32)()
                 ctx._chk(ctx.lib.h2hip_plonk_pk_last_exchanges(pk.handle, sizes, 32, _C.byref(cnt)))
+                ntt_cols = args.shard_ntt_columns == "on" or (args.shard_ntt_columns == "auto" and world >= 8)
                 what = ["hello (shape, point range, stages sharded, RNG digest)", "round 1: advice + permuted lookup columns",
                         "grand products: the row ranges' total products (and the go-ahead of their all-gather)",
-                        ] + (["go-ahead before the all-gather of the first-round columns' coefficient forms (status only)"] if world >= 8 else []) + [
+                        ] + (["go-ahead before the all-gather of the first-round columns' coefficient forms (status only)"] if ntt_cols else []) + [
                         "round 2: grand products + random polynomial",
-                        ] + (["go-ahead before the all-gather of the product columns' coefficient forms (status only)"] if world >= 8 else []) + [
+                        ] + (["go-ahead before the all-gather of the product columns' coefficient forms (status only)"] if ntt_cols else []) + [
                         "go-ahead before the coset all-gather (status only)", "h(X) pieces",
                         "evaluations: partial sums over the coefficient ranges", "SHPLONK: the ranges' partial evaluations at the rotation sets' points (carries)",
                         "SHPLONK W", "SHPLONK: the linearisation's partial evaluation at u (carry)", "SHPLONK W'"]

@@ -616,9 +616,11 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     const size_t psz = affine ? sizeof(G1Affine) : sizeof(G1Jac);
     // lanes: the kernels of one MSM are issue-bound or latency-bound, so lanes that overlap whole MSMs mostly contend (measured,
     // tools/batch_ab.py, batches of 4 with the deferred reduction: 2^20 1.71 / 1.75 / 1.80 / 1.84 ms per MSM on 1 / 2 / 3 / 4 lanes, 2^19
-    // 0.99 / 0.95 / 0.98 / 1.00) — auto picks 1 lane from 2^20 points, 3 below
+    // 0.99 / 0.95 / 0.98 / 1.00: r02's kernels) — auto picks 2 lanes from 2^20 points (r04, measured in proofs), 3 below
     int NL = ctx->msm_lanes;
-    if (NL <= 0) NL = n >= ((size_t)1 << 20) ? 1 : 3;   // (2^18 / 2^19 were on 2 lanes until the window model moved them to c = 15: 3 lanes now win by 2 %, k = 18 / 19 proofs)
+    if (NL <= 0) NL = n >= ((size_t)1 << 20) ? 2 : 3;   // (2^18 / 2^19 were on 2 lanes until the window model moved them to c = 15: 3 lanes now win by 2 %, k = 18 / 19 proofs;
+                                                        //  r04: 2^21 on 2 lanes 60.3 ms per k = 21 proof against 62.2 on one and 61.0 on three — the next column's sort
+                                                        //  runs beside the accumulation: profiles/r04_msm_lanes_large.log)
     if (NL > 4) NL = 4;
     for (int l = 0; l < NL; ++l) {
         if (!ctx->lane[l]) {
