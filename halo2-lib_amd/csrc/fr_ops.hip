@@ -3,6 +3,7 @@
 // sub / mul / mul_add on column values) plus the diagnostic multiplier micro-benchmark that defines the
 // integer roofline quoted by bench.py.
 #include "internal.h"
+#include "fr29.cuh"
 #include "fq29.cuh"
 
 namespace h2 {
@@ -848,6 +849,53 @@ __global__ __launch_bounds__(256) void quotient_permutation_kernel(Fr *__restric
     }
 }
 
+// The same kernel on unsaturated limbs (fr29.cuh): every product at the 9 x 29 rate, acc*y + term with ONE reduction.  One operand of every
+// data x data product carries the factor 32 — taken when a stored element is split (r29_load32) or folded into the constants of the factor
+// it is built from: the X term's start value, beta and gamma arrive as 32 beta zeta delta^j0, 32 beta, 32 gamma.  Bounds (multiples of r):
+// acc < 1.64, the factors 32 p + 32 beta s + 32 gamma < 34.02, left / right < 1.25, every term's operands 32 x 3.3 at most.
+struct PermArgs29 {
+    const Fr *z, *z_prev, *l0, *l_last, *l_blind;
+    const Fr *cols[PERM_MAX_COLS], *sigmas[PERM_MAX_COLS];
+    uint32_t ncols, terms, last_rot_points;
+    Fr29 beta32, delta, y, x0_delta32, xstep;   // R' form (r29_const) of 32 beta, delta, y, 32 beta zeta delta^j0, ext_omega^(grid stride)
+    Fr29 gamma32;                               // raw split of (32 gamma mod r) in the stored domain
+    Fr ext_omega;
+};
+__global__ __launch_bounds__(256, 3) void quotient_permutation29_kernel(Fr *__restrict__ acc, PermArgs29 g, size_t ne, uint32_t step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = ne - 1;
+    const Fr one_sat = Fr::one();
+    const Fr29 one = r29_load(one_sat);
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr29 xbase = f29_mul(r29_load(fe_pow_u64(g.ext_omega, (uint64_t)i0)), g.x0_delta32);   // 32 beta delta^j0 zeta w_ext^i, < 1.01
+    for (size_t i = i0; i < ne; i += stride, xbase = f29_mul(xbase, g.xstep)) {
+        const size_t inext = (i + step) & mask;
+        const Fr z_sat = g.z[i], ll_sat = g.l_last[i];
+        const Fr29 z = r29_load(z_sat);
+        Fr29 v = r29_load(acc[i]);
+        if (g.terms & H2HIP_PERM_FIRST) v = f29_mul2(v, g.y, r29_load32(g.l0[i]), f29_sub<2>(one, z));            // 1.64 + 32 * 3
+        if (g.terms & H2HIP_PERM_LAST) {
+            const Fr29 zz = f29_mul(r29_load32(z_sat), f29_sub<2>(z, one));                                       // z (z - 1) < 1.57
+            v = f29_mul2(v, g.y, r29_load32(ll_sat), zz);
+        }
+        if (g.terms & H2HIP_PERM_CHAIN)
+            v = f29_mul2(v, g.y, r29_load32(g.l0[i]), f29_sub<2>(z, r29_load(g.z_prev[(i + g.last_rot_points) & mask])));
+        if (g.terms & H2HIP_PERM_PRODUCT) {
+            Fr29 left = r29_load(g.z[inext]), right = z, xterm = xbase;
+            for (uint32_t j = 0; j < g.ncols; ++j) {
+                const Fr29 p32 = f29_add(r29_load32(g.cols[j][i]), g.gamma32);                                    // lazy, limbs < 2^30
+                const Fr29 fl = f29_norm(f29_add(p32, f29_mul(r29_load(g.sigmas[j][i]), g.beta32)));              // 32 (p + beta s + gamma) < 34.02
+                const Fr29 fr = f29_norm(f29_add(p32, xterm));
+                left = f29_mul(left, fl);
+                right = f29_mul(right, fr);
+                xterm = f29_mul(xterm, g.delta);
+            }
+            const Fr active = fe_sub(one_sat, fe_add(ll_sat, g.l_blind[i]));
+            v = f29_mul2(v, g.y, r29_load32(active), f29_sub<2>(left, right));                                    // 1.64 + 32 * 3.25
+        }
+        acc[i] = r29_store(v);
+    }
+}
+
 // ---- the same identities for MANY columns / sets / lookups per launch (wide shapes: hundreds of columns of a few thousand rows): every
 // launch reads and writes the accumulator once and folds its jobs in order, acc = acc*y + term per job — the same values as one launch per
 // job, without a few-hundred-workgroup launch (and an accumulator round trip) per column.  Job tables travel as kernel arguments.
@@ -943,6 +991,93 @@ __global__ __launch_bounds__(256) void quotient_permutation_batch_kernel(Fr *__r
             }
         }
         acc[i] = v;
+    }
+}
+
+// ---- the batched kernels on unsaturated limbs (fr29.cuh; see quotient_permutation29_kernel for the factor-of-32 bookkeeping).  Differences of
+// stored elements that enter a data x data product are formed in saturated arithmetic first (an add-with-carry chain) and split with the factor.
+__global__ __launch_bounds__(256) void quotient_flex_gate_batch29_kernel(Fr *__restrict__ acc, GateBatchArgs g, Fr29 y, size_t n_ext, uint32_t rot_step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = n_ext - 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ext; i += stride) {
+        const size_t i1 = (i + rot_step) & mask, i2 = (i + 2 * (size_t)rot_step) & mask, i3 = (i + 3 * (size_t)rot_step) & mask;
+        Fr29 v = r29_load(acc[i]);
+        for (uint32_t j = 0; j < g.count; ++j) {
+            const Fr *__restrict__ a = g.a[j];
+            const Fr29 bc = f29_mul(r29_load32(a[i1]), r29_load(a[i2]));                        // < 1.19
+            const Fr29 t = f29_sub<2>(f29_add(r29_load(a[i]), bc), r29_load(a[i3]));          // a + b c - d + 2 r < 4.2
+            v = f29_mul2(v, y, r29_load32(g.q[j][i]), t);                                     // 1.8 + 32 * 4.2 = 136.2 -> < 1.81
+        }
+        acc[i] = r29_store(v);
+    }
+}
+struct LookupConsts29 {
+    Fr29 y;                  // R' form
+    Fr29 beta32, gamma32;    // raw splits of 32 beta, 32 gamma (stored domain)
+};
+__global__ __launch_bounds__(256, 3) void quotient_lookup_batch29_kernel(Fr *__restrict__ acc, LookupBatchArgs g, LookupConsts29 k29, size_t ne, uint32_t step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = ne - 1;
+    const Fr one_sat = Fr::one();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += stride) {
+        const size_t inext = (i + step) & mask, iprev = (i + ne - step) & mask;
+        const Fr ll_sat = g.l_last[i];
+        const Fr29 l0 = r29_load32(g.l0[i]), ll = r29_load32(ll_sat), active = r29_load32(fe_sub(one_sat, fe_add(ll_sat, g.l_blind[i])));
+        Fr29 v = r29_load(acc[i]);
+        for (uint32_t j = 0; j < g.count; ++j) {
+            const LookupJob &q = g.jobs[j];
+            const Fr z_sat = q.z[i], ap_sat = q.ap[i], sp_sat = q.sp[i];
+            const Fr29 z = r29_load(z_sat);
+            v = f29_mul2(v, k29.y, l0, r29_load(fe_sub(one_sat, z_sat)));                                          // l0 (1 - z): 1.7 + 32
+            v = f29_mul2(v, k29.y, ll, f29_mul(r29_load32(z_sat), r29_load(fe_sub(z_sat, one_sat))));              // l_last z (z - 1)
+            Fr29 left = f29_mul(r29_load(q.z[inext]), f29_add(r29_load32(ap_sat), k29.beta32));                    // 1 x 33
+            left = f29_mul(left, f29_add(r29_load32(sp_sat), k29.gamma32));                                        // 1.2 x 33
+            Fr29 right = f29_mul(z, f29_add(r29_load32(q.a[i]), k29.beta32));
+            right = f29_mul(right, f29_add(r29_load32(q.s[i]), k29.gamma32));
+            v = f29_mul2(v, k29.y, active, f29_sub<2>(left, right));                                               // 1.7 + 32 * 3.25
+            const Fr d_sat = fe_sub(ap_sat, sp_sat);
+            v = f29_mul2(v, k29.y, l0, r29_load(d_sat));                                                           // l0 (a' - s')
+            v = f29_mul2(v, k29.y, active, f29_mul(r29_load32(d_sat), r29_load(fe_sub(ap_sat, q.ap[iprev]))));     // active (a' - s')(a' - a'(w^-1 X))
+        }
+        acc[i] = r29_store(v);
+    }
+}
+struct PermConsts29 {
+    Fr29 beta32, delta, y, xstep;   // R' form of 32 beta, delta, y, ext_omega^(grid stride)
+    Fr29 gamma32;                   // raw split of 32 gamma
+    Fr29 x0_delta32[PERM_BATCH];    // R' form of 32 beta zeta delta^(first column of the job's set)
+};
+__global__ __launch_bounds__(256, 3) void quotient_permutation_batch29_kernel(Fr *__restrict__ acc, PermBatchArgs g, PermConsts29 k29, size_t ne, uint32_t step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, mask = ne - 1;
+    const Fr one_sat = Fr::one();
+    const Fr29 one = r29_load(one_sat);
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr29 wpow = r29_load(fe_pow_u64(g.ext_omega, (uint64_t)i0));   // w_ext^i in the stored domain
+    for (size_t i = i0; i < ne; i += stride, wpow = f29_mul(wpow, k29.xstep)) {
+        const size_t inext = (i + step) & mask;
+        const Fr ll_sat = g.l_last[i];
+        const Fr29 l0 = r29_load32(g.l0[i]), ll = r29_load32(ll_sat), active = r29_load32(fe_sub(one_sat, fe_add(ll_sat, g.l_blind[i])));
+        Fr29 v = r29_load(acc[i]);
+        for (uint32_t jb = 0; jb < g.njobs; ++jb) {
+            const PermJob &q = g.jobs[jb];
+            const Fr z_sat = q.z[i];
+            const Fr29 z = r29_load(z_sat);
+            if (q.terms & H2HIP_PERM_FIRST) v = f29_mul2(v, k29.y, l0, f29_sub<2>(one, z));
+            if (q.terms & H2HIP_PERM_LAST) v = f29_mul2(v, k29.y, ll, f29_mul(r29_load32(z_sat), f29_sub<2>(z, one)));
+            if (q.terms & H2HIP_PERM_CHAIN) v = f29_mul2(v, k29.y, l0, f29_sub<2>(z, r29_load(q.z_prev[(i + g.last_rot_points) & mask])));
+            if (q.terms & H2HIP_PERM_PRODUCT) {
+                Fr29 left = r29_load(q.z[inext]), right = z;
+                Fr29 xterm = f29_mul(wpow, k29.x0_delta32[jb]);
+                for (uint32_t j = 0; j < q.ncols; ++j) {
+                    const Fr29 p32 = f29_add(r29_load32(q.cols[j][i]), k29.gamma32);
+                    const Fr29 fl = f29_norm(f29_add(p32, f29_mul(r29_load(q.sigmas[j][i]), k29.beta32)));
+                    const Fr29 fr = f29_norm(f29_add(p32, xterm));
+                    left = f29_mul(left, fl);
+                    right = f29_mul(right, fr);
+                    xterm = f29_mul(xterm, k29.delta);
+                }
+                v = f29_mul2(v, k29.y, active, f29_sub<2>(left, right));
+            }
+        }
+        acc[i] = r29_store(v);
     }
 }
 
@@ -1552,7 +1687,26 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z,
     const uint32_t pgrid = perm_grid(ne);
     g.xstep = fe_pow_u64(g.ext_omega, (uint64_t)pgrid * 256);
     prof_begin(ctx, "quotient_permutation_kernel");
-    hipLaunchKernelGGL(quotient_permutation_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
+    if (ctx->quotient_29) {
+        PermArgs29 h;
+        memset((void *)&h, 0, sizeof(h));
+        h.z = g.z; h.z_prev = g.z_prev; h.l0 = g.l0; h.l_last = g.l_last; h.l_blind = g.l_blind;
+        for (uint32_t j = 0; j < ncols; ++j) {
+            h.cols[j] = g.cols[j];
+            h.sigmas[j] = g.sigmas[j];
+        }
+        h.ncols = g.ncols; h.terms = g.terms; h.last_rot_points = g.last_rot_points;
+        h.beta32 = r29_const(fe_x32(g.beta));
+        h.delta = r29_const(g.delta);
+        h.y = r29_const(g.y);
+        h.x0_delta32 = r29_const(fe_x32(g.x0_delta));
+        h.xstep = r29_const(g.xstep);
+        h.gamma32 = r29_load(fe_x32(g.gamma));
+        h.ext_omega = g.ext_omega;
+        hipLaunchKernelGGL(quotient_permutation29_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, h, ne, step);
+    } else {
+        hipLaunchKernelGGL(quotient_permutation_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
+    }
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
@@ -1576,7 +1730,11 @@ int h2hip_quotient_flex_gate_batch_dev(h2hip_ctx *ctx, void *acc, const void *co
             g.a[j] = (const Fr *)a[j0 + j];
         }
         prof_begin(ctx, "quotient_flex_gate_batch_kernel");
-        hipLaunchKernelGGL(quotient_flex_gate_batch_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)acc, g, n_ext, 1u << (ext_k - k));
+        if (ctx->quotient_29)
+            hipLaunchKernelGGL(quotient_flex_gate_batch29_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)acc, g, r29_const(g.y), n_ext,
+                               1u << (ext_k - k));
+        else
+            hipLaunchKernelGGL(quotient_flex_gate_batch_kernel, dim3(grid_for(ctx, n_ext)), dim3(256), 0, ctx->stream, (Fr *)acc, g, n_ext, 1u << (ext_k - k));
         prof_end(ctx);
     }
     H2_HIPCHK(hipGetLastError());
@@ -1602,7 +1760,15 @@ int h2hip_quotient_lookups_dev(h2hip_ctx *ctx, void *acc, const void *const *z, 
             g.jobs[j].ap = (const Fr *)a_perm[t]; g.jobs[j].sp = (const Fr *)s_perm[t];
         }
         prof_begin(ctx, "quotient_lookup_batch_kernel");
-        hipLaunchKernelGGL(quotient_lookup_batch_kernel, dim3(grid_for(ctx, ne)), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, 1u << (ext_k - k));
+        if (ctx->quotient_29) {
+            LookupConsts29 k29;
+            k29.y = r29_const(g.y);
+            k29.beta32 = r29_load(fe_x32(g.beta));
+            k29.gamma32 = r29_load(fe_x32(g.gamma));
+            hipLaunchKernelGGL(quotient_lookup_batch29_kernel, dim3(grid_for(ctx, ne)), dim3(256), 0, ctx->stream, (Fr *)acc, g, k29, ne, 1u << (ext_k - k));
+        } else {
+            hipLaunchKernelGGL(quotient_lookup_batch_kernel, dim3(grid_for(ctx, ne)), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, 1u << (ext_k - k));
+        }
         prof_end(ctx);
     }
     H2_HIPCHK(hipGetLastError());
@@ -1676,7 +1842,18 @@ int h2hip_quotient_permutation_sets_dev(h2hip_ctx *ctx, void *acc, const void *c
             }
         }
         prof_begin(ctx, "quotient_permutation_batch_kernel");
-        hipLaunchKernelGGL(quotient_permutation_batch_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
+        if (ctx->quotient_29) {
+            PermConsts29 k29;
+            k29.beta32 = r29_const(fe_x32(g.beta));
+            k29.delta = r29_const(g.delta);
+            k29.y = r29_const(g.y);
+            k29.xstep = r29_const(g.xstep);
+            k29.gamma32 = r29_load(fe_x32(g.gamma));
+            for (uint32_t j = 0; j < PERM_BATCH; ++j) k29.x0_delta32[j] = j < g.njobs ? r29_const(fe_x32(g.jobs[j].x0_delta)) : Fr29::zero();
+            hipLaunchKernelGGL(quotient_permutation_batch29_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, k29, ne, step);
+        } else {
+            hipLaunchKernelGGL(quotient_permutation_batch_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
+        }
         prof_end(ctx);
     }
     H2_HIPCHK(hipGetLastError());

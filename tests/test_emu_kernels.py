@@ -278,9 +278,16 @@ def test_division_step_inversion_matches_fermat(tmp_path):
     assert out.returncode == 0 and "modinv selftest OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def _quotient_identity_checks(ctx, k, ek):
+def _quotient_identity_checks(ctx, k, ek, edge_patterns=False):
     ne, step = 1 << ek, 1 << (ek - k)
     rs = lambda seed: O.random_scalars(ne, seed)
+    if edge_patterns:
+        # field elements whose STORED limb patterns (Montgomery form) are the edge patterns of tests/util.edge_fr_values — 0, 1, r - 1, around 2^252 and
+        # 2^253, the Montgomery constants — in every combination the cyclic offsets produce: the unsaturated kernels' bounds at their extremes
+        from tests.util import edge_fr_values
+        rinv = O.inv_mod(pow(2, 256, R), R)
+        edge = [e * rinv % R for e in edge_fr_values()]
+        rs = lambda seed: [edge[(i * (2 * seed + 1) + seed) % len(edge)] for i in range(ne)]
     acc, z, a, s, ap, sp, l0, ll, lb = [rs(i) for i in range(1, 10)]
     beta, gamma, y = O.random_scalars(3, 77)
     got = ctx.quotient_lookup(fr(acc), fr(z), fr(a), fr(s), fr(ap), fr(sp), fr(l0), fr(ll), fr(lb), ek, k, fr([beta]), fr([gamma]), fr([y]))
@@ -298,8 +305,15 @@ def _quotient_identity_checks(ctx, k, ek):
         assert O.limbs_to_ints(got, R) == want
 
 
-def test_quotient_lookup_and_permutation_identities(ctx):
-    _quotient_identity_checks(ctx, 4, 6)
+@pytest.mark.parametrize("unsaturated", [1, 0])
+def test_quotient_lookup_and_permutation_identities(ctx, unsaturated):
+    """both arithmetic forms of the quotient kernels (fr29.cuh's 9 x 29-bit limbs: the default; the saturated kernels) against big-int arithmetic"""
+    ctx.set_param("quotient_29", unsaturated)
+    try:
+        _quotient_identity_checks(ctx, 4, 6)
+        _quotient_identity_checks(ctx, 4, 6, edge_patterns=True)
+    finally:
+        ctx.set_param("quotient_29", 1)
 
 
 def test_msm_quad_and_serial_tails_agree(ctx):
@@ -418,10 +432,15 @@ def test_prover_steps_emulated(ctx, n):
     check_prover_steps(ctx, n)
 
 
-def test_quotient_batches_emulated(ctx):
+@pytest.mark.parametrize("unsaturated", [1, 0])
+def test_quotient_batches_emulated(ctx, unsaturated):
     from tests.golden_checks import check_quotient_batches
 
-    check_quotient_batches(ctx)
+    ctx.set_param("quotient_29", unsaturated)
+    try:
+        check_quotient_batches(ctx)
+    finally:
+        ctx.set_param("quotient_29", 1)
 
 
 def test_ntt_batches_emulated(ctx):

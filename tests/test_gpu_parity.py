@@ -262,10 +262,16 @@ def test_msm_batch_bench_path_closed_form(ctx, log_n, batch):
     b.free()
 
 
-def test_quotient_lookup_and_permutation_identities(ctx):
+@pytest.mark.parametrize("unsaturated", [1, 0])
+def test_quotient_lookup_and_permutation_identities(ctx, unsaturated):
     from tests.test_emu_kernels import _quotient_identity_checks
 
-    _quotient_identity_checks(ctx, 7, 9)
+    ctx.set_param("quotient_29", unsaturated)
+    try:
+        _quotient_identity_checks(ctx, 7, 9)
+        _quotient_identity_checks(ctx, 7, 9, edge_patterns=True)
+    finally:
+        ctx.set_param("quotient_29", 1)
 
 
 def test_lookup_permute_expression_pair(ctx):
@@ -389,10 +395,15 @@ def test_lookup_permute_batch(ctx):
 
 
 @pytest.mark.gpu
-def test_quotient_batches(ctx):
+@pytest.mark.parametrize("unsaturated", [1, 0])
+def test_quotient_batches(ctx, unsaturated):
     from tests.golden_checks import check_quotient_batches
 
-    check_quotient_batches(ctx, k=9, gate_cols=130)
+    ctx.set_param("quotient_29", unsaturated)
+    try:
+        check_quotient_batches(ctx, k=9, gate_cols=130)
+    finally:
+        ctx.set_param("quotient_29", 1)
 
 
 @pytest.mark.gpu
