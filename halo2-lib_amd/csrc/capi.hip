@@ -289,6 +289,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "plonk_side_on_lanes")) return &ctx->plonk_side_on_lanes;
     if (!strcmp(name, "kate_coeffs_per_lane")) return &ctx->kate_coeffs_per_lane;
     if (!strcmp(name, "quotient_29")) return &ctx->quotient_29;
+    if (!strcmp(name, "kate_29")) return &ctx->kate_29;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;

@@ -454,6 +454,7 @@ struct EvalJob {
     size_t n;
     Fr x;
     PowTable pw;
+    Fr29 x29, one29, pw29[8];   // R' form of x, 1 and x^(EVAL_J * 2^l): the tile kernel on unsaturated limbs (fr29.cuh)
 };
 __global__ __launch_bounds__(256) void fr_eval_tile_batch_kernel(const EvalJob *__restrict__ jobs, uint32_t ntiles_max, Fr *__restrict__ tile_val) {
     __shared__ Fr sh[256];
@@ -476,6 +477,31 @@ __global__ __launch_bounds__(256) void fr_eval_tile_batch_kernel(const EvalJob *
         __syncthreads();
     }
     if (tid == 0) tile_val[(size_t)blockIdx.y * ntiles_max + blockIdx.x] = sh[0];
+}
+// the tile kernel on unsaturated limbs: the point is a per-job constant (R' form), coefficients enter as raw splits, the Horner value stays lazy
+// between products; the tile's value (< 11 r after the tree) leaves through one product with R'(1)
+__global__ __launch_bounds__(256) void fr_eval_tile_batch29_kernel(const EvalJob *__restrict__ jobs, uint32_t ntiles_max, Fr *__restrict__ tile_val) {
+    __shared__ Fr29 sh[256];
+    const EvalJob &job = jobs[blockIdx.y];
+    const size_t n = job.n;
+    const uint32_t tid = threadIdx.x;
+    const size_t base = ((size_t)blockIdx.x * 256 + tid) * EVAL_J;
+    if ((size_t)blockIdx.x * 256 * EVAL_J >= n && blockIdx.x) return;   // tile past the end of this polynomial (uniform per workgroup)
+    const Fr29 x = job.x29;
+    const Fr *__restrict__ coeffs = job.coeffs;
+    Fr29 acc = Fr29::zero();
+#pragma unroll 1
+    for (int k = EVAL_J - 1; k >= 0; --k) {
+        acc = f29_mul(acc, x);
+        if (base + k < n) acc = f29_add(acc, r29_load(coeffs[base + k]));
+    }
+    sh[tid] = f29_norm(acc);
+    __syncthreads();
+    for (uint32_t d = 1, l = 0; d < 256; d <<= 1, ++l) {
+        if ((tid & (2 * d - 1)) == 0) sh[tid] = f29_norm(f29_add(sh[tid], f29_mul(sh[tid + d], job.pw29[l])));
+        __syncthreads();
+    }
+    if (tid == 0) tile_val[(size_t)blockIdx.y * ntiles_max + blockIdx.x] = r29_store(f29_mul(sh[0], job.one29));
 }
 __global__ __launch_bounds__(256) void fr_eval_final_batch_kernel(const EvalJob *__restrict__ jobs, uint32_t ntiles_max, const Fr *__restrict__ tile_val,
                                                                   Fr *__restrict__ out) {
@@ -506,12 +532,9 @@ __global__ __launch_bounds__(256) void fr_eval_final_batch_kernel(const EvalJob 
 // kate_division: q[m] = sum_{j>m} c_j b^(j-m-1), m = 0..n-2  (suffix Horner).  Stage 1 computes every
 // workgroup's head H = sum_{j in tile} c_j b^(j-lo); stage 2 turns heads into carries
 // carry[blk] = sum_{blk'>blk} H[blk'] * (b^TILE)^(blk'-blk-1); stage 3 replays the tile with its carry.
-constexpr uint32_t KATE_J = 8, KATE_TILE = 256 * KATE_J;
+// (the head of one tile of 256 * J coefficients, saturated arithmetic; `top`: a virtual coefficient of index n, see KateJob::top)
 template <uint32_t J>
-__device__ __forceinline__ Fr kate_tile_scan(const Fr *__restrict__ c, size_t n, size_t lo, Fr b, const PowTable &pw, Fr *sh, Fr carry_in,
-                                             Fr *__restrict__ q, const Fr *top = nullptr) {
-    // returns the tile head; when q != nullptr also writes the quotient coefficients of this tile (256 * J coefficients, J per lane).
-    // `top`: a virtual coefficient of index n (range division: what the coefficients above this range contribute, see KateJob::top)
+__device__ __forceinline__ Fr kate_tile_head(const Fr *__restrict__ c, size_t n, size_t lo, Fr b, const PowTable &pw, Fr *sh, const Fr *top) {
     const uint32_t tid = threadIdx.x;
     const size_t base = lo + (size_t)tid * J;
     Fr h = Fr::zero();
@@ -530,63 +553,8 @@ __device__ __forceinline__ Fr kate_tile_scan(const Fr *__restrict__ c, size_t n,
         if (tid + d < 256) sh[tid] = fe_add(sh[tid], fe_mul(o, pw.p[l]));   // p[l] = b^(J*2^l)
         __syncthreads();
     }
-    Fr head = sh[0];
-    if (q) {
-        // carry into this lane = I_{t+1} + b^(J*(255-t)) * carry_in
-        Fr car = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
-        car = fe_add(car, fe_mul(fe_pow_u64(pw.p[0], 255 - tid), carry_in));
-        Fr tmp = car;
-        for (int k = (int)J - 1; k >= 0; --k) {
-            if (base + k < n) {
-                tmp = fe_add(c[base + k], fe_mul(tmp, b));
-                if (base + k >= 1) q[base + k - 1] = tmp;
-            }
-        }
-    }
-    return head;
+    return sh[0];
 }
-__global__ __launch_bounds__(256) void fr_kate_heads_kernel(const Fr *__restrict__ c, size_t n, Fr b, PowTable pw, Fr *__restrict__ heads) {
-    __shared__ Fr sh[256];
-    Fr h = kate_tile_scan<KATE_J>(c, n, (size_t)blockIdx.x * KATE_TILE, b, pw, sh, Fr::zero(), nullptr);
-    if (threadIdx.x == 0) heads[blockIdx.x] = h;
-}
-// carry[blk] = sum_{blk'>blk} H[blk'] * B^(blk'-blk-1), B = b^TILE = pw.p[8]: one workgroup, lane-serial runs of
-// `per` tiles + a suffix scan across lanes
-__global__ __launch_bounds__(256) void fr_kate_carry_kernel(const Fr *__restrict__ heads, Fr *__restrict__ carry, uint32_t ntiles, PowTable pw) {
-    __shared__ Fr sh[256];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (ntiles + 255) / 256, lo = tid * per;
-    const Fr B = pw.p[8];
-    Fr h = Fr::zero();
-    for (int k = (int)per - 1; k >= 0; --k) {
-        h = fe_mul(h, B);
-        if (lo + k < ntiles) h = fe_add(h, heads[lo + k]);
-    }
-    sh[tid] = h;
-    __syncthreads();
-    Fr Y = fe_pow_u64(B, per);
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-        Fr o = Fr::zero();
-        if (tid + d < 256) o = sh[tid + d];
-        __syncthreads();
-        if (tid + d < 256) sh[tid] = fe_add(sh[tid], fe_mul(o, Y));
-        Y = fe_sqr(Y);
-        __syncthreads();
-    }
-    Fr car = (tid + 1 < 256) ? sh[tid + 1] : Fr::zero();
-    for (int k = (int)per - 1; k >= 0; --k) {
-        if (lo + k < ntiles) {
-            carry[lo + k] = car;
-            car = fe_add(heads[lo + k], fe_mul(car, B));
-        }
-    }
-}
-__global__ __launch_bounds__(256) void fr_kate_apply_kernel(const Fr *__restrict__ c, size_t n, Fr b, PowTable pw, const Fr *__restrict__ carry,
-                                                            Fr *__restrict__ q) {
-    __shared__ Fr sh[256];
-    kate_tile_scan<KATE_J>(c, n, (size_t)blockIdx.x * KATE_TILE, b, pw, sh, carry[blockIdx.x], q);
-}
-
 // Division by the vanishing polynomial of SEVERAL points in one pass (ProverSHPLONK's per-rotation-set quotient): by partial fractions,
 //   (f(X) - r(X)) / prod_j (X - b_j)  =  sum_j w_j * (f(X) - f(b_j)) / (X - b_j),   w_j = 1 / prod_{i != j} (b_j - b_i),
 // where r is the interpolant of f on the b_j — so the quotient is a weighted sum of independent kate divisions of the SAME polynomial: the
@@ -605,7 +573,7 @@ __global__ __launch_bounds__(256) void fr_kate_heads_multi_kernel(const Fr *__re
                                                                   Fr *__restrict__ heads) {
     __shared__ Fr sh[256];
     const KateJob &job = jobs[blockIdx.y];
-    Fr h = kate_tile_scan<J>(c, n, (size_t)blockIdx.x * (256 * J), job.b, job.pw, sh, Fr::zero(), nullptr, &job.top);
+    Fr h = kate_tile_head<J>(c, n, (size_t)blockIdx.x * (256 * J), job.b, job.pw, sh, &job.top);
     if (threadIdx.x == 0) heads[(size_t)blockIdx.y * (ntiles + 1) + blockIdx.x] = h;
 }
 __global__ __launch_bounds__(256) void fr_kate_carry_multi_kernel(const Fr *__restrict__ heads, Fr *__restrict__ carry, uint32_t ntiles,
@@ -708,6 +676,105 @@ __global__ __launch_bounds__(256) void fr_kate_apply_multi_kernel(const Fr *__re
             if (TOP && k == ktop) tmp[j] = fe_add(tmp[j], jobs[j].top);
             acc = fe_add(acc, fe_mul(w[j], tmp[j]));
         });
+        if (base + k < n_out && base + k >= 1) q[base + k - 1] = accumulate ? fe_add(q[base + k - 1], acc) : acc;
+    }
+}
+
+// ---- the multi-point division on unsaturated limbs (fr29.cuh).  Every product of these kernels has a per-root CONSTANT operand (b, the scan's
+// powers of b, the weights), which arrive in R' form: stored coefficients enter as raw splits and everything stays in the stored domain.  Horner
+// values are kept lazy (h b + c: limbs < 2^30) where the next product takes them, normalised where LDS or a dot product needs it; the scan's
+// values grow by about r per doubling step (< 12 r: far inside the product's input range); a tile's head leaves through one product with R' (1).
+struct KateJob29 {
+    Fr29 b, w, one;        // R' form of the root, the weight and 1
+    Fr29 top;              // raw split of KateJob::top
+    Fr29 pw[9];            // R' form of b^(J * 2^l), l <= 8
+};
+template <uint32_t J>
+__global__ __launch_bounds__(256) void fr_kate_heads_multi29_kernel(const Fr *__restrict__ c, size_t n, const KateJob29 *__restrict__ jobs, uint32_t ntiles,
+                                                                    Fr *__restrict__ heads, int with_top) {
+    __shared__ Fr29 sh[256];
+    const KateJob29 &job = jobs[blockIdx.y];
+    const uint32_t tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * (256 * J) + (size_t)tid * J;
+    const Fr29 b = job.b;
+    Fr29 h = Fr29::zero();
+#pragma unroll 1
+    for (int k = (int)J - 1; k >= 0; --k) {
+        h = f29_mul(h, b);
+        if (base + k < n) h = f29_add(h, r29_load(c[base + k]));
+        else if (with_top && base + k == n) h = f29_add(h, job.top);
+    }
+    sh[tid] = f29_norm(h);
+    __syncthreads();
+    for (uint32_t d = 1, l = 0; d < 256; d <<= 1, ++l) {   // inclusive suffix scan: I_t = h_t + b^J * I_{t+1}
+        Fr29 o = Fr29::zero();
+        if (tid + d < 256) o = sh[tid + d];
+        __syncthreads();
+        if (tid + d < 256) sh[tid] = f29_norm(f29_add(sh[tid], f29_mul(o, job.pw[l])));
+        __syncthreads();
+    }
+    if (tid == 0) heads[(size_t)blockIdx.y * (ntiles + 1) + blockIdx.x] = r29_store(f29_mul(sh[0], job.one));
+}
+template <int M, uint32_t J, bool TOP>
+__global__ __launch_bounds__(256) void fr_kate_apply_multi29_kernel(const Fr *__restrict__ c, size_t n, const KateJob29 *__restrict__ jobs, uint32_t m,
+                                                                    uint32_t ntiles, const Fr *__restrict__ carry, Fr *__restrict__ q, int accumulate) {
+    __shared__ Fr29 sh[M][257];
+    const uint32_t tid = threadIdx.x;
+    const size_t lo = (size_t)blockIdx.x * (256 * J), base = lo + (size_t)tid * J;
+    const int ktop = TOP && n >= base && n < base + J ? (int)(n - base) : -1;
+    const size_t n_out = n + (TOP ? 1 : 0);
+    Fr29 b[M], h[M];
+    static_for<M>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        b[j] = jobs[j].b;   // (zero jobs behind the last point: weight 0)
+        h[j] = Fr29::zero();
+    });
+#pragma unroll 1
+    for (int k = (int)J - 1; k >= 0; --k) {
+        const Fr29 cvk = base + k < n ? r29_load(c[base + k]) : Fr29::zero();
+        static_for<M>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            h[j] = f29_add(f29_mul(h[j], b[j]), cvk);                              // lazy: limbs < 2^30, value < 2.02 r
+            if (TOP && k == ktop) h[j] = f29_norm(f29_add(h[j], jobs[j].top));
+        });
+    }
+    static_for<M>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        sh[j][tid] = f29_norm(h[j]);
+        if (tid == 0) sh[j][256] = (uint32_t)j < m ? r29_load(carry[(size_t)j * (ntiles + 1) + blockIdx.x]) : Fr29::zero();
+    });
+    __syncthreads();
+    for (uint32_t d = 1, l = 0; d <= 256; d <<= 1, ++l) {   // inclusive suffix scan over 257 slots: I_t = h_t + b^J * I_{t+1}, I_256 = carry
+        Fr29 o[M];
+        static_for<M>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            o[j] = tid + d <= 256 ? sh[j][tid + d] : Fr29::zero();
+        });
+        __syncthreads();
+        if (tid + d <= 256) {
+            static_for<M>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if ((uint32_t)j < m) sh[j][tid] = f29_norm(f29_add(sh[j][tid], f29_mul(o[j], jobs[j].pw[l])));
+            });
+        }
+        __syncthreads();
+    }
+    Fr29 tmp[M], w[M];
+    static_for<M>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        tmp[j] = sh[j][tid + 1];
+        w[j] = jobs[j].w;
+    });
+#pragma unroll 1
+    for (int k = (int)J - 1; k >= 0; --k) {
+        const Fr29 cvk = base + k < n ? r29_load(c[base + k]) : Fr29::zero();
+        static_for<M>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            tmp[j] = f29_add(cvk, f29_mul(tmp[j], b[j]));                          // = quotient coefficient of index base + k - 1 for point j
+            if (TOP && k == ktop) tmp[j] = f29_add(tmp[j], jobs[j].top);
+            tmp[j] = f29_norm(tmp[j]);                                             // N, < 3.03 r
+        });
+        const Fr acc = r29_store(f29_dot<M>(w, tmp));                              // sum_j w_j q_j with one reduction: < 1 + M * 3.06 / 169
         if (base + k < n_out && base + k >= 1) q[base + k - 1] = accumulate ? fe_add(q[base + k - 1], acc) : acc;
     }
 }
@@ -1385,8 +1452,14 @@ int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs
             }
         if (seen != j) {
             jobs[j].pw = jobs[seen].pw;
+            jobs[j].x29 = jobs[seen].x29;
+            jobs[j].one29 = jobs[seen].one29;
+            for (int l = 0; l < 8; ++l) jobs[j].pw29[l] = jobs[seen].pw29[l];
         } else {
             pow_table(jobs[j].x, EVAL_J, jobs[j].pw);
+            jobs[j].x29 = r29_const(jobs[j].x);
+            jobs[j].one29 = r29_const(Fr::one());
+            for (int l = 0; l < 8; ++l) jobs[j].pw29[l] = r29_const(jobs[j].pw.p[l]);
             if (distinct.size() < 16) distinct.push_back(j);
         }
         if (lens[j] > nmax) nmax = lens[j];
@@ -1401,7 +1474,10 @@ int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs
     Fr *tv = (Fr *)(buf + jobs_bytes), *res = tv + (size_t)ntiles * count;
     H2_HIPCHK(hipMemcpyAsync(djobs, jobs.data(), sizeof(EvalJob) * count, hipMemcpyHostToDevice, ctx->stream));
     prof_begin(ctx, "fr_eval_kernels");
-    hipLaunchKernelGGL(fr_eval_tile_batch_kernel, dim3(ntiles, (uint32_t)count), dim3(256), 0, ctx->stream, (const EvalJob *)djobs, ntiles, tv);
+    if (ctx->kate_29)
+        hipLaunchKernelGGL(fr_eval_tile_batch29_kernel, dim3(ntiles, (uint32_t)count), dim3(256), 0, ctx->stream, (const EvalJob *)djobs, ntiles, tv);
+    else
+        hipLaunchKernelGGL(fr_eval_tile_batch_kernel, dim3(ntiles, (uint32_t)count), dim3(256), 0, ctx->stream, (const EvalJob *)djobs, ntiles, tv);
     hipLaunchKernelGGL(fr_eval_final_batch_kernel, dim3((uint32_t)count), dim3(256), 0, ctx->stream, (const EvalJob *)djobs, ntiles, (const Fr *)tv, res);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
@@ -1409,29 +1485,6 @@ int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));   // also keeps `jobs` alive until the upload has been consumed
     return H2HIP_OK;
 }
-// q[0..n-1) = (f(X) - f(b)) / (X - b)   [UPSTREAM arithmetic::kate_division]
-int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *b) {
-    H2_DEVICE_GUARD(ctx);
-    H2_REQUIRE(ctx && b && n >= 1 && coeffs && (n == 1 || q), "bad argument");
-    H2_REQUIRE(q != coeffs, "q must not alias coeffs");
-    if (n == 1) return H2HIP_OK;
-    Fr bv;
-    memcpy(&bv, b, sizeof(Fr));
-    uint32_t ntiles = (uint32_t)((n + KATE_TILE - 1) / KATE_TILE);
-    PowTable pw;
-    pow_table(bv, KATE_J, pw);   // p[8] = b^KATE_TILE
-    Fr *heads = nullptr;
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, sizeof(Fr) * 2 * (ntiles + 1), (void **)&heads));
-    Fr *carry = heads + ntiles + 1;
-    prof_begin(ctx, "fr_kate_kernels");
-    hipLaunchKernelGGL(fr_kate_heads_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, bv, pw, heads);
-    hipLaunchKernelGGL(fr_kate_carry_kernel, dim3(1), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles, pw);
-    hipLaunchKernelGGL(fr_kate_apply_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, bv, pw, (const Fr *)carry, (Fr *)q);
-    prof_end(ctx);
-    H2_HIPCHK(hipGetLastError());
-    return H2HIP_OK;
-}
-
 }  // extern "C"
 // q[0..n-1) = sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j]),  m <= 8 points; q_dev must not alias coeffs_dev
 template <uint32_t J>
@@ -1450,14 +1503,31 @@ static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, 
         else jobs[j].top = Fr::zero();
         pow_table(jobs[j].b, J, jobs[j].pw);   // p[l] = b^(J * 2^l): p[8] = b^tile
     }
+    // the same jobs for the kernels on unsaturated limbs (ctx->kate_29): constants in R' form
+    const bool k29 = ctx->kate_29 != 0;
+    std::vector<KateJob29> jobs29(k29 ? m_pad : 0);
+    if (k29) memset((void *)jobs29.data(), 0, sizeof(KateJob29) * m_pad);
+    for (uint32_t j = 0; k29 && j < m; ++j) {
+        jobs29[j].b = r29_const(jobs[j].b);
+        jobs29[j].w = r29_const(jobs[j].w);
+        jobs29[j].one = r29_const(Fr::one());
+        jobs29[j].top = r29_load(jobs[j].top);
+        for (int l = 0; l < 9; ++l) jobs29[j].pw[l] = r29_const(jobs[j].pw.p[l]);
+    }
     char *buf = nullptr;
-    const size_t jobs_bytes = (sizeof(KateJob) * m_pad + 255) / 256 * 256;
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, jobs_bytes + sizeof(Fr) * 2 * (size_t)m * (ntiles + 1), (void **)&buf));
+    const size_t jobs_bytes = (sizeof(KateJob) * m_pad + 255) / 256 * 256, jobs29_bytes = (sizeof(KateJob29) * jobs29.size() + 255) / 256 * 256;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, jobs_bytes + jobs29_bytes + sizeof(Fr) * 2 * (size_t)m * (ntiles + 1), (void **)&buf));
     KateJob *djobs = (KateJob *)buf;
-    Fr *heads = (Fr *)(buf + jobs_bytes), *carry = heads + (size_t)m * (ntiles + 1);
+    KateJob29 *djobs29 = (KateJob29 *)(buf + jobs_bytes);
+    Fr *heads = (Fr *)(buf + jobs_bytes + jobs29_bytes), *carry = heads + (size_t)m * (ntiles + 1);
     H2_CHK(upload_jobs(ctx, djobs, jobs.data(), sizeof(KateJob) * m_pad));   // through the pinned ring: no synchronisation per call
+    if (k29) H2_CHK(upload_jobs(ctx, djobs29, jobs29.data(), sizeof(KateJob29) * m_pad));
     prof_begin(ctx, "fr_kate_kernels");
-    hipLaunchKernelGGL(fr_kate_heads_multi_kernel<J>, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, ntiles, heads);
+    if (k29)
+        hipLaunchKernelGGL(fr_kate_heads_multi29_kernel<J>, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob29 *)djobs29, ntiles, heads,
+                           with_top);
+    else
+        hipLaunchKernelGGL(fr_kate_heads_multi_kernel<J>, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, ntiles, heads);
     hipLaunchKernelGGL(fr_kate_carry_multi_kernel, dim3(m), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles, (const KateJob *)djobs);
     for (uint32_t j0 = 0; j0 < m; j0 += 4) {   // four points per pass (the scans of a pass share the workgroup's LDS); halo2-base's sets stop at 4
         const uint32_t mm = m - j0 < 4 ? m - j0 : 4;
@@ -1465,7 +1535,17 @@ static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, 
         const Fr *cr = carry + (size_t)j0 * (ntiles + 1);
         const int accumulate = j0 ? 1 : 0;
         auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate); };
-        if (with_top) {
+        const KateJob29 *jb29 = djobs29 + j0;
+        auto go29 = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb29, mm, ntiles, cr, (Fr *)q, accumulate); };
+        if (k29 && with_top) {
+            if (mm == 1) go29(fr_kate_apply_multi29_kernel<1, J, true>);
+            else if (mm == 2) go29(fr_kate_apply_multi29_kernel<2, J, true>);
+            else go29(fr_kate_apply_multi29_kernel<4, J, true>);
+        } else if (k29) {
+            if (mm == 1) go29(fr_kate_apply_multi29_kernel<1, J, false>);
+            else if (mm == 2) go29(fr_kate_apply_multi29_kernel<2, J, false>);
+            else go29(fr_kate_apply_multi29_kernel<4, J, false>);
+        } else if (with_top) {
             if (mm == 1) go(fr_kate_apply_multi_kernel<1, J, true>);
             else if (mm == 2) go(fr_kate_apply_multi_kernel<2, J, true>);
             else go(fr_kate_apply_multi_kernel<4, J, true>);
@@ -1495,6 +1575,15 @@ int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs
     H2_REQUIRE(q != coeffs, "q must not alias coeffs");
     if (n == 1) return H2HIP_OK;
     return kate_division_multi_pick(ctx, q, coeffs, n, points, weights, m, nullptr);
+}
+// q[0..n-1) = (f(X) - f(b)) / (X - b)   [UPSTREAM arithmetic::kate_division]: the one-point case of the kernels above (weight 1)
+int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *b) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && b && n >= 1 && coeffs && (n == 1 || q), "bad argument");
+    H2_REQUIRE(q != coeffs, "q must not alias coeffs");
+    if (n == 1) return H2HIP_OK;
+    const Fr one = Fr::one();
+    return kate_division_multi_pick(ctx, q, coeffs, n, b, &one, 1, nullptr);
 }
 // The same division for ONE COEFFICIENT RANGE [lo, lo + n) of f (the multi-GPU prover: a rank holds the range of its SRS slice): coeffs_dev = that
 // range, carries[j] = sum_{i >= lo + n} f_i points[j]^(i - lo - n) — what the ranges above contribute, assembled by the caller from the ranks'

@@ -116,6 +116,7 @@ struct h2hip_ctx {
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
     int plonk_tail_overlap = 1;      // create_proof: the challenge-independent transforms of rounds 1 and 3 run on a side stream next to the commitment MSMs' bucket reduction
     int quotient_29 = 1;             // the quotient identities' kernels on unsaturated 9 x 29-bit limbs (fr29.cuh); 0: the saturated kernels
+    int kate_29 = 1;                 // the kate division and batched evaluation kernels on unsaturated 9 x 29-bit limbs; 0: the saturated kernels
     int kate_coeffs_per_lane = 0;    // multi-point kate division: coefficients per lane (1, 2, 4, 8); 0 = by length
     int plonk_side_on_lanes = 1;     // the side work of plonk_tail_overlap runs on the batch MSM's last (idle) lane context instead of a context of its own
 #ifdef H2_HIPEMU

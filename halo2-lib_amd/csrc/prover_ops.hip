@@ -4,6 +4,7 @@
 // 69,124-128, halo2-base/src/gates/range/mod.rs:104) and RangeConfig's lookups (range/mod.rs:131-150) — the argument formulas are
 // upstream halo2's (permutation/prover.rs, lookup/prover.rs [UPSTREAM]).
 #include "internal.h"
+#include "fr29.cuh"
 
 namespace h2 {
 
@@ -67,6 +68,36 @@ __global__ __launch_bounds__(256) void perm_product_terms_batch_kernel(Fr *__res
             }
             num[(size_t)set * rows + i] = nu;
             den[(size_t)set * rows + i] = de;
+        }
+    }
+}
+
+// the same factors on unsaturated limbs (fr29.cuh): every factor is formed 32-fold — 32 v from the split, 32 gamma and 32 beta from the constants, the
+// X term's chain started at 32 beta delta^j0 omega^i — which is what a product of two stored-domain values needs; products start from 1
+struct PermProductConsts29 {
+    Fr29 beta32, delta, xstep, x0_32;   // R' form of 32 beta, delta, omega^(grid stride), 32 beta delta^(first column of the launch)
+    Fr29 gamma32, one;                  // raw splits of 32 gamma and of 1
+    Fr omega;
+};
+__global__ __launch_bounds__(256) void perm_product_terms_batch29_kernel(Fr *__restrict__ num, Fr *__restrict__ den, PermProductBatchArgs g, PermProductConsts29 k29,
+                                                                         size_t rows) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= rows) return;
+    Fr29 xbase = f29_mul(r29_load(fe_pow_u64(k29.omega, (uint64_t)i0)), k29.x0_32);
+    for (size_t i = i0; i < rows; i += stride, xbase = f29_mul(xbase, k29.xstep)) {
+        Fr29 xterm = xbase;
+        for (uint32_t c0 = 0, set = 0; c0 < g.ncols; c0 += g.chunk, ++set) {
+            const uint32_t c1 = c0 + g.chunk < g.ncols ? c0 + g.chunk : g.ncols;
+            Fr29 nu = k29.one, de = k29.one;
+            for (uint32_t j = c0; j < c1; ++j) {
+                const Fr29 v32 = f29_add(r29_load32(g.cols[j][i]), k29.gamma32);                                    // lazy
+                nu = f29_mul(nu, f29_norm(f29_add(v32, xterm)));                                                    // < 1.25 x 34.02
+                de = f29_mul(de, f29_norm(f29_add(v32, f29_mul(r29_load(g.sigmas[j][i]), k29.beta32))));
+                xterm = f29_mul(xterm, k29.delta);
+            }
+            num[(size_t)set * rows + i] = r29_store(nu);
+            den[(size_t)set * rows + i] = r29_store(de);
         }
     }
 }
@@ -251,8 +282,21 @@ int h2hip_permutation_product_terms_rows_dev(h2hip_ctx *ctx, void *num_dev, void
         }
         const size_t first_set = c0 / chunk_len;
         prof_begin(ctx, "perm_product_terms_batch_kernel");
-        hipLaunchKernelGGL(perm_product_terms_batch_kernel, dim3(grid), dim3(256), 0, ctx->stream, (Fr *)num_dev + first_set * rows,
-                           (Fr *)den_dev + first_set * rows, g, rows);
+        if (ctx->quotient_29) {
+            PermProductConsts29 k29;
+            k29.beta32 = r29_const(fe_x32(g.beta));
+            k29.delta = r29_const(g.delta);
+            k29.xstep = r29_const(g.xstep);
+            k29.x0_32 = r29_const(fe_x32(g.x0));
+            k29.gamma32 = r29_load(fe_x32(g.gamma));
+            k29.one = r29_load(Fr::one());
+            k29.omega = g.omega;
+            hipLaunchKernelGGL(perm_product_terms_batch29_kernel, dim3(grid), dim3(256), 0, ctx->stream, (Fr *)num_dev + first_set * rows,
+                               (Fr *)den_dev + first_set * rows, g, k29, rows);
+        } else {
+            hipLaunchKernelGGL(perm_product_terms_batch_kernel, dim3(grid), dim3(256), 0, ctx->stream, (Fr *)num_dev + first_set * rows,
+                               (Fr *)den_dev + first_set * rows, g, rows);
+        }
         prof_end(ctx);
     }
     H2_HIPCHK(hipGetLastError());

@@ -430,6 +430,12 @@ def test_prover_steps_emulated(ctx, n):
     from tests.golden_checks import check_prover_steps
 
     check_prover_steps(ctx, n)
+    if n > 1:   # the multi-point division's saturated kernels (the default runs on unsaturated limbs: fr29.cuh)
+        ctx.set_param("kate_29", 0)
+        try:
+            check_prover_steps(ctx, n)
+        finally:
+            ctx.set_param("kate_29", 1)
 
 
 @pytest.mark.parametrize("unsaturated", [1, 0])

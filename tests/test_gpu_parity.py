@@ -385,6 +385,11 @@ def test_kate_division_multi_tile_lengths(ctx, n):
         pts, ws = rand_fr(m, 32 + m), rand_fr(m, 40 + m)
         want = ctx.fr_linear_combination([ctx.fr_kate_division(f, pts[j:j + 1]) for j in range(m)], ws)
         assert np.array_equal(ctx.fr_kate_division_multi(f, pts, ws), want), (n, m)
+        ctx.set_param("kate_29", 0)   # ... and the saturated kernels (the default runs on unsaturated limbs)
+        try:
+            assert np.array_equal(ctx.fr_kate_division_multi(f, pts, ws), want), (n, m)
+        finally:
+            ctx.set_param("kate_29", 1)
 
 
 @pytest.mark.gpu
