@@ -5,7 +5,6 @@
 #   kernel_trace.md           rocprofv3 --kernel-trace --stats of the same command's timed workload (k = 19 create_proof x 20)
 #   pmc_hbm.{md,json}, pmc_accum.json   FETCH_SIZE / WRITE_SIZE passes (separate) of that workload: HBM traffic per launch, every kernel
 #   create_proof_k19_kernels.md, create_proof_k21_kernels.md   per-kernel account of ONE proof (tools/prove_time.py under rocprofv3)
-#   ntt_pmc.log               PMC view of the NTT pass kernel at 2^22
 #   config_sweep.md           the reference's 18 benchmark shapes
 #   bench_2rank_shared_gpu_gloo_k21.json   bench.py --gpus 2 --share-device --dist-backend gloo --k 21 (functional evidence of the sharded path at config #5's size)
 set -u
@@ -40,9 +39,8 @@ except Exception as e:
     print("pmc_accum:", e)
 PY
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/p19 $OUT/p21
-NTT_PARAMS="" timeout 400 bash tools/ntt_pmc.sh > $OUT/ntt_pmc.log 2>&1
 timeout 300 python tools/ntt_r04.py ntt_tile_kernel=1:0 > $OUT/ntt_times.log 2>&1
 timeout 300 python tools/msm_r03.py 19,20 > $OUT/msm_breakdown.log 2>&1
 timeout 900 python tools/config_sweep.py all 5 > $OUT/config_sweep.md 2> $OUT/config_sweep.err
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --share-device --dist-backend gloo --k 21 --steps 3 --warmup 1 --no-replay --no-sweep --no-pmc-traffic 2> $OUT/bench_2rank.err | tail -1 > $OUT/bench_2rank_shared_gpu_gloo_k21.json
-tail -24 $OUT/pytest_gpu.log; head -c 700 $OUT/bench.json; echo; head -14 $OUT/kernel_trace.md; head -8 $OUT/pmc_hbm.md; head -30 $OUT/create_proof_k19_kernels.md; cat $OUT/ntt_pmc.log; head -c 600 $OUT/bench_2rank_shared_gpu_gloo_k21.json; tail -3 $OUT/bench_2rank.err
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --share-device --dist-backend gloo --k 21 --steps 3 --warmup 1 --no-replay --no-sweep --no-pmc-traffic --shard-ntt-columns on 2> $OUT/bench_2rank.err | tail -1 > $OUT/bench_2rank_shared_gpu_gloo_k21.json
+tail -24 $OUT/pytest_gpu.log; head -c 700 $OUT/bench.json; echo; head -14 $OUT/kernel_trace.md; head -8 $OUT/pmc_hbm.md; head -30 $OUT/create_proof_k19_kernels.md; head -c 600 $OUT/bench_2rank_shared_gpu_gloo_k21.json; tail -3 $OUT/bench_2rank.err
