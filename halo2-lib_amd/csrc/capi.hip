@@ -23,7 +23,8 @@ int ws_reserve(h2hip_ctx *ctx, int slot, size_t bytes, void **out) {
     if (b.cap < bytes) {
         if (b.p) {
             H2_HIPCHK(hipStreamSynchronize(ctx->stream));
-            if (ctx->clean_stream) H2_HIPCHK(hipStreamSynchronize(ctx->clean_stream));   // a pending zero-fill of this buffer
+            if (ctx->clean_stream) H2_HIPCHK(hipStreamSynchronize(ctx->clean_stream));   // a pending zero-fill of this buffer ...
+            if (ctx->lane[0]) H2_HIPCHK(hipStreamSynchronize(ctx->lane[0]->stream));      // ... (the batch's runs on its first lane's stream)
             H2_HIPCHK(hipFree(b.p));
             b.p = nullptr;
             b.cap = 0;
@@ -235,10 +236,13 @@ void h2hip_destroy(h2hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    for (int l = 0; l < 4; ++l)
+        if (ctx->lane[l]) hipStreamSynchronize(ctx->lane[l]->stream);   // (a zero-fill of this context's bucket array may be queued on a lane's stream)
     if (ctx->clean_stream) {
         hipStreamSynchronize(ctx->clean_stream);
         hipStreamDestroy(ctx->clean_stream);
         hipEventDestroy(ctx->clean_ev);
+        hipEventDestroy(ctx->clean_ev1);
         if (ctx->tail_ev) hipEventDestroy(ctx->tail_ev);
         hipEventDestroy(ctx->used_ev);
     }
@@ -290,6 +294,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "kate_coeffs_per_lane")) return &ctx->kate_coeffs_per_lane;
     if (!strcmp(name, "quotient_29")) return &ctx->quotient_29;
     if (!strcmp(name, "kate_29")) return &ctx->kate_29;
+    if (!strcmp(name, "clean_on_lane")) return &ctx->clean_on_lane;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
@@ -693,7 +698,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     // the shared bucket array was zero-filled behind the previous batch's reduction (side stream): the lanes wait for that instead of filling
     const bool buckets_zeroed = deferred && buckets_prezeroed(ctx, 1, all_buckets, sizeof(XYZZ29) * keys_per_col * count);
     if (buckets_zeroed)
-        for (int l = 0; l < NL; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->clean_ev, 0));
+        for (int l = 0; l < NL; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->clean_ev1, 0));
     // host columns: one staging area for all of them; column j is copied on its lane's stream right before its kernels are
     // queued, so the (host-blocking, pageable) copy of column j+1 overlaps the GPU work of column j
     std::vector<const void *> staged(count, nullptr);
@@ -731,13 +736,18 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));
         H2_HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
     }
-    // the accumulations are queued and joined: what follows on this stream is the reduction's tail.  The event is recorded HERE; the hook
-    // itself runs after the tail has been queued (its own launches take host time that must not delay the reduction)
-    std::function<int(hipEvent_t)> tail_hook;
+    // the accumulations are queued and joined: what follows on this stream is the reduction's tail.  The hook runs HERE, before the tail is
+    // queued: the device is still hundreds of microseconds of accumulation behind the host at this point, so the hook's few launches do not
+    // delay the reduction — and a wait on the event must be issued before more work follows it on this stream (r04 timeline,
+    // profiles/r04_timeline_k19.md: issued after the tail and the result copy had been queued, the side transforms started 20 us after that
+    // copy FINISHED — the runtime resolved the cross-stream wait against what the stream held at the time of the wait, not of the record)
+    int hook_rc = H2HIP_OK;
     if (ctx->msm_tail_hook) {
+        std::function<int(hipEvent_t)> tail_hook;
         tail_hook.swap(ctx->msm_tail_hook);
         if (!ctx->tail_ev) H2_HIPCHK(hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming));
         H2_HIPCHK(hipEventRecord(ctx->tail_ev, ctx->stream));
+        hook_rc = tail_hook(ctx->tail_ev);
     }
     if (deferred) {   // one bucket reduction per 64 columns, on the caller's stream
         XYZZ *sums = nullptr;
@@ -746,7 +756,6 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
             const uint32_t cc = (uint32_t)(count - c0 < 64 ? count - c0 : 64);
             H2_CHK(msm_reduce_cols(ctx, bases, bases->window_bits, all_buckets + keys_per_col * c0, cc, sums + c0));
         }
-        H2_CHK(buckets_clean_after_use(ctx, 1, all_buckets, sizeof(XYZZ29) * keys_per_col * count));   // zero-fill for the next batch, off its critical path
         prof_begin(ctx, "point_finish_kernel");
         hipLaunchKernelGGL(point_finish_slot_kernel, dim3((uint32_t)count), dim3(64), 0, ctx->stream, (const XYZZ *)sums,
                            affine ? (G1Jac *)nullptr : (G1Jac *)results, affine ? (G1Affine *)results : (G1Affine *)nullptr, 0u);
@@ -754,8 +763,9 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         H2_HIPCHK(hipGetLastError());
     }
     H2_HIPCHK(hipMemcpyAsync(out_host, results, psz * count, hipMemcpyDeviceToHost, ctx->stream));
-    int hook_rc = H2HIP_OK;
-    if (tail_hook) hook_rc = tail_hook(ctx->tail_ev);
+    // zero-fill of the shared bucket array for the next batch, off its critical path — queued AFTER the hook's work and on the first lane's stream
+    // (the hook works on the last lane's): a fill that waits for the reduction must not sit in front of that work in a shared hardware queue
+    if (deferred) H2_CHK(buckets_clean_after_use(ctx, 1, all_buckets, sizeof(XYZZ29) * keys_per_col * count, ctx->clean_on_lane ? ctx->lane[0]->stream : nullptr));
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
     H2_CHK(hook_rc);
     if (ctx->profiling)   // fold the lanes' kernel timers into the parent's table

@@ -116,6 +116,7 @@ struct h2hip_ctx {
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
     int plonk_tail_overlap = 1;      // create_proof: the challenge-independent transforms of rounds 1 and 3 run on a side stream next to the commitment MSMs' bucket reduction
     int quotient_29 = 1;             // the quotient identities' kernels on unsaturated 9 x 29-bit limbs (fr29.cuh); 0: the saturated kernels
+    int clean_on_lane = 1;           // the batch MSM's bucket zero-fill on its first lane's stream (0: the context's clean stream)
     int kate_29 = 1;                 // the kate division and batched evaluation kernels on unsaturated 9 x 29-bit limbs; 0: the saturated kernels
     int kate_coeffs_per_lane = 0;    // multi-point kate division: coefficients per lane (1, 2, 4, 8); 0 = by length
     int plonk_side_on_lanes = 1;     // the side work of plonk_tail_overlap runs on the batch MSM's last (idle) lane context instead of a context of its own
@@ -133,7 +134,7 @@ struct h2hip_ctx {
     // fill per 2^19-point MSM on the lane's critical path): clean_bytes[i] leading bytes of clean_ptr[i] are zero once clean_ev has fired.
     // [0] = WS_BUCKETS (an MSM reduced by its own context), [1] = WS_BATCH_BUCKETS (a batch's deferred reduction).
     hipStream_t clean_stream = nullptr;
-    hipEvent_t clean_ev = nullptr, used_ev = nullptr;
+    hipEvent_t clean_ev = nullptr, clean_ev1 = nullptr, used_ev = nullptr;   // clean_ev: slot 0 (a lone MSM's buckets), clean_ev1: slot 1 (the batch's shared array): the fills may run on different streams
     void *clean_ptr[2] = {nullptr, nullptr};
     size_t clean_bytes[2] = {0, 0};
     hipEvent_t fork_ev = nullptr;
@@ -196,7 +197,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 // zero-fill-after-use of the bucket arrays (see h2hip_ctx::clean_*): is the buffer's head already (scheduled to be) zero?  (a true answer
 // CONSUMES the state: the caller dirties the array) / schedule the fill
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);
-int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes);
+int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes, hipStream_t on = nullptr);
 // capi.hip: a child context's (MSM lane, the prover's side stream) kernel timers folded into the parent's table
 void prof_fold_child(h2hip_ctx *parent, h2hip_ctx *child);
 // rng.hip: n elements of the ChaCha Fr::random stream from element first_block on, on `stream`

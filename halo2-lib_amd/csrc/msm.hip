@@ -815,16 +815,21 @@ bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes)
     if (ok) ctx->clean_bytes[which] = 0;
     return ok;
 }
-int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes) {
+// `on`: the stream the zero-fill is queued on (default: the context's own clean stream).  HIP serves all streams through four hardware queues:
+// a fill that waits for the reduction blocks whatever is queued BEHIND it on a stream sharing its queue — the batch MSM therefore queues its fill
+// after the tail hook's work and on its first lane's stream, which that work never uses (r04: profiles/r04_timeline_k19.md)
+int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes, hipStream_t on) {
     if (!ctx->clean_stream) {
         H2_HIPCHK(hipStreamCreateWithFlags(&ctx->clean_stream, hipStreamNonBlocking));
         H2_HIPCHK(hipEventCreateWithFlags(&ctx->clean_ev, hipEventDisableTiming));
+        H2_HIPCHK(hipEventCreateWithFlags(&ctx->clean_ev1, hipEventDisableTiming));
         H2_HIPCHK(hipEventCreateWithFlags(&ctx->used_ev, hipEventDisableTiming));
     }
+    const hipStream_t cs = on ? on : ctx->clean_stream;
     H2_HIPCHK(hipEventRecord(ctx->used_ev, ctx->stream));               // everything that reads the buckets is queued on the context's stream
-    H2_HIPCHK(hipStreamWaitEvent(ctx->clean_stream, ctx->used_ev, 0));
-    H2_HIPCHK(hipMemsetAsync(buf, 0, bytes, ctx->clean_stream));
-    H2_HIPCHK(hipEventRecord(ctx->clean_ev, ctx->clean_stream));
+    H2_HIPCHK(hipStreamWaitEvent(cs, ctx->used_ev, 0));
+    H2_HIPCHK(hipMemsetAsync(buf, 0, bytes, cs));
+    H2_HIPCHK(hipEventRecord(which ? ctx->clean_ev1 : ctx->clean_ev, cs));
     ctx->clean_ptr[which] = buf;
     ctx->clean_bytes[which] = bytes;
     return H2HIP_OK;
