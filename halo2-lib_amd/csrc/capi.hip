@@ -268,6 +268,7 @@ void h2hip_destroy(h2hip_ctx *ctx) {
             hipEventDestroy(ctx->lane_ev[l]);
         }
     if (ctx->fork_ev) hipEventDestroy(ctx->fork_ev);
+    if (ctx->fork_ev2) hipEventDestroy(ctx->fork_ev2);
     for (auto e : ctx->timer_ev)
         if (e) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -295,6 +296,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "quotient_29")) return &ctx->quotient_29;
     if (!strcmp(name, "kate_29")) return &ctx->kate_29;
     if (!strcmp(name, "clean_on_lane")) return &ctx->clean_on_lane;
+    if (!strcmp(name, "plonk_permute_in_commit")) return &ctx->plonk_permute_in_commit;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
     if (!strcmp(name, "ntt_min_col_bits")) return &ctx->ntt_min_col_bits;
     if (!strcmp(name, "msm_lanes")) return &ctx->msm_lanes;
@@ -712,9 +714,24 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     // (two other schedules were built, measured slower and removed in r04: every accumulation on one stream with all sorts / merges on a
     // second, higher-priority one — 2^19 1.00 vs 0.95 ms per MSM, tools/batch_ab.py in r02 — and a column's windows dealt to two lanes —
     // the k = 19 proof 15.7-15.8 vs 14.7 ms, profiles/r03_msm_split_windows_ab.log)
+    // late columns (msm_mid_hook, internal.h): the hook runs once, before the first group that holds a column >= msm_mid_after
+    std::function<int()> mid_hook;
+    mid_hook.swap(ctx->msm_mid_hook);
+    const size_t mid_after = ctx->msm_mid_after;
+    auto run_mid = [&]() -> int {
+        if (!mid_hook) return H2HIP_OK;
+        std::function<int()> f;
+        f.swap(mid_hook);
+        H2_CHK(f());
+        if (!ctx->fork_ev2) H2_HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev2, hipEventDisableTiming));
+        H2_HIPCHK(hipEventRecord(ctx->fork_ev2, ctx->stream));   // what the hook queued on the caller's stream produces the remaining columns
+        for (int l = 0; l < NL; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->fork_ev2, 0));
+        return H2HIP_OK;
+    };
     const size_t ngroups = groups.size();
     for (size_t g = 0; g < ngroups; ++g) {
         const size_t j0 = groups[g].first, gsize = groups[g].second;
+        if (mid_hook && j0 + gsize > mid_after) H2_LANES_RC(run_mid());
         h2hip_ctx *c = ctx->lane[g % NL];
         const h2hip_bases *gb = bases_of(j0);
         for (size_t j = j0; j < j0 + gsize; ++j) {
@@ -732,6 +749,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         }
         H2_LANES(hipGetLastError());
     }
+    if (mid_hook) H2_LANES_RC(run_mid());   // (no column behind msm_mid_after: the hook still runs, before the join)
     for (int l = 0; l < NL; ++l) {
         H2_HIPCHK(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]->stream));
         H2_HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));

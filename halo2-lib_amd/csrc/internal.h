@@ -111,11 +111,18 @@ struct h2hip_ctx {
     // merges have been joined into `stream` — `ev` is recorded there at that point — and BEFORE the latency-bound bucket reduction is queued, so
     // that work the caller queues on another stream behind `ev` runs next to the reduction's few waves instead of after them (plonk.hip: the
     // round's challenge-independent transforms).  Cleared before it is called; left set if the call took a path without lanes.
+    // a batch MSM whose LAST columns are still being produced when it is called (round 1 of create_proof: the permuted lookup columns): the
+    // batch queues its first msm_mid_after columns on the lanes, calls the hook — the caller queues the producing work on this context's stream,
+    // host synchronisations allowed — makes the lanes wait for that stream, and goes on with the remaining columns.  Consumed by the batch call.
+    std::function<int()> msm_mid_hook;
+    size_t msm_mid_after = 0;
+    hipEvent_t fork_ev2 = nullptr;
     std::function<int(hipEvent_t ev)> msm_tail_hook;
     hipEvent_t tail_ev = nullptr;
     int msm_lanes = 0;   // lanes used by h2hip_msm_g1_batch_dev: 0 = auto by size, 1..4
     int plonk_tail_overlap = 1;      // create_proof: the challenge-independent transforms of rounds 1 and 3 run on a side stream next to the commitment MSMs' bucket reduction
     int quotient_29 = 1;             // the quotient identities' kernels on unsaturated 9 x 29-bit limbs (fr29.cuh); 0: the saturated kernels
+    int plonk_permute_in_commit = 1; // round 1: the lookup permutation runs inside the commitment batch, behind the advice columns' MSMs (msm_mid_hook)
     int clean_on_lane = 1;           // the batch MSM's bucket zero-fill on its first lane's stream (0: the context's clean stream)
     int kate_29 = 1;                 // the kate division and batched evaluation kernels on unsaturated 9 x 29-bit limbs; 0: the saturated kernels
     int kate_coeffs_per_lane = 0;    // multi-point kate division: coefficients per lane (1, 2, 4, 8); 0 = by length
