@@ -1489,7 +1489,7 @@ int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs
 // q[0..n-1) = sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j]),  m <= 8 points; q_dev must not alias coeffs_dev
 template <uint32_t J>
 static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m,
-                                   const void *tops = nullptr) {
+                                   const void *tops = nullptr, bool add_to_q = false) {
     const uint32_t tile = 256 * J;
     const int with_top = tops != nullptr;
     const uint32_t ntiles = (uint32_t)((n + (with_top ? 1 : 0) + tile - 1) / tile);   // the virtual coefficient n may open a tile of its own
@@ -1533,7 +1533,7 @@ static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, 
         const uint32_t mm = m - j0 < 4 ? m - j0 : 4;
         const KateJob *jb = djobs + j0;
         const Fr *cr = carry + (size_t)j0 * (ntiles + 1);
-        const int accumulate = j0 ? 1 : 0;
+        const int accumulate = (j0 || add_to_q) ? 1 : 0;
         auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate); };
         const KateJob29 *jb29 = djobs29 + j0;
         auto go29 = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb29, mm, ntiles, cr, (Fr *)q, accumulate); };
@@ -1560,13 +1560,14 @@ static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, 
     return H2HIP_OK;
 }
 // coefficients per lane: a tile is 256 * J coefficients; about one wave per SIMD or more (ctx->kate_coeffs_per_lane overrides: 1, 2, 4, 8)
-static int kate_division_multi_pick(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m, const void *tops) {
+static int kate_division_multi_pick(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m, const void *tops,
+                                    bool add_to_q = false) {
     uint32_t j = ctx->kate_coeffs_per_lane;
     if (j != 1 && j != 2 && j != 4 && j != 8) j = n >= ((size_t)1 << 20) ? 8 : n >= ((size_t)1 << 18) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;   // (2^19: 4 and 8 within noise, 4 ahead by 0.04 ms per proof; 2^21: 8 ahead by 0.4 ms — profiles/r04_kate_tile_ab.log)
-    if (j == 8) return kate_division_multi_run<8>(ctx, q, coeffs, n, points, weights, m, tops);
-    if (j == 4) return kate_division_multi_run<4>(ctx, q, coeffs, n, points, weights, m, tops);
-    if (j == 2) return kate_division_multi_run<2>(ctx, q, coeffs, n, points, weights, m, tops);
-    return kate_division_multi_run<1>(ctx, q, coeffs, n, points, weights, m, tops);
+    if (j == 8) return kate_division_multi_run<8>(ctx, q, coeffs, n, points, weights, m, tops, add_to_q);
+    if (j == 4) return kate_division_multi_run<4>(ctx, q, coeffs, n, points, weights, m, tops, add_to_q);
+    if (j == 2) return kate_division_multi_run<2>(ctx, q, coeffs, n, points, weights, m, tops, add_to_q);
+    return kate_division_multi_run<1>(ctx, q, coeffs, n, points, weights, m, tops, add_to_q);
 }
 extern "C" {
 int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m) {
@@ -1575,6 +1576,15 @@ int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs
     H2_REQUIRE(q != coeffs, "q must not alias coeffs");
     if (n == 1) return H2HIP_OK;
     return kate_division_multi_pick(ctx, q, coeffs, n, points, weights, m, nullptr);
+}
+// q[0..n-1) += the same sum: SHPLONK adds the rotation sets' quotients up with weights v^i — folded into weights[], the sum lands in its
+// accumulator without a pass of its own
+int h2hip_fr_kate_division_multi_acc_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && points && weights && n >= 1 && coeffs && (n == 1 || q) && m >= 1 && m <= 8, "bad argument (1..8 points)");
+    H2_REQUIRE(q != coeffs, "q must not alias coeffs");
+    if (n == 1) return H2HIP_OK;
+    return kate_division_multi_pick(ctx, q, coeffs, n, points, weights, m, nullptr, true);
 }
 // q[0..n-1) = (f(X) - f(b)) / (X - b)   [UPSTREAM arithmetic::kate_division]: the one-point case of the kernels above (weight 1)
 int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *b) {

@@ -1676,8 +1676,10 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             // (S_i - r_i) / prod_j (X - point_j) = sum_j w_j (S_i(X) - S_i(point_j)) / (X - point_j) (partial fractions; r_i interpolates S_i
             // on the points by construction): all roots in ONE pass over S_i, no copy and no explicit subtraction of r_i
             if (!sharded_any) {
-                H2_CHK(h2hip_fr_kate_division_multi_dev(ctx, buf_b, S[i], n, rs.points.data(), pf_weights[i].data(), (uint32_t)rs.points.size()));
-                H2_CHK(h2hip_fr_axpy_dev(ctx, h_x, &vpow, buf_b, (size_t)n - 1));   // the coefficients above degree n - 1 - #points come out as zeros
+                // (v^i folded into the partial-fraction weights: the set's quotient is added straight into h_x — no buffer, no axpy pass)
+                std::vector<Fr> wv(pf_weights[i]);
+                for (Fr &w_ : wv) w_ = fe_mul(w_, vpow);
+                H2_CHK(h2hip_fr_kate_division_multi_acc_dev(ctx, h_x, S[i], n, rs.points.data(), wv.data(), (uint32_t)rs.points.size()));
             } else if (L) {
                 H2_CHK(h2hip_fr_kate_division_range_dev(ctx, buf_b + lo, S[i] + lo, L, rs.points.data(), pf_weights[i].data(), carries[i].data(),
                                                         (uint32_t)rs.points.size()));

@@ -81,6 +81,7 @@ _PROTOS = {
     "h2hip_fr_eval_polynomial_batch_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _vp, _sz, _vp]),
     "h2hip_fr_kate_division_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_fr_kate_division_multi_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _u32]),
+    "h2hip_fr_kate_division_multi_acc_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _u32]),
     "h2hip_fr_kate_division_range_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _u32]),
     "h2hip_quotient_flex_gate_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),
@@ -715,6 +716,17 @@ class Context:
         finally:
             for p in d + [dn, dd]:
                 self.free(p)
+
+    def fr_kate_division_multi_acc(self, acc: np.ndarray, coeffs: np.ndarray, points: np.ndarray, weights: np.ndarray) -> np.ndarray:
+        """acc[0..n-1) + sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j])"""
+        c, pts, w, a = _fe(coeffs), _fe(points), _fe(weights), _fe(acc)
+        d, q = self.to_device(c), self.to_device(a)
+        try:
+            self._chk(self.lib.h2hip_fr_kate_division_multi_acc_dev(self.handle, _vp(q), _vp(d), len(c), _ptr(pts), _ptr(w), len(pts)))
+            return self.download(q, (len(a), 4))
+        finally:
+            self.free(d)
+            self.free(q)
 
     def fr_kate_division_range(self, coeffs: np.ndarray, points: np.ndarray, weights: np.ndarray, carries: np.ndarray) -> np.ndarray:
         """the quotient coefficients lo .. lo + n - 1 of sum_j weights[j] * f(X) / (X - points[j]) from f's coefficient range [lo, lo + n) and the

@@ -210,6 +210,9 @@ def check_prover_steps(ctx, n, seed=5):
                 want = [w_ * ws[j] % R for w_ in qj] if want is None else [(a0 + w_ * ws[j]) % R for a0, w_ in zip(want, qj)]
             got = to_i(ctx.fr_kate_division_multi(a_, fr(bs), fr(ws)))
             assert got == want
+            acc0 = to_i(s_)                              # the accumulating form: acc[0..n-1) + the same sum, the last element untouched
+            got_acc = to_i(ctx.fr_kate_division_multi_acc(s_, a_, fr(bs), fr(ws)))
+            assert got_acc == [(x + y) % R for x, y in zip(acc0, want)] + acc0[len(want):]
             if m > 1:                                # ... and it IS the quotient by the product of the roots: top m-1 coefficients vanish
                 assert got[len(got) - (m - 1):] == [0] * (m - 1)
             # the same quotient by COEFFICIENT RANGES (the multi-GPU prover's form): each range divided on its own with the carries of the
