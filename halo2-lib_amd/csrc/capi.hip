@@ -631,7 +631,10 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
                                                         //  r04: 2^21 on 2 lanes 60.3 ms per k = 21 proof against 62.2 on one and 61.0 on three — the next column's sort
                                                         //  runs beside the accumulation: profiles/r04_msm_lanes_large.log)
     if (NL > 4) NL = 4;
-    for (int l = 0; l < NL; ++l) {
+    // (a third context exists even where only two lanes carry columns: the prover's side transforms run on the LAST lane's context, and with two
+    // lanes a context of their own ended up behind the grand products on a shared hardware queue — k = 21: the products waited 3.5 ms for
+    // the transforms they were meant to run beside, profiles/r04_timeline_k21.md)
+    for (int l = 0; l < (NL < 3 ? 3 : NL); ++l) {
         if (!ctx->lane[l]) {
             h2hip_ctx *c = nullptr;
             H2_CHK(h2hip_init(ctx->device, nullptr, &c));
