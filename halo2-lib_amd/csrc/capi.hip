@@ -61,6 +61,19 @@ void prof_begin(h2hip_ctx *ctx, const char *name) {
     hipEventRecord(a, ctx->stream);
     ctx->pending.push_back({name, a, b, false});
 }
+// a bracket whose two events the LAUNCH itself records (hipExtLaunchKernelGGL's start / stop events: no marker packets of their own in the
+// stream — the bench's timed region brackets every accumulation launch, and separate event records cost the proof ~0.3 ms).  false: not profiled
+bool prof_launch_events(h2hip_ctx *ctx, const char *name, hipEvent_t *start, hipEvent_t *stop) {
+    *start = *stop = nullptr;
+    if (!ctx->profiling) return false;
+    if (!ctx->prof_filter.empty() && strncmp(name, ctx->prof_filter.c_str(), ctx->prof_filter.size()) != 0) return false;
+    hipEvent_t a = get_event(ctx), b = get_event(ctx);
+    if (!a || !b) return false;
+    ctx->pending.push_back({name, a, b, true});
+    *start = a;
+    *stop = b;
+    return true;
+}
 // closes the innermost open bracket (brackets nest: the lookup permutation's bracket contains the scan's)
 void prof_end(h2hip_ctx *ctx) {
     if (!ctx->profiling || !ctx->prof_filter.empty()) {
@@ -97,6 +110,7 @@ static void prof_collect(h2hip_ctx *ctx) {
     ctx->pending.clear();
 }
 
+static void prof_collect_all(h2hip_ctx *ctx);
 // a child context's (MSM lane, the prover's side stream) kernel timers into the parent's table
 void prof_fold_child(h2hip_ctx *parent, h2hip_ctx *child) {
     prof_collect(child);
@@ -106,6 +120,13 @@ void prof_fold_child(h2hip_ctx *parent, h2hip_ctx *child) {
         parent->stats[kv.first].spans.insert(parent->stats[kv.first].spans.end(), kv.second.spans.begin(), kv.second.spans.end());
     }
     child->stats.clear();
+}
+// this context's timers and its lanes': the lanes' are folded when the table is READ, not after every batch (the elapsed-time queries of a
+// proof's bracketed launches are host time inside the bench's timed region otherwise)
+static void prof_collect_all(h2hip_ctx *ctx) {
+    prof_collect(ctx);
+    for (h2hip_ctx *l : ctx->lane)
+        if (l) prof_fold_child(ctx, l);
 }
 
 __global__ void point_finish_kernel(const XYZZ *__restrict__ in, G1Jac *__restrict__ jac, G1Affine *__restrict__ aff) {
@@ -392,21 +413,21 @@ int h2hip_download(h2hip_ctx *ctx, void *dst_host, const void *src_dev, size_t b
 int h2hip_profile_enable(h2hip_ctx *ctx, int on) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx, "ctx is NULL");
-    prof_collect(ctx);
+    prof_collect_all(ctx);
     ctx->profiling = on != 0;
     return H2HIP_OK;
 }
 int h2hip_profile_filter(h2hip_ctx *ctx, const char *prefix) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx, "ctx is NULL");
-    prof_collect(ctx);
+    prof_collect_all(ctx);
     ctx->prof_filter = prefix ? prefix : "";
     return H2HIP_OK;
 }
 int h2hip_profile_reset(h2hip_ctx *ctx) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx, "ctx is NULL");
-    prof_collect(ctx);
+    prof_collect_all(ctx);
     ctx->stats.clear();
     if (!ctx->prof_ref) {
         H2_HIPCHK(hipEventCreate(&ctx->prof_ref));
@@ -423,7 +444,7 @@ int h2hip_profile_reset(h2hip_ctx *ctx) {
 int h2hip_profile_get_busy(h2hip_ctx *ctx, const char *prefix, double *busy_ms) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && prefix && busy_ms, "NULL argument");
-    prof_collect(ctx);
+    prof_collect_all(ctx);
     std::vector<std::pair<float, float>> all;
     size_t len = strlen(prefix);
     for (auto &kv : ctx->stats)
@@ -447,7 +468,7 @@ int h2hip_profile_get_busy(h2hip_ctx *ctx, const char *prefix, double *busy_ms) 
 int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && prefix, "NULL argument");
-    prof_collect(ctx);
+    prof_collect_all(ctx);
     double ms = 0;
     uint64_t cnt = 0;
     size_t len = strlen(prefix);
@@ -464,7 +485,7 @@ int h2hip_profile_get(h2hip_ctx *ctx, const char *prefix, double *total_ms, uint
 int h2hip_profile_dump(h2hip_ctx *ctx, char *out, size_t cap, size_t *needed) {
     H2_DEVICE_GUARD(ctx);
     H2_REQUIRE(ctx && (out || cap == 0), "NULL argument");
-    prof_collect(ctx);
+    prof_collect_all(ctx);
     std::string text;
     for (auto &kv : ctx->stats) {
         std::vector<std::pair<float, float>> all(kv.second.spans.begin(), kv.second.spans.end());
@@ -789,11 +810,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     if (deferred) H2_CHK(buckets_clean_after_use(ctx, 1, all_buckets, sizeof(XYZZ29) * keys_per_col * count, ctx->clean_on_lane ? ctx->lane[0]->stream : nullptr));
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));
     H2_CHK(hook_rc);
-    if (ctx->profiling)   // fold the lanes' kernel timers into the parent's table
-        for (int l = 0; l < NL; ++l) {
-            prof_fold_child(ctx, ctx->lane[l]);
-        }
-    return H2HIP_OK;
+    return H2HIP_OK;   // (the lanes' kernel timers are folded into this context's table when it is read: prof_collect_all)
 }
 
 int h2hip_msm_g1_batch_dev(h2hip_ctx *ctx, const h2hip_bases *bases, const void *const *scalars_dev, size_t n, size_t count, int point_format,

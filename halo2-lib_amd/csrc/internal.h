@@ -182,6 +182,7 @@ int ws_reserve(h2hip_ctx *ctx, int slot, size_t bytes, void **out);
 // RAII-less kernel timer: prof_begin/prof_end bracket one launch with events when ctx->profiling.
 void prof_begin(h2hip_ctx *ctx, const char *name);
 void prof_end(h2hip_ctx *ctx);
+bool prof_launch_events(h2hip_ctx *ctx, const char *name, hipEvent_t *start, hipEvent_t *stop);   // events for hipExtLaunchKernelGGL to record
 
 // implemented in ntt.hip / msm.hip / fr_ops.hip, all on device pointers
 int ntt_run(h2hip_ctx *ctx, Fr *a, uint32_t log_n, const Fr &omega, const Fr *in_override, uint64_t in_len, const Fr *in_scale3,

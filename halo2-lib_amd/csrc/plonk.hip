@@ -2003,10 +2003,7 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     int rc = create_proof_impl(ctx, pk, advice, advice_on_device != 0, instances_host, instance_lens, rng, rng_user, proof, stage_ms);
     ctx->msm_tail_hook = nullptr;   // (never leave a hook of this proof behind: it captures the proof's frame)
     ctx->msm_mid_hook = nullptr;
-    if (pk->side && ctx->profiling) prof_fold_child(ctx, pk->side);
-    if (ctx->profiling)
-        for (h2hip_ctx *l : ctx->lane)
-            if (l) prof_fold_child(ctx, l);
+    if (pk->side && ctx->profiling && ctx->prof_filter.empty()) prof_fold_child(ctx, pk->side);   // (the lanes' timers are folded when the table is read)
     if (rc != H2HIP_OK) {
         if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
         if (pk->side) hipStreamSynchronize(pk->side->stream);
