@@ -959,8 +959,12 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
                                   nkeys, K1, buckets, pkey[0], pval[0], T1);
         else
 #endif
+        {
+            prof_begin(ctx, "msm_accum_kernel");   // (a no-op unless profiling without launch events: the emulated build)
             hipLaunchKernelGGL(msm_accum_kernel, dim3(accum_blocks), dim3(256), 0, st, (const uint32_t *)sval, table, (const uint32_t *)offsets, nkeys, K1, buckets,
                                pkey[0], pval[0], T1);
+            prof_end(ctx);
+        }
         (void)ev_a;
         (void)ev_b;
     }
