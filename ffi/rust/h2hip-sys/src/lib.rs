@@ -148,6 +148,7 @@ extern "C" {
     pub fn h2hip_fr_kate_division_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, b: *const c_void) -> c_int;
     pub fn h2hip_fr_kate_division_multi_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, points: *const c_void, weights: *const c_void, m: u32) -> c_int;
     pub fn h2hip_fr_kate_division_multi_acc_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, points: *const c_void, weights: *const c_void, m: u32) -> c_int;
+    pub fn h2hip_fr_kate_division_sets_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const *const c_void, n: usize, points: *const c_void, weights: *const c_void, set_sizes: *const u32, nsets: usize, accumulate: c_int) -> c_int;
     pub fn h2hip_fr_kate_division_range_dev(ctx: *mut h2hip_ctx, q_dev: *mut c_void, coeffs_dev: *const c_void, n: usize, points: *const c_void, weights: *const c_void, carries: *const c_void, m: u32) -> c_int;
     pub fn h2hip_quotient_flex_gate_dev(ctx: *mut h2hip_ctx, acc_dev: *mut c_void, q_dev: *const c_void, a_dev: *const c_void, ext_k: u32, k: u32, y: *const c_void) -> c_int;
     pub fn h2hip_fr_add_batch_dev(ctx: *mut h2hip_ctx, out_dev: *mut c_void, a_dev: *const c_void, b_dev: *const c_void, n: usize) -> c_int;

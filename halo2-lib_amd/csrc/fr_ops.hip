@@ -1487,87 +1487,119 @@ int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs
 }
 }  // extern "C"
 // q[0..n-1) = sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j]),  m <= 8 points; q_dev must not alias coeffs_dev
+// one quotient of the kind above per SET: sets[i] = (coefficients, points, weights, tops or NULL, m, output, add to the output?), all of n coefficients.
+// The sets share one job table, one upload and ONE launch of the latency-bound carry kernel (a workgroup per job); heads and apply run per set.
+struct KateSet {
+    const void *coeffs, *points, *weights, *tops;
+    uint32_t m;
+    void *q;
+    bool add_to_q;
+};
 template <uint32_t J>
-static int kate_division_multi_run(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m,
-                                   const void *tops = nullptr, bool add_to_q = false) {
+static int kate_division_sets_run(h2hip_ctx *ctx, const KateSet *sets, size_t nsets, size_t n) {
     const uint32_t tile = 256 * J;
-    const int with_top = tops != nullptr;
-    const uint32_t ntiles = (uint32_t)((n + (with_top ? 1 : 0) + tile - 1) / tile);   // the virtual coefficient n may open a tile of its own
-    const uint32_t m_pad = (m + 3) / 4 * 4;   // a pass handles up to four points and reads that many jobs: zero jobs (b = w = top = 0) behind the last
-    std::vector<KateJob> jobs(m_pad);
-    memset((void *)jobs.data(), 0, sizeof(KateJob) * m_pad);
-    for (uint32_t j = 0; j < m; ++j) {
-        memcpy(&jobs[j].b, (const char *)points + sizeof(Fr) * j, sizeof(Fr));
-        memcpy(&jobs[j].w, (const char *)weights + sizeof(Fr) * j, sizeof(Fr));
-        if (with_top) memcpy(&jobs[j].top, (const char *)tops + sizeof(Fr) * j, sizeof(Fr));
-        else jobs[j].top = Fr::zero();
-        pow_table(jobs[j].b, J, jobs[j].pw);   // p[l] = b^(J * 2^l): p[8] = b^tile
+    bool any_top = false;
+    for (size_t i = 0; i < nsets; ++i) any_top |= sets[i].tops != nullptr;
+    const uint32_t ntiles = (uint32_t)((n + (any_top ? 1 : 0) + tile - 1) / tile);   // the virtual coefficient n may open a tile of its own
+    // a pass handles up to four points and reads that many jobs: every set's jobs are padded with zero jobs (b = w = top = 0) to a multiple of four
+    std::vector<uint32_t> first(nsets);
+    uint32_t total = 0;
+    for (size_t i = 0; i < nsets; ++i) {
+        first[i] = total;
+        total += (sets[i].m + 3) / 4 * 4;
     }
-    // the same jobs for the kernels on unsaturated limbs (ctx->kate_29): constants in R' form
+    std::vector<KateJob> jobs(total);
+    memset((void *)jobs.data(), 0, sizeof(KateJob) * total);
     const bool k29 = ctx->kate_29 != 0;
-    std::vector<KateJob29> jobs29(k29 ? m_pad : 0);
-    if (k29) memset((void *)jobs29.data(), 0, sizeof(KateJob29) * m_pad);
-    for (uint32_t j = 0; k29 && j < m; ++j) {
-        jobs29[j].b = r29_const(jobs[j].b);
-        jobs29[j].w = r29_const(jobs[j].w);
-        jobs29[j].one = r29_const(Fr::one());
-        jobs29[j].top = r29_load(jobs[j].top);
-        for (int l = 0; l < 9; ++l) jobs29[j].pw[l] = r29_const(jobs[j].pw.p[l]);
-    }
+    std::vector<KateJob29> jobs29(k29 ? total : 0);
+    if (k29) memset((void *)jobs29.data(), 0, sizeof(KateJob29) * total);
+    for (size_t i = 0; i < nsets; ++i)
+        for (uint32_t j = 0; j < sets[i].m; ++j) {
+            KateJob &jb = jobs[first[i] + j];
+            memcpy(&jb.b, (const char *)sets[i].points + sizeof(Fr) * j, sizeof(Fr));
+            memcpy(&jb.w, (const char *)sets[i].weights + sizeof(Fr) * j, sizeof(Fr));
+            if (sets[i].tops) memcpy(&jb.top, (const char *)sets[i].tops + sizeof(Fr) * j, sizeof(Fr));
+            pow_table(jb.b, J, jb.pw);   // p[l] = b^(J * 2^l): p[8] = b^tile
+            if (k29) {   // the same job for the kernels on unsaturated limbs: constants in R' form
+                KateJob29 &j9 = jobs29[first[i] + j];
+                j9.b = r29_const(jb.b);
+                j9.w = r29_const(jb.w);
+                j9.one = r29_const(Fr::one());
+                j9.top = r29_load(jb.top);
+                for (int l = 0; l < 9; ++l) j9.pw[l] = r29_const(jb.pw.p[l]);
+            }
+        }
     char *buf = nullptr;
-    const size_t jobs_bytes = (sizeof(KateJob) * m_pad + 255) / 256 * 256, jobs29_bytes = (sizeof(KateJob29) * jobs29.size() + 255) / 256 * 256;
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, jobs_bytes + jobs29_bytes + sizeof(Fr) * 2 * (size_t)m * (ntiles + 1), (void **)&buf));
+    const size_t jobs_bytes = (sizeof(KateJob) * total + 255) / 256 * 256, jobs29_bytes = (sizeof(KateJob29) * jobs29.size() + 255) / 256 * 256;
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP2, jobs_bytes + jobs29_bytes + sizeof(Fr) * 2 * (size_t)total * (ntiles + 1), (void **)&buf));
     KateJob *djobs = (KateJob *)buf;
     KateJob29 *djobs29 = (KateJob29 *)(buf + jobs_bytes);
-    Fr *heads = (Fr *)(buf + jobs_bytes + jobs29_bytes), *carry = heads + (size_t)m * (ntiles + 1);
-    H2_CHK(upload_jobs(ctx, djobs, jobs.data(), sizeof(KateJob) * m_pad));   // through the pinned ring: no synchronisation per call
-    if (k29) H2_CHK(upload_jobs(ctx, djobs29, jobs29.data(), sizeof(KateJob29) * m_pad));
+    Fr *heads = (Fr *)(buf + jobs_bytes + jobs29_bytes), *carry = heads + (size_t)total * (ntiles + 1);
+    H2_CHK(upload_jobs(ctx, djobs, jobs.data(), sizeof(KateJob) * total));   // through the pinned ring: no synchronisation per call
+    if (k29) H2_CHK(upload_jobs(ctx, djobs29, jobs29.data(), sizeof(KateJob29) * total));
     prof_begin(ctx, "fr_kate_kernels");
-    if (k29)
-        hipLaunchKernelGGL(fr_kate_heads_multi29_kernel<J>, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob29 *)djobs29, ntiles, heads,
-                           with_top);
-    else
-        hipLaunchKernelGGL(fr_kate_heads_multi_kernel<J>, dim3(ntiles, m), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, (const KateJob *)djobs, ntiles, heads);
-    hipLaunchKernelGGL(fr_kate_carry_multi_kernel, dim3(m), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles, (const KateJob *)djobs);
-    for (uint32_t j0 = 0; j0 < m; j0 += 4) {   // four points per pass (the scans of a pass share the workgroup's LDS); halo2-base's sets stop at 4
-        const uint32_t mm = m - j0 < 4 ? m - j0 : 4;
-        const KateJob *jb = djobs + j0;
-        const Fr *cr = carry + (size_t)j0 * (ntiles + 1);
-        const int accumulate = (j0 || add_to_q) ? 1 : 0;
-        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb, mm, ntiles, cr, (Fr *)q, accumulate); };
-        const KateJob29 *jb29 = djobs29 + j0;
-        auto go29 = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), 0, ctx->stream, (const Fr *)coeffs, n, jb29, mm, ntiles, cr, (Fr *)q, accumulate); };
-        if (k29 && with_top) {
-            if (mm == 1) go29(fr_kate_apply_multi29_kernel<1, J, true>);
-            else if (mm == 2) go29(fr_kate_apply_multi29_kernel<2, J, true>);
-            else go29(fr_kate_apply_multi29_kernel<4, J, true>);
-        } else if (k29) {
-            if (mm == 1) go29(fr_kate_apply_multi29_kernel<1, J, false>);
-            else if (mm == 2) go29(fr_kate_apply_multi29_kernel<2, J, false>);
-            else go29(fr_kate_apply_multi29_kernel<4, J, false>);
-        } else if (with_top) {
-            if (mm == 1) go(fr_kate_apply_multi_kernel<1, J, true>);
-            else if (mm == 2) go(fr_kate_apply_multi_kernel<2, J, true>);
-            else go(fr_kate_apply_multi_kernel<4, J, true>);
-        } else {
-            if (mm == 1) go(fr_kate_apply_multi_kernel<1, J, false>);
-            else if (mm == 2) go(fr_kate_apply_multi_kernel<2, J, false>);
-            else go(fr_kate_apply_multi_kernel<4, J, false>);
+    if (nsets > 1) H2_HIPCHK(hipMemsetAsync(heads, 0, sizeof(Fr) * (size_t)total * (ntiles + 1), ctx->stream));   // (the padding jobs' rows: the carry launch reads them)
+    for (size_t i = 0; i < nsets; ++i) {
+        const uint32_t g0 = first[i];
+        Fr *hd = heads + (size_t)g0 * (ntiles + 1);
+        if (k29)
+            hipLaunchKernelGGL(fr_kate_heads_multi29_kernel<J>, dim3(ntiles, sets[i].m), dim3(256), 0, ctx->stream, (const Fr *)sets[i].coeffs, n,
+                               (const KateJob29 *)(djobs29 + g0), ntiles, hd, sets[i].tops ? 1 : 0);
+        else
+            hipLaunchKernelGGL(fr_kate_heads_multi_kernel<J>, dim3(ntiles, sets[i].m), dim3(256), 0, ctx->stream, (const Fr *)sets[i].coeffs, n,
+                               (const KateJob *)(djobs + g0), ntiles, hd);
+    }
+    hipLaunchKernelGGL(fr_kate_carry_multi_kernel, dim3(nsets > 1 ? total : sets[0].m), dim3(256), 0, ctx->stream, (const Fr *)heads, carry, ntiles,
+                       (const KateJob *)djobs);
+    for (size_t i = 0; i < nsets; ++i) {
+        const uint32_t m = sets[i].m;
+        const int with_top = sets[i].tops != nullptr;
+        for (uint32_t j0 = 0; j0 < m; j0 += 4) {   // four points per pass (the scans of a pass share the workgroup's LDS); halo2-base's sets stop at 4
+            const uint32_t mm = m - j0 < 4 ? m - j0 : 4, g0 = first[i] + j0;
+            const KateJob *jb = djobs + g0;
+            const Fr *cr = carry + (size_t)g0 * (ntiles + 1);
+            const int accumulate = (j0 || sets[i].add_to_q) ? 1 : 0;
+            const Fr *cf = (const Fr *)sets[i].coeffs;
+            Fr *qo = (Fr *)sets[i].q;
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), 0, ctx->stream, cf, n, jb, mm, ntiles, cr, qo, accumulate); };
+            const KateJob29 *jb29 = djobs29 + g0;
+            auto go29 = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), 0, ctx->stream, cf, n, jb29, mm, ntiles, cr, qo, accumulate); };
+            if (k29 && with_top) {
+                if (mm == 1) go29(fr_kate_apply_multi29_kernel<1, J, true>);
+                else if (mm == 2) go29(fr_kate_apply_multi29_kernel<2, J, true>);
+                else go29(fr_kate_apply_multi29_kernel<4, J, true>);
+            } else if (k29) {
+                if (mm == 1) go29(fr_kate_apply_multi29_kernel<1, J, false>);
+                else if (mm == 2) go29(fr_kate_apply_multi29_kernel<2, J, false>);
+                else go29(fr_kate_apply_multi29_kernel<4, J, false>);
+            } else if (with_top) {
+                if (mm == 1) go(fr_kate_apply_multi_kernel<1, J, true>);
+                else if (mm == 2) go(fr_kate_apply_multi_kernel<2, J, true>);
+                else go(fr_kate_apply_multi_kernel<4, J, true>);
+            } else {
+                if (mm == 1) go(fr_kate_apply_multi_kernel<1, J, false>);
+                else if (mm == 2) go(fr_kate_apply_multi_kernel<2, J, false>);
+                else go(fr_kate_apply_multi_kernel<4, J, false>);
+            }
         }
     }
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
 }
+static int kate_division_sets_pick(h2hip_ctx *ctx, const KateSet *sets, size_t nsets, size_t n) {
+    uint32_t j = ctx->kate_coeffs_per_lane;
+    if (j != 1 && j != 2 && j != 4 && j != 8) j = n >= ((size_t)1 << 20) ? 8 : n >= ((size_t)1 << 18) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;   // (2^19: 4 and 8 within noise, 4 ahead by 0.04 ms per proof; 2^21: 8 ahead by 0.4 ms — profiles/r04_kate_tile_ab.log)
+    if (j == 8) return kate_division_sets_run<8>(ctx, sets, nsets, n);
+    if (j == 4) return kate_division_sets_run<4>(ctx, sets, nsets, n);
+    if (j == 2) return kate_division_sets_run<2>(ctx, sets, nsets, n);
+    return kate_division_sets_run<1>(ctx, sets, nsets, n);
+}
 // coefficients per lane: a tile is 256 * J coefficients; about one wave per SIMD or more (ctx->kate_coeffs_per_lane overrides: 1, 2, 4, 8)
 static int kate_division_multi_pick(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m, const void *tops,
                                     bool add_to_q = false) {
-    uint32_t j = ctx->kate_coeffs_per_lane;
-    if (j != 1 && j != 2 && j != 4 && j != 8) j = n >= ((size_t)1 << 20) ? 8 : n >= ((size_t)1 << 18) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;   // (2^19: 4 and 8 within noise, 4 ahead by 0.04 ms per proof; 2^21: 8 ahead by 0.4 ms — profiles/r04_kate_tile_ab.log)
-    if (j == 8) return kate_division_multi_run<8>(ctx, q, coeffs, n, points, weights, m, tops, add_to_q);
-    if (j == 4) return kate_division_multi_run<4>(ctx, q, coeffs, n, points, weights, m, tops, add_to_q);
-    if (j == 2) return kate_division_multi_run<2>(ctx, q, coeffs, n, points, weights, m, tops, add_to_q);
-    return kate_division_multi_run<1>(ctx, q, coeffs, n, points, weights, m, tops, add_to_q);
+    const KateSet one = {coeffs, points, weights, tops, m, q, add_to_q};
+    return kate_division_sets_pick(ctx, &one, 1, n);
 }
 extern "C" {
 int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *points, const void *weights, uint32_t m) {
@@ -1585,6 +1617,23 @@ int h2hip_fr_kate_division_multi_acc_dev(h2hip_ctx *ctx, void *q, const void *co
     H2_REQUIRE(q != coeffs, "q must not alias coeffs");
     if (n == 1) return H2HIP_OK;
     return kate_division_multi_pick(ctx, q, coeffs, n, points, weights, m, nullptr, true);
+}
+// q[0..n-1) (+)= sum over `nsets` polynomials of that sum: coeffs_dev[i] with set_sizes[i] points / weights taken from the flat arrays in order (every
+// set 1..8 points, all polynomials of n coefficients).  SHPLONK's whole v-weighted sum over the rotation sets in one call: one job table, one upload,
+// ONE launch of the latency-bound carry kernel for all (set, point) pairs.  accumulate = 0: q is overwritten (by the first set).
+int h2hip_fr_kate_division_sets_dev(h2hip_ctx *ctx, void *q, const void *const *coeffs, size_t n, const void *points, const void *weights,
+                                    const uint32_t *set_sizes, size_t nsets, int accumulate) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && n >= 1 && (nsets == 0 || (coeffs && points && weights && set_sizes)) && (n == 1 || q) && nsets <= 64, "bad argument");
+    if (n == 1 || !nsets) return H2HIP_OK;
+    std::vector<KateSet> sets(nsets);
+    size_t off = 0;
+    for (size_t i = 0; i < nsets; ++i) {
+        H2_REQUIRE(coeffs[i] && coeffs[i] != q && set_sizes[i] >= 1 && set_sizes[i] <= 8, "bad set (1..8 points, q must not alias a polynomial)");
+        sets[i] = {coeffs[i], (const char *)points + sizeof(Fr) * off, (const char *)weights + sizeof(Fr) * off, nullptr, set_sizes[i], q, accumulate != 0 || i > 0};
+        off += set_sizes[i];
+    }
+    return kate_division_sets_pick(ctx, sets.data(), nsets, n);
 }
 // q[0..n-1) = (f(X) - f(b)) / (X - b)   [UPSTREAM arithmetic::kate_division]: the one-point case of the kernels above (weight 1)
 int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q, const void *coeffs, size_t n, const void *b) {

@@ -1671,21 +1671,33 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                 for (const Fr &pt : sets[i].points) carries[i].push_back(carry_from(all, 8 + sizeof(Fr) * SHPLONK_MAX_OPENINGS, idx++, pt));
         }
         Fr vpow = Fr::one();
-        for (size_t i = 0; i < sets.size(); ++i) {
-            const RotationSet &rs = sets[i];
-            // (S_i - r_i) / prod_j (X - point_j) = sum_j w_j (S_i(X) - S_i(point_j)) / (X - point_j) (partial fractions; r_i interpolates S_i
-            // on the points by construction): all roots in ONE pass over S_i, no copy and no explicit subtraction of r_i
-            if (!sharded_any) {
-                // (v^i folded into the partial-fraction weights: the set's quotient is added straight into h_x — no buffer, no axpy pass)
-                std::vector<Fr> wv(pf_weights[i]);
-                for (Fr &w_ : wv) w_ = fe_mul(w_, vpow);
-                H2_CHK(h2hip_fr_kate_division_multi_acc_dev(ctx, h_x, S[i], n, rs.points.data(), wv.data(), (uint32_t)rs.points.size()));
-            } else if (L) {
-                H2_CHK(h2hip_fr_kate_division_range_dev(ctx, buf_b + lo, S[i] + lo, L, rs.points.data(), pf_weights[i].data(), carries[i].data(),
-                                                        (uint32_t)rs.points.size()));
-                H2_CHK(h2hip_fr_axpy_dev(ctx, h_x + lo, &vpow, buf_b + lo, L));
+        // (S_i - r_i) / prod_j (X - point_j) = sum_j w_j (S_i(X) - S_i(point_j)) / (X - point_j) (partial fractions; r_i interpolates S_i
+        // on the points by construction): all roots in ONE pass over S_i, no copy and no explicit subtraction of r_i; v^i folded into the
+        // weights, the sets' quotients add up in h_x — single GPU: ALL sets in one call (one job table, one carry launch)
+        if (!sharded_any) {
+            std::vector<const void *> polys_s(sets.size());
+            std::vector<Fr> pts, wts;
+            std::vector<uint32_t> sizes(sets.size());
+            for (size_t i = 0; i < sets.size(); ++i) {
+                polys_s[i] = S[i];
+                sizes[i] = (uint32_t)sets[i].points.size();
+                for (size_t j = 0; j < sets[i].points.size(); ++j) {
+                    pts.push_back(sets[i].points[j]);
+                    wts.push_back(fe_mul(pf_weights[i][j], vpow));
+                }
+                vpow = fe_mul(vpow, v);
             }
-            vpow = fe_mul(vpow, v);
+            H2_CHK(h2hip_fr_kate_division_sets_dev(ctx, h_x, polys_s.data(), n, pts.data(), wts.data(), sizes.data(), sets.size(), 1));   // (h_x starts as zeros)
+        } else {
+            for (size_t i = 0; i < sets.size(); ++i) {
+                const RotationSet &rs = sets[i];
+                if (L) {
+                    H2_CHK(h2hip_fr_kate_division_range_dev(ctx, buf_b + lo, S[i] + lo, L, rs.points.data(), pf_weights[i].data(), carries[i].data(),
+                                                            (uint32_t)rs.points.size()));
+                    H2_CHK(h2hip_fr_axpy_dev(ctx, h_x + lo, &vpow, buf_b + lo, L));
+                }
+                vpow = fe_mul(vpow, v);
+            }
         }
         {
             std::vector<const void *> cols(1, h_x);

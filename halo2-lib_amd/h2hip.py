@@ -82,6 +82,7 @@ _PROTOS = {
     "h2hip_fr_kate_division_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_fr_kate_division_multi_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _u32]),
     "h2hip_fr_kate_division_multi_acc_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _u32]),
+    "h2hip_fr_kate_division_sets_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, C.POINTER(_u32), _sz, _int]),
     "h2hip_fr_kate_division_range_dev": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _u32]),
     "h2hip_quotient_flex_gate_dev": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "h2hip_quotient_lookup_dev": (_int, [_vp] * 10 + [_u32, _u32, _vp, _vp, _vp]),
@@ -726,6 +727,22 @@ class Context:
             return self.download(q, (len(a), 4))
         finally:
             self.free(d)
+            self.free(q)
+
+    def fr_kate_division_sets(self, polys, point_sets, weight_sets) -> np.ndarray:
+        """sum over the sets i of sum_j weight_sets[i][j] * (polys[i](X) - polys[i](p_ij)) / (X - p_ij): one call for all sets"""
+        n = len(_fe(polys[0]))
+        dp, pp = self._ptr_table(polys)
+        pts = np.concatenate([_fe(p) for p in point_sets])
+        ws = np.concatenate([_fe(w) for w in weight_sets])
+        sizes = (_u32 * len(polys))(*[len(_fe(p)) for p in point_sets])
+        q = self.malloc(32 * max(n - 1, 1))
+        try:
+            self._chk(self.lib.h2hip_fr_kate_division_sets_dev(self.handle, _vp(q), pp, n, _ptr(pts), _ptr(ws), sizes, len(polys), 0))
+            return self.download(q, (n - 1, 4))
+        finally:
+            for d in dp:
+                self.free(d)
             self.free(q)
 
     def fr_kate_division_range(self, coeffs: np.ndarray, points: np.ndarray, weights: np.ndarray, carries: np.ndarray) -> np.ndarray:

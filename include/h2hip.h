@@ -261,6 +261,10 @@ int h2hip_fr_kate_division_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_d
 int h2hip_fr_kate_division_multi_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_dev, size_t n, const void *points, const void *weights, uint32_t m);
 /* q[0..n-1) += the same sum (SHPLONK's v-weighted sum over the rotation sets: v^i folded into the weights, no pass of its own) */
 int h2hip_fr_kate_division_multi_acc_dev(h2hip_ctx *ctx, void *q_dev, const void *coeffs_dev, size_t n, const void *points, const void *weights, uint32_t m);
+/* ... and for `nsets` polynomials at once (coeffs_dev: host array of device pointers, all of n coefficients; set i has set_sizes[i] points / weights, taken
+ * from the flat host arrays in order): q[0..n-1) (accumulate ? += : =) the sum over the sets — SHPLONK's v-weighted sum over its rotation sets in one call */
+int h2hip_fr_kate_division_sets_dev(h2hip_ctx *ctx, void *q_dev, const void *const *coeffs_dev, size_t n, const void *points, const void *weights,
+                                    const uint32_t *set_sizes, size_t nsets, int accumulate);
 /* The same quotient for ONE COEFFICIENT RANGE [lo, lo + n) of f (the multi-GPU prover, where a rank holds the coefficient range of its SRS
  * slice): coeffs_dev = that range; carries[j] = sum_{i >= lo + n} f_i points[j]^(i - lo - n), i.e. what the ranges above contribute (the caller
  * assembles it from the other ranks' partial evaluations; zeros for the top range); q_dev[0..n) = the quotient's coefficients lo .. lo + n - 1. */

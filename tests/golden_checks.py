@@ -210,6 +210,15 @@ def check_prover_steps(ctx, n, seed=5):
                 want = [w_ * ws[j] % R for w_ in qj] if want is None else [(a0 + w_ * ws[j]) % R for a0, w_ in zip(want, qj)]
             got = to_i(ctx.fr_kate_division_multi(a_, fr(bs), fr(ws)))
             assert got == want
+            if m == 3:                               # several polynomials in one call (SHPLONK's sum over its rotation sets): = the sum of the single calls
+                polys3 = [a_, s_, ap]
+                psets = [fr(bs), fr(bs[:1]), fr(bs[:2])]
+                w2 = [O.inv_mod((bs[0] - bs[1]) % R, R), O.inv_mod((bs[1] - bs[0]) % R, R)]
+                wsets = [fr(ws), fr([5]), fr(w2)]
+                want3 = [0] * (n - 1)
+                for pl, ps_, ws_ in zip(polys3, psets, wsets):
+                    want3 = [(x + y) % R for x, y in zip(want3, to_i(ctx.fr_kate_division_multi(pl, ps_, ws_)))]
+                assert to_i(ctx.fr_kate_division_sets(polys3, psets, wsets)) == want3
             acc0 = to_i(s_)                              # the accumulating form: acc[0..n-1) + the same sum, the last element untouched
             got_acc = to_i(ctx.fr_kate_division_multi_acc(s_, a_, fr(bs), fr(ws)))
             assert got_acc == [(x + y) % R for x, y in zip(acc0, want)] + acc0[len(want):]
