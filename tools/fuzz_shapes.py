@@ -4,8 +4,8 @@ tests/test_plonk_prover.py::_check).  Shapes are drawn over the whole range the 
 with and without lookups / instances / precomputed bases — so that batching boundaries the fixed test list does not name are crossed too.
 
     python tools/fuzz_shapes.py [seconds=120] [seed=1] [kmin kmax]      (kmin kmax: draw k uniformly from that range instead, e.g. 13 16)
-    H2HIP_FUZZ_KNOBS=1: every shape also draws the selectable kernel paths (two-level sort, window split, accumulation variants, radix-8 NTT,
-    fused columns, lanes) — the non-default code on the real GPU, where an LDS race shows
+    H2HIP_FUZZ_KNOBS=1: every shape also draws the selectable kernel paths (NTT kernel / tile, fused columns, lanes, deferred reduction, the
+    pointwise kernels' arithmetic form, the prover's scheduling switches) — the non-default code on the real GPU, where a race shows
 """
 import os, random, sys, time
 
@@ -32,7 +32,10 @@ while time.time() - t0 < budget:
     knobs = {}
     if os.environ.get("H2HIP_FUZZ_KNOBS"):
         knobs = {"ntt_tile_kernel": rnd.choice([1, 1, 0]), "ntt_tile_bits": rnd.choice([10, 10, 8, 6]), "msm_fuse_cols": rnd.choice([0, 1, 4]),
-                 "msm_lanes": rnd.choice([0, 1, 2]), "msm_defer_reduce": rnd.choice([1, 1, 0])}
+                 "msm_lanes": rnd.choice([0, 1, 2]), "msm_defer_reduce": rnd.choice([1, 1, 0]),
+                 # r04: the pointwise kernels' arithmetic form and the prover's scheduling switches
+                 "quotient_29": rnd.choice([1, 1, 0]), "kate_29": rnd.choice([1, 1, 0]), "plonk_tail_overlap": rnd.choice([1, 1, 0]),
+                 "plonk_permute_in_commit": rnd.choice([1, 1, 0]), "plonk_side_on_lanes": rnd.choice([1, 1, 0]), "clean_on_lane": rnd.choice([1, 0])}
         for name, val in knobs.items():
             ctx.set_param(name, val)
     try:
