@@ -189,6 +189,15 @@ def _worker_scenarios(rank, world, port, q):
             sk = shard_proving_key(pk, g, gl, precompute=False, shard_ntt_columns=True)   # every stage that can be sharded
             out[name] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
             if name == "multi":
+                # the exchange schedule libh2hip reports for that proof (bench.py --gpus N prints it): 13 host exchanges with every stage sharded,
+                # the status-only go-aheads at their places, the SHPLONK carry slots at a fixed 64 x 32 bytes
+                import ctypes as C_
+                cnt, sizes = C_.c_size_t(0), (C_.c_size_t * 32)()
+                ctx._chk(ctx.lib.h2hip_plonk_pk_last_exchanges(pk.handle, sizes, 32, C_.byref(cnt)))
+                sched = [int(sizes[i]) for i in range(cnt.value)]
+                out["sched"] = (len(sched) == 13 and sched[0] == 72 and sched[3] == 0 and sched[5] == 0 and sched[6] == 0 and sched[9] == 64 * 32 and sched[11] == 32
+                                and sched[10] == 96 and sched[12] == 96)
+            if name == "multi":
                 # a witness outside the lookup table on ONE rank: that rank reports the cause, the others H2HIP_ERR_PEER; nobody hangs
                 adv = [np.array(c) for c in circ.advice]
                 if rank == world - 1:
@@ -252,6 +261,6 @@ def test_sharded_create_proof_scenarios(world):
     for r in range(world):
         o = res[r]
         assert o["multi"] and o["single"] and o["msm_only"] and o["multi_unsharded_again"] and o["single_unsharded_again"], (r, o)
-        assert o["after_fail"] and o["after_rng"] and o.get("ragged", True), (r, o)
+        assert o["after_fail"] and o["after_rng"] and o.get("ragged", True) and o["sched"], (r, o)
         assert o["fail"] == (-1 if r == world - 1 else -5), (r, o)     # H2HIP_ERR_INVALID where the witness is wrong, H2HIP_ERR_PEER elsewhere
         assert o["rng"] == -1, (r, o)                                   # every rank sees the mismatch in the hello exchange
