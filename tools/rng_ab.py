@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import halo2_lib_amd as H
 from halo2_lib_amd import halo2_proofs as HP, plonk as PL, testing as T
 
-k = int(sys.argv[1]) if len(sys.argv) > 1 else 19
+args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
+k = int(args_[0]) if args_ else 19
 ctx = H.Context()
 kzg = HP.ParamsKZG.setup(ctx, k, 0x1D0C0FFEE1234567890ABCDEF, precompute=True)
 bp = PL.BaseCircuitParams.new(k, 1, 1, 1, 0, k - 1)
@@ -46,3 +47,18 @@ for mode in ("device", "array", "device", "array"):
             stages.append(tm)
     print("%s: min %.2f median %.2f ms" % (mode, min(tot[1:6]), sorted(tot[1:6])[2]), flush=True)
     print("   " + " ".join("%s=%.2f" % (kk[:14], v) for kk, v in stages[-1].items()))
+
+for opt in sys.argv[1:]:   # --ab=name:a,b: a context parameter alternated with the device generator (what the bench's timed loop uses)
+    if opt.startswith("--ab="):
+        import hashlib
+        name, _, pair = opt[len("--ab="):].partition(":")
+        lo, hi = [int(v) for v in (pair or "0,1").split(",")]
+        for value in (lo, hi, lo, hi):
+            ctx.set_param(name, value)
+            tot = []
+            for rep in range(8):
+                t = time.time()
+                proof = PL.create_proof(pk, adv_dev, circ.instances, PL.ChaChaRng(ctx.lib, 0, 12), None, advice_on_device=True)
+                tot.append((time.time() - t) * 1e3)
+            print("%s=%d: create_proof min %.2f median %.2f ms  sha256 %s" % (name, value, min(tot[1:]), sorted(tot[1:])[3], hashlib.sha256(bytes(proof)).hexdigest()[:16]),
+                  flush=True)
