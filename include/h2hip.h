@@ -58,7 +58,11 @@ void h2hip_destroy(h2hip_ctx *ctx);
 int h2hip_sync(h2hip_ctx *ctx);
 /* tuning knobs (defaults are the tuned values): "msm_window_bits" (0 = auto), "msm_chunk" (0 = auto), "msm_seg",
  * "msm_scatter_split" (0 = auto), "msm_lanes", "msm_quad_tails", "msm_fuse_cols", "msm_defer_reduce", "ntt_tile_bits" (10),
- * "ntt_tile_kernel" (1 = the specialised full-tile pass kernel, 0 = the generic one), "ntt_min_col_bits", "ntt_full_table";
+ * "ntt_tile_kernel" (1 = the specialised full-tile pass kernel, 0 = the generic one), "ntt_min_col_bits", "ntt_full_table",
+ * "msm_scatter_full_lds", "msm_sort_threads", "msm_quad_seg_max", "fr_invert_run" (0 = auto), "lookup_big_tile_bits",
+ * "kate_coeffs_per_lane" (0 = by length); arithmetic form of the pointwise kernels: "quotient_29", "kate_29" (1 = unsaturated 9 x 29-bit
+ * limbs, 0 = the saturated kernels: same results); the prover's scheduling: "plonk_tail_overlap", "plonk_side_on_lanes",
+ * "plonk_permute_in_commit", "plonk_warm_keygen", "clean_on_lane" (1 everywhere: 0 switches the overlap off, same proof bytes);
  * profiling aid: "ntt_debug_skip" (produces wrong results).  The variants r01-r03 measured slower (two-level sort, bucket-major sort,
  * split streams, split windows, accumulation builds 2/5/6/7, radix-8 and wave-local NTT passes) were removed in r04; their A/B logs stay
  * under profiles/. */
