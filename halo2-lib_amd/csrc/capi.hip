@@ -264,9 +264,9 @@ void h2hip_destroy(h2hip_ctx *ctx) {
         hipStreamDestroy(ctx->clean_stream);
         hipEventDestroy(ctx->clean_ev);
         hipEventDestroy(ctx->clean_ev1);
-        if (ctx->tail_ev) hipEventDestroy(ctx->tail_ev);
         hipEventDestroy(ctx->used_ev);
     }
+    if (ctx->tail_ev) hipEventDestroy(ctx->tail_ev);
     if (ctx->job_ring) hipHostFree(ctx->job_ring);
     for (auto &b : ctx->ws)
         if (b.p) hipFree(b.p);
@@ -722,8 +722,11 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     XYZZ29 *all_buckets = nullptr;
     if (deferred) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_BATCH_BUCKETS, sizeof(XYZZ29) * keys_per_col * count, (void **)&all_buckets));
     // the shared bucket array was zero-filled behind the previous batch's reduction (side stream): the lanes wait for that instead of filling
+    // (a fill of the SAME buffer may still be pending on lane 0's stream even when it covered fewer bytes than this batch needs: the lanes wait
+    // for it either way, or it could wipe partial sums of lanes 1 / 2 that zero their own regions and start accumulating — ADVICE r04)
+    const bool fill_pending = deferred && ctx->clean_ev1 && ctx->clean_ptr[1] == all_buckets;
     const bool buckets_zeroed = deferred && buckets_prezeroed(ctx, 1, all_buckets, sizeof(XYZZ29) * keys_per_col * count);
-    if (buckets_zeroed)
+    if (buckets_zeroed || fill_pending)
         for (int l = 0; l < NL; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->clean_ev1, 0));
     // host columns: one staging area for all of them; column j is copied on its lane's stream right before its kernels are
     // queued, so the (host-blocking, pageable) copy of column j+1 overlaps the GPU work of column j

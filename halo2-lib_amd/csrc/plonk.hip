@@ -1865,7 +1865,8 @@ int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, 
             pk->transcript_repr = Fr::zero();
             const int wrc = create_proof_impl(ctx, pk, adv.data(), true, inst.data(), inst_len.data(), h2hip_chacha_rng_fill, &wr, throwaway, nullptr);
             pk->transcript_repr = saved;
-            ctx->msm_tail_hook = nullptr;
+            ctx->msm_tail_hook = nullptr;   // both hooks capture create_proof_impl's frame: never leave one on the context
+            ctx->msm_mid_hook = nullptr;
             if (pk->side) hipStreamSynchronize(pk->side->stream);
             for (h2hip_ctx *l : ctx->lane)
                 if (l) hipStreamSynchronize(l->stream);
@@ -2011,6 +2012,11 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     H2_REQUIRE(pk->sh.p.num_instance == 0 || instance_lens, "instance_lens is required");
     const size_t need = 32 * (size_t)(pk->sh.num_commitments() + pk->sh.num_evals());
     H2_REQUIRE(proof_cap >= need, "proof buffer too small");
+    if (rng == h2hip_chacha_rng_fill) {   // the library's own generator: the device fill reads its state, so check it once, here
+        const h2hip_chacha_rng *cr = (const h2hip_chacha_rng *)rng_user;
+        H2_REQUIRE(cr, "h2hip_chacha_rng_fill needs its h2hip_chacha_rng as rng_user");
+        H2_REQUIRE(cr->rounds == 8 || cr->rounds == 12 || cr->rounds == 20, "h2hip_chacha_rng: rounds must be 8, 12 or 20");
+    }
     std::vector<uint8_t> proof;
     int rc = create_proof_impl(ctx, pk, advice, advice_on_device != 0, instances_host, instance_lens, rng, rng_user, proof, stage_ms);
     ctx->msm_tail_hook = nullptr;   // (never leave a hook of this proof behind: it captures the proof's frame)

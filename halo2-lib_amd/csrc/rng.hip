@@ -105,8 +105,9 @@ void h2hip_rng_seed_from_u64(uint64_t state, uint8_t *seed_out) {
 
 void h2hip_chacha_rng_init(h2hip_chacha_rng *rng, const uint8_t *seed, int rounds) {
     if (!rng) return;
-    memcpy(rng->seed, seed, 32);
-    rng->rounds = rounds;
+    if (seed) memcpy(rng->seed, seed, 32);
+    else memset(rng->seed, 0, 32);   // (a NULL seed is the all-zero seed, not a crash)
+    rng->rounds = (rounds == 8 || rounds == 12 || rounds == 20) ? rounds : 0;   // create_proof rejects a generator whose round count no path supports
     rng->pos = 0;
 }
 

@@ -4,6 +4,7 @@
 // openings, SHPLONK's folded opening and ONE pairing check e(h2, s*g2) == e(right, g2).  [UPSTREAM-RECALL for the protocol order, like
 // plonk.hip.]  The pairing is the plain ate pairing f_{t-1,Q}(P)^((q^12-1)/r) over the tower Fq2 = Fq[u]/(u^2+1), Fq6 = Fq2[v]/(v^3 - (9+u)),
 // Fq12 = Fq6[w]/(w^2 - v) — any non-degenerate pairing decides e(L, sQ) == e(R, Q), which is all a KZG verifier needs.
+#include <mutex>
 #include <algorithm>
 #include <map>
 #include <vector>
@@ -110,16 +111,70 @@ static bool g2_on_curve(const G2A &Q) {
     return f2_eq(f2_sqr(Q.y), f2_add(f2_mul(f2_sqr(Q.x), Q.x), b));
 }
 // Q in the order-r subgroup G2 of the twist?  The twist's group has a large cofactor (2q - r), so "on the twist" is not enough: EIP-197
-// rejects such points, and the pairing of one is not what the protocol's equations mean.  [r]Q by double-and-add over the
-// affine formulas above — ~380 additions with a field inversion each, a few milliseconds on the host, paid once per G2 input.
+// rejects such points, and the pairing of one is not what the protocol's equations mean.  [r]Q by double-and-add in JACOBIAN
+// coordinates over F_q2 (a = 0: dbl-2009-l, madd-2007-bl) — no field inversion anywhere (the affine ladder paid ~380 F_q2
+// inversions, tens of milliseconds, per G2 input and call) — and the points a verifier passes again and again (the SRS's g2 and s_g2) are
+// remembered: a point that passed once is recognised by its bytes.
+struct G2J {
+    F2 x, y, z;   // z = 0: the identity
+};
+static G2J g2j_dbl(const G2J &P) {
+    if (f2_is_zero(P.z)) return P;
+    const F2 A = f2_sqr(P.x), B = f2_sqr(P.y), C = f2_sqr(B);
+    F2 D = f2_sub(f2_sub(f2_sqr(f2_add(P.x, B)), A), C);
+    D = f2_add(D, D);
+    const F2 E = f2_add(f2_add(A, A), A), F = f2_sqr(E);
+    G2J R;
+    R.x = f2_sub(F, f2_add(D, D));
+    F2 C8 = f2_add(C, C);
+    C8 = f2_add(C8, C8);
+    C8 = f2_add(C8, C8);
+    R.y = f2_sub(f2_mul(E, f2_sub(D, R.x)), C8);
+    const F2 yz = f2_mul(P.y, P.z);
+    R.z = f2_add(yz, yz);
+    return R;
+}
+static G2J g2j_madd(const G2J &P, const G2A &Q) {   // Q affine, not the identity
+    if (f2_is_zero(P.z)) return {Q.x, Q.y, f2_one()};
+    const F2 Z1Z1 = f2_sqr(P.z), U2 = f2_mul(Q.x, Z1Z1), S2 = f2_mul(f2_mul(Q.y, P.z), Z1Z1);
+    const F2 H = f2_sub(U2, P.x);
+    F2 r = f2_sub(S2, P.y);
+    if (f2_is_zero(H)) return f2_is_zero(r) ? g2j_dbl(P) : G2J{f2_one(), f2_one(), f2_zero()};
+    r = f2_add(r, r);
+    const F2 HH = f2_sqr(H);
+    F2 I = f2_add(HH, HH);
+    I = f2_add(I, I);
+    const F2 J = f2_mul(H, I), V = f2_mul(P.x, I);
+    G2J R;
+    R.x = f2_sub(f2_sub(f2_sqr(r), J), f2_add(V, V));
+    const F2 YJ = f2_mul(P.y, J);
+    R.y = f2_sub(f2_mul(r, f2_sub(V, R.x)), f2_add(YJ, YJ));
+    R.z = f2_sub(f2_sub(f2_sqr(f2_add(P.z, H)), Z1Z1), HH);
+    return R;
+}
 static bool g2_in_subgroup(const G2A &Q) {
     if (Q.inf) return true;
-    G2A acc = {f2_zero(), f2_zero(), true};
-    for (int bit = 253; bit >= 0; --bit) {
-        acc = g2_add(acc, acc);
-        if ((FrP::m(bit >> 5) >> (bit & 31)) & 1u) acc = g2_add(acc, Q);
+    static std::mutex mu;
+    static G2A seen[8];
+    static int seen_n = 0, seen_next = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (int i = 0; i < seen_n; ++i)
+            if (f2_eq(seen[i].x, Q.x) && f2_eq(seen[i].y, Q.y)) return true;
     }
-    return acc.inf;
+    G2J acc = {f2_one(), f2_one(), f2_zero()};
+    for (int bit = 253; bit >= 0; --bit) {
+        acc = g2j_dbl(acc);
+        if ((FrP::m(bit >> 5) >> (bit & 31)) & 1u) acc = g2j_madd(acc, Q);
+    }
+    const bool ok = f2_is_zero(acc.z);
+    if (ok) {
+        std::lock_guard<std::mutex> lk(mu);
+        seen[seen_next] = Q;
+        seen_next = (seen_next + 1) % 8;
+        if (seen_n < 8) ++seen_n;
+    }
+    return ok;
 }
 // line through T with twist-slope lam, evaluated at the G1 point (xP, yP) after untwisting: yP - lam*xP*w + (lam*xT - yT)*w^3
 static F12 line_eval(const G2A &T, const F2 &lam, const Fq &xP, const Fq &yP) {

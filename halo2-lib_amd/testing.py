@@ -39,9 +39,19 @@ class SyntheticCircuit:
         self.advice, self.fixed, self.copies, self.instances = advice, fixed, copies, instances
 
 
-def build_circuit(shape, seed: int, backend, num_instance_values: int = 3) -> SyntheticCircuit:
+def build_circuit(shape, seed: int, backend, num_instance_values: int = 3, cell_mix=None, range_checked_bits=None) -> SyntheticCircuit:
     """`shape`: an object with the attributes of the BaseConfig constraint system (k, n, usable_rows, num_advice, gate_advice,
-    lookup_advice, lookups, table_col, constant_cols, q_lookup_col, q_enable_cols, num_fixed_total, num_instance, lookup_bits)."""
+    lookup_advice, lookups, table_col, constant_cols, q_lookup_col, q_enable_cols, num_fixed_total, num_instance, lookup_bits).
+
+    Cell statistics.  Every gate's a, b, c cells are drawn independently from four kinds — 0, 1, small (< 2^lookup_bits, or < 2^16 without a
+    table), full-width (uniform below 2^252) — with probabilities `cell_mix` = (p0, p1, p_small, p_full), default 1/4 each; then the `a` cell of
+    every third gate is overwritten by a range-checked value < 2^lookup_bits, every fifth gate's `d` feeds the next gate's `a`, and
+    d = a + b*c (full-width whenever b*c or a is).  Resulting column at the default mix (measured by `cell_statistics`, k = 14 ... 19): 17-18 % zeros,
+    18 % ones, 33 % other values below 2^lookup_bits, 2-3 % below 2^88, 29 % wider (full-width).  `range_checked_bits`: width of the range-checked
+    values (default lookup_bits).  A real halo2-ecc column (secp256k1/tests/ecdsa.rs:104-146 through the
+    CRT limbs of fields/fp.rs) holds mostly 0/1 bits, lookup-sized limbs and < 2^88 / 2^90 limbs and FEWER full-width cells: `bench.py` brackets the
+    dependence of the proof time on this distribution with cell_mix = (1/2, 1/2, 0, 0) + range_checked_bits = 1 ("all bits": 0 / 1 / 2 only) and
+    (0, 0, 0, 1) ("all uniform": 92 % full-width, the rest the range-checked cells)."""
     n, u = shape.n, shape.usable_rows
     g = np.random.default_rng(seed)
     r2 = np.repeat(_limbs_of(_R2), 1, axis=0)
@@ -68,13 +78,15 @@ def build_circuit(shape, seed: int, backend, num_instance_values: int = 3) -> Sy
             full[:, 3] &= np.uint64((1 << 60) - 1)
             out[idx] = full
             return out
-        A = draw(m, g.integers(0, 4, size=m))
-        B = draw(m, g.integers(0, 4, size=m))
-        Cc = draw(m, g.integers(0, 4, size=m))
+        # (the default mix keeps the generator's original stream: the committed golden digests were made from it)
+        kinds = (lambda: g.integers(0, 4, size=m)) if cell_mix is None else (lambda: g.choice(4, size=m, p=np.asarray(cell_mix, dtype=np.float64)))
+        A = draw(m, kinds())
+        B = draw(m, kinds())
+        Cc = draw(m, kinds())
         j = np.arange(m)
         look = (j % 3 == 0) if lb else np.zeros(m, dtype=bool)          # gates whose `a` cell is range-checked
         if lb:
-            raw_small = g.integers(0, 1 << lb, size=int(look.sum()), dtype=np.uint64)
+            raw_small = g.integers(0, 1 << (lb if range_checked_bits is None else min(lb, range_checked_bits)), size=int(look.sum()), dtype=np.uint64)
             raw_small[: min(len(raw_small), 8)] = (1 << lb) - 1            # the table's largest value appears too
             A[look] = mont(_raw(raw_small))
             small_vals[col] = (np.where(look)[0], A[look])
@@ -116,3 +128,22 @@ def build_circuit(shape, seed: int, backend, num_instance_values: int = 3) -> Sy
         for t in range(cnt):
             copies.append(((("instance", i), t), (("advice", shape.gate_advice[0]), 4 * t + 2)))
     return SyntheticCircuit(advice, fixed, copies, instances)
+
+
+def cell_statistics(column: np.ndarray, usable_rows: int, lookup_bits: int) -> dict:
+    """fractions of a column's assigned cells (raw Montgomery limbs, (n,4) u64) that are 0, 1, another value below 2^lookup_bits, another value
+    below 2^88 (a CRT limb), anything wider — what the counting sort of the commitment MSM and its zero-digit skipping see"""
+    a = np.ascontiguousarray(column[:usable_rows], dtype=np.uint64)
+    rinv = pow(1 << 256, -1, R_MOD)
+    one = _limbs_of((1 << 256) % R_MOD)[0]
+    zero = ~a.any(axis=1)
+    is_one = (a == one).all(axis=1)
+    rest = np.where(~zero & ~is_one)[0]
+    # canonical values of a sample of the remaining cells (big-int conversion: 4096 cells are plenty for two-digit fractions)
+    pick = rest if len(rest) <= 4096 else rest[np.random.default_rng(1).choice(len(rest), 4096, replace=False)]
+    vals = [((int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192) * rinv) % R_MOD for r in a[pick]]
+    small = sum(1 for v in vals if v < (1 << max(lookup_bits, 1)))
+    limb = sum(1 for v in vals if (1 << max(lookup_bits, 1)) <= v < (1 << 88))
+    tot, nrest, ns = float(len(a)), float(len(rest)), float(max(len(vals), 1))
+    return {"cells": int(tot), "zero": float(zero.sum()) / tot, "one": float(is_one.sum()) / tot, "below_2^lookup_bits": nrest / tot * small / ns,
+            "below_2^88": nrest / tot * limb / ns, "wider": nrest / tot * (len(vals) - small - limb) / ns}

@@ -42,10 +42,39 @@ ECDSA = [(19, 1, 1, 1, 18), (18, 2, 1, 1, 17), (17, 4, 1, 1, 16), (16, 8, 2, 1, 
          (13, 68, 12, 1, 12), (12, 139, 24, 2, 11), (11, 291, 53, 4, 10)]
 
 
+# r05: the reference's other three benchmark files (README.md:297-305), every line in file order — halo2-ecc/configs/bn254/bench_msm.config:1-13,
+# bench_fixed_msm.config:1-12 (num_fixed up to 7), bench_ec_add.config:1-5.  A line with num_lookup_advice = 0 configures NO lookup table at all
+# (halo2-base/src/gates/circuit/mod.rs:76-78), whatever its lookup_bits says.
+MSM = [(16, 170, 23, 1, 15), (17, 84, 11, 1, 16), (18, 42, 6, 1, 17), (19, 20, 3, 1, 18), (20, 11, 2, 1, 19), (21, 6, 1, 1, 20), (22, 3, 1, 1, 21),
+       (23, 2, 1, 1, 22), (24, 1, 0, 1, 22), (19, 6, 1, 1, 18), (20, 6, 1, 1, 19), (21, 21, 3, 1, 20), (23, 6, 1, 1, 22)]
+FIXED_MSM = [(17, 83, 9, 7, 16), (18, 42, 5, 4, 17), (19, 20, 2, 2, 18), (20, 10, 1, 1, 19), (21, 5, 1, 1, 20), (22, 3, 1, 1, 21), (23, 2, 1, 1, 22),
+             (24, 1, 0, 1, 22), (19, 6, 1, 1, 18), (20, 6, 1, 1, 19), (21, 21, 3, 3, 20), (23, 6, 1, 1, 22)]
+EC_ADD = [(15, 10, 2, 1, 14), (16, 5, 1, 1, 15), (17, 3, 1, 1, 16), (18, 2, 1, 1, 17), (19, 1, 0, 1, 18)]
+
+
 def shapes():
+    """the 18 shapes of the two sweeps the README times line by line (bench_ecdsa.config, bench_pairing.config)"""
     for name, lst in (("ecdsa", ECDSA), ("pairing", PAIRING)):
         for k, na, nl, nf, lb in lst:
             yield "%s-%d" % (name, k), (k, na, nl, nf, 0, lb)
+
+
+def more_shapes():
+    """(name, shape, alias_of) for every line of the other three benchmark files: name = <file>-L<line>; alias_of = the entry that already holds the
+    same BaseCircuitParams (several lines of these files repeat a shape of another file or line), else None"""
+    seen = {p: n for n, p in shapes()}
+    for fname, lst in (("msm", MSM), ("fixed_msm", FIXED_MSM), ("ec_add", EC_ADD)):
+        for line, (k, na, nl, nf, lb) in enumerate(lst, 1):
+            name, p = "%s-L%d" % (fname, line), (k, na, nl, nf, 0, lb)
+            yield name, p, seen.get(p)
+            seen.setdefault(p, name)
+
+
+def all_shapes():
+    yield from shapes()
+    for name, p, alias in more_shapes():
+        if alias is None:
+            yield name, p
 
 
 class OracleBackend:
@@ -67,14 +96,15 @@ def sha(a) -> str:
 def main():
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
-    doc = {"what": "oracle-prover proof digests for the reference's 18 benchmark shapes; generator: tests/golden/make_proof_goldens.py",
+    doc = {"what": "oracle-prover proof digests for the BaseCircuitParams shapes of the reference's five benchmark files; generator: tests/golden/make_proof_goldens.py",
            "toxic_s": hex(TOXIC_S), "circuit_seed": CIRCUIT_SEED, "rng_seed": RNG_SEED, "shapes": {}}
     if os.path.exists(OUT):
         old = json.load(open(OUT))
         if (old.get("toxic_s"), old.get("circuit_seed"), old.get("rng_seed")) == (doc["toxic_s"], CIRCUIT_SEED, RNG_SEED):
             doc["shapes"] = old["shapes"]
     g_full = None   # g[i] = s^i G does not depend on k: computed once at the largest k and sliced
-    todo = [(name, p) for name, p in shapes() if flt in name and name not in doc["shapes"]]
+    kcap = int(os.environ.get("GOLDEN_MAX_K", "24"))
+    todo = [(name, p) for name, p in all_shapes() if flt in name and name not in doc["shapes"] and p[0] <= kcap]
     if not todo:
         print("nothing to do")
         return
