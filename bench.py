@@ -583,7 +583,7 @@ def main():
         # BASELINE configs[4] AS north_star STATES IT: the k = 21 BN254-pairing shape (bench_pairing.config:8: 2 gate + 1 lookup advice columns, 1 constants
         # column, lookup_bits 20) sharded over the N GPUs — every rank runs this block; the one-GPU proof of the same key is timed in the same run
         try:
-            blk = create_proof_shape(ctx, 21, 2, 1, 1, 0, 20, reps=3, modmul_peak=modmul_peak if rank == 0 else None,
+            blk = create_proof_shape(ctx, 21, 2, 1, 1, 0, 20, reps=3, modmul_peak=modmul_peak if rank == 0 else None, golden=_golden_entry("pairing-21"),
                                      what="BASELINE configs[4]: the k=21 BN254-pairing configuration (halo2-ecc/configs/bn254/bench_pairing.config:8), 14 MSMs of 2^21, "
                                           "extended_k 23; `seconds` = one GPU (rank 0), `sharded` = the same proof over %d GPUs" % world,
                                      sharding={"comm": comm, "dist": dist, "torch": torch, "dev": dev, "xdev": xdev, "backend": args.dist_backend, "world": world, "rank": rank,
@@ -597,7 +597,7 @@ def main():
                          ("k8_witness_batches", lambda: k8_batches(ctx, torch, dev, modmul_peak_sat, modmul_peak)),
                          ("witness_distribution", lambda: witness_distribution(ctx, args.k)),
                          ("create_proof_k21_pairing_shape", lambda: create_proof_shape(
-                             ctx, 21, 2, 1, 1, 0, 20, reps=3, modmul_peak=modmul_peak, account_proofs=2,
+                             ctx, 21, 2, 1, 1, 0, 20, reps=3, modmul_peak=modmul_peak, account_proofs=2, golden=_golden_entry("pairing-21"),
                              what="BASELINE configs[4] on ONE GPU: the k=21 BN254-pairing configuration "
                                   "(halo2-ecc/configs/bn254/bench_pairing.config:8), 14 MSMs of 2^21, extended_k 23"))):
             try:
@@ -839,18 +839,39 @@ def create_proof_k19(ctx, with_cpu_baseline: bool, reps: int = 10):
     return out
 
 
-def create_proof_shape(ctx, k, na, nl, nf, ni, lb, reps, what, modmul_peak=None, account_proofs=0, sharding=None):
+def _golden_entry(name):
+    """the committed oracle-prover digest of a reference shape (tests/golden/reference_shapes_proof_digests.json: written by the ORACLE prover alone,
+    tests/golden/make_proof_goldens.py) with the generator's toxic scalar and seeds — plain data, nothing of oracle/ is imported or run here"""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "reference_shapes_proof_digests.json")) as f:
+            doc = json.load(f)
+        return {"name": name, "toxic_s": int(doc["toxic_s"], 16), "circuit_seed": doc["circuit_seed"], "rng_seed": doc["rng_seed"], **doc["shapes"][name]}
+    except Exception:
+        return None
+
+
+def _predrawn_stream(count, seed):
+    """tests/util.py:rand_fr — the pre-drawn Fr::random stream the golden generator hands both provers"""
+    a = np.random.default_rng(seed).integers(0, 2**63, size=(count, 4), dtype=np.uint64) * np.uint64(2) + \
+        np.random.default_rng(seed + 1).integers(0, 2, size=(count, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    return a
+
+
+def create_proof_shape(ctx, k, na, nl, nf, ni, lb, reps, what, modmul_peak=None, account_proofs=0, sharding=None, golden=None):
     """create_proof for another BaseCircuitParams shape (no CPU leg): seconds per proof, stages, verified by libh2hip's verifier.
     modmul_peak: adds `roofline_proof` (the shape's algorithmic products / bytes over its wall time, SURVEY.md §8d's formulas);
     account_proofs: that many further proofs with every launch bracketed -> `kernel_ms_per_proof`;
     sharding = {"comm", "dist", "torch", "dev", "backend", "shard_ntt_columns", "world", "rank"}: ALL ranks call this together — the same key is put on
     the sharded path, ONE proof per step over the N GPUs is timed between barriers (max over ranks), the exchange schedule is read
-    back, and the sharded bytes are compared with the unsharded proof of the same key and with every other rank's."""
+    back, and the sharded bytes are compared with the unsharded proof of the same key and with every other rank's.
+    golden = _golden_entry(name): the SRS, the synthetic circuit and the RNG stream are the golden generator's, so that sha256(proof) can be compared
+    with the digest the oracle prover alone produced for this shape (`equals_committed_oracle_prover_digest`)."""
     from halo2_lib_amd import halo2_proofs as HP
     from halo2_lib_amd import plonk as PL
     from halo2_lib_amd import testing as T
 
-    kzg = HP.ParamsKZG.setup(ctx, k, 0x1D0C0FFEE1234567890ABCDEF, precompute=True)
+    kzg = HP.ParamsKZG.setup(ctx, k, golden["toxic_s"] if golden else 0x1D0C0FFEE1234567890ABCDEF, precompute=True)
     bp = PL.BaseCircuitParams.new(k, na, nl, nf, ni, lb)
     sh = PL.shape_of(ctx, bp)
 
@@ -858,9 +879,14 @@ def create_proof_shape(ctx, k, na, nl, nf, ni, lb, reps, what, modmul_peak=None,
         mul = staticmethod(ctx.fr_mul)
         add = staticmethod(ctx.fr_add)
 
-    circ = T.build_circuit(_ShapeView(bp, sh), k, Backend)
+    circ = T.build_circuit(_ShapeView(bp, sh), golden["circuit_seed"] + k if golden else k, Backend)
     pk = PL.keygen(kzg, bp, circ.fixed, circ.copies)
-    draws = synthetic_scalars((1 << k) + 65536, 4243)
+    if golden:   # tests/golden/make_proof_goldens.py:rng_budget — the stream's length does not change its prefix, the seed does
+        bf = (1 << k) - sh.usable_rows - 1
+        budget = sh.num_advice_total * (bf + 2) + sh.num_lookups * (2 * (bf + 1) + 2 + bf + 1) + sh.num_perm_sets * (bf + 1) + (1 << k) + 1 + (sh.degree - 1) + 16
+        draws = _predrawn_stream(budget, golden["rng_seed"] + k)
+    else:
+        draws = synthetic_scalars((1 << k) + 65536, 4243)
     PL.create_proof(pk, circ.advice, circ.instances, PL.ArrayRng(draws))
     ctx.sync()
     each = []
@@ -878,6 +904,13 @@ def create_proof_shape(ctx, k, na, nl, nf, ni, lb, reps, what, modmul_peak=None,
            "proof_bytes": len(proof), "constraints": cells, "constraints_per_sec": cells / seconds,
            "msm_count": sh.num_commitments, "msm_size": 1 << k, "extended_k": sh.extended_k, "stage_ms": {k_: round(v, 3) for k_, v in stages.items()},
            "verified_by_h2hip_plonk_verify_proof": bool(ok)}
+    if golden:
+        import hashlib
+
+        out["proof_sha256"] = hashlib.sha256(proof).hexdigest()
+        out["golden"] = {"entry": "tests/golden/reference_shapes_proof_digests.json:" + golden["name"], "oracle_prover_proof_sha256": golden["proof_sha256"],
+                         "verifying_keys_equal": hex(pk.transcript_repr) == golden["transcript_repr"]}
+        out["equals_committed_oracle_prover_digest"] = out["proof_sha256"] == golden["proof_sha256"]
     if modmul_peak:
         work = proof_algorithmic_work(ctx, bp, sh)
         med = out["seconds_median"]
@@ -927,6 +960,7 @@ def create_proof_shape(ctx, k, na, nl, nf, ni, lb, reps, what, modmul_peak=None,
                           "seconds": float(te.item()) / steps, "steps": steps, "speedup_vs_one_gpu_same_run": seconds / (float(te.item()) / steps),
                           "stage_ms_rank0": {k_: round(v, 3) for k_, v in sstages.items()},
                           "sharded_bytes_equal_unsharded": sproof == proof, "ranks_emit_identical_bytes": len(set(digests)) == 1, "proof_sha256": digests[0],
+                          "equals_committed_oracle_prover_digest": (digests[0] == golden["proof_sha256"]) if golden else None,
                           "lagrange_to_coeff_by_column": bool(sharding["shard_ntt_columns"]) if sharding["shard_ntt_columns"] is not None else world >= 8,
                           "host_allgather_payload_bytes_per_rank": [int(sizes[i]) for i in range(cnt.value)],
                           "device_allgathers_bytes_per_rank": {"grand product columns, this rank's rows": 32 * nprod * (rows + 1),
