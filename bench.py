@@ -346,7 +346,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for step in range(args.steps):
+        if args.pmc_child and step == args.steps - 1:
+            ctx.bench_modmul(1, 1)       # a kernel the prover never launches: tools/rocprof_proof.py / rocprof_timeline.py take what follows the last one as ONE timed proof
         proof = prove()                  # returns after the proof bytes are on the host
     torch.cuda.synchronize()
     if world > 1:

@@ -42,6 +42,62 @@ int ws_reserve(h2hip_ctx *ctx, int slot, size_t bytes, void **out) {
     return H2HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- host round trips through a host-mapped flag (r05)
+constexpr size_t POLL_BYTES = 16384;
+__global__ __launch_bounds__(256) void publish_kernel(const uint32_t *__restrict__ src, uint32_t *dst_host, uint32_t nwords, unsigned long long *flag_host,
+                                                      unsigned long long seq) {
+    for (uint32_t i = threadIdx.x; i < nwords; i += 256) dst_host[i] = src[i];
+#ifdef H2_HIPEMU
+    __syncthreads();
+    if (threadIdx.x == 0) *flag_host = seq;
+#else
+    __threadfence_system();   // every lane's payload stores are visible to the host before ...
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the flag is
+#endif
+}
+static int poll_init(h2hip_ctx *ctx) {
+    if (ctx->poll_host) return H2HIP_OK;
+    void *h = nullptr;
+    H2_HIPCHK(hipHostMalloc(&h, 64 + POLL_BYTES, hipHostMallocMapped));
+    memset(h, 0, 64 + POLL_BYTES);
+    ctx->poll_host = (char *)h;
+#ifdef H2_HIPEMU
+    ctx->poll_dev = ctx->poll_host;
+#else
+    void *d = nullptr;
+    H2_HIPCHK(hipHostGetDevicePointer(&d, h, 0));
+    ctx->poll_dev = (char *)d;
+#endif
+    return H2HIP_OK;
+}
+int sync_results(h2hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    if (!ctx->host_poll || bytes > POLL_BYTES || (bytes & 3) || ((uintptr_t)src_dev & 3)) {
+        if (bytes) H2_HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+        return H2HIP_OK;
+    }
+    H2_CHK(poll_init(ctx));
+    const unsigned long long seq = ++ctx->poll_seq;
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *)src_dev, (uint32_t *)(ctx->poll_dev + 64), (uint32_t)(bytes / 4),
+                       (unsigned long long *)ctx->poll_dev, seq);
+    H2_HIPCHK(hipGetLastError());
+    const volatile unsigned long long *flag = (const volatile unsigned long long *)ctx->poll_host;
+    for (uint64_t spins = 1; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spins) {
+        if ((spins & 0x3FFFF) == 0) {   // every ~10 ms: a faulted stream would never raise the flag
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) break;   // (the stream has drained: the kernel's stores are complete)
+            if (e != hipErrorNotReady) H2_HIPCHK(e);
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (bytes) memcpy(dst_host, ctx->poll_host + 64, bytes);
+    return H2HIP_OK;
+}
+int sync_stream(h2hip_ctx *ctx) { return sync_results(ctx, nullptr, ctx->poll_dev ? ctx->poll_dev + 64 : nullptr, 0); }
+
 static hipEvent_t get_event(h2hip_ctx *ctx) {
     if (!ctx->event_pool.empty()) {
         hipEvent_t e = ctx->event_pool.back();
@@ -268,6 +324,7 @@ void h2hip_destroy(h2hip_ctx *ctx) {
     }
     if (ctx->tail_ev) hipEventDestroy(ctx->tail_ev);
     if (ctx->job_ring) hipHostFree(ctx->job_ring);
+    if (ctx->poll_host) hipHostFree(ctx->poll_host);
     for (auto &b : ctx->ws)
         if (b.p) hipFree(b.p);
     for (auto &t : ctx->twiddles) {
@@ -316,6 +373,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "kate_coeffs_per_lane")) return &ctx->kate_coeffs_per_lane;
     if (!strcmp(name, "quotient_29")) return &ctx->quotient_29;
     if (!strcmp(name, "kate_29")) return &ctx->kate_29;
+    if (!strcmp(name, "host_poll")) return &ctx->host_poll;
     if (!strcmp(name, "clean_on_lane")) return &ctx->clean_on_lane;
     if (!strcmp(name, "plonk_permute_in_commit")) return &ctx->plonk_permute_in_commit;
     if (!strcmp(name, "ntt_full_table")) return &ctx->ntt_full_table;
@@ -807,11 +865,10 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         prof_end(ctx);
         H2_HIPCHK(hipGetLastError());
     }
-    H2_HIPCHK(hipMemcpyAsync(out_host, results, psz * count, hipMemcpyDeviceToHost, ctx->stream));
     // zero-fill of the shared bucket array for the next batch, off its critical path — queued AFTER the hook's work and on the first lane's stream
     // (the hook works on the last lane's): a fill that waits for the reduction must not sit in front of that work in a shared hardware queue
     if (deferred) H2_CHK(buckets_clean_after_use(ctx, 1, all_buckets, sizeof(XYZZ29) * keys_per_col * count, ctx->clean_on_lane ? ctx->lane[0]->stream : nullptr));
-    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    H2_CHK(sync_results(ctx, out_host, results, psz * count));   // the commitments come back (r05: through the host-mapped flag, no runtime wait)
     H2_CHK(hook_rc);
     return H2HIP_OK;   // (the lanes' kernel timers are folded into this context's table when it is read: prof_collect_all)
 }
@@ -853,10 +910,7 @@ static int finish_point(h2hip_ctx *ctx, char *outbuf, int point_format, void *ou
                        affine ? aff : (G1Affine *)nullptr);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    H2_HIPCHK(hipMemcpyAsync(out_host, affine ? (void *)aff : (void *)jac, affine ? sizeof(G1Affine) : sizeof(G1Jac), hipMemcpyDeviceToHost,
-                             ctx->stream));
-    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
-    return H2HIP_OK;
+    return sync_results(ctx, out_host, affine ? (void *)aff : (void *)jac, affine ? sizeof(G1Affine) : sizeof(G1Jac));
 }
 
 int h2hip_g1_sum_jacobian_dev(h2hip_ctx *ctx, const void *points_dev, size_t n, int point_format, void *out_host) {

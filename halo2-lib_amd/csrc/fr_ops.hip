@@ -1425,9 +1425,7 @@ int h2hip_fr_eval_polynomial_dev(h2hip_ctx *ctx, const void *coeffs, size_t n, c
     hipLaunchKernelGGL(fr_eval_final_kernel, dim3(1), dim3(256), 0, ctx->stream, (const Fr *)tv, ntiles, pw, tv + ntiles);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    H2_HIPCHK(hipMemcpyAsync(out_host, tv + ntiles, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
-    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
-    return H2HIP_OK;
+    return sync_results(ctx, out_host, tv + ntiles, sizeof(Fr));
 }
 int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs_dev, const size_t *lens, const void *points, size_t count,
                                        void *out_host) {
@@ -1481,9 +1479,7 @@ int h2hip_fr_eval_polynomial_batch_dev(h2hip_ctx *ctx, const void *const *coeffs
     hipLaunchKernelGGL(fr_eval_final_batch_kernel, dim3((uint32_t)count), dim3(256), 0, ctx->stream, (const EvalJob *)djobs, ntiles, (const Fr *)tv, res);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    H2_HIPCHK(hipMemcpyAsync(out_host, res, sizeof(Fr) * count, hipMemcpyDeviceToHost, ctx->stream));
-    H2_HIPCHK(hipStreamSynchronize(ctx->stream));   // also keeps `jobs` alive until the upload has been consumed
-    return H2HIP_OK;
+    return sync_results(ctx, out_host, res, sizeof(Fr) * count);   // (the wait also keeps `jobs` alive until the upload has been consumed)
 }
 }  // extern "C"
 // q[0..n-1) = sum_j weights[j] * (f(X) - f(points[j])) / (X - points[j]),  m <= 8 points; q_dev must not alias coeffs_dev

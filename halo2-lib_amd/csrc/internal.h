@@ -146,6 +146,13 @@ struct h2hip_ctx {
     size_t clean_bytes[2] = {0, 0};
     hipEvent_t fork_ev = nullptr;
     hipEvent_t timer_ev[2] = {nullptr, nullptr};   // h2hip_timer_start / _stop
+    // Host round trips without the runtime's wait (r05): a one-workgroup kernel copies a small result into HOST-MAPPED memory and raises a sequence
+    // flag there with a system-scope release; the host spins on the flag (sync_results / sync_stream in capi.hip).  Replaces hipMemcpyAsync(D2H) +
+    // hipStreamSynchronize on the prover's ~12 round trips per proof (commitments out, challenges in).  0: the runtime's memcpy + wait.
+    int host_poll = 1;
+    char *poll_host = nullptr;                 // hipHostMalloc'ed (mapped, coherent): [0, 8) the flag, [64, 64 + POLL_BYTES) the payload
+    char *poll_dev = nullptr;                  // the same memory as the device sees it
+    unsigned long long poll_seq = 0;
     bool msm_lds_attr_set = false, lookup_lds_attr_set = false, ntt_lds_attr_set = false;   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this context's device
 };
 
@@ -206,6 +213,10 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 // CONSUMES the state: the caller dirties the array) / schedule the fill
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);
 int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes, hipStream_t on = nullptr);
+// capi.hip: the host waits for everything queued on ctx->stream (sync_stream), optionally fetching `bytes` (<= 16 KiB with host_poll, any size without)
+// of results from device memory first (sync_results) — through the host-mapped flag when ctx->host_poll, else hipMemcpyAsync + hipStreamSynchronize
+int sync_stream(h2hip_ctx *ctx);
+int sync_results(h2hip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 // capi.hip: a child context's (MSM lane, the prover's side stream) kernel timers folded into the parent's table
 void prof_fold_child(h2hip_ctx *parent, h2hip_ctx *child);
 // rng.hip: n elements of the ChaCha Fr::random stream from element first_block on, on `stream`

@@ -303,8 +303,7 @@ static int sort_columns_keys(h2hip_ctx *ctx, const Fr *const *in, uint32_t count
     for (uint32_t j = 0; j < LK_BATCH; ++j) cols.p[j] = in[j < count ? j : 0];
     hipLaunchKernelGGL(lk_keys_kernel, dim3((std::max(N, u) + 255) / 256, count), dim3(256), 0, st, cols, keys, u, N, small_max);
     uint32_t host_max[LK_BATCH];
-    H2_HIPCHK(hipMemcpyAsync(host_max, small_max, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, st));
-    H2_HIPCHK(hipStreamSynchronize(st));
+    H2_CHK(sync_results(ctx, host_max, small_max, sizeof(uint32_t) * count));
     uint32_t all_max = 0;
     for (uint32_t j = 0; j < count; ++j) all_max = std::max(all_max, host_max[j]);
     const uint32_t bins = all_max + 1;
@@ -401,8 +400,7 @@ static int lookup_permute_many(h2hip_ctx *ctx, const void *const *a_dev, const v
         hipLaunchKernelGGL(lk_status_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)err, (const uint32_t *)rep_rank, (const uint32_t *)unused_rank, u,
                            cc, flag_words, rank_words, status);
         uint32_t host[3 * LK_BATCH];
-        H2_HIPCHK(hipMemcpyAsync(host, status, sizeof(uint32_t) * 3 * cc, hipMemcpyDeviceToHost, st));
-        H2_HIPCHK(hipStreamSynchronize(st));
+        H2_CHK(sync_results(ctx, host, status, sizeof(uint32_t) * 3 * cc));
         for (uint32_t j = 0; j < cc; ++j) {
             if (host[3 * j]) {
                 prof_end(ctx);

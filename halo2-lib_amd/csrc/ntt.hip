@@ -252,10 +252,17 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
 
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     v4u pre[4][2];
+    // r05: coeff_to_extended by a factor of >= 4 (every coset transform of the prover: n coefficients on a 4n- or 8n-point domain) pads with zeros
+    // from row R/4 on, and a lane's element k sits in rows [k R/4, (k+1) R/4): elements 1..3 of EVERY lane are zero.  Their loads, splits and
+    // coset-scaling products are skipped (3 of the 4 scale products), and the first butterfly round sees (x0, 0, 0, 0) per group: for an even m
+    // it is a copy of x0 to the group's four rows (no product), for an odd m the radix-2 stage is a copy and the first radix-4 round drops the
+    // two products by zero (`quarter`, wave-uniform).  Same residues, hence the same canonical output bits.
+    const bool quarter = FIRST && in_len <= ((1u << log_n) >> 2) && log_n >= 2;
     auto fetch = [&](uint32_t tile) {
         const uint32_t j0 = tile << cb;
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
+            if (FIRST && k && quarter) continue;
             const uint32_t e = tid + T * k;
             uint32_t idx = j0 + (e & (C - 1)) + (e >> cb) * rows_stride;
             if (FIRST) idx = idx < in_len ? idx : 0u;   // implicit zero padding: a harmless in-range address, the zero is selected at the fill
@@ -271,10 +278,28 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
 
     // one radix-4 group per lane and round
     const uint32_t gc = tid & (C - 1), gp = tid >> cb;
-    auto round4 = [&](uint32_t st) {
+    // zeros: 0 = a general round; 1 = (st == 0, quarter) x1 = x2 = x3 = 0: the round is a copy; 2 = (st == 1, quarter, odd m) x1 = x3 = 0
+    auto round4 = [&](uint32_t st, int zeros) {
         const uint32_t h = 1u << st;
         const uint32_t i = gp & (h - 1), blk = gp >> st;
         const uint32_t e0 = (((blk << (st + 2)) + i) << cb) + gc, stride = h << cb;
+        if (zeros == 1) {
+            const Fr29 x0 = E::ld(&lds[e0]);
+            E::st(&lds[e0 + stride], x0);
+            E::st(&lds[e0 + 2 * stride], x0);
+            E::st(&lds[e0 + 3 * stride], x0);
+            return;
+        }
+        if (zeros == 2) {   // y0 = y1 = x0 (mod r), y2 = x2 w, y3 = x2 w'
+            const Fr29 x0 = E::ld(&lds[e0]), x2 = E::ld(&lds[e0 + 2 * stride]);
+            const Fr29 y2 = f29_mul(x2, ld29(&tw_s[i << (m - 2 - st)]));
+            const Fr29 y3 = f29_mul(x2, ld29(&tw_s[(i + h) << (m - 2 - st)]));
+            E::st(&lds[e0], f29_norm(f29_add(x0, y2)));
+            E::st(&lds[e0 + 2 * stride], f29_sub<2>(x0, y2));
+            E::st(&lds[e0 + stride], f29_norm(f29_add(x0, y3)));
+            E::st(&lds[e0 + 3 * stride], f29_sub<2>(x0, y3));
+            return;
+        }
         Fr29 x0 = E::ld(&lds[e0]), x1 = E::ld(&lds[e0 + stride]), x2 = E::ld(&lds[e0 + 2 * stride]), x3 = E::ld(&lds[e0 + 3 * stride]);
         if (st) {   // stage st: omega_{2h}^i (for st == 0 it is 1)
             const Fr29 w1 = ld29(&tw_s[i << (m - 1 - st)]);
@@ -299,6 +324,10 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t e = tid + T * k;
             const uint32_t t = e >> cb, c = e & (C - 1);
+            if (FIRST && k && quarter) {   // a zero row; with an even m the first round (a copy of x0) overwrites it anyway
+                if (m & 1) E::st(&lds[(bitrev_m(t, m) << cb) + c], Fr29::zero());
+                continue;
+            }
             Fr s;
             s.l[0] = pre[k][0].x; s.l[1] = pre[k][0].y; s.l[2] = pre[k][0].z; s.l[3] = pre[k][0].w;
             s.l[4] = pre[k][1].x; s.l[5] = pre[k][1].y; s.l[6] = pre[k][1].z; s.l[7] = pre[k][1].w;
@@ -329,10 +358,12 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
             __syncthreads();
         }
         for (; st + 2 < m; st += 2) {
-            round4(st);
+            if (FIRST && quarter && st < 2) round4(st, st == 0 ? 1 : 2);
+            else round4(st, 0);
             __syncthreads();
         }
-        round4(st);   // st == m - 2
+        if (FIRST && quarter && st < 2) round4(st, st == 0 ? 1 : 2);   // (m = 2 or 3: the only round)
+        else round4(st, 0);   // st == m - 2
         // ---- the lane's four read-out positions and their inter-pass twiddles, requested between the last round's LDS writes and the barrier that ends it (the round's
         // temporaries are dead by then: requesting them before the round costs 40 more registers per lane, i.e. a wave per SIMD)
         uint32_t oidx[4], lidx[4];

@@ -318,7 +318,7 @@ typedef int hipError_t;
 typedef struct hipemu_stream *hipStream_t;
 struct hipemu_event { std::chrono::steady_clock::time_point t; };
 typedef hipemu_event *hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2 };
 struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchName[64]; size_t totalGlobalMem; };
@@ -341,6 +341,8 @@ template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMall
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+enum { hipHostMallocMapped = 2 };
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 enum { hipHostRegisterDefault = 0 };
 inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
