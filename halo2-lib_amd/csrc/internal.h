@@ -149,6 +149,7 @@ struct h2hip_ctx {
     // Host round trips without the runtime's wait (r05): a one-workgroup kernel copies a small result into HOST-MAPPED memory and raises a sequence
     // flag there with a system-scope release; the host spins on the flag (sync_results / sync_stream in capi.hip).  Replaces hipMemcpyAsync(D2H) +
     // hipStreamSynchronize on the prover's ~12 round trips per proof (commitments out, challenges in).  0: the runtime's memcpy + wait.
+    int msm_table_split = 1;   // base sets are prepared with 128-byte table entries pre-split into 9 x 29-bit limbs (read when a base set is uploaded / generated)
     int host_poll = 1;
     char *poll_host = nullptr;                 // hipHostMalloc'ed (mapped, coherent): [0, 8) the flag, [64, 64 + POLL_BYTES) the payload
     char *poll_dev = nullptr;                  // the same memory as the device sees it
@@ -177,13 +178,23 @@ struct DeviceGuard {
 
 struct h2hip_bases {
     h2::G1Affine *pts = nullptr;      // [n] affine, saturated Montgomery limbs (as uploaded; h2hip_bases_download)
-    h2::G1Affine *pts29 = nullptr;    // [tables][n] the same points packed in the unsaturated domain (x*2^261, y*2^261; 64 B)
+    h2::G1Affine *pts29 = nullptr;    // [tables][n] the same points in the unsaturated domain (x*2^261, y*2^261): packed 8 x 32-bit limbs, 64 B per entry — or,
+                                      // with `split`, 128-byte entries that hold the 9 x 29-bit limbs the accumulation consumes (h2::TableEntry29)
+    bool split = false;               // r05 (msm_table_split): pts29 holds TableEntry29, not G1Affine
     size_t n = 0;
     uint32_t window_bits = 0;      // precomputed mode: window the table was built for
     uint32_t tables = 1;           // 1 = plain; W = precomputed 2^(c*w) multiples
 };
 
 namespace h2 {
+// A table entry as msm_accum_kernel consumes it (r05): x and y already split into 9 x 29-bit limbs, 72 of the 128 bytes used.  A 64-byte gather
+// costs the memory system a 128-byte line anyway (profiles/r02_hbm_counter_calibration.md), so the wider entry moves the same HBM bytes and saves the
+// two f29_split per addition (54 of ~2440 VALU instructions per step).  Identity = all-zero.
+struct alignas(128) TableEntry29 {
+    uint32_t x[9], y[9];
+    uint32_t pad[14];
+};
+static_assert(sizeof(TableEntry29) == 128, "one entry per 128-byte line");
 int ws_reserve(h2hip_ctx *ctx, int slot, size_t bytes, void **out);
 
 // RAII-less kernel timer: prof_begin/prof_end bracket one launch with events when ctx->profiling.

@@ -312,6 +312,28 @@ __device__ __forceinline__ G1Affine load_table_entry(const G1Affine *__restrict_
     return r;
 #endif
 }
+// the pre-split entry (TableEntry29): 72 bytes of its 128-byte line, four 16-byte loads and one of 8, the limbs as the point addition takes them
+__device__ __forceinline__ bool load_table_entry_split(const TableEntry29 *__restrict__ p, Fq29 &x, Fq29 &y) {
+#ifdef H2_HIPEMU
+    for (int i = 0; i < 9; ++i) {
+        x.l[i] = p->x[i];
+        y.l[i] = p->y[i];
+    }
+#else
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    const v4u *q = reinterpret_cast<const v4u *>(p);
+    const v4u a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1), c = __builtin_nontemporal_load(q + 2),
+              d = __builtin_nontemporal_load(q + 3);
+    const v2u e = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(q + 4));
+    x.l[0] = a.x; x.l[1] = a.y; x.l[2] = a.z; x.l[3] = a.w; x.l[4] = b.x; x.l[5] = b.y; x.l[6] = b.z; x.l[7] = b.w; x.l[8] = c.x;
+    y.l[0] = c.y; y.l[1] = c.z; y.l[2] = c.w; y.l[3] = d.x; y.l[4] = d.y; y.l[5] = d.z; y.l[6] = d.w; y.l[7] = e.x; y.l[8] = e.y;
+#endif
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o |= x.l[i] | y.l[i];
+    return o != 0;   // false: the identity
+}
 
 // a lane's XYZZ29 from lane `src` of its wave (36 ds_bpermute; no LDS allocation)
 __device__ __forceinline__ XYZZ29 xyzz29_shfl(const XYZZ29 &v, uint32_t src) {
@@ -341,6 +363,7 @@ __device__ __forceinline__ XYZZ29 xyzz29_shfl(const XYZZ29 &v, uint32_t src) {
 // boundaries leave as (key, XYZZ) partials — slot 2*wave (left) and 2*wave + 1 (right) of a sorted, hole-free list that msm_merge_kernel
 // finishes: 2 slots per 64 lanes instead of 2 per lane (r02: 0.5 M partials of 144 B per 2^19-point MSM through HBM and a first merge level
 // of 2048 workgroups).  No lane leaves early: lanes without entries take part in the shuffles with empty sums.
+template <bool SPLIT>
 __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
                                                const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
                                                XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals,
@@ -392,8 +415,14 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
             next2 = offsets[cur + 2];   // needed at the next boundary only
         }
         const uint32_t v = entry(e);
-        const G1Affine p = load_table_entry(bases + (v & 0x7fffffffu));   // packed R'-domain point, one aligned 64-byte gather
-        if (!p.is_identity()) xyzz29_add_affine_flag(acc, empty, f29_split<Q29P>(p.x), f29_split<Q29P>(p.y), (v >> 31) != 0);
+        if (SPLIT) {   // r05: 128-byte entries that already hold the 29-bit limbs (the same line of HBM traffic, no split)
+            Fq29 px, py;
+            if (load_table_entry_split(reinterpret_cast<const TableEntry29 *>(bases) + (v & 0x7fffffffu), px, py))
+                xyzz29_add_affine_flag(acc, empty, px, py, (v >> 31) != 0);
+        } else {
+            const G1Affine p = load_table_entry(bases + (v & 0x7fffffffu));   // packed R'-domain point, one aligned 64-byte gather
+            if (!p.is_identity()) xyzz29_add_affine_flag(acc, empty, f29_split<Q29P>(p.x), f29_split<Q29P>(p.y), (v >> 31) != 0);
+        }
     }
     if (empty) acc = XYZZ29::identity();
     // ---- close the shared runs inside the wave
@@ -478,11 +507,12 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
 // three waves per SIMD (168 registers per lane); measured and left behind (profiles/r03_msm_tune_*.log, r03_knob_ab.log): two waves per
 // SIMD by launch bounds or by register padding (2 % slower / equal in isolation, nothing end to end), four (spills), the next table entry
 // requested one addition ahead (5 % slower: the gather is not what the kernel waits for), plain instead of non-temporal table loads
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 3) void msm_accum_kernel(const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases,
                                                           const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
                                                           XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
                                                           XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
-    msm_accum_body(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
+    msm_accum_body<SPLIT>(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
 }
 
 // ------------------------------------------------------------------ 6. segmented merge of the partial list
@@ -954,15 +984,23 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         // cost it ~0.3 ms)
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
 #ifndef H2_HIPEMU
-        if (prof_launch_events(ctx, "msm_accum_kernel", &ev_a, &ev_b))
-            hipExtLaunchKernelGGL(msm_accum_kernel, dim3(accum_blocks), dim3(256), 0, st, ev_a, ev_b, 0, (const uint32_t *)sval, table, (const uint32_t *)offsets,
-                                  nkeys, K1, buckets, pkey[0], pval[0], T1);
-        else
+        if (prof_launch_events(ctx, "msm_accum_kernel", &ev_a, &ev_b)) {
+            if (bases->split)
+                hipExtLaunchKernelGGL(msm_accum_kernel<true>, dim3(accum_blocks), dim3(256), 0, st, ev_a, ev_b, 0, (const uint32_t *)sval, table,
+                                      (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+            else
+                hipExtLaunchKernelGGL(msm_accum_kernel<false>, dim3(accum_blocks), dim3(256), 0, st, ev_a, ev_b, 0, (const uint32_t *)sval, table,
+                                      (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1);
+        } else
 #endif
         {
             prof_begin(ctx, "msm_accum_kernel");   // (a no-op unless profiling without launch events: the emulated build)
-            hipLaunchKernelGGL(msm_accum_kernel, dim3(accum_blocks), dim3(256), 0, st, (const uint32_t *)sval, table, (const uint32_t *)offsets, nkeys, K1, buckets,
-                               pkey[0], pval[0], T1);
+            if (bases->split)
+                hipLaunchKernelGGL(msm_accum_kernel<true>, dim3(accum_blocks), dim3(256), 0, st, (const uint32_t *)sval, table, (const uint32_t *)offsets, nkeys, K1,
+                                   buckets, pkey[0], pval[0], T1);
+            else
+                hipLaunchKernelGGL(msm_accum_kernel<false>, dim3(accum_blocks), dim3(256), 0, st, (const uint32_t *)sval, table, (const uint32_t *)offsets, nkeys, K1,
+                                   buckets, pkey[0], pval[0], T1);
             prof_end(ctx);
         }
         (void)ev_a;

@@ -78,6 +78,28 @@ __global__ __launch_bounds__(256) void bases_to_29_kernel(const G1Affine *__rest
     }
     out[i] = r;
 }
+// ... or into 128-byte entries that already hold the 9 x 29-bit limbs (TableEntry29, internal.h)
+__global__ __launch_bounds__(256) void bases_to_29_split_kernel(const G1Affine *__restrict__ in, TableEntry29 *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Affine p = in[i];
+    TableEntry29 e;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) e.pad[j] = 0;
+    if (p.is_identity()) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) e.x[j] = e.y[j] = 0;
+    } else {
+        // the SAME limbs the packed format yields after f29_split: canonical value of x*2^261, split at 29-bit boundaries
+        const Fq29 x = f29_split<Q29P>(f29_pack_canonical<FqP>(f29_from_sat(p.x))), y = f29_split<Q29P>(f29_pack_canonical<FqP>(f29_from_sat(p.y)));
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            e.x[j] = x.l[j];
+            e.y[j] = y.l[j];
+        }
+    }
+    out[i] = e;
+}
 
 // Window size by a cost model in field multiplications.  Plain bases: every window has its own bucket set, reduced at
 // ~28 multiplications per bucket.  Precomputed tables: ONE bucket set, but its reduction is a chain of dependent
@@ -113,8 +135,10 @@ int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *b, bool precompute) {
         W = (255 + c - 1) / c;
         H2_REQUIRE((uint64_t)b->n * W < (1ull << 31), "precomputed table too large for 31-bit indices");
     }
-    G1Affine *t29 = nullptr;
-    hipError_t e = hipMalloc((void **)&t29, sizeof(G1Affine) * (size_t)(n ? n : 1) * W);
+    const bool split = ctx->msm_table_split != 0;
+    const size_t entry_bytes = split ? sizeof(TableEntry29) : sizeof(G1Affine);
+    G1Affine *t29 = nullptr;   // (typed as the packed format; the split format is addressed through TableEntry29 *)
+    hipError_t e = hipMalloc((void **)&t29, entry_bytes * (size_t)(n ? n : 1) * W);
     if (e != hipSuccess) {
         set_error("hipMalloc for %zu bases x %u windows failed: %s", b->n, W, hipGetErrorString(e));
         return H2HIP_ERR_NOMEM;
@@ -122,7 +146,10 @@ int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *b, bool precompute) {
     auto convert = [&](const G1Affine *src, uint32_t level) -> int {
         if (!n) return H2HIP_OK;
         prof_begin(ctx, "bases_to_29_kernel");
-        hipLaunchKernelGGL(bases_to_29_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, t29 + (size_t)level * n, (size_t)n);
+        if (split)
+            hipLaunchKernelGGL(bases_to_29_split_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, (TableEntry29 *)t29 + (size_t)level * n, (size_t)n);
+        else
+            hipLaunchKernelGGL(bases_to_29_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, t29 + (size_t)level * n, (size_t)n);
         prof_end(ctx);
         H2_HIPCHK(hipGetLastError());
         return H2HIP_OK;
@@ -153,6 +180,7 @@ int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *b, bool precompute) {
     }
     if (b->pts29) hipFree(b->pts29);
     b->pts29 = t29;
+    b->split = split;
     b->tables = W;
     b->window_bits = c;
     return H2HIP_OK;
