@@ -761,7 +761,10 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // twiddle cache) behind the event the batch MSM records once its accumulations are done, read the Lagrange values the MSM also reads and
     // write NEW buffers, so they run next to the reduction and to the pointwise kernels that follow.  Single GPU only.
     const bool overlap = !sharded_any && ctx->plonk_tail_overlap != 0;
-    if (overlap && !pk->side_ev) H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
+    // r05, sharded proofs: lagrange_to_coeff (with its all-gather of the coefficient forms when the columns are dealt to the ranks) and the cosets'
+    // coeff_to_extended of the FIRST-ROUND columns run on the side context next to round 2's commitments instead of in front of them
+    const bool side_sharded = sharded_any && ctx->plonk_shard_side != 0;
+    if ((overlap || side_sharded) && !pk->side_ev) H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
     // (r04 also computed the random polynomial's COMMITMENT ahead — its scalars depend on nothing once the generator is counter-mode — as one
     // MSM on a second side context behind round 1's accumulations: 14.72-14.99 vs 14.71-14.98 ms, profiles/r04_tail_overlap_ab.log.  The
     // chip is busy with something ~97 % of the time; only work moved into LOW-occupancy stretches gains, and that MSM is not such work.  Removed.)
@@ -1164,7 +1167,14 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // needs the Lagrange values of the first-round columns: their coefficient and extended forms — RNG, upload (own stream) and NTTs overlap.
     if (!random_poly) H2_CHK(sc.take(n, &random_poly));
     // all columns of a round go through the transforms together (32 per launch): a wide shape's 2^14-row columns are far too small to fill the chip alone
-    auto to_coeff = [&](const std::vector<Fr *> &cols) -> int {
+    // `xc`: the context (stream, NTT scratch) the transforms are queued on — this one, or (r05, sharded) the side context, so that the coefficient
+    // forms' all-gather and the cosets' transforms of the first-round columns run NEXT TO the round's commitments; `deferred`: buffers that go back
+    // to the pool only after the side stream has been joined (the pool hands buffers out in the order of THIS stream)
+    std::vector<Fr *> side_deferred;
+    auto to_coeff = [&](const std::vector<Fr *> &cols, h2hip_ctx *xc) -> int {
+        hipStream_t st = xc->stream;
+        h2hip_ctx *ctx = xc;
+        const bool defer = xc != pk->ctx;
         if (!(sharded_any && pk->shard_ntt))
             return h2hip_ifft_batch_dev(ctx, (void *const *)cols.data(), cols.size(), &dom.omega_inv, k, &dom.ifft_divisor);
         // Sharded by COLUMN (H2HIP_SHARD_NTT_COLUMNS; north_star: "independent NTT columns shard across the GPUs"): column j is transformed by rank
@@ -1178,6 +1188,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             std::vector<uint8_t> all;
             return exchange_host(nullptr, 0, all);
         }
+        (void)defer;
         Fr *sendb = nullptr, *recvb = nullptr;
         H2_CHK(sc.take(slot_elems, &sendb));
         H2_CHK(sc.take(slot_elems * N, &recvb));
@@ -1194,13 +1205,19 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(h2hip_comm_allgather_dev(pk->comm, ctx, sendb, sizeof(Fr) * slot_elems, recvb));
         for (size_t j = 0; j < cols.size(); ++j)
             H2_HIPCHK(hipMemcpyAsync(cols[j], recvb + (j % N) * slot_elems + (j / N) * (size_t)n, sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
-        sc.release(recvb);
-        sc.release(sendb);
+        if (defer) {
+            side_deferred.push_back(recvb);
+            side_deferred.push_back(sendb);
+        } else {
+            sc.release(recvb);
+            sc.release(sendb);
+        }
         return H2HIP_OK;
     };
     // the shift of coset c of the extended domain: s_c = zeta * omega_e^c (rows i = (j << (ek - k)) + c are the points s_c * omega^j)
     auto coset_shift = [&](uint32_t c) -> Fr { return fe_mul(dom.zeta, fe_pow_u64(dom.ext_omega, c)); };
-    auto to_ext = [&](const std::vector<Fr *> &polys, const std::vector<Fr **> &outs) -> int {
+    auto to_ext = [&](const std::vector<Fr *> &polys, const std::vector<Fr **> &outs, h2hip_ctx *xc) -> int {
+        h2hip_ctx *ctx = xc;
         std::vector<void *> o(outs.size());
         for (size_t i = 0; i < outs.size(); ++i) {
             H2_CHK(sc.take(ne_loc, outs[i]));
@@ -1273,8 +1290,22 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             round1.push_back(s.sp);
             round1_cos.push_back(&lk_cos[li].sp);
         }
-        H2_CHK(to_coeff(round1));
-        H2_CHK(to_ext(round1, round1_cos));
+        if (side_sharded) {
+            // everything the main stream holds so far (the grand products: the last readers of these columns' Lagrange values) precedes the side
+            // work; the main stream goes on with this round's commitments and joins the side stream before the first reader of the cosets
+            side_c = pick_side(nullptr, &pk->side);
+            H2_REQUIRE(side_c, "create_proof: no side context");
+            if (!ctx->tail_ev) H2_HIPCHK(hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming));
+            H2_HIPCHK(hipEventRecord(ctx->tail_ev, st));
+            H2_HIPCHK(hipStreamWaitEvent(side_c->stream, ctx->tail_ev, 0));
+            H2_CHK(to_coeff(round1, side_c));
+            H2_CHK(to_ext(round1, round1_cos, side_c));
+            H2_HIPCHK(hipEventRecord(pk->side_ev, side_c->stream));
+            side_busy = true;
+        } else {
+            H2_CHK(to_coeff(round1, ctx));
+            H2_CHK(to_ext(round1, round1_cos, ctx));
+        }
     }
     auto lookup_input_cosets = [&]() -> int {
         for (size_t li = 0; li < lks.size(); ++li) {
@@ -1292,7 +1323,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         c.z = nullptr;
         c.inp = nullptr;
     }
-    if (!overlap) H2_CHK(lookup_input_cosets());   // (overlapping: after the side stream's extended forms have been joined, below)
+    if (!overlap && !side_sharded) H2_CHK(lookup_input_cosets());   // (overlapping: after the side stream's extended forms have been joined, below)
     G1Affine random_commitment;
     {
         if (rng == h2hip_chacha_rng_fill) {
@@ -1353,6 +1384,12 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_CHK(lookup_input_cosets());
         if (stage_ms) laps.lap(ST_TO_COEFF);
     } else {
+        if (side_sharded) {   // the first-round columns' coefficient forms and cosets are complete; their helpers go back to the pool
+            H2_CHK(side_join());
+            for (Fr *p : side_deferred) sc.release(p);
+            side_deferred.clear();
+            H2_CHK(lookup_input_cosets());
+        }
         std::vector<Fr *> zs(perm_z.begin(), perm_z.end());
         std::vector<Fr **> zs_cos;
         for (uint32_t si = 0; si < sh.num_perm_sets; ++si) zs_cos.push_back(&perm_cos[si]);
@@ -1360,9 +1397,9 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             zs.push_back(lks[li].z);
             zs_cos.push_back(&lk_cos[li].z);
         }
-        H2_CHK(to_coeff(zs));
+        H2_CHK(to_coeff(zs, ctx));
         if (stage_ms) laps.lap(ST_TO_COEFF);
-        H2_CHK(to_ext(zs, zs_cos));
+        H2_CHK(to_ext(zs, zs_cos, ctx));
     }
     Fr *acc = nullptr;
     H2_CHK(sc.take(ne, &acc));

@@ -217,6 +217,50 @@ class Comm:
 SHARD_QUOTIENT, SHARD_FORCE, SHARD_PRODUCTS, SHARD_NTT_COLUMNS = 1, 2, 4, 8
 
 
+def decide_shard_ntt_columns(ctx: Context, comm: "Comm", k: int, num_columns: int, reps: int = 3):
+    """Should lagrange_to_coeff be dealt by column (H2HIP_SHARD_NTT_COLUMNS)?  MEASURED on the machine the proof will run on (r05; r04 switched it
+    on from 8 ranks): one 2^k inverse transform on this GPU against one all-gather of a 2^k-element column per rank through the communicator the
+    proof will use (RCCL over xGMI, or the callback).  Dealing `num_columns` columns over N ranks costs ceil(C/N) transforms plus an all-gather of
+    ceil(C/N) columns per rank; not dealing costs C transforms.  Every rank measures; the ranks exchange their figures and all take the SLOWEST
+    rank's, so that all of them decide the same way (the exchange schedule depends on the decision).  Returns (decision, figures)."""
+    import ctypes as C
+    import time
+
+    n, world = 1 << k, comm.world
+    if world == 1 or num_columns == 0:
+        return False, {"world": world}
+    from .halo2_proofs import EvaluationDomain
+
+    dom = EvaluationDomain(ctx, 4, k)
+    d_col, d_all = ctx.to_device(np.zeros((n, 4), dtype=np.uint64)), ctx.malloc(32 * n * world)   # (zeros: valid field elements; the time does not depend on the values)
+    try:
+        ctx.ifft_dev(d_col, dom.omega_inv, k, dom.ifft_divisor)   # warm: twiddle tables
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.ifft_dev(d_col, dom.omega_inv, k, dom.ifft_divisor)
+        ctx.sync()
+        t_intt = (time.perf_counter() - t0) / reps
+        comm.allgather_dev(d_col, 32 * n, d_all)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            comm.allgather_dev(d_col, 32 * n, d_all)
+        ctx.sync()
+        t_gather = (time.perf_counter() - t0) / reps
+    finally:
+        ctx.free(d_col)
+        ctx.free(d_all)
+    mine = np.array([t_intt, t_gather], dtype=np.float64)
+    allv = np.zeros((world, 2), dtype=np.float64)
+    ctx._chk(ctx.lib.h2hip_comm_allgather_host(comm.handle, ctx.handle, mine.ctypes.data, mine.nbytes, allv.ctypes.data))
+    t_intt, t_gather = float(allv[:, 0].max()), float(allv[:, 1].max())
+    per_rank = -(-num_columns // world)
+    dealt, local = per_rank * (t_intt + t_gather), num_columns * t_intt
+    return dealt < local, {"world": world, "k": k, "columns": num_columns, "intt_ms": t_intt * 1e3, "allgather_one_column_per_rank_ms": t_gather * 1e3,
+                           "dealt_ms": dealt * 1e3, "local_ms": local * 1e3}
+
+
 class ShardedKey:
     """keeps the shard base sets and the communicator of a sharded proving key alive"""
 
@@ -237,8 +281,8 @@ def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, g
     the SRS (g_points / g_lagrange_points: the full (n, 8) affine arrays or anything sliceable that yields them) as base sets with their own
     window tables; h(X)'s numerator is evaluated by cosets of the extended domain (shard_quotient), the grand products by row range
     (shard_products); evaluations and SHPLONK's polynomial work always run on the rank's coefficient range.  point_range: this rank's (lo, hi) instead
-    of the even split.  shard_ntt_columns: lagrange_to_coeff dealt by column with an all-gather of the coefficient forms (None: from 8 ranks, where a
-    rank receives on seven links at once — with fewer, moving a column costs more than transforming it).  The exchange runs inside libh2hip:
+    of the even split.  shard_ntt_columns: lagrange_to_coeff dealt by column with an all-gather of the coefficient forms (None: decided by
+    `decide_shard_ntt_columns` — one transform timed against one column-per-rank all-gather through this communicator, slowest rank's figures).  The exchange runs inside libh2hip:
     over its own RCCL communicator when the process group's backend is nccl (rccl=None: decided from the backend), else over a
     torch.distributed callback (gloo on the CPU)."""
     import torch.distributed as dist
@@ -248,8 +292,6 @@ def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, g
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = 1 << pk.params.k
-    if shard_ntt_columns is None:
-        shard_ntt_columns = world >= 8
     lo, hi = point_range if point_range is not None else shard_range(n, rank, world)   # (the ranks' ranges must tile [0, n): checked by the proof's first exchange)
     ctx = pk.ctx
     own_comm = comm is None
@@ -257,10 +299,16 @@ def shard_proving_key(pk, g_points: np.ndarray, g_lagrange_points: np.ndarray, g
         if rccl is None:
             rccl = dist.get_backend(group) == "nccl"
         comm = Comm(ctx, group=group, rccl=rccl, device=device)
+    ntt_decision = None
+    if shard_ntt_columns is None:   # measured here, on this machine's links (r04: "from 8 ranks")
+        sh = pk.shape
+        shard_ntt_columns, ntt_decision = decide_shard_ntt_columns(ctx, comm, pk.params.k, sh.num_advice_total + 2 * sh.num_lookups)
     flags = BASES_PRECOMPUTE if precompute else BASES_PLAIN
     gs = ctx.bases_upload(np.ascontiguousarray(g_points[lo:hi]), flags)
     gls = ctx.bases_upload(np.ascontiguousarray(g_lagrange_points[lo:hi]), flags)
     ctx._chk(ctx.lib.h2hip_plonk_pk_set_sharding(pk.handle, comm.handle, gs.handle, gls.handle, lo, hi - lo,
                                                  (SHARD_QUOTIENT if shard_quotient else 0) | (SHARD_PRODUCTS if shard_products else 0) |
                                                  (SHARD_NTT_COLUMNS if shard_ntt_columns else 0)))
-    return ShardedKey(pk, gs, gls, comm, own_comm)
+    sk = ShardedKey(pk, gs, gls, comm, own_comm)
+    sk.shard_ntt_columns, sk.ntt_decision = bool(shard_ntt_columns), ntt_decision
+    return sk

@@ -11,6 +11,7 @@ through h2hip_plonk_create_proof (the prover call of halo2-base/src/utils/testin
     SHPLONK by coefficient range, and lagrange_to_coeff by column (`shard_ntt_columns=True`: the code path an 8-GPU run takes);
   * commitments (+ evaluations + SHPLONK) only;
   * a ragged point-range tiling (uneven slices),
+  * the column-dealt lagrange_to_coeff switched by the MEASURED decision (multi_gpu.decide_shard_ntt_columns: one transform against one all-gather),
 
 and EVERY rank must emit sha256(proof) == the digest the ORACLE prover alone produced for that shape
 (tests/golden/reference_shapes_proof_digests.json, generator tests/golden/make_proof_goldens.py).  Each rank also reports the exchange schedule
@@ -75,10 +76,13 @@ def _worker(rank, world, port, names, q):
             cuts[-2] = n - 3 if world > 2 else cuts[-2]                                          # world 3: the last rank holds 3 blinding rows only
             for label, kw in (("all_stages", dict(shard_ntt_columns=True)),
                               ("commitments_only", dict(shard_quotient=False, shard_products=False, shard_ntt_columns=False)),
-                              ("ragged", dict(shard_ntt_columns=True, point_range=(cuts[rank], cuts[rank + 1])))):
+                              ("ragged", dict(shard_ntt_columns=True, point_range=(cuts[rank], cuts[rank + 1]))),
+                              ("measured_decision", dict(shard_ntt_columns=None))):   # lagrange_to_coeff by column or not: timed on this machine, all ranks agree
                 sk = shard_proving_key(pk, g, gl, precompute=True, comm=comm, **kw)
                 proof = PL.create_proof(pk, circ.advice, circ.instances, rng())
                 res[label] = _sha(proof) == e["proof_sha256"]
+                if label == "measured_decision":
+                    res["ntt_decision"] = (sk.shard_ntt_columns, sk.ntt_decision)
                 if label == "all_stages":
                     cnt, sizes = C.c_size_t(0), (C.c_size_t * 32)()
                     ctx._chk(ctx.lib.h2hip_plonk_pk_last_exchanges(pk.handle, sizes, 32, C.byref(cnt)))
@@ -125,7 +129,9 @@ def test_sharded_prover_multirank_shared_gpu_golden_digests(world):
         assert o["comm"] == (world, r, 0), (r, o)   # libh2hip's communicator: `world` ranks, this rank, callback transport (not RCCL)
         for name in names:
             e = o[name]
-            assert e["vk"] and e["all_stages"] and e["commitments_only"] and e["ragged"] and e["unsharded_again"] and e["verified"], (r, name, e)
+            assert e["vk"] and e["all_stages"] and e["commitments_only"] and e["ragged"] and e["measured_decision"] and e["unsharded_again"] and e["verified"], (r, name, e)
+            assert e["ntt_decision"][0] == res[0][name]["ntt_decision"][0], (r, name, e["ntt_decision"])   # every rank took the same decision
             # every stage sharded incl. the column-dealt lagrange_to_coeff: 13 host exchanges, three of them status-only go-aheads
             assert len(e["exchanges"]) == 13 and e["exchanges"][0] == 72, (r, name, e["exchanges"])
     assert res[0]["ecdsa-19"]["exchanges"] == res[world - 1]["ecdsa-19"]["exchanges"]
+    print("world %d: measured lagrange_to_coeff-by-column decisions: %r" % (world, {n: res[0][n]["ntt_decision"] for n in names}))
