@@ -1,6 +1,8 @@
 """Proof BYTES of libh2hip against the oracle prover at every BaseCircuitParams shape of the reference's two benchmark sweeps
 (halo2-ecc/configs/secp256k1/bench_ecdsa.config:1-9, halo2-ecc/configs/bn254/bench_pairing.config:1-9; the prover call is
-halo2-base/src/utils/testing.rs:32-50) — k = 11 ... 22, 18 shapes — through committed digests:
+halo2-base/src/utils/testing.rs:32-50) — k = 11 ... 22, 18 shapes — and (r05) at the shapes of its other three benchmark files
+(halo2-ecc/configs/bn254/bench_msm.config:1-13, bench_fixed_msm.config:1-12 with up to 7 constants columns, bench_ec_add.config:1-5;
+README.md:297-305: 30 lines, 22 shapes that the sweeps do not already hold, two of them without any lookup) through committed digests:
 
   tests/golden/reference_shapes_proof_digests.json   written by tests/golden/make_proof_goldens.py: the ORACLE alone (its own CPU-made SRS,
                                                      keygen, create_proof, verify_proof), no GPU library involved
@@ -27,10 +29,18 @@ def _doc():
         return json.load(f)
 
 
-def _names():
-    from tests.golden.make_proof_goldens import shapes
+def _cells(p):
+    return (p[1] + p[2]) << p[0]
 
-    return [n for n, _ in shapes()]
+
+def _more_names():
+    """the other three benchmark files' shapes that run in the default -m gpu suite: k <= 22 and at most 2^24 advice cells (the k = 21 shapes
+    with 24 columns and the k = 23 / 24 lines take minutes of witness building each: H2HIP_GOLDEN_BIG=1 adds every entry the file holds)"""
+    from tests.golden.make_proof_goldens import more_shapes
+
+    have = _doc()["shapes"]
+    big = os.environ.get("H2HIP_GOLDEN_BIG") == "1"
+    return [n for n, p, alias in more_shapes() if alias is None and n in have and (big or (p[0] <= 22 and _cells(p) <= 1 << 24))]
 
 
 def _sha(a) -> str:
@@ -44,16 +54,27 @@ def test_golden_file_covers_the_reference_sweeps():
     doc = _doc()
     assert (int(doc["toxic_s"], 16), doc["circuit_seed"], doc["rng_seed"]) == (TOXIC_S, CIRCUIT_SEED, RNG_SEED)
     want = dict(shapes())
-    assert len(want) == 18 and set(doc["shapes"]) == set(want)
+    assert len(want) == 18 and set(want) <= set(doc["shapes"])
+    # the other three files: every line is either an entry of its own or repeats a shape that has one; all lines up to k = 22 are present
+    from tests.golden.make_proof_goldens import more_shapes
+
+    lines = list(more_shapes())
+    assert len(lines) == 13 + 12 + 5 and sum(1 for _, _, a in lines if a is None) == 22
+    for name, p, alias in lines:
+        assert (alias is None) or (alias in want) or any(alias == n2 and a2 is None for n2, _, a2 in lines), (name, alias)
+        if alias is None and p[0] <= 22:
+            assert name in doc["shapes"], name
+        if alias is None and name in doc["shapes"]:
+            want[name] = p
+    assert max(p[3] for _, p, _ in lines) == 7 and any(p[2] == 0 for _, p, _ in lines)   # up to 7 constants columns; shapes without a lookup
     for name, (k, na, nl, nf, ni, lb) in want.items():
         e = doc["shapes"][name]
         assert (e["k"], e["num_advice"], e["num_lookup_advice"], e["num_fixed"], e["num_instance"], e["lookup_bits"]) == (k, na, nl, nf, ni, lb)
         assert e["verified_by_oracle_verifier"] is True and len(e["proof_sha256"]) == 64 and e["proof_len"] > 0
     # the config files' own k / column counts (halo2-ecc/configs/...: {"strategy":"Simple","degree":19,"num_advice":1,"num_lookup_advice":1,
     # "num_fixed":1,"lookup_bits":18,...}): every line keeps about the same number of advice cells
-    cells = lambda p: (p[1] + p[2]) << p[0]
-    assert all(1 << 19 <= cells(want[n]) <= 1 << 21 for n in want if n.startswith("ecdsa"))
-    assert all(1 << 21 <= cells(want[n]) <= 1 << 23 for n in want if n.startswith("pairing"))
+    assert all(1 << 19 <= _cells(want[n]) <= 1 << 21 for n in want if n.startswith("ecdsa"))
+    assert all(1 << 21 <= _cells(want[n]) <= 1 << 23 for n in want if n.startswith("pairing"))
 
 
 def test_oracle_reproduces_a_golden_entry():
@@ -105,7 +126,7 @@ def _comm(ctx, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ecdsa-%d" % k for k in range(19, 10, -1)] + ["pairing-%d" % k for k in range(14, 23)])
+@pytest.mark.parametrize("name", ["ecdsa-%d" % k for k in range(19, 10, -1)] + ["pairing-%d" % k for k in range(14, 23)] + _more_names())
 def test_proof_bytes_equal_oracle_prover_at_reference_shape(name):
     import halo2_lib_amd as H
     from halo2_lib_amd import halo2_proofs as HP
