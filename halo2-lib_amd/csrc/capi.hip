@@ -374,6 +374,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "quotient_29")) return &ctx->quotient_29;
     if (!strcmp(name, "kate_29")) return &ctx->kate_29;
     if (!strcmp(name, "host_poll")) return &ctx->host_poll;
+    if (!strcmp(name, "msm_accum_waves")) return &ctx->msm_accum_waves;
     if (!strcmp(name, "plonk_shard_side")) return &ctx->plonk_shard_side;
     if (!strcmp(name, "msm_table_split")) return &ctx->msm_table_split;
     if (!strcmp(name, "clean_on_lane")) return &ctx->clean_on_lane;
@@ -728,6 +729,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         c->msm_seg = ctx->msm_seg;
         c->msm_scatter_split = ctx->msm_scatter_split;
         c->msm_scatter_full_lds = ctx->msm_scatter_full_lds;
+        c->msm_accum_waves = ctx->msm_accum_waves;
         c->msm_sort_threads = ctx->msm_sort_threads;
         c->msm_quad_tails = ctx->msm_quad_tails;
         c->msm_quad_seg_max = ctx->msm_quad_seg_max;

@@ -150,6 +150,7 @@ struct h2hip_ctx {
     // Host round trips without the runtime's wait (r05): a one-workgroup kernel copies a small result into HOST-MAPPED memory and raises a sequence
     // flag there with a system-scope release; the host spins on the flag (sync_results / sync_stream in capi.hip).  Replaces hipMemcpyAsync(D2H) +
     // hipStreamSynchronize on the prover's ~12 round trips per proof (commitments out, challenges in).  0: the runtime's memcpy + wait.
+    int msm_accum_waves = 3;   // waves per SIMD of the accumulation: 3 (168 registers) or 2 (176 registers: room for another lane's sort workgroups on the same CU)
     int msm_table_split = 1;   // base sets are prepared with 128-byte table entries pre-split into 9 x 29-bit limbs (read when a base set is uploaded / generated)
     int host_poll = 1;
     char *poll_host = nullptr;                 // hipHostMalloc'ed (mapped, coherent): [0, 8) the flag, [64, 64 + POLL_BYTES) the payload

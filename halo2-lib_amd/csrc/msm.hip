@@ -514,6 +514,16 @@ __global__ __launch_bounds__(256, 3) void msm_accum_kernel(const uint32_t *__res
                                                           XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
     msm_accum_body<SPLIT>(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
 }
+// r05 (msm_accum_waves = 2): the same body at TWO waves per SIMD (205 registers, no spills), so that a fifth of every register file — and, with
+// 72 KiB of LDS for its two workgroups per CU, more than half of the LDS — stays free: a 1024-lane histogram / scatter workgroup of ANOTHER
+// lane's sort (24 registers per lane in the histogram, 40 in the scatter: with msm_sort_threads = 512 both fit; 64 KiB of LDS at c = 15) can then start on a CU that runs the accumulation instead of waiting for one to drain
+// (profiles/r04_timeline_k19.md: msm_scatter_kernel 656 us and msm_hist_kernel 700 us beside an accumulation, 75 / 21 us alone).
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void msm_accum2_kernel(
+    const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases, const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
+    XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
+    msm_accum_body<SPLIT>(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
+}
 
 // ------------------------------------------------------------------ 6. segmented merge of the partial list
 // One slot per lane, 256 slots per workgroup.  keys are non-decreasing; KEY_INVALID only at the tail.
@@ -983,6 +993,22 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         // (profiled launches carry their events themselves: hipExtLaunchKernelGGL — separate records around the twelve accumulations of a proof
         // cost it ~0.3 ms)
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        const bool two = ctx->msm_accum_waves == 2;
+#define H2_ACCUM_ARGS (const uint32_t *)sval, table, (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1
+        if (two) {
+#ifndef H2_HIPEMU
+            if (prof_launch_events(ctx, "msm_accum_kernel", &ev_a, &ev_b)) {
+                if (bases->split) hipExtLaunchKernelGGL(msm_accum2_kernel<true>, dim3(accum_blocks), dim3(256), 0, st, ev_a, ev_b, 0, H2_ACCUM_ARGS);
+                else hipExtLaunchKernelGGL(msm_accum2_kernel<false>, dim3(accum_blocks), dim3(256), 0, st, ev_a, ev_b, 0, H2_ACCUM_ARGS);
+            } else
+#endif
+            {
+                prof_begin(ctx, "msm_accum_kernel");
+                if (bases->split) hipLaunchKernelGGL(msm_accum2_kernel<true>, dim3(accum_blocks), dim3(256), 0, st, H2_ACCUM_ARGS);
+                else hipLaunchKernelGGL(msm_accum2_kernel<false>, dim3(accum_blocks), dim3(256), 0, st, H2_ACCUM_ARGS);
+                prof_end(ctx);
+            }
+        } else
 #ifndef H2_HIPEMU
         if (prof_launch_events(ctx, "msm_accum_kernel", &ev_a, &ev_b)) {
             if (bases->split)
