@@ -167,7 +167,7 @@ def measure_hbm_traffic(k, kernel="msm_accum_kernel"):
     """roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md's HBM / rocprofv3
     section prescribes — two SEPARATE `rocprofv3 --kernel-trace --pmc <counter>` passes (FETCH_SIZE, WRITE_SIZE) over a child run of this file's
     timed workload only (`--pmc-child`), bytes = (2 x FETCH_SIZE_KB + WRITE_SIZE_KB) x 1024: on gfx950 FETCH_SIZE tallies 128-byte requests as
-    64 B (the guide's correction; calibration in profiles/r02_hbm_counter_calibration.md).  Returns None (with the reason) if rocprofv3 is missing."""
+    64 B (the guide's correction; calibration in profiles/archive/r02_hbm_counter_calibration.md).  Returns None (with the reason) if rocprofv3 is missing."""
     import glob
     import shutil
     import sqlite3

@@ -5,7 +5,7 @@
 // issue time.  With 29-bit limbs the 81 partial products of a row-less schoolbook product (and the 81 of the
 // interleaved Montgomery reduction) accumulate straight into 64-bit column registers with v_mad_u64_u32 and no
 // carry handling at all (9*2^60 + 9*2^58 < 2^64): 171 multiplies + ~57 other instructions, measured 1.745e11
-// products/s vs 1.27e11 saturated on MI355X (profiles/r01_modmul_repr.md).
+// products/s vs 1.27e11 saturated on MI355X (profiles/archive/r01_modmul_repr.md).
 //
 // Value semantics: an Fq29 holds an integer v = sum l[i]*2^(29 i) that represents the field element
 // v * 2^-261 mod q (Montgomery radix R' = 2^261) and is only WEAKLY reduced: 0 <= v < X*q for a small bound X that

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 3) void ntt_round_probe_kernel(Fr *__restrict_
 // values).  Montgomery reduction (R = 2^260, one 52-bit digit m_k per step, m_k * r by the same hi/lo pairs) interleaved as in fq29.cuh.
 // Per product: 25 + 25 limb products = 100 FMAs + 50 exact FP subtractions + 100 64-bit integer additions + the five m_k digits, carries
 // and int <-> double conversions — against 171 v_mad_u64_u32 + 57 others for the 9 x 29-bit form, whose multiply-add already accumulates
-// 64 bits in the same instruction (profiles/r01_modmul_repr.md has the measured rates side by side).
+// 64 bits in the same instruction (profiles/archive/r01_modmul_repr.md has the measured rates side by side).
 struct Mod52 {
     // r in 52-bit limbs and -r^-1 mod 2^52
     static constexpr uint64_t P0 = 0x1f593f0000001ull, P1 = 0x4879b9709143eull, P2 = 0x181585d2833e8ull, P3 = 0xa029b85045b68ull, P4 = 0x30644e72e131ull;
@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(256, 3) void quotient_permutation_batch29_kernel(Fr
     }
 }
 
-// HBM-counter calibration probes (profiles/r02_*_pmc_*.md): a random gather of aligned ENTRY-byte table entries — the access pattern
+// HBM-counter calibration probes (profiles/archive/r02_*_pmc_*.md): a random gather of aligned ENTRY-byte table entries — the access pattern
 // of msm_accum_kernel's base-table reads (one aligned 64-byte entry per mixed addition out of a table far larger than the 256 MiB
 // Infinity Cache) — with an exactly known useful byte count, and a coalesced stream of the same volume.
 template <int ENTRY>

@@ -190,7 +190,7 @@ struct h2hip_bases {
 
 namespace h2 {
 // A table entry as msm_accum_kernel consumes it (r05): x and y already split into 9 x 29-bit limbs, 72 of the 128 bytes used.  A 64-byte gather
-// costs the memory system a 128-byte line anyway (profiles/r02_hbm_counter_calibration.md), so the wider entry moves the same HBM bytes and saves the
+// costs the memory system a 128-byte line anyway (profiles/archive/r02_hbm_counter_calibration.md), so the wider entry moves the same HBM bytes and saves the
 // two f29_split per addition (54 of ~2440 VALU instructions per step).  Identity = all-zero.
 struct alignas(128) TableEntry29 {
     uint32_t x[9], y[9];

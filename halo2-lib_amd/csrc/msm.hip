@@ -41,7 +41,7 @@ namespace h2 {
 // one workgroup per CU the compiler pads the kernel's register allocation to 96 VGPRs per lane ("occupancy is LDS-bound
 // anyway"), and a 1024-lane workgroup (4 waves per SIMD) then never fits next to three resident accumulation waves
 // (3 x 144 of 512 registers) — the sort of MSM i+1 waited for the accumulation of MSM i to drain (rocprofv3 timeline,
-// profiles/r01_pipeline_timeline_*.md).  With dynamic LDS the kernels allocate the 8-16 registers they use.
+// profiles/archive/r01_pipeline_timeline_*.md).  With dynamic LDS the kernels allocate the 8-16 registers they use.
 #ifdef H2_HIPEMU
 #define H2_TAIL_PRIORITY() ((void)0)
 #define H2_SORT_PRIORITY() ((void)0)
@@ -294,7 +294,7 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t *__restrict__ offset
 
 // One aligned 64-byte table entry.  The gather has no reuse (a 1 GiB table, one entry per addition): loaded NON-TEMPORALLY it streams past
 // the L2 instead of evicting the lines the kernel does reuse — each lane's slice of the sorted entry list (32 entries per 128-byte line,
-// touched over ~32 additions) and the bucket offsets.  rocprofv3 PMC (profiles/r02_hbm_counter_calibration.md): with plain loads the
+// touched over ~32 additions) and the bucket offsets.  rocprofv3 PMC (profiles/archive/r02_hbm_counter_calibration.md): with plain loads the
 // kernel issued 2.0 memory-side line requests per addition, one of them a re-fetch of such an evicted line.
 __device__ __forceinline__ G1Affine load_table_entry(const G1Affine *__restrict__ p) {
 #ifdef H2_HIPEMU

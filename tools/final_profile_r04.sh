@@ -33,7 +33,7 @@ try:
     k = [n for n in d if n.startswith("msm_accum_kernel")][0]
     json.dump({"kernel": k, **d[k], "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python bench.py --pmc-child --steps 4 --warmup 1` "
                "(tools/final_profile_r04.sh); bytes = (2 * FETCH_SIZE_KB + WRITE_SIZE_KB) * 1024: FETCH_SIZE tallies 128-byte requests as 64 B on gfx950 "
-               "(MI355X_MICROARCH.md, profiles/r02_hbm_counter_calibration.md); mean over the run's launches (keygen's and the proofs' 2^19-point MSMs); every kernel "
+               "(MI355X_MICROARCH.md, profiles/archive/r02_hbm_counter_calibration.md); mean over the run's launches (keygen's and the proofs' 2^19-point MSMs); every kernel "
                "of the run: profiles/r04_bench_pmc_hbm.md"}, open(os.path.join(out, "pmc_accum.json"), "w"), indent=1)
 except Exception as e:
     print("pmc_accum:", e)

@@ -24,6 +24,6 @@ if "--msm" in sys.argv:
     s = g.integers(0, 2**63, size=(1 << k, 4), dtype=np.uint64)
     s[:, 3] &= np.uint64((1 << 60) - 1)
     d = ctx.to_device(s)
-    for _ in range(4):   # (r02 compared plain against non-temporal table gathers here: profiles/r02_hbm_counter_calibration.md; only the latter is left)
+    for _ in range(4):   # (r02 compared plain against non-temporal table gathers here: profiles/archive/r02_hbm_counter_calibration.md; only the latter is left)
         ctx.msm_dev(params.g, d, 1 << k)
     print("msm done")
