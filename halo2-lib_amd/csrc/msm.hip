@@ -504,6 +504,9 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
 // r04: the accumulator's emptiness is a flag (not 36 zeroed registers tested every step) and the next bucket's end offset is requested one
 // boundary ahead: SQ_INSTS_VALU per 2^20-point launch 6.417e8 -> 6.322e8 (-1.5 %), time within noise (profiles/r04_accum_flag_ab.log) — the
 // loop is VALU-bound at ~2440 instructions per step, 1467 of them multiplies, ~560 the nine reductions' carries and quotient digits.
+// r05: two waves per SIMD once more, this time WITH room made for the other lanes' sorts beside it (205 registers without spills, 72 KiB of LDS for
+// its two workgroups per CU, the scatter on 64 KiB and 512-lane workgroups so that a histogram / scatter workgroup fits next to it): the k = 19
+// proof 13.2-13.45 vs 13.1-13.2 ms, k = 21 50.7-53.0 vs 50.1-50.7 — slower in every combination (profiles/r05_accum_two_waves_ab.log), removed.
 // three waves per SIMD (168 registers per lane); measured and left behind (profiles/r03_msm_tune_*.log, r03_knob_ab.log): two waves per
 // SIMD by launch bounds or by register padding (2 % slower / equal in isolation, nothing end to end), four (spills), the next table entry
 // requested one addition ahead (5 % slower: the gather is not what the kernel waits for), plain instead of non-temporal table loads
@@ -512,16 +515,6 @@ __global__ __launch_bounds__(256, 3) void msm_accum_kernel(const uint32_t *__res
                                                           const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
                                                           XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys,
                                                           XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
-    msm_accum_body<SPLIT>(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
-}
-// r05 (msm_accum_waves = 2): the same body at TWO waves per SIMD (205 registers, no spills), so that a fifth of every register file — and, with
-// 72 KiB of LDS for its two workgroups per CU, more than half of the LDS — stays free: a 1024-lane histogram / scatter workgroup of ANOTHER
-// lane's sort (24 registers per lane in the histogram, 40 in the scatter: with msm_sort_threads = 512 both fit; 64 KiB of LDS at c = 15) can then start on a CU that runs the accumulation instead of waiting for one to drain
-// (profiles/r04_timeline_k19.md: msm_scatter_kernel 656 us and msm_hist_kernel 700 us beside an accumulation, 75 / 21 us alone).
-template <bool SPLIT>
-__global__ __launch_bounds__(256, 2) void msm_accum2_kernel(
-    const uint32_t *__restrict__ sval, const G1Affine *__restrict__ bases, const uint32_t *__restrict__ offsets, uint32_t nkeys, uint32_t K,
-    XYZZ29 *__restrict__ buckets, uint32_t *__restrict__ out_keys, XYZZ29 *__restrict__ out_vals, uint32_t nthreads) {
     msm_accum_body<SPLIT>(sval, bases, offsets, nkeys, K, buckets, out_keys, out_vals, nthreads);
 }
 
@@ -878,8 +871,11 @@ int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes, 
     return H2HIP_OK;
 }
 
+// phase: 0 = the whole MSM; 1 = up to and including the sort (digits, histograms, scan, scatter); 2 = everything after it (same arguments: the
+// scratch buffers and launch geometry are recomputed identically).  The batch API uses 1 / 2 to queue the sorts of all its lanes' columns before
+// any accumulation (msm_sort_first).
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out, XYZZ29 *ext_buckets,
-                 bool ext_buckets_zeroed) {
+                 bool ext_buckets_zeroed, int phase) {
     H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..32 columns per fused MSM");
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
@@ -887,7 +883,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     hipStream_t st = ctx->stream;
     if (n == 0) {
         H2_REQUIRE(!ext_buckets, "empty MSM in a deferred-reduction batch");
-        H2_HIPCHK(hipMemsetAsync(out, 0, sizeof(XYZZ) * ncols, st));
+        if (phase != 1) H2_HIPCHK(hipMemsetAsync(out, 0, sizeof(XYZZ) * ncols, st));
         return H2HIP_OK;
     }
     const bool precomp = bases->tables > 1;
@@ -944,6 +940,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ29) * 2 * (size_t)blocks1, (void **)&pval[1]));
 
     // ---- sort
+    if (phase != 2) {
     if (ext_buckets) {   // a batch's shared array: zeroed by the batch (after its previous use) or here
         if (!ext_buckets_zeroed) H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
     } else if (buckets_prezeroed(ctx, 0, buckets, sizeof(XYZZ29) * nkeys)) {
@@ -987,28 +984,14 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
                        (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
+    }   // phase != 2
+    if (phase == 1) return H2HIP_OK;
 
     // ---- accumulate (+ wave-level merge), then the block-level merge of the wave-boundary partials
     {
         // (profiled launches carry their events themselves: hipExtLaunchKernelGGL — separate records around the twelve accumulations of a proof
         // cost it ~0.3 ms)
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
-        const bool two = ctx->msm_accum_waves == 2;
-#define H2_ACCUM_ARGS (const uint32_t *)sval, table, (const uint32_t *)offsets, nkeys, K1, buckets, pkey[0], pval[0], T1
-        if (two) {
-#ifndef H2_HIPEMU
-            if (prof_launch_events(ctx, "msm_accum_kernel", &ev_a, &ev_b)) {
-                if (bases->split) hipExtLaunchKernelGGL(msm_accum2_kernel<true>, dim3(accum_blocks), dim3(256), 0, st, ev_a, ev_b, 0, H2_ACCUM_ARGS);
-                else hipExtLaunchKernelGGL(msm_accum2_kernel<false>, dim3(accum_blocks), dim3(256), 0, st, ev_a, ev_b, 0, H2_ACCUM_ARGS);
-            } else
-#endif
-            {
-                prof_begin(ctx, "msm_accum_kernel");
-                if (bases->split) hipLaunchKernelGGL(msm_accum2_kernel<true>, dim3(accum_blocks), dim3(256), 0, st, H2_ACCUM_ARGS);
-                else hipLaunchKernelGGL(msm_accum2_kernel<false>, dim3(accum_blocks), dim3(256), 0, st, H2_ACCUM_ARGS);
-                prof_end(ctx);
-            }
-        } else
 #ifndef H2_HIPEMU
         if (prof_launch_events(ctx, "msm_accum_kernel", &ev_a, &ev_b)) {
             if (bases->split)
@@ -1054,7 +1037,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 }
 
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
-    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr, false);
+    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr, false, 0);
 }
 
 }  // namespace h2
