@@ -374,7 +374,6 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "quotient_29")) return &ctx->quotient_29;
     if (!strcmp(name, "kate_29")) return &ctx->kate_29;
     if (!strcmp(name, "host_poll")) return &ctx->host_poll;
-    if (!strcmp(name, "msm_sort_first")) return &ctx->msm_sort_first;
     if (!strcmp(name, "plonk_shard_side")) return &ctx->plonk_shard_side;
     if (!strcmp(name, "msm_table_split")) return &ctx->msm_table_split;
     if (!strcmp(name, "clean_on_lane")) return &ctx->clean_on_lane;
@@ -817,15 +816,9 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         return H2HIP_OK;
     };
     const size_t ngroups = groups.size();
-    // r05 (msm_sort_first): a lane's sort that starts while another lane's accumulation holds every CU takes 5 - 10 x its time (its 1024-lane
-    // workgroups need a CU's LDS to themselves: profiles/r04_timeline_k19.md, round 4: scatter 656 us, histogram 700 us beside an accumulation, 75 /
-    // 21 us alone) and the accumulation it delays then runs alone at the end of the round.  With the switch the groups go in rounds of NL: the
-    // sorts of a round's groups are queued on all lanes first, every lane waits for all of them, then the accumulations start together.
-    const bool sort_first = ctx->msm_sort_first != 0 && deferred && NL > 1 && ngroups > 1 && !scalars_on_host;
-    if (sort_first)
-        for (int l = 0; l < NL; ++l)
-            if (!ctx->lane[l]->tail_ev) H2_HIPCHK(hipEventCreateWithFlags(&ctx->lane[l]->tail_ev, hipEventDisableTiming));
-    size_t round_start = 0;
+    // (r05 built and measured a third schedule — the sorts of a round of columns queued on ALL lanes before any of their accumulations, so that no
+    // sort starts beside an accumulation that holds every CU: the k = 19 proof 13.8-14.0 vs 13.7-13.9 ms, k = 21 53.4-54.0 vs 52.8-53.2, k = 15 / 18
+    // equal — profiles/r05_msm_sort_first_ab.log; removed)
     for (size_t g = 0; g < ngroups; ++g) {
         const size_t j0 = groups[g].first, gsize = groups[g].second;
         if (mid_hook && j0 + gsize > mid_after) H2_LANES_RC(run_mid());
@@ -836,25 +829,6 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         }
         char *outbuf = nullptr;
         H2_LANES_RC(ws_reserve(c, h2hip_ctx::WS_OUT, sizeof(XYZZ) * MSM_MAX_COLS, (void **)&outbuf));
-        if (sort_first) {
-            H2_LANES_RC(msm_run_cols(c, gb, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf, all_buckets + keys_per_col * j0, buckets_zeroed, 1));
-            H2_LANES(hipEventRecord(c->tail_ev, c->stream));
-            const bool round_end = g + 1 - round_start == (size_t)NL || g + 1 == ngroups || (mid_hook && groups[g + 1].first + groups[g + 1].second > mid_after);
-            if (!round_end) continue;
-            const size_t g0 = round_start;   // the round's groups: g0 .. g, on distinct lanes (consecutive groups, at most NL of them)
-            round_start = g + 1;
-            for (size_t a = g0; a <= g; ++a)
-                for (size_t b = g0; b <= g; ++b)
-                    if (a != b) H2_LANES(hipStreamWaitEvent(ctx->lane[a % NL]->stream, ctx->lane[b % NL]->tail_ev, 0));
-            for (size_t a = g0; a <= g; ++a) {
-                h2hip_ctx *ca = ctx->lane[a % NL];
-                char *ob = nullptr;
-                H2_LANES_RC(ws_reserve(ca, h2hip_ctx::WS_OUT, sizeof(XYZZ) * MSM_MAX_COLS, (void **)&ob));
-                H2_LANES_RC(msm_run_cols(ca, bases_of(groups[a].first), (const Fr *const *)(scalars_dev + groups[a].first), (uint32_t)groups[a].second, n, (XYZZ *)ob,
-                                         all_buckets + keys_per_col * groups[a].first, buckets_zeroed, 2));
-            }
-            continue;
-        }
         H2_LANES_RC(msm_run_cols(c, gb, (const Fr *const *)(scalars_dev + j0), (uint32_t)gsize, n, (XYZZ *)outbuf,
                                  deferred ? all_buckets + keys_per_col * j0 : nullptr, buckets_zeroed));
         if (!deferred) {   // the group's results, one lane each, into their slots of the batch's result array

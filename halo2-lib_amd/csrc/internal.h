@@ -150,7 +150,6 @@ struct h2hip_ctx {
     // Host round trips without the runtime's wait (r05): a one-workgroup kernel copies a small result into HOST-MAPPED memory and raises a sequence
     // flag there with a system-scope release; the host spins on the flag (sync_results / sync_stream in capi.hip).  Replaces hipMemcpyAsync(D2H) +
     // hipStreamSynchronize on the prover's ~12 round trips per proof (commitments out, challenges in).  0: the runtime's memcpy + wait.
-    int msm_sort_first = 0;    // batch MSM: the sorts of a round of columns (one per lane) are all queued before any of their accumulations
     int msm_table_split = 1;   // base sets are prepared with 128-byte table entries pre-split into 9 x 29-bit limbs (read when a base set is uploaded / generated)
     int host_poll = 1;
     char *poll_host = nullptr;                 // hipHostMalloc'ed (mapped, coherent): [0, 8) the flag, [64, 64 + POLL_BYTES) the payload
@@ -221,7 +220,7 @@ int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars_dev, siz
 constexpr uint32_t MSM_MAX_COLS = 32;   // columns one fused multi-column MSM handles
 // ext_buckets != nullptr: stop after the merge and leave the columns' buckets ([col][windows][B]; zeroed here unless ext_buckets_zeroed) there for msm_reduce_cols
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars_dev, uint32_t ncols, size_t n, XYZZ *out_dev,
-                 XYZZ29 *ext_buckets, bool ext_buckets_zeroed = false, int phase = 0);   // phase 1: the sort only, 2: what follows it
+                 XYZZ29 *ext_buckets, bool ext_buckets_zeroed = false);
 // zero-fill-after-use of the bucket arrays (see h2hip_ctx::clean_*): is the buffer's head already (scheduled to be) zero?  (a true answer
 // CONSUMES the state: the caller dirties the array) / schedule the fill
 bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes);

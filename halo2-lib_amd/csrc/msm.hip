@@ -871,11 +871,8 @@ int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes, 
     return H2HIP_OK;
 }
 
-// phase: 0 = the whole MSM; 1 = up to and including the sort (digits, histograms, scan, scatter); 2 = everything after it (same arguments: the
-// scratch buffers and launch geometry are recomputed identically).  The batch API uses 1 / 2 to queue the sorts of all its lanes' columns before
-// any accumulation (msm_sort_first).
 int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scalars, uint32_t ncols, size_t n, XYZZ *out, XYZZ29 *ext_buckets,
-                 bool ext_buckets_zeroed, int phase) {
+                 bool ext_buckets_zeroed) {
     H2_REQUIRE(ncols >= 1 && ncols <= MSM_MAX_COLS, "1..32 columns per fused MSM");
     H2_REQUIRE(n <= bases->n, "more scalars than resident bases");
     H2_REQUIRE(bases->pts29 != nullptr || bases->n == 0, "bases are not prepared");
@@ -883,7 +880,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     hipStream_t st = ctx->stream;
     if (n == 0) {
         H2_REQUIRE(!ext_buckets, "empty MSM in a deferred-reduction batch");
-        if (phase != 1) H2_HIPCHK(hipMemsetAsync(out, 0, sizeof(XYZZ) * ncols, st));
+        H2_HIPCHK(hipMemsetAsync(out, 0, sizeof(XYZZ) * ncols, st));
         return H2HIP_OK;
     }
     const bool precomp = bases->tables > 1;
@@ -940,7 +937,6 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_PVAL1, sizeof(XYZZ29) * 2 * (size_t)blocks1, (void **)&pval[1]));
 
     // ---- sort
-    if (phase != 2) {
     if (ext_buckets) {   // a batch's shared array: zeroed by the batch (after its previous use) or here
         if (!ext_buckets_zeroed) H2_HIPCHK(hipMemsetAsync(buckets, 0, sizeof(XYZZ29) * nkeys, st));
     } else if (buckets_prezeroed(ctx, 0, buckets, sizeof(XYZZ29) * nkeys)) {
@@ -984,8 +980,6 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
                        (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
-    }   // phase != 2
-    if (phase == 1) return H2HIP_OK;
 
     // ---- accumulate (+ wave-level merge), then the block-level merge of the wave-boundary partials
     {
@@ -1037,7 +1031,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
 }
 
 int msm_run(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *scalars, size_t n, XYZZ *out) {
-    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr, false, 0);
+    return msm_run_cols(ctx, bases, &scalars, 1, n, out, nullptr, false);
 }
 
 }  // namespace h2
