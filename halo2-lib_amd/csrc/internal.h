@@ -126,6 +126,7 @@ struct h2hip_ctx {
     int clean_on_lane = 1;           // the batch MSM's bucket zero-fill on its first lane's stream (0: the context's clean stream)
     int kate_29 = 1;                 // the kate division and batched evaluation kernels on unsaturated 9 x 29-bit limbs; 0: the saturated kernels
     int kate_coeffs_per_lane = 0;    // multi-point kate division: coefficients per lane (1, 2, 4, 8); 0 = by length
+    int plonk_merge_products = 1;    // one permutation set: its factors and the lookups' go through ONE batched inversion / prefix product
     int plonk_shard_side = 1;        // sharded create_proof: the first-round columns' lagrange_to_coeff (+ all-gather) and coset transforms on a side stream next to round 2's commitments
     int plonk_side_on_lanes = 1;     // the side work of plonk_tail_overlap runs on the batch MSM's last (idle) lane context instead of a context of its own
 #ifdef H2_HIPEMU

@@ -1112,7 +1112,11 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         if (num) sc.release(num);
         if (stage_ms) laps.lap(ST_PRODUCTS);
     } else {
-        const size_t segs = std::max<size_t>(sh.num_perm_sets, lks.size());
+        // r05: with ONE permutation set (nothing to chain) the permutation's and the lookups' factors go through ONE batched inversion and ONE
+        // prefix product — segments [set | lookup 0 | lookup 1 ...] — instead of two passes of seven launches each (the k = 19 ECDSA shape: the second
+        // pass was ~0.25 ms of small launches on the critical path).  Same values: every segment is its own product either way.
+        const bool merged = ctx->plonk_merge_products != 0 && sh.num_perm_sets == 1 && !lks.empty();
+        const size_t segs = merged ? 1 + lks.size() : std::max<size_t>(sh.num_perm_sets, lks.size());
         Fr *num = nullptr, *den = nullptr;
         if (segs) {
             H2_CHK(sc.take(segs * (size_t)u, &num));
@@ -1128,7 +1132,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                                                             &dom.delta, &dom.omega));
         }
         for (uint32_t si = 0; si < sh.num_perm_sets; ++si) H2_CHK(sc.take(n, &perm_z[si]));
-        if (sh.num_perm_sets) H2_CHK(h2hip_fr_grand_products_dev(ctx, (void *const *)perm_z.data(), num, den, sh.num_perm_sets, u, 1));
+        if (sh.num_perm_sets && !merged) H2_CHK(h2hip_fr_grand_products_dev(ctx, (void *const *)perm_z.data(), num, den, sh.num_perm_sets, u, 1));
         {
             TailRun tz;
             tails_reserve(tz, sh.num_perm_sets, (size_t)bf + 1, bf);
@@ -1140,14 +1144,21 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             H2_CHK(tails_flush(tz));
         }
         std::vector<void *> lk_z(lks.size());
+        const size_t lk0 = merged ? 1 : 0;   // the lookups' first segment
         for (size_t li = 0; li < lks.size(); ++li) {
             LookupState &s = lks[li];
-            H2_CHK(h2hip_lookup_product_terms_dev(ctx, num + li * (size_t)u, den + li * (size_t)u, s.inp, pk->fixed_values[sh.lookups[li].table_col], s.ap, s.sp,
-                                                  u, &beta, &gamma));
+            H2_CHK(h2hip_lookup_product_terms_dev(ctx, num + (lk0 + li) * (size_t)u, den + (lk0 + li) * (size_t)u, s.inp, pk->fixed_values[sh.lookups[li].table_col],
+                                                  s.ap, s.sp, u, &beta, &gamma));
             H2_CHK(sc.take(n, &s.z));
             lk_z[li] = s.z;
         }
-        if (!lks.empty()) H2_CHK(h2hip_fr_grand_products_dev(ctx, lk_z.data(), num, den, lks.size(), u, 0));
+        if (merged) {
+            std::vector<void *> all_z(1, perm_z[0]);
+            all_z.insert(all_z.end(), lk_z.begin(), lk_z.end());
+            H2_CHK(h2hip_fr_grand_products_dev(ctx, all_z.data(), num, den, all_z.size(), u, 0));
+        } else if (!lks.empty()) {
+            H2_CHK(h2hip_fr_grand_products_dev(ctx, lk_z.data(), num, den, lks.size(), u, 0));
+        }
         {
             TailRun tz;
             tails_reserve(tz, lks.size(), (size_t)bf + 1, bf);
