@@ -374,7 +374,6 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "quotient_29")) return &ctx->quotient_29;
     if (!strcmp(name, "kate_29")) return &ctx->kate_29;
     if (!strcmp(name, "host_poll")) return &ctx->host_poll;
-    if (!strcmp(name, "plonk_split_single_msm")) return &ctx->plonk_split_single_msm;
     if (!strcmp(name, "plonk_merge_products")) return &ctx->plonk_merge_products;
     if (!strcmp(name, "plonk_shard_side")) return &ctx->plonk_shard_side;
     if (!strcmp(name, "msm_table_split")) return &ctx->msm_table_split;

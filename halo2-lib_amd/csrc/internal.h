@@ -126,8 +126,6 @@ struct h2hip_ctx {
     int clean_on_lane = 1;           // the batch MSM's bucket zero-fill on its first lane's stream (0: the context's clean stream)
     int kate_29 = 1;                 // the kate division and batched evaluation kernels on unsaturated 9 x 29-bit limbs; 0: the saturated kernels
     int kate_coeffs_per_lane = 0;    // multi-point kate division: coefficients per lane (1, 2, 4, 8); 0 = by length
-    int plonk_split_single_msm = 0;  // a round with ONE commitment (SHPLONK's W and W'): 2 / 4 = the MSM runs as that many point-range parts through the batch API (co-running
-                                     // accumulations, shorter sorts, one shared reduction), the parts' sums added on the host; 0 / 1 = one MSM
     int plonk_merge_products = 1;    // one permutation set: its factors and the lookups' go through ONE batched inversion / prefix product
     int plonk_shard_side = 1;        // sharded create_proof: the first-round columns' lagrange_to_coeff (+ all-gather) and coset transforms on a side stream next to round 2's commitments
     int plonk_side_on_lanes = 1;     // the side work of plonk_tail_overlap runs on the batch MSM's last (idle) lane context instead of a context of its own
@@ -185,8 +183,6 @@ struct h2hip_bases {
     h2::G1Affine *pts29 = nullptr;    // [tables][n] the same points in the unsaturated domain (x*2^261, y*2^261): packed 8 x 32-bit limbs, 64 B per entry — or,
                                       // with `split`, 128-byte entries that hold the 9 x 29-bit limbs the accumulation consumes (h2::TableEntry29)
     bool split = false;               // r05 (msm_table_split): pts29 holds TableEntry29, not G1Affine
-    size_t stride = 0;                // entries between two table levels; 0 = n.  A VIEW of a point range [lo, lo + len) of a base set (pts29 advanced by lo
-                                      // entries, n = len) keeps its parent's stride: the prover splits a lone commitment into co-running partial MSMs with it
     size_t n = 0;
     uint32_t window_bits = 0;      // precomputed mode: window the table was built for
     uint32_t tables = 1;           // 1 = plain; W = precomputed 2^(c*w) multiples

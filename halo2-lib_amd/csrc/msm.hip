@@ -976,7 +976,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     if (S > B) S = B;
     const uint32_t scatter_grid = sort_grid_size(W * S, G);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(sort_threads), ctx->msm_scatter_full_lds ? sizeof(uint32_t) * MAX_LDS_BUCKETS : sizeof(uint32_t) * (B / S), st,   // full 128 KiB: one workgroup per CU keeps a segment's writes on one XCD
-                       (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S, precomp ? (uint32_t)(bases->stride ? bases->stride : bases->n) : 0u, Wcol, (const uint32_t *)offsets,
+                       (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S, precomp ? (uint32_t)bases->n : 0u, Wcol, (const uint32_t *)offsets,
                        (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());

@@ -713,42 +713,6 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         const size_t lo = sharded ? std::min(pk->shard_offset, len) : 0, hi = sharded ? std::min(pk->shard_offset + pk->shard_len, len) : len;
         std::vector<const void *> local(cols.size());
         for (size_t i = 0; i < cols.size(); ++i) local[i] = (const Fr *)cols[i] + lo;
-        const uint32_t parts = (uint32_t)ctx->plonk_split_single_msm;
-#ifdef H2_HIPEMU
-        const size_t split_min = 32;   // (the CPU-emulated tests prove 2^6-row circuits)
-#else
-        const size_t split_min = (size_t)1 << 18;
-#endif
-        if (cols.size() == 1 && !sharded && (parts == 2 || parts == 4) && bpc[0]->tables > 1 && hi - lo >= split_min && (hi - lo) % parts == 0) {
-            // r05: a lone commitment as `parts` point-range MSMs on the batch API's lanes — views of the base set that keep its table-level stride —
-            // whose partial sums are added here (a group element has one affine form: same bytes)
-            const size_t part = (hi - lo) / parts, entry = bpc[0]->split ? sizeof(TableEntry29) : sizeof(G1Affine);
-            std::vector<h2hip_bases> views(parts, *bpc[0]);
-            std::vector<const h2hip_bases *> vp(parts);
-            std::vector<const void *> sp(parts);
-            std::vector<G1Jac> pj(parts);
-            for (uint32_t p = 0; p < parts; ++p) {
-                views[p].pts = nullptr;
-                views[p].pts29 = (G1Affine *)((char *)bpc[0]->pts29 + entry * (p * part));
-                views[p].n = part;
-                views[p].stride = bpc[0]->stride ? bpc[0]->stride : bpc[0]->n;
-                vp[p] = &views[p];
-                sp[p] = (const Fr *)local[0] + p * part;
-            }
-            H2_CHK(h2hip_msm_g1_multi_dev(ctx, vp.data(), sp.data(), part, parts, H2HIP_POINT_JACOBIAN, pj.data()));
-            XYZZ acc = XYZZ::identity();
-            for (uint32_t p = 0; p < parts; ++p) {
-                if (pj[p].z.is_zero()) continue;
-                XYZZ q;
-                q.x = pj[p].x;
-                q.y = pj[p].y;
-                q.zz = fe_sqr(pj[p].z);
-                q.zzz = fe_mul(q.zz, pj[p].z);
-                xyzz_add(acc, q);
-            }
-            pts.assign(1, xyzz_to_affine(acc));
-            return H2HIP_OK;
-        }
         if (cols.size() == 1)
             H2_CHK(h2hip_msm_g1_dev(ctx, bpc[0], local[0], hi - lo, H2HIP_POINT_JACOBIAN, jac.data()));
         else if (!cols.empty())
