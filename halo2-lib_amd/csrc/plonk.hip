@@ -713,6 +713,9 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         const size_t lo = sharded ? std::min(pk->shard_offset, len) : 0, hi = sharded ? std::min(pk->shard_offset + pk->shard_len, len) : len;
         std::vector<const void *> local(cols.size());
         for (size_t i = 0; i < cols.size(); ++i) local[i] = (const Fr *)cols[i] + lo;
+        // (r05 ran a lone commitment — SHPLONK's W and W' — as 2 / 4 point-range parts on the batch API's lanes, co-running accumulations and shorter
+        // sorts against one more join: the k = 19 proof 13.2-13.4 / 13.5-13.7 vs 13.0-13.1 ms, k = 21 51.6-52.5 vs 49.8-51.8: slower, removed —
+        // profiles/r05_split_single_msm_ab.log)
         if (cols.size() == 1)
             H2_CHK(h2hip_msm_g1_dev(ctx, bpc[0], local[0], hi - lo, H2HIP_POINT_JACOBIAN, jac.data()));
         else if (!cols.empty())
