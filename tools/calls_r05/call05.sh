@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05 GPU call 5: the accumulation at two waves per SIMD (205 registers, no spills) with the sorts' LDS / workgroup size chosen so that another lane's
+# (msm_accum_waves was removed after this call: slower, profiles/r05_accum_two_waves_ab.log) r05 GPU call 5: the accumulation at two waves per SIMD (205 registers, no spills) with the sorts' LDS / workgroup size chosen so that another lane's
 # histogram / scatter workgroups can co-reside with it — whole proofs at k = 19 and k = 21, batches of 4 MSMs
 set -u
 O=$PWD/gpurun_out/r05c05; mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05 GPU call 6: sort-first scheduling of the batch MSM (msm_sort_first: the sorts of a round of columns are queued on all lanes before any of their
+# (msm_sort_first was removed after this call: neutral-to-slower, profiles/r05_msm_sort_first_ab.log) r05 GPU call 6: sort-first scheduling of the batch MSM (msm_sort_first: the sorts of a round of columns are queued on all lanes before any of their
 # accumulations) — whole proofs at k = 19 / 21 / 15 (17 + 3 columns), with 3 and 4 lanes; MSM parity tests under the switch
 set -u
 O=$PWD/gpurun_out/r05c06; mkdir -p $O
