@@ -63,9 +63,13 @@ int h2hip_sync(h2hip_ctx *ctx);
  * "kate_coeffs_per_lane" (0 = by length); arithmetic form of the pointwise kernels: "quotient_29", "kate_29" (1 = unsaturated 9 x 29-bit
  * limbs, 0 = the saturated kernels: same results); the prover's scheduling: "plonk_tail_overlap", "plonk_side_on_lanes",
  * "plonk_permute_in_commit", "plonk_warm_keygen", "clean_on_lane" (1 everywhere: 0 switches the overlap off, same proof bytes);
+ * r05: "host_poll" (1: results of a round come back through a host-mapped flag instead of hipMemcpyAsync + hipStreamSynchronize),
+ * "msm_table_split" (1: base sets uploaded / generated AFTER the call get 128-byte table entries pre-split into 9 x 29-bit limbs),
+ * "plonk_merge_products" (1: one batched inversion / prefix product for the permutation set and the lookups when nothing chains),
+ * "plonk_shard_side" (1: sharded proofs run the first-round columns' transforms and all-gather on a side stream);
  * profiling aid: "ntt_debug_skip" (produces wrong results).  The variants r01-r03 measured slower (two-level sort, bucket-major sort,
- * split streams, split windows, accumulation builds 2/5/6/7, radix-8 and wave-local NTT passes) were removed in r04; their A/B logs stay
- * under profiles/. */
+ * split streams, split windows, accumulation builds 2/5/6/7, radix-8 and wave-local NTT passes) were removed in r04, r05's (two-wave
+ * accumulation, sort-first batches, split lone commitments) in r05; their A/B logs stay under profiles/. */
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value);
 int h2hip_get_param(h2hip_ctx *ctx, const char *name, int *value);
 

@@ -44,6 +44,8 @@ except Exception as e:
 PY
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/p19 $OUT/p21
 timeout 300 python tools/ntt_r04.py ntt_tile_kernel=1:0 > $OUT/ntt_times.log 2>&1
+bash tools/ntt_pmc.sh > $OUT/ntt_pmc.log 2>&1
+bash tools/accum_pmc.sh > $OUT/accum_pmc.log 2>&1
 timeout 300 python tools/msm_r03.py 19,20 > $OUT/msm_breakdown.log 2>&1
 timeout 900 python tools/config_sweep.py all 5 > $OUT/config_sweep.md 2> $OUT/config_sweep.err
 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --share-device --dist-backend gloo --steps 5 --warmup 2 --no-sweep --shard-ntt-columns on 2> $OUT/bench_2rank.err | tail -1 > $OUT/bench_2rank_shared_gpu_gloo_pairing21.json
