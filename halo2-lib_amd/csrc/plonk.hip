@@ -787,6 +787,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         c->ntt_min_col_bits = ctx->ntt_min_col_bits;
         c->ntt_full_table = ctx->ntt_full_table;
         c->ntt_tile_kernel = ctx->ntt_tile_kernel;
+        c->ntt_w8 = ctx->ntt_w8;
         c->msm_chunk = ctx->msm_chunk;
         c->msm_seg = ctx->msm_seg;
         c->profiling = ctx->profiling;

@@ -50,17 +50,32 @@ __device__ __forceinline__ void dft8(Fr29 (&a)[8], const W8 &t) {
 struct P36 {
     uint32_t l[9];
 };
+// (template recursion instead of `#pragma unroll`: with the pragma the compiler re-rolled the loop and moved v[] to scratch memory)
+template <int R>
+__device__ __forceinline__ void twiddle_all(Fr29 (&v)[8], const P36 *twl, uint32_t lane, uint32_t it) {
+    if constexpr (R < 8) {
+        const P36 *tp = &twl[(lane + 64 * R + it) & 511];   // (consecutive lanes, 36-byte stride: conflict-free)
+        Fr29 w;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) w.l[l] = tp->l[l];
+        v[R] = f29_mul(v[R], w);
+        twiddle_all<R + 1>(v, twl, lane, it);
+    }
+}
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 // MODE 0: registers only (DFT8 + 8 twiddle products, twiddles from LDS); MODE 1: + the wave-private LDS transposition (three planes); MODE 2: + a block barrier per round
-template <int MODE>
+// CODE (r05, second question — is the loop's SIZE what holds the waves back?): 0 = both blocks unrolled (13 products, ~31 KB of code per iteration);
+// 1 = the DFT8 only (5 products, ~13 KB); 2 = the 8 twiddle products only (~14 KB); 3 = the DFT8 unrolled, the twiddle products as a ROLLED loop
+// over elements parked in the wave's LDS buffer (one product's code: ~15 KB in all)
+template <int MODE, int CODE = 0>
 __global__ __launch_bounds__(256, 3) void w8_probe(uint32_t *out, int iters, W8 t) {
     __shared__ P36 twl[512];
     __shared__ v4u xbuf[4][8 * 68];   // per wave: 8 rows of 64 chunks (+4 pad) of 16 bytes
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t i = tid; i < 512; i += 256) {
 #pragma unroll
-        for (int l = 0; l < 9; ++l) twl[i].l[l] = (t.w[1 + (i & 1)][l] + i) & MASK29;
+        for (int l = 0; l < 9; ++l) twl[i].l[l] = (((i & 1) ? t.w[2][l] : t.w[1][l]) + i) & MASK29;
     }
     __syncthreads();
     Fr29 v[8];
@@ -70,14 +85,34 @@ __global__ __launch_bounds__(256, 3) void w8_probe(uint32_t *out, int iters, W8 
         for (int l = 0; l < 9; ++l) v[r].l[l] = (t.w[r & 3][l] ^ (lane * 0x9E37u + r)) & (l == 8 ? 0x3FFFFFu : MASK29);
     v4u *xb = xbuf[wave];
     for (int it = 0; it < iters; ++it) {
-        dft8(v, t);
+        if (CODE != 2) dft8(v, t);
+        if (CODE == 0 || CODE == 2) twiddle_all<0>(v, twl, lane, (uint32_t)it);
+        if (CODE == 3) {   // park the eight elements in LDS (three planes of the wave's buffer would do; here: 9 words per element, lane-major), multiply them in a rolled loop
+            P36 *park = reinterpret_cast<P36 *>(xb);   // 64 lanes x 8 x 36 B = 18 KB > the 8.5 KB buffer: the probe parks FOUR elements at a time
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const P36 *tp = &twl[(lane * 8 + r * 37 + it) & 511];
-            Fr29 w;
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int l = 0; l < 9; ++l) w.l[l] = tp->l[l];
-            v[r] = f29_mul(v[r], w);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int l = 0; l < 9; ++l) park[(r * 64 + lane)].l[l] = v[half * 4 + r].l[l];
+#pragma unroll 1
+                for (int r = 0; r < 4; ++r) {
+                    const P36 *tp = &twl[(lane + 64 * (half * 4 + r) + it) & 511];
+                    Fr29 w, x;
+#pragma unroll
+                    for (int l = 0; l < 9; ++l) {
+                        w.l[l] = tp->l[l];
+                        x.l[l] = park[r * 64 + lane].l[l];
+                    }
+                    x = f29_mul(x, w);
+#pragma unroll
+                    for (int l = 0; l < 9; ++l) park[r * 64 + lane].l[l] = x.l[l];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int l = 0; l < 9; ++l) v[half * 4 + r].l[l] = park[(r * 64 + lane)].l[l];
+            }
         }
         if (MODE >= 1) {
             // transposition among the wave's 64 x 8 elements, plane by plane: write row r at chunk (lane), read 8 consecutive chunks of row (lane >> 3)...
@@ -163,6 +198,15 @@ int main() {
     printf("radix-8 rounds in registers (DFT8 + 8 twiddle products, twiddles from LDS): %.4g products/s = %.2f of the peak\n", work / (m0 * 1e-3), work / (m0 * 1e-3) / peak);
     printf("  + wave-private LDS transposition, three planes, no block barrier:          %.4g products/s = %.2f of the peak\n", work / (m1 * 1e-3), work / (m1 * 1e-3) / peak);
     printf("  + a block barrier per round:                                               %.4g products/s = %.2f of the peak\n", work / (m2 * 1e-3), work / (m2 * 1e-3) / peak);
+    {
+        const double a = time_ms([&] { hipLaunchKernelGGL((w8_probe<0, 1>), dim3(blocks), dim3(256), 0, 0, out, iters, t); });
+        const double b = time_ms([&] { hipLaunchKernelGGL((w8_probe<0, 2>), dim3(blocks), dim3(256), 0, 0, out, iters, t); });
+        const double c = time_ms([&] { hipLaunchKernelGGL((w8_probe<0, 3>), dim3(blocks), dim3(256), 0, 0, out, iters, t); });
+        const double w5 = 5.0 * 256 * blocks * iters, w8 = 8.0 * 256 * blocks * iters;
+        printf("code size: the DFT8 alone (5 products, ~13 KB per iteration):        %.4g products/s = %.2f of the peak\n", w5 / (a * 1e-3), w5 / (a * 1e-3) / peak);
+        printf("code size: the 8 twiddle products alone (~14 KB):                    %.4g products/s = %.2f of the peak\n", w8 / (b * 1e-3), w8 / (b * 1e-3) / peak);
+        printf("code size: DFT8 unrolled + twiddle products ROLLED through LDS (~15 KB): %.4g products/s = %.2f of the peak\n", work / (c * 1e-3), work / (c * 1e-3) / peak);
+    }
     printf("(ntt_tile_kernel today: 0.47-0.51 of the peak by algorithmic products at 2^22 .. 2^24, x 11.5 / 11 executed)\n");
     hipFree(out);
     return 0;
