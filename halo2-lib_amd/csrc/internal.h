@@ -80,7 +80,7 @@ struct h2hip_ctx {
     int ntt_tile_bits = 10;
     int ntt_min_col_bits = 2;    // log2 of the minimum number of adjacent columns per tile (coalescing vs number of passes)
     int ntt_full_table = 1;      // first pass reads a full omega^e table instead of composing two table entries
-    int ntt_w8 = 1;              // r05: transforms of 2^12+ points run on the wave-owned radix-8 pass (ntt_w8_kernel); 0: the tile / generic pass kernels
+    int ntt_w8 = 0;              // r05: 1 / 2 = transforms of 2^12+ points on the wave-owned radix-8 pass (ntt_w8_kernel) at three / two waves per SIMD — bit-exact, measured 8-12 % slower; 0: the tile / generic pass kernels
     int ntt_tile_kernel = 1;     // 1 (default): full 1024-element tiles go through ntt_tile_kernel (r04: no exposed global-memory latency); 0: the generic pass kernel
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)

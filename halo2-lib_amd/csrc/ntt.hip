@@ -421,6 +421,11 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
 // no __syncthreads anywhere in the tile loop, no LDS element storage, global loads straight into the first step's register layout and stores
 // straight out of the last one's.  What the r05 probe (tools/probes/w8_probe.hip) measured for this inner structure: 0.77 of the 9 x 29-bit
 // product peak, against ~0.50 (executed products) for the block-barrier radix-4 LDS rounds of ntt_tile_kernel above.
+// MEASURED AS A WHOLE KERNEL (profiles/r05_ntt_w8_ab.log): bit-exact, and 8 - 12 % SLOWER than ntt_tile_kernel (2^22 0.63-0.65 vs 0.583 ms, the k = 21
+// proof 53.6-54.0 vs 52.0-52.7 ms).  PMC: half the LDS instructions and a third of the bank conflicts, as designed — but 8 % more VALU instructions
+// (every in-register stage normalises both outputs where the radix-4 round's lazy sums feed a wide product) and waves parked on memory 30 % of
+// their time against 17 % (228 registers at two waves per SIMD leave none for a prefetched tile; at three waves 43-88 registers spill).  It stays
+// selectable (ntt_w8 = 1 / 2: three / two waves per SIMD; default 0) and tested; the tile kernel remains the product path.
 //
 // Index algebra.  Row t = t1 * 2^(m-3) + t2 * R3 + t3 (t1, t2: 3 bits; t3: m3 = m - 6 bits; R3 = 2^m3), output u = u1 + 8 u2 + 64 u3:
 //   step 1   A[u1; t2, t3] = sum_t1 x[t1, t2, t3] w_8^(t1 u1)                      registers = t1, lane = (t2 | t3, c)
@@ -585,19 +590,21 @@ __global__ __launch_bounds__(256, WPS) void ntt_w8_kernel(NttCols cols, uint32_t
         }
         // ---- output: u = u1 + 8 u2 + 64 u3 from register (x, u3) [m3 > 0] or u2 [m3 = 0]
         const uint32_t j = j0 + cc, q = j & smask, jq = j - q;
-        static_for<8>([&](auto rc) {
-            constexpr uint32_t r = (uint32_t)decltype(rc)::value;
-            const uint32_t u = m3 ? (u1 + 8u * (((r >> m3) << m3) | u2lo) + 64u * (r & (R3 - 1))) : (u1 + 8u * r);
-            const uint32_t oidx = FIRST ? (j << m) + u : (jq << m) + q + (u << log_s);
-            Fr29 e = v[r];
-            if (!LAST) {   // omega^(jq * u): jq is a multiple of s; the direct table holds omega^(s * t) (the composed lookup where no table exists)
-                const Fr29 w = tdirect ? tdirect[(size_t)(jq >> log_s) * u].v : tw_lookup(t1, t2, lo_bits, (uint64_t)jq * u);
-                e = f29_mul(e, w);
-            }
-            if (LAST && MUL) e = f29_mul(e, ld29(&scale_s[oidx % 3u]));
-            if (LAST && !MUL) e = f29_weak_reduce(e);   // (< 12 r -> < 2 r before packing, no multiply)
-            y[oidx] = f29_pack_canonical<FrP>(e);
-        });
+        {
+            static_for<8>([&](auto rc) {
+                constexpr uint32_t r = (uint32_t)decltype(rc)::value;
+                const uint32_t u = m3 ? (u1 + 8u * (((r >> m3) << m3) | u2lo) + 64u * (r & (R3 - 1))) : (u1 + 8u * r);
+                const uint32_t oidx = FIRST ? (j << m) + u : (jq << m) + q + (u << log_s);
+                Fr29 e = v[r];
+                if (!LAST) {   // omega^(jq * u): jq is a multiple of s; the direct table holds omega^(s * t) (the composed lookup where no table exists)
+                    const Fr29 w = tdirect ? tdirect[(size_t)(jq >> log_s) * u].v : tw_lookup(t1, t2, lo_bits, (uint64_t)jq * u);
+                    e = f29_mul(e, w);
+                }
+                if (LAST && MUL) e = f29_mul(e, ld29(&scale_s[oidx % 3u]));
+                if (LAST && !MUL) e = f29_weak_reduce(e);   // (< 12 r -> < 2 r before packing, no multiply)
+                y[oidx] = f29_pack_canonical<FrP>(e);
+            });
+        }
     }
 }
 
@@ -697,7 +704,7 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
     plan(LT);
     TwiddleSet *tw = nullptr;
     H2_CHK(get_twiddles(ctx, log_n, omega, &tw));
-    // r05: transforms of 2^12 points and more go through the wave-owned radix-8 pass (ntt_w8_kernel): ceil(log_n / 9) passes of 6 .. 9 bits each
+    // r05, ntt_w8 = 1 / 2 (default 0: measured slower): transforms of 2^12 points and more through the wave-owned radix-8 pass (ntt_w8_kernel), ceil(log_n / 9) passes of 6 .. 9 bits
     const bool w8 = ctx->ntt_w8 != 0 && log_n >= 12 && log_n <= 28;
     W8Twiddles w8tw;
     if (w8) {

@@ -593,3 +593,29 @@ def test_ntt_full_tile_kernels(ctx, tile_bits, tile_kernel):
     finally:
         ctx.set_param("ntt_tile_bits", 10)
         ctx.set_param("ntt_tile_kernel", 1)
+
+
+@pytest.mark.parametrize("w8", [1, 2])
+def test_ntt_wave_owned_radix8_pass(ctx, w8):
+    """ntt_w8_kernel (r05; selectable, not the default): every pass width 6 .. 9 in two- and three-pass plans, the fused coset scalings, the zero-row
+    skip of padded coset transforms (in_len <= N / 4), full-range inputs — bit-exact against the oracle and round trips"""
+    from tests.util import full_range_fr
+
+    ctx.set_param("ntt_w8", w8)
+    try:
+        for log_n in ((12, 13, 15, 18) if w8 == 1 else (14, 16, 17, 19)):
+            a = full_range_fr(1 << log_n, 170 + log_n)
+            w, winv, div = domain_consts(log_n)
+            got = ctx.best_fft(a, w, log_n)
+            assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=4)), log_n
+            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a), log_n
+        for k, ek in (((10, 12), (13, 15)) if w8 == 1 else ((11, 14), (12, 14))):
+            a = full_range_fr(1 << k, k)
+            we, weinv, ediv = domain_consts(ek)
+            z, zinv = fr([O.ZETA]), fr([O.ZETA * O.ZETA % R])
+            ext = ctx.coeff_to_extended(a, k, ek, we, z)
+            assert np.array_equal(ext, CO.coeff_to_extended(a, k, ek, we, z, threads=4)), (k, ek)
+            back = ctx.extended_to_coeff(ext, ek, weinv, ediv, zinv)
+            assert np.array_equal(back[: 1 << k], a) and not back[1 << k:].any()
+    finally:
+        ctx.set_param("ntt_w8", 0)

@@ -28,6 +28,28 @@ def test_ntt_bit_exact(ctx, log_n):
     assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
 
 
+@pytest.mark.parametrize("w8", [1, 2])
+def test_ntt_wave_owned_radix8_pass_gpu(ctx, w8):
+    """ntt_w8_kernel (r05, selectable): the wave-owned radix-8 pass at three / two waves per SIMD, 2^14 .. 2^22 and the prover's coset transforms"""
+    ctx.set_param("ntt_w8", w8)
+    try:
+        for log_n in (14, 19, 21, 22):
+            a = rand_fr(1 << log_n, 300 + log_n)
+            w, winv, div = domain_consts(log_n)
+            got = ctx.best_fft(a, w, log_n)
+            assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=NT)), log_n
+            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a), log_n
+        for k, ek in ((17, 19), (19, 21)):
+            a = rand_fr(1 << k, k)
+            we, weinv, ediv = domain_consts(ek)
+            z, zinv = fr([O.ZETA]), fr([O.ZETA * O.ZETA % R])
+            ext = ctx.coeff_to_extended(a, k, ek, we, z)
+            assert np.array_equal(ext, CO.coeff_to_extended(a, k, ek, we, z, threads=NT)), (k, ek)
+            assert np.array_equal(ctx.extended_to_coeff(ext, ek, weinv, ediv, zinv)[: 1 << k], a)
+    finally:
+        ctx.set_param("ntt_w8", 0)
+
+
 def test_ntt_22_properties(ctx):
     # config #3 size: linearity + Horner spot checks (size-independent properties)
     log_n = 22

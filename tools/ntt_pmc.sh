@@ -14,7 +14,7 @@ p=glob.glob("$OUT/p$i/*.db")
 if p:
     db=sqlite3.connect(p[0])
     try:
-        for r in db.execute("select counter_name, count(*), avg(value) from counters_collection where kernel_name like '%ntt_%kernel%' and kernel_name not like '%twiddle%' group by counter_name"):
+        for r in db.execute("select counter_name, count(*), avg(value) from counters_collection where kernel_name like '%ntt_%kernel%' and kernel_name not like '%ntt_twiddle_kernel%' and kernel_name not like '%direct_twiddle%' group by counter_name"):
             print(r[0], r[1], f"{r[2]:.4g}")
     except Exception as e: print("err", e)
 PY
