@@ -48,5 +48,10 @@ bash tools/ntt_pmc.sh > $OUT/ntt_pmc.log 2>&1
 bash tools/accum_pmc.sh > $OUT/accum_pmc.log 2>&1
 timeout 300 python tools/msm_r03.py 19,20 > $OUT/msm_breakdown.log 2>&1
 timeout 900 python tools/config_sweep.py all 5 > $OUT/config_sweep.md 2> $OUT/config_sweep.err
+timeout 300 python tools/fuzz_shapes.py 150 4 > $OUT/fuzz_small.log 2>&1
+H2HIP_FUZZ_KNOBS=1 timeout 300 python tools/fuzz_shapes.py 120 6 > $OUT/fuzz_knobs.log 2>&1
+timeout 300 python tools/fuzz_shapes.py 100 5 13 16 > $OUT/fuzz_mid.log 2>&1
+timeout 400 python tools/soak.py 200 > $OUT/soak.log 2>&1
+( tail -2 $OUT/fuzz_small.log; tail -2 $OUT/fuzz_knobs.log; tail -2 $OUT/fuzz_mid.log; tail -3 $OUT/soak.log ) > $OUT/fuzz_soak.log 2>&1
 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --share-device --dist-backend gloo --steps 5 --warmup 2 --no-sweep --shard-ntt-columns on 2> $OUT/bench_2rank.err | tail -1 > $OUT/bench_2rank_shared_gpu_gloo_pairing21.json
 tail -24 $OUT/pytest_gpu.log; head -c 700 $OUT/bench.json; echo; head -14 $OUT/kernel_trace.md; head -8 $OUT/pmc_hbm.md; head -30 $OUT/create_proof_k19_kernels.md; head -c 600 $OUT/bench_2rank_shared_gpu_gloo_pairing21.json; tail -3 $OUT/bench_2rank.err

@@ -35,7 +35,11 @@ while time.time() - t0 < budget:
                  "msm_lanes": rnd.choice([0, 1, 2]), "msm_defer_reduce": rnd.choice([1, 1, 0]),
                  # r04: the pointwise kernels' arithmetic form and the prover's scheduling switches
                  "quotient_29": rnd.choice([1, 1, 0]), "kate_29": rnd.choice([1, 1, 0]), "plonk_tail_overlap": rnd.choice([1, 1, 0]),
-                 "plonk_permute_in_commit": rnd.choice([1, 1, 0]), "plonk_side_on_lanes": rnd.choice([1, 1, 0]), "clean_on_lane": rnd.choice([1, 0])}
+                 "plonk_permute_in_commit": rnd.choice([1, 1, 0]), "plonk_side_on_lanes": rnd.choice([1, 1, 0]), "clean_on_lane": rnd.choice([1, 0]),
+                 # r05: host round trips through the mapped flag, the table-entry format (read when the SRS is set up), one-pass grand products,
+                 # the wave-owned NTT pass (2^12+ points only)
+                 "host_poll": rnd.choice([1, 1, 0]), "msm_table_split": rnd.choice([1, 1, 0]), "plonk_merge_products": rnd.choice([1, 1, 0]),
+                 "ntt_w8": rnd.choice([0, 0, 1, 2])}
         for name, val in knobs.items():
             ctx.set_param(name, val)
     try:
