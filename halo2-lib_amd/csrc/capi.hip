@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void publish_kernel(const uint32_t *__restrict
 static int poll_init(h2hip_ctx *ctx) {
     if (ctx->poll_host) return H2HIP_OK;
     void *h = nullptr;
-    H2_HIPCHK(hipHostMalloc(&h, 64 + POLL_BYTES, hipHostMallocMapped));
+    H2_HIPCHK(hipHostMalloc(&h, 64 + POLL_BYTES, hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: the flag store is visible while the stream goes on
     memset(h, 0, 64 + POLL_BYTES);
     ctx->poll_host = (char *)h;
 #ifdef H2_HIPEMU

@@ -341,7 +341,7 @@ template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMall
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
-enum { hipHostMallocMapped = 2 };
+enum { hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
 inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 enum { hipHostRegisterDefault = 0 };
 inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
