@@ -39,8 +39,7 @@ def _more_names():
     from tests.golden.make_proof_goldens import more_shapes
 
     have = _doc()["shapes"]
-    big = os.environ.get("H2HIP_GOLDEN_BIG") == "1"
-    return [n for n, p, alias in more_shapes() if alias is None and n in have and (big or p[0] <= 24)]
+    return [n for n, p, alias in more_shapes() if alias is None and n in have]
 
 
 def _sha(a) -> str:

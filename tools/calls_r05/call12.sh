@@ -15,4 +15,4 @@ e=json.load(open("gpurun_out/r05c12/bench_2rank_shared_gpu_gloo_pairing21.json")
 b=e["create_proof_k21_pairing_shape"]
 print("N=2", e["ms_per_step"], e["sharded_bytes_equal_unsharded"], "cpu_baseline" in e, b["equals_committed_oracle_prover_digest"], b["sharded"]["equals_committed_oracle_prover_digest"], "msm blk", e.get("msm_2_20",{}).get("ms_per_msm"), e.get("msm_2_20",{}).get("error"))
 PY
-tail -2 $O/bench.err $O/bench_2rank.err
+for f in $O/bench.err $O/bench_2rank.err; do tail -n 2 $f; done   # (as run, this line read `tail -2 a b`, which tail rejects: the call reported rc=1 for that alone)
