@@ -323,6 +323,7 @@ void h2hip_destroy(h2hip_ctx *ctx) {
         hipEventDestroy(ctx->used_ev);
     }
     if (ctx->tail_ev) hipEventDestroy(ctx->tail_ev);
+    if (ctx->sorted_ev) hipEventDestroy(ctx->sorted_ev);
     if (ctx->job_ring) hipHostFree(ctx->job_ring);
     if (ctx->poll_host) hipHostFree(ctx->poll_host);
     for (auto &b : ctx->ws)
@@ -377,6 +378,8 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "host_poll")) return &ctx->host_poll;
     if (!strcmp(name, "plonk_merge_products")) return &ctx->plonk_merge_products;
     if (!strcmp(name, "plonk_shard_side")) return &ctx->plonk_shard_side;
+    if (!strcmp(name, "plonk_early_intt")) return &ctx->plonk_early_intt;
+    if (!strcmp(name, "msm_stagger_sorts")) return &ctx->msm_stagger_sorts;
     if (!strcmp(name, "msm_table_split")) return &ctx->msm_table_split;
     if (!strcmp(name, "clean_on_lane")) return &ctx->clean_on_lane;
     if (!strcmp(name, "plonk_permute_in_commit")) return &ctx->plonk_permute_in_commit;
@@ -826,6 +829,13 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         if (mid_hook && j0 + gsize > mid_after) H2_LANES_RC(run_mid());
         h2hip_ctx *c = ctx->lane[g % NL];
         const h2hip_bases *gb = bases_of(j0);
+        if ((ctx->msm_stagger_sorts > 0 || (ctx->msm_stagger_sorts < 0 && NL == 2)) && precomp && fuse == 1 && g < (size_t)NL) {   // the first round of columns: lane g sorts behind lane g - 1's sort
+            if (g > 0 && ctx->lane[g - 1]->sorted_ev) H2_LANES(hipStreamWaitEvent(c->stream, ctx->lane[g - 1]->sorted_ev, 0));
+            if (g + 1 < (size_t)NL && g + 1 < ngroups) {
+                if (!c->sorted_ev) H2_LANES(hipEventCreateWithFlags(&c->sorted_ev, hipEventDisableTiming));
+                c->sorted_arm = true;
+            }
+        }
         for (size_t j = j0; j < j0 + gsize; ++j) {
             if (scalars_on_host && n) H2_LANES(hipMemcpyAsync((void *)staged[j], scalars_in[j], sizeof(Fr) * n, hipMemcpyHostToDevice, c->stream));
         }

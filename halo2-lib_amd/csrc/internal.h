@@ -129,6 +129,10 @@ struct h2hip_ctx {
     int kate_coeffs_per_lane = 0;    // multi-point kate division: coefficients per lane (1, 2, 4, 8); 0 = by length
     int plonk_merge_products = 1;    // one permutation set: its factors and the lookups' go through ONE batched inversion / prefix product
     int plonk_shard_side = 1;        // sharded create_proof: the first-round columns' lagrange_to_coeff (+ all-gather) and coset transforms on a side stream next to round 2's commitments
+    int plonk_early_intt = 1;        // round 3: the grand products' lagrange_to_coeff is queued on the side context BEFORE the round's commitments (next to their sorts), only the coset transforms behind the accumulations
+    int msm_stagger_sorts = -1;      // batch MSM: lane l's first sort starts when lane l-1's sort is done (the first accumulation starts after ONE sort, not next to NL of them); -1 = auto: with two lanes (from 2^20 points), where it measured -1 % per k = 20 proof; with three lanes it costs 1 - 2.5 % (profiles/r05_early_intt_stagger_ab.log)
+    hipEvent_t sorted_ev = nullptr;  // (a lane context) recorded behind the scatter of the next msm_run_cols when sorted_arm is set
+    bool sorted_arm = false;
     int plonk_side_on_lanes = 1;     // the side work of plonk_tail_overlap runs on the batch MSM's last (idle) lane context instead of a context of its own
 #ifdef H2_HIPEMU
     int plonk_warm_keygen = 0;       // (the CPU-emulated test build does not pay for a second proof per key)

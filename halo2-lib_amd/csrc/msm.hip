@@ -980,6 +980,10 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
                        (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
+    if (ctx->sorted_arm) {   // (msm_stagger_sorts) the next lane's sort may start
+        ctx->sorted_arm = false;
+        H2_HIPCHK(hipEventRecord(ctx->sorted_ev, st));
+    }
 
     // ---- accumulate (+ wave-level merge), then the block-level merge of the wave-boundary partials
     {

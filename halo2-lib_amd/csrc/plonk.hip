@@ -823,14 +823,21 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         return H2HIP_OK;
     };
     // out-of-place lagrange_to_coeff + coeff_to_extended of `src` columns on the side context: coef[i] / cos[i] are taken here
-    auto side_transforms = [&](const std::vector<Fr *> &src, std::vector<Fr *> &coef, std::vector<Fr *> &cos) -> int {
+    // (two halves: plonk_early_intt queues the first in front of a round's commitments and only the second behind their accumulations)
+    auto side_to_coeff = [&](const std::vector<Fr *> &src, std::vector<Fr *> &coef) -> int {
         coef.assign(src.size(), nullptr);
-        cos.assign(src.size(), nullptr);
         for (size_t i = 0; i < src.size(); ++i) H2_CHK(sc.take(n, &coef[i]));
-        for (size_t i = 0; i < src.size(); ++i) H2_CHK(sc.take(ne, &cos[i]));
         const Fr out3[3] = {dom.ifft_divisor, dom.ifft_divisor, dom.ifft_divisor};
-        H2_CHK(ntt_run_batch(side_c, coef.data(), (const Fr *const *)src.data(), src.size(), k, dom.omega_inv, n, nullptr, out3));
-        return h2hip_coeff_to_extended_batch_dev(side_c, (const void *const *)coef.data(), k, (void *const *)cos.data(), ek, src.size(), &dom.ext_omega, &dom.zeta);
+        return ntt_run_batch(side_c, coef.data(), (const Fr *const *)src.data(), src.size(), k, dom.omega_inv, n, nullptr, out3);
+    };
+    auto side_to_ext = [&](const std::vector<Fr *> &coef, std::vector<Fr *> &cos) -> int {
+        cos.assign(coef.size(), nullptr);
+        for (size_t i = 0; i < coef.size(); ++i) H2_CHK(sc.take(ne, &cos[i]));
+        return h2hip_coeff_to_extended_batch_dev(side_c, (const void *const *)coef.data(), k, (void *const *)cos.data(), ek, coef.size(), &dom.ext_omega, &dom.zeta);
+    };
+    auto side_transforms = [&](const std::vector<Fr *> &src, std::vector<Fr *> &coef, std::vector<Fr *> &cos) -> int {
+        H2_CHK(side_to_coeff(src, coef));
+        return side_to_ext(coef, cos);
     };
     std::vector<Fr *> r1_src, r1_coef, r1_cos, r3_src, r3_coef, r3_cos;
     const size_t ncm = qshard ? pk->my_cosets.size() : 0;                 // cosets of the extended domain evaluated here
@@ -1372,7 +1379,20 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         if (overlap) {   // the grand products' coefficient and extended forms do not depend on y: next to this round's reduction
             r3_src.assign(perm_z.begin(), perm_z.end());
             for (LookupState &s : lks) r3_src.push_back(s.z);
-            side_arm([&]() -> int { return side_transforms(r3_src, r3_coef, r3_cos); });
+            if (ctx->plonk_early_intt) {
+                // the products are complete on this stream: their lagrange_to_coeff goes to the side context NOW — it runs next to the round's sorts
+                // (and, on the last lane's context, in front of that lane's column: the third accumulation of the round, a millisecond away)
+                if (!side_c) side_c = pick_side(ctx->lane[2], &pk->side);
+                H2_REQUIRE(side_c, "create_proof: no side context");
+                if (!ctx->tail_ev) H2_HIPCHK(hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming));
+                H2_HIPCHK(hipEventRecord(ctx->tail_ev, st));
+                H2_HIPCHK(hipStreamWaitEvent(side_c->stream, ctx->tail_ev, 0));
+                H2_CHK(side_to_coeff(r3_src, r3_coef));
+                H2_HIPCHK(hipEventRecord(pk->side_ev, side_c->stream));
+                side_busy = true;
+                side_arm([&]() -> int { return side_to_ext(r3_coef, r3_cos); });
+            } else
+                side_arm([&]() -> int { return side_transforms(r3_src, r3_coef, r3_cos); });
         }
         H2_CHK(commit_points_multi(nullptr, bases, cols, n, pts));
         H2_CHK(side_fire_if_pending());

@@ -201,6 +201,33 @@ def test_create_proof_with_kernel_profile_emulated():
         ctx.close()
 
 
+def test_create_proof_schedule_switches_emulated():
+    """the schedule switches of r05's last measurements give the same bytes: the grand products' lagrange_to_coeff queued in front of the round's
+    commitments (plonk_early_intt), the lanes' first sorts one behind the other (msm_stagger_sorts; msm_fuse_cols = 1 takes the per-column lanes the
+    large sizes use), precomputed window tables so that the batch path with its deferred reduction runs"""
+    from tests.emu_util import emu_context
+
+    ctx = emu_context()
+    try:
+        sh, kzg, params, circ, gpk = _setup(ctx, 6, 2, 2, 1, 0, 4, 1, 1, True)
+        rng = lambda: PreDrawnRng(_rng_budget(sh), 1)
+        plain = PL.create_proof(gpk, circ.advice, circ.instances, rng())
+        names = ("plonk_early_intt", "msm_stagger_sorts", "msm_fuse_cols")
+        old = {n: ctx.get_param(n) for n in names}
+        try:
+            for vals in ((1, 0, 0), (0, 1, 1), (1, 1, 1)):
+                for n, v in zip(names, vals):
+                    ctx.set_param(n, v)
+                assert PL.create_proof(gpk, circ.advice, circ.instances, rng()) == plain, vals
+        finally:
+            for n, v in old.items():
+                ctx.set_param(n, v)
+        gpk.free()
+        kzg.free()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(9, 1, 1, 1, 0, 8), (12, 1, 1, 1, 1, 11), (12, 2, 1, 1, 1, 11), (13, 4, 2, 2, 2, 10), (10, 1, 0, 1, 0, None),
                                    (11, 20, 4, 2, 1, 10), (9, 1, 1, 0, 0, 7), (9, 2, 0, 0, 1, None), (10, 1, 2, 1, 0, 8)])   # (11, 20, 4, ...): a wide shape like the reference's low-k configurations (13 chained permutation sets); then: no constants column, no range chip with an instance column, one advice column with num_lookup_advice > 1
