@@ -379,6 +379,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "plonk_merge_products")) return &ctx->plonk_merge_products;
     if (!strcmp(name, "plonk_shard_side")) return &ctx->plonk_shard_side;
     if (!strcmp(name, "plonk_early_intt")) return &ctx->plonk_early_intt;
+    if (!strcmp(name, "plonk_gate_before_join")) return &ctx->plonk_gate_before_join;
     if (!strcmp(name, "msm_stagger_sorts")) return &ctx->msm_stagger_sorts;
     if (!strcmp(name, "msm_table_split")) return &ctx->msm_table_split;
     if (!strcmp(name, "clean_on_lane")) return &ctx->clean_on_lane;

@@ -130,6 +130,7 @@ struct h2hip_ctx {
     int plonk_merge_products = 1;    // one permutation set: its factors and the lookups' go through ONE batched inversion / prefix product
     int plonk_shard_side = 1;        // sharded create_proof: the first-round columns' lagrange_to_coeff (+ all-gather) and coset transforms on a side stream next to round 2's commitments
     int plonk_early_intt = 1;        // round 3: the grand products' lagrange_to_coeff is queued on the side context BEFORE the round's commitments (next to their sorts), only the coset transforms behind the accumulations
+    int plonk_gate_before_join = 0;  // the quotient's gate identities start when the FIRST-round columns' cosets are done; the grand products' transforms are joined behind them
     int msm_stagger_sorts = -1;      // batch MSM: lane l's first sort starts when lane l-1's sort is done (the first accumulation starts after ONE sort, not next to NL of them); -1 = auto: with two lanes (from 2^20 points), where it measured -1 % per k = 20 proof; with three lanes it costs 1 - 2.5 % (profiles/r05_early_intt_stagger_ab.log)
     hipEvent_t sorted_ev = nullptr;  // (a lane context) recorded behind the scatter of the next msm_run_cols when sorted_arm is set
     bool sorted_arm = false;

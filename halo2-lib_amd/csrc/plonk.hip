@@ -249,7 +249,7 @@ struct h2hip_plonk_pk {
     hipStream_t copy_stream = nullptr;   // the RNG-drawn random polynomial is uploaded on its own stream, next to the NTTs
     hipEvent_t copy_ev = nullptr;
     h2hip_ctx *side = nullptr;           // child context (own stream, NTT scratch and twiddle cache): the transforms that run next to an MSM's tail
-    hipEvent_t side_ev = nullptr;
+    hipEvent_t side_ev = nullptr, side_ev1 = nullptr;   // side_ev: everything queued on the side stream so far; side_ev1: the first-round columns' transforms
     Fr *host_stage = nullptr;   // pinned staging for the RNG-drawn scalars (the n coefficients of the random polynomial, the blinding rows)
     size_t host_stage_elems = 0;
 };
@@ -768,6 +768,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     // coeff_to_extended of the FIRST-ROUND columns run on the side context next to round 2's commitments instead of in front of them
     const bool side_sharded = sharded_any && ctx->plonk_shard_side != 0;
     if ((overlap || side_sharded) && !pk->side_ev) H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
+    if (overlap && !pk->side_ev1) H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev1, hipEventDisableTiming));
     // (r04 also computed the random polynomial's COMMITMENT ahead — its scalars depend on nothing once the generator is counter-mode — as one
     // MSM on a second side context behind round 1's accumulations: 14.72-14.99 vs 14.71-14.98 ms, profiles/r04_tail_overlap_ab.log.  The
     // chip is busy with something ~97 % of the time; only work moved into LOW-occupancy stretches gains, and that MSM is not such work.  Removed.)
@@ -798,13 +799,18 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     bool side_busy = false;   // work is queued on the side stream that the main stream has not waited for yet
     // queues `fn` on the side stream behind the batch MSM's accumulations (or, if the commitment took a path without lanes, behind what
     // the main stream holds after it) — `arm` before the commitment, `fire_if_pending` after it
-    auto side_arm = [&](std::function<int()> fn) {
-        ctx->msm_tail_hook = [&, fn](hipEvent_t ev) -> int {
+    bool side_r1_recorded = false;   // side_ev1 marks the end of the first-round columns' transforms on the side stream
+    auto side_arm = [&](std::function<int()> fn, bool first_round = false) {
+        ctx->msm_tail_hook = [&, fn, first_round](hipEvent_t ev) -> int {
             if (!side_c) side_c = pick_side(ctx->lane[2], &pk->side);   // chosen once per proof: side_join() waits for ONE stream's event
             H2_REQUIRE(side_c, "create_proof: no side context");
             H2_HIPCHK(hipStreamWaitEvent(side_c->stream, ev, 0));
             H2_CHK(fn());
             H2_HIPCHK(hipEventRecord(pk->side_ev, side_c->stream));
+            if (first_round) {
+                H2_HIPCHK(hipEventRecord(pk->side_ev1, side_c->stream));
+                side_r1_recorded = true;
+            }
             side_busy = true;
             return H2HIP_OK;
         };
@@ -1006,7 +1012,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                 r1_src.push_back(s.ap);
                 r1_src.push_back(s.sp);
             }
-            side_arm([&]() -> int { return side_transforms(r1_src, r1_coef, r1_cos); });
+            side_arm([&]() -> int { return side_transforms(r1_src, r1_coef, r1_cos); }, true);
         }
         H2_CHK(commit_points(pk->g_lagrange, cols, n, pts));
         H2_REQUIRE(!ctx->msm_mid_hook, "internal: the commitment round did not run the lookup permutation");
@@ -1402,20 +1408,31 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     }
     H2_CHK(tr.write_point(random_commitment));
     const Fr y = tr.squeeze_challenge();
+    std::function<int()> late_join;   // (plonk_gate_before_join) the grand products' transforms are joined inside the quotient pass, behind the gate identities
     if (overlap) {
-        H2_CHK(side_join());   // both rounds' transforms are complete before anything below reads their results or reuses their inputs
+        auto join_products = [&]() -> int {   // both rounds' transforms are complete before anything behind this reads their results or reuses their inputs
+            H2_CHK(side_join());
+            size_t i = 0;
+            for (uint32_t si = 0; si < sh.num_perm_sets; ++si, ++i) {
+                sc.release(perm_z[si]);
+                perm_z[si] = r3_coef[i];
+                perm_cos[si] = r3_cos[i];
+            }
+            for (size_t li = 0; li < lks.size(); ++li, ++i) {
+                sc.release(lks[li].z);
+                lks[li].z = r3_coef[i];
+                lk_cos[li].z = r3_cos[i];
+            }
+            return H2HIP_OK;
+        };
+        if (ctx->plonk_gate_before_join && side_r1_recorded && !stage_ms) {
+            // the gate identities (and q_lookup * a's cosets) read first-round columns only: they start when THOSE transforms are done — the grand
+            // products' coset transforms, queued behind this round's accumulations, are usually still running when y arrives
+            H2_HIPCHK(hipStreamWaitEvent(st, pk->side_ev1, 0));
+            late_join = join_products;
+        } else
+            H2_CHK(join_products());
         for (Fr *p : lagrange_done) sc.release(p);
-        size_t i = 0;
-        for (uint32_t si = 0; si < sh.num_perm_sets; ++si, ++i) {
-            sc.release(perm_z[si]);
-            perm_z[si] = r3_coef[i];
-            perm_cos[si] = r3_cos[i];
-        }
-        for (size_t li = 0; li < lks.size(); ++li, ++i) {
-            sc.release(lks[li].z);
-            lks[li].z = r3_coef[i];
-            lk_cos[li].z = r3_cos[i];
-        }
         H2_CHK(lookup_input_cosets());
         if (stage_ms) laps.lap(ST_TO_COEFF);
     } else {
@@ -1454,6 +1471,11 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                 ga[a] = adv_cos[a] + off;
             }
             H2_CHK(h2hip_quotient_flex_gate_batch_dev(ctx, acc_loc + off, gq.data(), ga.data(), gq.size(), ek_, k, &y));
+        }
+        if (late_join) {
+            std::function<int()> f;
+            f.swap(late_join);
+            H2_CHK(f());
         }
         const Fr *l0 = (qshard ? pk->l0_sh : pk->l0) + off, *l_last = (qshard ? pk->l_last_sh : pk->l_last) + off,
                  *l_blind = (qshard ? pk->l_blind_sh : pk->l_blind) + off;
@@ -1964,6 +1986,7 @@ void h2hip_plonk_pk_free(h2hip_ctx *ctx, h2hip_plonk_pk *pk) {
     if (pk->copy_ev) hipEventDestroy(pk->copy_ev);
     if (pk->copy_stream) hipStreamDestroy(pk->copy_stream);
     if (pk->side_ev) hipEventDestroy(pk->side_ev);
+    if (pk->side_ev1) hipEventDestroy(pk->side_ev1);
     if (pk->side) h2hip_destroy(pk->side);
     pk->pool.destroy();
     delete pk;

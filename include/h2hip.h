@@ -68,6 +68,7 @@ int h2hip_sync(h2hip_ctx *ctx);
  * "plonk_merge_products" (1: one batched inversion / prefix product for the permutation set and the lookups when nothing chains),
  * "plonk_shard_side" (1: sharded proofs run the first-round columns' transforms and all-gather on a side stream),
  * "plonk_early_intt" (1: the grand products' lagrange_to_coeff is queued on the side context in front of their commitment round),
+ * "plonk_gate_before_join" (0; 1: the quotient's gate identities start before the grand products' transforms are joined — measured neutral),
  * "msm_stagger_sorts" (-1 = auto: two-lane batches; 1 / 0: a batch's lanes start their first sorts one behind the other / together),
  * "ntt_w8" (0; 1 / 2: transforms of 2^12+ points on the wave-owned radix-8 pass at three / two waves per SIMD — bit-exact, measured 8-12 % slower);
  * profiling aid: "ntt_debug_skip" (produces wrong results).  The variants r01-r03 measured slower (two-level sort, bucket-major sort,

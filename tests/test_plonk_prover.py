@@ -204,7 +204,8 @@ def test_create_proof_with_kernel_profile_emulated():
 def test_create_proof_schedule_switches_emulated():
     """the schedule switches of r05's last measurements give the same bytes: the grand products' lagrange_to_coeff queued in front of the round's
     commitments (plonk_early_intt), the lanes' first sorts one behind the other (msm_stagger_sorts; msm_fuse_cols = 1 takes the per-column lanes the
-    large sizes use), precomputed window tables so that the batch path with its deferred reduction runs"""
+    large sizes use), the quotient's gate identities in front of the join of the grand products' transforms (plonk_gate_before_join); precomputed
+    window tables so that the batch path with its deferred reduction runs"""
     from tests.emu_util import emu_context
 
     ctx = emu_context()
@@ -212,10 +213,10 @@ def test_create_proof_schedule_switches_emulated():
         sh, kzg, params, circ, gpk = _setup(ctx, 6, 2, 2, 1, 0, 4, 1, 1, True)
         rng = lambda: PreDrawnRng(_rng_budget(sh), 1)
         plain = PL.create_proof(gpk, circ.advice, circ.instances, rng())
-        names = ("plonk_early_intt", "msm_stagger_sorts", "msm_fuse_cols")
+        names = ("plonk_early_intt", "msm_stagger_sorts", "msm_fuse_cols", "plonk_gate_before_join")
         old = {n: ctx.get_param(n) for n in names}
         try:
-            for vals in ((1, 0, 0), (0, 1, 1), (1, 1, 1)):
+            for vals in ((1, 0, 0, 0), (0, 1, 1, 1), (1, 1, 1, 1), (0, 0, 0, 0)):
                 for n, v in zip(names, vals):
                     ctx.set_param(n, v)
                 assert PL.create_proof(gpk, circ.advice, circ.instances, rng()) == plain, vals
