@@ -1108,20 +1108,26 @@ def ntt_config3(ctx, torch, dev, modmul_peak):
     torch.cuda.synchronize()
     roundtrip_ok = bool(torch.equal(a, ref))
     reps = 10
-    ctx.timer_start()   # (timed WITHOUT the per-launch event brackets: r04 timed this loop with them and reported 0.63-0.65 ms for a 0.58 ms transform)
-    for _ in range(reps):
-        ctx.best_fft_dev(a.data_ptr(), dom.omega, log_n)
-    fwd_ms = ctx.timer_stop() / reps
+
+    def timed(fn, rounds=3):   # the block follows host-side setup (the clocks have dropped): 2 * reps untimed, then the best of `rounds` loops of `reps`
+        for _ in range(2 * reps):
+            fn()
+        best = []
+        for _ in range(rounds):
+            ctx.timer_start()   # (timed WITHOUT the per-launch event brackets: r04 timed this loop with them and reported 0.63-0.65 ms for a 0.58 ms transform)
+            for _ in range(reps):
+                fn()
+            best.append(ctx.timer_stop() / reps)
+        return min(best), sorted(best)[len(best) // 2]
+
+    fwd_ms, fwd_med = timed(lambda: ctx.best_fft_dev(a.data_ptr(), dom.omega, log_n))
     ctx.profile_reset()
     ctx.profile_enable(True)
     for _ in range(reps):
         ctx.best_fft_dev(a.data_ptr(), dom.omega, log_n)
     k_ms, k_cnt = ctx.profile_get("ntt_pass_kernel")
     ctx.profile_enable(False)
-    ctx.timer_start()
-    for _ in range(reps):
-        ctx.ifft_dev(a.data_ptr(), dom.omega_inv, log_n, dom.ifft_divisor)
-    inv_ms = ctx.timer_stop() / reps
+    inv_ms, inv_med = timed(lambda: ctx.ifft_dev(a.data_ptr(), dom.omega_inv, log_n, dom.ifft_divisor))
     alg_bytes = 64.0 * n
     alg_mul = (n / 2) * log_n
     # the transforms create_proof actually runs at k = 19: lagrange_to_coeff (iNTT 2^19), coeff_to_extended (coset NTT 2^19 -> 2^21),
@@ -1133,15 +1139,12 @@ def ntt_config3(ctx, torch, dev, modmul_peak):
     for name, fn in (("intt_2_19", lambda: ctx.ifft_dev(src.data_ptr(), d19.omega_inv, 19, d19.ifft_divisor)),
                      ("coset_ntt_2_19_to_2_21", lambda: ctx.coeff_to_extended_dev(src.data_ptr(), 19, ext.data_ptr(), 21, d19.extended_omega, d19.g_coset)),
                      ("coset_intt_2_21", lambda: ctx.extended_to_coeff_dev(ext.data_ptr(), 21, d19.extended_omega_inv, d19.extended_ifft_divisor, d19.g_coset_inv))):
-        fn()
-        ctx.timer_start()
-        for _ in range(reps):
-            fn()
-        ms = ctx.timer_stop() / reps
+        ms, _ = timed(fn, rounds=2)
         out_n, lg = (1 << 19, 19) if name == "intt_2_19" else (1 << 21, 21)
         in_n = 1 << 19 if name != "coset_intt_2_21" else 1 << 21
         work[name] = {"ms": ms, "hbm_frac": 32.0 * (in_n + out_n) / (ms * 1e-3) / 8e12, "int_frac": (out_n / 2) * lg / (ms * 1e-3) / modmul_peak}
     return {"workload": "BASELINE configs[2]: 2^22-length radix-2 NTT and iNTT over F_r, data resident in HBM", "ntt_ms": fwd_ms, "intt_ms": inv_ms,
+            "ntt_ms_median": fwd_med, "intt_ms_median": inv_med, "timing": "per transform: best (and median) of 3 loops of 10 after 20 untimed",
             "k19_workhorses": work,
             "roundtrip_bit_exact": roundtrip_ok, "passes": int(k_cnt // reps), "avg_pass_kernel_ms": k_ms / max(k_cnt, 1),
             "roofline": {"bound": "hbm", "kernel": "ntt_pass_kernel (3 launches per transform)", "achieved": alg_bytes / (fwd_ms * 1e-3) / 1e9, "peak": 8000.0,
