@@ -15,7 +15,9 @@
  * Conventions: every function returns H2HIP_OK (0) or a negative H2HIP_ERR_* code and never throws or
  * aborts; h2hip_last_error() returns a thread-local message.  Host buffers stay caller-owned.  A context
  * serialises its work on one HIP stream; use it from one thread at a time (the reference calls
- * create_proof from a single thread, halo2-base/src/utils/testing.rs:32-50).  There is NO CPU fallback:
+ * create_proof from a single thread, halo2-base/src/utils/testing.rs:32-50).  DIFFERENT contexts (each with its own
+ * base sets and proving keys) may be used from different threads at the same time, also on one device: the library holds no
+ * mutable global state (tests/test_plonk_prover.py::test_create_proof_gpu_three_contexts_in_flight).  There is NO CPU fallback:
  * without a usable HIP device h2hip_init fails with H2HIP_ERR_NO_DEVICE.
  *
  * Functions ending in `_dev` take device pointers (from h2hip_malloc, or any HIP allocation on the

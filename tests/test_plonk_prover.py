@@ -306,6 +306,48 @@ def test_create_proof_repeatable_with_interleaved_keys():
 
 
 @pytest.mark.gpu
+def test_create_proof_gpu_three_contexts_in_flight():
+    """the C ABI's threading contract (include/h2hip.h: one context per thread, no shared mutable state): three host threads, each with its own
+    context, window tables and proving key of the same k = 16 circuit, prove concurrently on the one GPU — every proof has the bytes of the proof
+    made alone, which the oracle verifier accepts (tools/two_in_flight.py measures the throughput of this use)"""
+    import threading
+
+    provers = []
+    try:
+        for _ in range(3):
+            ctx = H.Context()
+            provers.append((ctx,) + _setup(ctx, 16, 2, 1, 1, 0, 15, 4, 8, True))
+        sh = provers[0][1]
+        rng = lambda: PreDrawnRng(_rng_budget(sh), 9)
+        alone = PL.create_proof(provers[0][5], provers[0][4].advice, provers[0][4].instances, rng())
+        got, errs = [[] for _ in provers], []
+        gate = threading.Barrier(len(provers))
+
+        def work(i):
+            try:
+                _, _, _, _, circ, pk = provers[i]
+                gate.wait()
+                for _ in range(6):
+                    got[i].append(PL.create_proof(pk, circ.advice, circ.instances, rng()))
+            except BaseException as e:   # noqa: BLE001 — reported by the parent
+                errs.append((i, repr(e)))
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(provers))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs
+        assert all(len(g) == 6 and all(p == alone for p in g) for g in got)
+        assert P.verify_proof(provers[0][3], _vk_from_gpu(sh, provers[0][5]), [], alone)
+    finally:
+        for pr in provers:
+            pr[5].free()
+            pr[2].free()
+            pr[0].close()
+
+
+@pytest.mark.gpu
 def test_create_proof_gpu_k21_pairing_shape():
     """BASELINE.json configs[4] on one GPU: the k = 21 BN254-pairing configuration (halo2-ecc/configs/bn254/bench_pairing.config:8: 2 gate advice
     columns, 1 lookup-advice column, 1 constants column, lookup_bits 20 -> degree 4, extended_k 23, 14 commitments of 2^21 points): proof BYTES
