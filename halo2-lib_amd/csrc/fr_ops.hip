@@ -308,6 +308,10 @@ __global__ __launch_bounds__(256) void fr_batch_invert_kernel(Fr *__restrict__ a
     }
 }
 
+// (r05 built the same kernel on unsaturated 9 x 29-bit limbs with the loads issued four elements ahead: bit-exact, 5 - 8 % slower alone — a lane's chain is
+// the division steps, not the products — and equal inside proofs, where this kernel's 0.4 ms are the transforms running beside it: 0.129 ms alone for 2^20
+// elements.  profiles/r05_invert29_ab.log; removed.)
+
 // ------------------------------------------------------------------ K5: prefix product (grand product core)
 // inclusive prefix product over tiles of 256 lanes x SCAN_J consecutive elements
 constexpr uint32_t SCAN_J = 8;
