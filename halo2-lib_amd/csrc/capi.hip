@@ -822,6 +822,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         return H2HIP_OK;
     };
     const size_t ngroups = groups.size();
+    // (r05, last: the lanes' streams created with the lowest / the highest HIP priority — either way 7 - 10 % slower at k = 17 / 19, profiles/r05_lane_priority_ab.log; removed)
     // (r05 built and measured a third schedule — the sorts of a round of columns queued on ALL lanes before any of their accumulations, so that no
     // sort starts beside an accumulation that holds every CU: the k = 19 proof 13.8-14.0 vs 13.7-13.9 ms, k = 21 53.4-54.0 vs 52.8-53.2, k = 15 / 18
     // equal — profiles/r05_msm_sort_first_ab.log; removed)
