@@ -16,7 +16,7 @@ timed beside it: `seconds_per_proof_host_advice`, the PCIe-inclusive rate.
   cpu_baseline = the oracle's restatement of the same prover ("port": identical step list, C kernels) on the box's host cores, one full
                  proof, whose BYTES are compared with the GPU proof's
   msm_2_20     = the other half of the metric (BASELINE configs[1]): G1-adds/s of 2^20-point MSMs with its own roofline and CPU line;
-  ntt_2_22, k8_witness_batches, create_proof_k21_pairing_shape, create_proof_config_sweep: further blocks, outside the timed region.
+  ntt_2_22, k8_witness_batches, create_proof_in_flight, create_proof_k21_pairing_shape, create_proof_config_sweep: further blocks, outside the timed region.
 
 Multi-GPU (`--gpus N` under torch.distributed.run): `--scaling strong` (default) = ONE k = 19 proof per step with its work sharded over the N
 GPUs, every rank emitting the same proof bytes; `--scaling weak` = an independent proof per GPU.
@@ -600,6 +600,7 @@ def main():
         for name, fn in (("ntt_2_22", lambda: ntt_config3(ctx, torch, dev, modmul_peak)),
                          ("k8_witness_batches", lambda: k8_batches(ctx, torch, dev, modmul_peak_sat, modmul_peak)),
                          ("witness_distribution", lambda: witness_distribution(ctx, args.k)),
+                         ("create_proof_in_flight", lambda: create_proof_in_flight(ctx.device if hasattr(ctx, "device") else 0, args.k)),
                          ("create_proof_k21_pairing_shape", lambda: create_proof_shape(
                              ctx, 21, 2, 1, 1, 0, 20, reps=3, modmul_peak=modmul_peak, account_proofs=2, golden=_golden_entry("pairing-21"),
                              what="BASELINE configs[4] on ONE GPU: the k=21 BN254-pairing configuration "
@@ -1026,6 +1027,84 @@ def witness_distribution(ctx, k, reps: int = 5):
     out["what"] = ("k=%d ECDSA shape, advice resident in HBM, %d proofs each: the headline's dependence on the synthetic column's statistics, bracketed "
                    "(cells: fractions of the advice column that are 0, 1, below 2^lookup_bits, below 2^88, wider)" % (k, reps))
     return out
+
+
+def create_proof_in_flight(device, k, threads: int = 3, proofs: int = 10):
+    """THROUGHPUT with several proofs in flight (tools/two_in_flight.py): `threads` host threads, each with its own libh2hip context, window tables and
+    proving key of the k = 19 ECDSA shape, call create_proof in a loop at the same time (ctypes releases the GIL inside the call).  ms per proof =
+    wall / proofs, for 1 .. threads threads; every proof must have the same bytes.  NOT the headline (that is one proof at a time, as the reference
+    times it): the figure says how much of the chip a single proof's Fiat-Shamir chain leaves unused — DESIGN.md §3a."""
+    import hashlib
+    import threading
+
+    import halo2_lib_amd as H
+    from halo2_lib_amd import halo2_proofs as HP
+    from halo2_lib_amd import plonk as PL
+    from halo2_lib_amd import testing as T
+
+    class Prover:
+        def __init__(self):
+            self.ctx = ctx = H.Context(device)
+            self.kzg = HP.ParamsKZG.setup(ctx, k, 0x1D0C0FFEE1234567890ABCDEF, precompute=True)
+            bp = PL.BaseCircuitParams.new(k, 1, 1, 1, 0, k - 1)
+            sh = PL.shape_of(ctx, bp)
+
+            class Backend:
+                mul = staticmethod(ctx.fr_mul)
+                add = staticmethod(ctx.fr_add)
+
+            self.circ = T.build_circuit(_ShapeView(bp, sh), 5, Backend)
+            self.pk = PL.keygen(self.kzg, bp, self.circ.fixed, self.circ.copies)
+            self.adv = [ctx.to_device(np.ascontiguousarray(c)) for c in self.circ.advice]
+            self.digests = set()
+
+        def prove(self):
+            p = PL.create_proof(self.pk, self.adv, self.circ.instances, PL.ChaChaRng(self.ctx.lib, 0, 12), advice_on_device=True)
+            self.digests.add(hashlib.sha256(bytes(p)).hexdigest())
+
+        def close(self):
+            for d in self.adv:
+                self.ctx.free(d)
+            self.pk.free()
+            self.kzg.free()
+            self.ctx.close()
+
+    provers = []
+    try:
+        for _ in range(threads):
+            provers.append(Prover())
+        for p in provers:
+            p.prove()
+            p.prove()
+
+        def run(nt):
+            gate = threading.Barrier(nt + 1)
+
+            def work(p):
+                gate.wait()
+                for _ in range(proofs):
+                    p.prove()
+
+            ths = [threading.Thread(target=work, args=(provers[i],)) for i in range(nt)]
+            for t in ths:
+                t.start()
+            gate.wait()
+            t0 = time.perf_counter()
+            for t in ths:
+                t.join()
+            return (time.perf_counter() - t0) * 1e3 / (nt * proofs)
+
+        per = {}
+        for nt in range(1, threads + 1):
+            per[str(nt)] = min(run(nt) for _ in range(2))
+        digests = set().union(*[p.digests for p in provers])
+        return {"what": "k=%d ECDSA shape, advice resident in HBM, %d proofs per thread, best of 2 rounds: ms per proof (wall / proofs) with 1 .. %d proofs in "
+                        "flight, one host thread + context + tables + key each" % (k, proofs, threads),
+                "ms_per_proof_by_proofs_in_flight": per, "all_proofs_byte_identical": len(digests) == 1,
+                "throughput_gain_over_one_at_a_time": per["1"] / min(per.values())}
+    finally:
+        for p in provers:
+            p.close()
 
 
 # the reference's two benchmark sweeps: (degree, num_advice, num_lookup_advice, num_fixed, lookup_bits) of every line of
