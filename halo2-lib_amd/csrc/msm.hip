@@ -507,6 +507,10 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
 // r05: two waves per SIMD once more, this time WITH room made for the other lanes' sorts beside it (205 registers without spills, 72 KiB of LDS for
 // its two workgroups per CU, the scatter on 64 KiB and 512-lane workgroups so that a histogram / scatter workgroup fits next to it): the k = 19
 // proof 13.2-13.45 vs 13.1-13.2 ms, k = 21 50.7-53.0 vs 50.1-50.7 — slower in every combination (profiles/r05_accum_two_waves_ab.log), removed.
+// r05, last: PMC + ISA showed a full memory drain behind every run boundary (the branch's offsets load merged with a move); builds without it, with
+// the sorted entries a group ahead and with the next table entry requested a whole addition ahead (two waves per SIMD, no spills) run NO faster
+// (0.682 / 0.707 ms per 2^19 points, proofs equal): the kernel does not wait for memory, its ~0.8 issue efficiency is dependent-issue latency that
+// three waves cannot cover (profiles/r05_accum_wait_prefetch.log); reverted.
 // three waves per SIMD (168 registers per lane); measured and left behind (profiles/r03_msm_tune_*.log, r03_knob_ab.log): two waves per
 // SIMD by launch bounds or by register padding (2 % slower / equal in isolation, nothing end to end), four (spills), the next table entry
 // requested one addition ahead (5 % slower: the gather is not what the kernel waits for), plain instead of non-temporal table loads
