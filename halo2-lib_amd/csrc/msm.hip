@@ -511,6 +511,9 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
 // the sorted entries a group ahead and with the next table entry requested a whole addition ahead (two waves per SIMD, no spills) run NO faster
 // (0.682 / 0.707 ms per 2^19 points, proofs equal): the kernel does not wait for memory, its ~0.8 issue efficiency is dependent-issue latency that
 // three waves cannot cover (profiles/r05_accum_wait_prefetch.log); reverted.
+// r05, last: the addition's ten products issued as five side-by-side pairs (two dependency chains per lane, pinned with scheduling barriers) at two / three
+// waves per SIMD: 0.702 / 0.680 against 0.690 ms, proofs equal — tools/probes/valu_rate.hip shows why: a dependent v_mad_u64_u32 chain issues as fast as
+// independent ones (every 4 cycles per SIMD, like every instruction here except plain 32-bit adds / ands at 2).  profiles/r05_accum_pair_valu_rate.log; removed.
 // three waves per SIMD (168 registers per lane); measured and left behind (profiles/r03_msm_tune_*.log, r03_knob_ab.log): two waves per
 // SIMD by launch bounds or by register padding (2 % slower / equal in isolation, nothing end to end), four (spills), the next table entry
 // requested one addition ahead (5 % slower: the gather is not what the kernel waits for), plain instead of non-temporal table loads
