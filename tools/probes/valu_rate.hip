@@ -59,6 +59,49 @@ __global__ __launch_bounds__(256) void rate_kernel(uint64_t *out, uint32_t iters
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint64_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) ^ b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7;
 }
 
+// operand-bank probe: the same multiply-add with its two 32-bit sources in the accumulator's register bank (v20, v24 with v[16:17]: all = 0 mod 4) or in three
+// different banks (v21, v26): fixed registers (values are garbage: only the timing matters), eight accumulators
+template <int SAME>
+__global__ __launch_bounds__(256) void bank_kernel(uint64_t *out, uint32_t iters, unsigned long long *cycles) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (uint32_t it = 0; it < iters; ++it) {
+        if (SAME) {
+            REP8(asm volatile("v_mad_u64_u32 v[16:17], vcc, v20, v24, v[16:17]\n v_mad_u64_u32 v[32:33], vcc, v36, v40, v[32:33]\n v_mad_u64_u32 v[48:49], vcc, v52, v56, v[48:49]\n v_mad_u64_u32 v[64:65], vcc, v68, v72, v[64:65]\n"
+                              "v_mad_u64_u32 v[80:81], vcc, v84, v88, v[80:81]\n v_mad_u64_u32 v[96:97], vcc, v100, v104, v[96:97]\n v_mad_u64_u32 v[112:113], vcc, v116, v120, v[112:113]\n v_mad_u64_u32 v[124:125], vcc, v20, v24, v[124:125]"
+                              ::: "vcc", "v16", "v17", "v20", "v24", "v32", "v33", "v36", "v40", "v48", "v49", "v52", "v56", "v64", "v65", "v68", "v72", "v80", "v81", "v84", "v88", "v96", "v97", "v100", "v104",
+                                  "v112", "v113", "v116", "v120", "v124", "v125");)
+        } else {
+            REP8(asm volatile("v_mad_u64_u32 v[16:17], vcc, v22, v27, v[16:17]\n v_mad_u64_u32 v[32:33], vcc, v38, v43, v[32:33]\n v_mad_u64_u32 v[48:49], vcc, v54, v59, v[48:49]\n v_mad_u64_u32 v[64:65], vcc, v70, v75, v[64:65]\n"
+                              "v_mad_u64_u32 v[80:81], vcc, v86, v91, v[80:81]\n v_mad_u64_u32 v[96:97], vcc, v102, v107, v[96:97]\n v_mad_u64_u32 v[112:113], vcc, v118, v123, v[112:113]\n v_mad_u64_u32 v[124:125], vcc, v22, v27, v[124:125]"
+                              ::: "vcc", "v16", "v17", "v22", "v27", "v32", "v33", "v38", "v43", "v48", "v49", "v54", "v59", "v64", "v65", "v70", "v75", "v80", "v81", "v86", "v91", "v96", "v97", "v102", "v107",
+                                  "v112", "v113", "v118", "v123", "v124", "v125");)
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cycles = t1 - t0;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = t1;
+}
+template <int SAME>
+static double run_bank(uint64_t *out, unsigned long long *cyc, int waves_per_simd) {
+    const uint32_t iters = 4096, blocks = 256 * waves_per_simd;
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    hipLaunchKernelGGL(bank_kernel<SAME>, dim3(blocks), dim3(256), 0, 0, out, iters, cyc);
+    hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+        hipEventRecord(a, 0);
+        hipLaunchKernelGGL(bank_kernel<SAME>, dim3(blocks), dim3(256), 0, 0, out, iters, cyc);
+        hipEventRecord(b, 0);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
 template <int OP>
 static void run(uint64_t *out, unsigned long long *cyc, int waves_per_simd, double *ms_out, double *cyc_out) {
     const uint32_t iters = 4096, blocks = 256 * waves_per_simd;   // 256 CUs x 4 SIMDs, 4 waves per workgroup: waves_per_simd workgroups per CU
@@ -102,6 +145,7 @@ int main() {
         run<ADD_CO_PAIR>(out, cyc, wps, &ms[ADD_CO_PAIR], &cy[ADD_CO_PAIR]);
         run<MAD64_DEP>(out, cyc, wps, &ms[MAD64_DEP], &cy[MAD64_DEP]);
         printf("waves per SIMD = %d (4096 x 64 instructions per lane)\n", wps);
+        printf("  v_mad_u64_u32, 32-bit sources in the accumulator's VGPR bank: %.3f ms; in three different banks: %.3f ms\n", run_bank<1>(out, cyc, wps), run_bank<0>(out, cyc, wps));
         for (int i = 0; i < NOPS; ++i)
             printf("  %-30s %8.3f ms   x%.2f of v_add_u32   (%.2f counter ticks per instruction in one wave)   %.3g wave-instr/s/SIMD\n", NAMES[i], ms[i], ms[i] / ms[ADD32], cy[i],
                    4096.0 * 64.0 * wps / (ms[i] * 1e-3));
