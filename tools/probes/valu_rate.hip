@@ -8,9 +8,9 @@
 #include <stdint.h>
 
 #define REP8(S) S S S S S S S S
-enum { ADD32, AND32, ALIGNBIT, MUL_LO, MUL_HI, MAD_U32_U24, MAD64, LSHR64, LSHL_ADD64, ADD_CO_PAIR, MAD64_DEP, NOPS };
+enum { ADD32, AND32, ALIGNBIT, MUL_LO, MUL_HI, MAD_U32_U24, MAD64, LSHR64, LSHL_ADD64, ADD_CO_PAIR, MAD64_DEP, MIX_MAD_AND, MIX_MAD_3AND, NOPS };
 static const char *NAMES[] = {"v_add_u32", "v_and_b32", "v_alignbit_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mad_u64_u32 (8 chains)", "v_lshrrev_b64",
-                              "v_lshl_add_u64", "v_add_co_u32 + v_addc_co_u32", "v_mad_u64_u32 (1 chain)"};
+                              "v_lshl_add_u64", "v_add_co_u32 + v_addc_co_u32", "v_mad_u64_u32 (1 chain)", "mix: mad64, and, mad64, and ...", "mix: mad64, and, and, and ..."};
 
 template <int OP>
 __global__ __launch_bounds__(256) void rate_kernel(uint64_t *out, uint32_t iters, uint32_t seed, unsigned long long *cycles) {
@@ -43,6 +43,12 @@ __global__ __launch_bounds__(256) void rate_kernel(uint64_t *out, uint32_t iters
         } else if (OP == MAD64_DEP) {
             REP8(asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0"
                               : "+v"(b0) : "v"(k), "v"(a0) : "vcc");)
+        } else if (OP == MIX_MAD_AND) {   // 4 multiply-adds and 4 ands, alternating
+            REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_and_b32 %4, %4, %8\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_and_b32 %5, %5, %8\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_and_b32 %6, %6, %8\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_and_b32 %7, %7, %8"
+                              : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "v"(a0) : "vcc");)
+        } else if (OP == MIX_MAD_3AND) {  // 2 multiply-adds and 6 ands
+            REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n v_and_b32 %4, %4, %8\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8"
+                              : "+v"(b0), "+v"(b1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "v"(a0) : "vcc");)
         } else if (OP == LSHR64) {
             REP8(asm volatile("v_lshrrev_b64 %0, 1, %0\n v_lshrrev_b64 %1, 1, %1\n v_lshrrev_b64 %2, 1, %2\n v_lshrrev_b64 %3, 1, %3\n v_lshrrev_b64 %4, 1, %4\n v_lshrrev_b64 %5, 1, %5\n v_lshrrev_b64 %6, 1, %6\n v_lshrrev_b64 %7, 1, %7"
                               : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));)
@@ -144,6 +150,8 @@ int main() {
         run<LSHL_ADD64>(out, cyc, wps, &ms[LSHL_ADD64], &cy[LSHL_ADD64]);
         run<ADD_CO_PAIR>(out, cyc, wps, &ms[ADD_CO_PAIR], &cy[ADD_CO_PAIR]);
         run<MAD64_DEP>(out, cyc, wps, &ms[MAD64_DEP], &cy[MAD64_DEP]);
+        run<MIX_MAD_AND>(out, cyc, wps, &ms[MIX_MAD_AND], &cy[MIX_MAD_AND]);
+        run<MIX_MAD_3AND>(out, cyc, wps, &ms[MIX_MAD_3AND], &cy[MIX_MAD_3AND]);
         printf("waves per SIMD = %d (4096 x 64 instructions per lane)\n", wps);
         printf("  v_mad_u64_u32, 32-bit sources in the accumulator's VGPR bank: %.3f ms; in three different banks: %.3f ms\n", run_bank<1>(out, cyc, wps), run_bank<0>(out, cyc, wps));
         for (int i = 0; i < NOPS; ++i)
