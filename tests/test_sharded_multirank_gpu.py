@@ -52,12 +52,13 @@ def _worker(rank, world, port, names, q):
         from tests.util import PreDrawnRng
 
         doc = json.load(open(GOLDEN))["shapes"]
-        ctx = H.Context(device=0)   # every rank on GPU 0
+        rccl = os.environ.get("H2_MULTIRANK_RCCL") == "1"   # tools/rccl_cpx_try.sh: a partitioned GPU shows several logical devices, one rank on each
+        ctx = H.Context(device=rank if rccl else 0)   # default: every rank on GPU 0
 
         class Backend:
             mul, add = staticmethod(ctx.fr_mul), staticmethod(ctx.fr_add)
 
-        comm = Comm(ctx)            # callback transport over the gloo group
+        comm = Comm(ctx, rccl=rccl)   # default: callback transport over the gloo group; RCCL: the 128-byte id travels over the gloo group
         cw, cr, crccl = C.c_int(), C.c_int(), C.c_int()
         ctx._chk(ctx.lib.h2hip_comm_info(comm.handle, C.byref(cw), C.byref(cr), C.byref(crccl)))
         out["comm"] = (cw.value, cr.value, crccl.value)
@@ -126,7 +127,8 @@ def test_sharded_prover_multirank_shared_gpu_golden_digests(world):
     for r in range(world):
         o = res[r]
         assert "error" not in o, (r, o)
-        assert o["comm"] == (world, r, 0), (r, o)   # libh2hip's communicator: `world` ranks, this rank, callback transport (not RCCL)
+        rccl = int(os.environ.get("H2_MULTIRANK_RCCL") == "1")
+        assert o["comm"] == (world, r, rccl), (r, o)   # libh2hip's communicator: `world` ranks, this rank, callback transport (RCCL only under tools/rccl_cpx_try.sh)
         for name in names:
             e = o[name]
             assert e["vk"] and e["all_stages"] and e["commitments_only"] and e["ragged"] and e["measured_decision"] and e["unsharded_again"] and e["verified"], (r, name, e)
