@@ -1,5 +1,5 @@
 #!/bin/bash
-# r06 GPU call 1: the default bench line as the driver runs it (the compact last line must parse: VERDICT r05 #1), then the CPX attempt
+# r06 GPU call 1: the default bench line as the driver runs it (the compact last line must parse: VERDICT r05 #1), then the partition state (read-only)
 set -u
 O=$PWD/gpurun_out/r06c01; mkdir -p $O; REPO=$PWD
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.stdout 2>$O/bench.err; echo "bench rc=$?"
@@ -11,4 +11,4 @@ print(d["ms_per_step"], d["roofline"], d["cpu_baseline"].get("value"), d.get("cr
 PY
 cp bench_extra.json $O/ 2>/dev/null
 tail -3 $O/bench.err
-bash tools/rccl_cpx_try.sh $O/rccl_cpx.log
+bash tools/rccl_cpx_try.sh $O/rccl_partition_state.log
