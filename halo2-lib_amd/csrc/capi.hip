@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include <sched.h>
 
 namespace h2 {
 
@@ -92,6 +93,7 @@ int sync_results(h2hip_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
+        if (spins > 20000 && (spins & 0x3F) == 0) sched_yield();   // a wait of more than ~1 ms: leave the core to the other contexts' host threads
     }
     if (bytes) memcpy(dst_host, ctx->poll_host + 64, bytes);
     return H2HIP_OK;
@@ -369,6 +371,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_tile_kernel")) return &ctx->ntt_tile_kernel;
     if (!strcmp(name, "ntt_w8")) return &ctx->ntt_w8;
+    if (!strcmp(name, "ntt_lds_planes")) return &ctx->ntt_lds_planes;
     if (!strcmp(name, "plonk_warm_keygen")) return &ctx->plonk_warm_keygen;
     if (!strcmp(name, "plonk_tail_overlap")) return &ctx->plonk_tail_overlap;
     if (!strcmp(name, "plonk_side_on_lanes")) return &ctx->plonk_side_on_lanes;
@@ -730,17 +733,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
             H2_HIPCHK(hipEventCreate(&ctx->lane_ev[l]));
         }
         h2hip_ctx *c = ctx->lane[l];
-        c->msm_chunk = ctx->msm_chunk;
-        c->msm_seg = ctx->msm_seg;
-        c->msm_scatter_split = ctx->msm_scatter_split;
-        c->msm_scatter_full_lds = ctx->msm_scatter_full_lds;
-        c->msm_sort_threads = ctx->msm_sort_threads;
-        c->msm_quad_tails = ctx->msm_quad_tails;
-        c->msm_quad_seg_max = ctx->msm_quad_seg_max;
-        c->msm_window_bits = ctx->msm_window_bits;
-        c->profiling = ctx->profiling;
-        c->prof_filter = ctx->prof_filter;
-        c->prof_ref = ctx->prof_ref;   // launch spans of all lanes share the parent's time origin
+        inherit_knobs(c, ctx);
     }
     if (!ctx->fork_ev) H2_HIPCHK(hipEventCreate(&ctx->fork_ev));
     char *results = nullptr;

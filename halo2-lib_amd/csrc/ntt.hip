@@ -223,31 +223,120 @@ __device__ __forceinline__ void st29(Fr29P *p, const Fr29 &v) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) p->l[i] = v.l[i];
 }
-struct TileElem {
-    typedef Fr29L type;
-    static __device__ __forceinline__ Fr29 ld(const type *p) { return p->v; }
-    static __device__ __forceinline__ void st(type *p, const Fr29 &v) { p->v = v; }
+// ---- r06: the tile's LDS layout.  PMC had the tile kernel at SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.42; tools/ntt_lds_model.py (the banking
+// rules of MI355X_MICROARCH.md §LDS applied to this kernel's index math, access class by access class) reproduces 0.40 for the 2^22 transform
+// and names the accesses:
+//   * the 9th limb of a 48-byte element moves as a ds_read/write_b32 at a 12-dword lane stride: 4-way, in EVERY access (a third of all conflicts);
+//   * rounds, fills and read-outs whose lanes step through elements at a stride of 4 / 8 (cb + st < 4, the bit-reversed fill, the first pass's
+//     u-contiguous read-out with cb = 2): 2- to 4-way on the 16-byte accesses;
+//   * the packed 36-byte stage twiddles read at power-of-two index strides: up to 4-way on nine 4-byte reads per twiddle.
+// Layout 1 (default) stores an element as three PLANES — limbs 0-3 (16 B), limbs 4-7 (16 B), limb 8 (4 B), 36 KiB per tile instead of 48 — at
+// the swizzled index e ^ X[e >> 5], X a fixed GF(2)-linear map of the upper five index bits into the lower five (found by hill climbing over the
+// model on all (m, cb, pass kind) the planner produces: 0.37 -> 0.06 conflict cycles per LDS cycle on the data), and the stage twiddles in the
+// same three planes at the skewed index k + (k >> 4) (0 conflicts).  Modelled LDS-array cycles per tile: 59.8 k -> 29.9 k.  Linear: swz(a ^ b)
+// = swz(a) ^ swz(b), so a round's four rows e0 + j * stride cost one swizzle and three wave-uniform XORs.
+struct TileLayout48 {   // r05: 48-byte elements, packed twiddles
+    static constexpr uint32_t kTwSlots(uint32_t half) { return half; }
+    static __host__ __device__ constexpr size_t bytes(uint32_t m) { return sizeof(Fr29L) * 1024 + sizeof(Fr29P) * (((size_t)1 << (m - 1)) + 3); }
+    Fr29L *lds;
+    Fr29P *tw_s, *scale_s;
+    __device__ __forceinline__ void init(void *raw, uint32_t m) {
+        lds = reinterpret_cast<Fr29L *>(raw);
+        tw_s = reinterpret_cast<Fr29P *>(lds + 1024);
+        scale_s = tw_s + (1u << (m - 1));
+    }
+    __device__ __forceinline__ uint32_t swz(uint32_t e) const { return e; }
+    __device__ __forceinline__ Fr29 ldp(uint32_t p) const { return lds[p].v; }
+    __device__ __forceinline__ void stp(uint32_t p, const Fr29 &v) const { lds[p].v = v; }
+    __device__ __forceinline__ Fr29 ldtw(uint32_t k) const { return ld29(&tw_s[k]); }
+    __device__ __forceinline__ void sttw(uint32_t k, const Fr29 &v) const { st29(&tw_s[k], v); }
 };
-template <int KIND, bool MUL>
+struct TileLayoutPlanes {
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    static __host__ __device__ constexpr uint32_t tw_slots(uint32_t m) { return (1u << (m - 1)) + (1u << (m - 1) >> 4) + 1; }
+    static __host__ __device__ constexpr size_t bytes(uint32_t m) { return (size_t)36 * 1024 + (size_t)36 * tw_slots(m) + sizeof(Fr29P) * 3 + 16; }
+    v4u *pa, *pb, *ta, *tb;
+    uint32_t *pc, *tc;
+    Fr29P *scale_s;
+    __device__ __forceinline__ void init(void *raw, uint32_t m) {
+        const uint32_t ts = (tw_slots(m) + 3u) & ~3u;   // keeps every plane 16-byte aligned
+        pa = reinterpret_cast<v4u *>(raw);
+        pb = pa + 1024;
+        ta = pb + 1024;
+        tb = ta + ts;
+        pc = reinterpret_cast<uint32_t *>(tb + ts);
+        tc = pc + 1024;
+        scale_s = reinterpret_cast<Fr29P *>(tc + ts);
+    }
+    // X[u] bit b = parity(u & ROW_b), ROW = {1, 6, 18, 15, 27}: bit u of the truth-table word TTb, one v_bfe_u32 per output bit
+    static constexpr uint32_t tt(uint32_t row) {
+        uint32_t w = 0;
+        for (uint32_t u = 0; u < 32; ++u) {
+            uint32_t x = u & row, par = 0;
+            for (; x; x >>= 1) par ^= x & 1;
+            w |= par << u;
+        }
+        return w;
+    }
+    __device__ __forceinline__ uint32_t swz(uint32_t e) const {
+        constexpr uint32_t T0 = tt(1), T1 = tt(6), T2 = tt(18), T3 = tt(15), T4 = tt(27);
+        const uint32_t u = e >> 5;
+        const uint32_t x = ((T0 >> u) & 1u) | (((T1 >> u) & 1u) << 1) | (((T2 >> u) & 1u) << 2) | (((T3 >> u) & 1u) << 3) | (((T4 >> u) & 1u) << 4);
+        return e ^ x;
+    }
+    __device__ __forceinline__ Fr29 ldp(uint32_t p) const {
+        const v4u a = pa[p], b = pb[p];
+        Fr29 r;
+        r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+        r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+        r.l[8] = pc[p];
+        return r;
+    }
+    __device__ __forceinline__ void stp(uint32_t p, const Fr29 &v) const {
+        v4u a, b;
+        a.x = v.l[0]; a.y = v.l[1]; a.z = v.l[2]; a.w = v.l[3];
+        b.x = v.l[4]; b.y = v.l[5]; b.z = v.l[6]; b.w = v.l[7];
+        pa[p] = a;
+        pb[p] = b;
+        pc[p] = v.l[8];
+    }
+    __device__ __forceinline__ Fr29 ldtw(uint32_t k) const {
+        const uint32_t p = k + (k >> 4);
+        const v4u a = ta[p], b = tb[p];
+        Fr29 r;
+        r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+        r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+        r.l[8] = tc[p];
+        return r;
+    }
+    __device__ __forceinline__ void sttw(uint32_t k, const Fr29 &v) const {
+        const uint32_t p = k + (k >> 4);
+        v4u a, b;
+        a.x = v.l[0]; a.y = v.l[1]; a.z = v.l[2]; a.w = v.l[3];
+        b.x = v.l[4]; b.y = v.l[5]; b.z = v.l[6]; b.w = v.l[7];
+        ta[p] = a;
+        tb[p] = b;
+        tc[p] = v.l[8];
+    }
+};
+template <int KIND, bool MUL, typename L>
 __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
                                                           const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
                                                           const Fr29L *__restrict__ tdirect, uint32_t in_len, NttScale sc) {
     constexpr bool FIRST = KIND == 0, LAST = KIND == 2, PREFETCH = true;
     constexpr uint32_t TB = 10, TILE = 1u << TB, T = TILE / 4;
-    typedef TileElem E;
-    typedef typename E::type Elem;
     HIP_DYNAMIC_SHARED(uint4, lds_tile_raw)
-    Elem *lds = reinterpret_cast<Elem *>(lds_tile_raw);
+    L lay;
+    lay.init(lds_tile_raw, m);
     const Fr *__restrict__ x = cols.x[blockIdx.y];
     Fr *__restrict__ y = cols.y[blockIdx.y];
     const uint32_t tid = threadIdx.x;
     const uint32_t R = 1u << m, C = 1u << cb;   // R * C = TILE
-    Fr29P *tw_s = reinterpret_cast<Fr29P *>(lds + TILE);   // omega_R^k, k < R/2
-    Fr29P *scale_s = tw_s + (R >> 1);                      // [0..3) the three scales (R' form)
+    Fr29P *scale_s = lay.scale_s;                          // [0..3) the three scales (R' form); the stage twiddles omega_R^k, k < R/2: lay.ldtw(k)
     const uint32_t rows_stride = 1u << (log_n - m);
     const uint32_t ntiles = 1u << (log_n - TB);
     const uint32_t smask = (1u << log_s) - 1;
-    for (uint32_t k = tid; k < (R >> 1); k += T) st29(&tw_s[k], tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m)));
+    for (uint32_t k = tid; k < (R >> 1); k += T) lay.sttw(k, tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m)));
     if (MUL && tid < 3) st29(&scale_s[tid], fr29_from_sat(FIRST ? sc.in3[tid] : sc.out3[tid]));
 
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -283,37 +372,39 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
         const uint32_t h = 1u << st;
         const uint32_t i = gp & (h - 1), blk = gp >> st;
         const uint32_t e0 = (((blk << (st + 2)) + i) << cb) + gc, stride = h << cb;
+        // the four rows e0 + j * stride (bits st + cb, st + cb + 1 of e0 are clear): one swizzle per lane, the rows' offsets are wave-uniform XORs
+        const uint32_t p0 = lay.swz(e0), p1 = p0 ^ lay.swz(stride), p2 = p0 ^ lay.swz(2 * stride), p3 = p0 ^ lay.swz(3 * stride);
         if (zeros == 1) {
-            const Fr29 x0 = E::ld(&lds[e0]);
-            E::st(&lds[e0 + stride], x0);
-            E::st(&lds[e0 + 2 * stride], x0);
-            E::st(&lds[e0 + 3 * stride], x0);
+            const Fr29 x0 = lay.ldp(p0);
+            lay.stp(p1, x0);
+            lay.stp(p2, x0);
+            lay.stp(p3, x0);
             return;
         }
         if (zeros == 2) {   // y0 = y1 = x0 (mod r), y2 = x2 w, y3 = x2 w'
-            const Fr29 x0 = E::ld(&lds[e0]), x2 = E::ld(&lds[e0 + 2 * stride]);
-            const Fr29 y2 = f29_mul(x2, ld29(&tw_s[i << (m - 2 - st)]));
-            const Fr29 y3 = f29_mul(x2, ld29(&tw_s[(i + h) << (m - 2 - st)]));
-            E::st(&lds[e0], f29_norm(f29_add(x0, y2)));
-            E::st(&lds[e0 + 2 * stride], f29_sub<2>(x0, y2));
-            E::st(&lds[e0 + stride], f29_norm(f29_add(x0, y3)));
-            E::st(&lds[e0 + 3 * stride], f29_sub<2>(x0, y3));
+            const Fr29 x0 = lay.ldp(p0), x2 = lay.ldp(p2);
+            const Fr29 y2 = f29_mul(x2, lay.ldtw(i << (m - 2 - st)));
+            const Fr29 y3 = f29_mul(x2, lay.ldtw((i + h) << (m - 2 - st)));
+            lay.stp(p0, f29_norm(f29_add(x0, y2)));
+            lay.stp(p2, f29_sub<2>(x0, y2));
+            lay.stp(p1, f29_norm(f29_add(x0, y3)));
+            lay.stp(p3, f29_sub<2>(x0, y3));
             return;
         }
-        Fr29 x0 = E::ld(&lds[e0]), x1 = E::ld(&lds[e0 + stride]), x2 = E::ld(&lds[e0 + 2 * stride]), x3 = E::ld(&lds[e0 + 3 * stride]);
+        Fr29 x0 = lay.ldp(p0), x1 = lay.ldp(p1), x2 = lay.ldp(p2), x3 = lay.ldp(p3);
         if (st) {   // stage st: omega_{2h}^i (for st == 0 it is 1)
-            const Fr29 w1 = ld29(&tw_s[i << (m - 1 - st)]);
+            const Fr29 w1 = lay.ldtw(i << (m - 1 - st));
             x1 = f29_mul(x1, w1);
             x3 = f29_mul(x3, w1);
         }
         const Fr29 y0 = f29_add(x0, x1), y1 = f29_sub_lazy<2>(x0, x1);
         // stage st+1 (half = 2h): omega_{4h}^i and omega_{4h}^(i+h)
-        const Fr29 y2 = f29_mul_wide(f29_add(x2, x3), ld29(&tw_s[i << (m - 2 - st)]));
-        const Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), ld29(&tw_s[(i + h) << (m - 2 - st)]));
-        E::st(&lds[e0], f29_norm(f29_add(y0, y2)));
-        E::st(&lds[e0 + 2 * stride], f29_sub<2>(y0, y2));
-        E::st(&lds[e0 + stride], f29_norm(f29_add(y1, y3)));
-        E::st(&lds[e0 + 3 * stride], f29_sub<2>(y1, y3));
+        const Fr29 y2 = f29_mul_wide(f29_add(x2, x3), lay.ldtw(i << (m - 2 - st)));
+        const Fr29 y3 = f29_mul_wide(f29_sub_lazy<2>(x2, x3), lay.ldtw((i + h) << (m - 2 - st)));
+        lay.stp(p0, f29_norm(f29_add(y0, y2)));
+        lay.stp(p2, f29_sub<2>(y0, y2));
+        lay.stp(p1, f29_norm(f29_add(y1, y3)));
+        lay.stp(p3, f29_sub<2>(y1, y3));
     };
 
     for (;;) {
@@ -325,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
             const uint32_t e = tid + T * k;
             const uint32_t t = e >> cb, c = e & (C - 1);
             if (FIRST && k && quarter) {   // a zero row; with an even m the first round (a copy of x0) overwrites it anyway
-                if (m & 1) E::st(&lds[(bitrev_m(t, m) << cb) + c], Fr29::zero());
+                if (m & 1) lay.stp(lay.swz((bitrev_m(t, m) << cb) + c), Fr29::zero());
                 continue;
             }
             Fr s;
@@ -337,7 +428,7 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
                 if (MUL) v = f29_mul(v, ld29(&scale_s[idx % 3u]));
                 if (idx >= in_len) v = Fr29::zero();
             }
-            E::st(&lds[(bitrev_m(t, m) << cb) + c], v);
+            lay.stp(lay.swz((bitrev_m(t, m) << cb) + c), v);
         }
         const uint32_t next = tile + gridDim.x;
         const bool has_next = next < ntiles;       // wave-uniform
@@ -349,10 +440,10 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
             for (uint32_t k = 0; k < 2; ++k) {
                 const uint32_t b = tid + T * k;
                 const uint32_t c = b & (C - 1), p = b >> cb;
-                const uint32_t e0 = ((p << 1) << cb) + c, e1 = e0 + C;
-                const Fr29 a = E::ld(&lds[e0]), t = E::ld(&lds[e1]);
-                E::st(&lds[e0], f29_norm(f29_add(a, t)));
-                E::st(&lds[e1], f29_sub<2>(a, t));
+                const uint32_t e0 = lay.swz(((p << 1) << cb) + c), e1 = e0 ^ lay.swz(C);   // bit cb of the row index is clear
+                const Fr29 a = lay.ldp(e0), t = lay.ldp(e1);
+                lay.stp(e0, f29_norm(f29_add(a, t)));
+                lay.stp(e1, f29_sub<2>(a, t));
             }
             st = 1;
             __syncthreads();
@@ -380,7 +471,7 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
                 c = e & (C - 1);
             }
             const uint32_t j = j0 + c, q = j & smask, jq = j - q;
-            lidx[k] = (u << cb) + c;
+            lidx[k] = lay.swz((u << cb) + c);
             oidx[k] = (jq << m) + q + (u << log_s);
             if (!LAST) {   // omega^(jq*u): jq is a multiple of s, the table holds omega^(s*t)
                 const v4u *tp = reinterpret_cast<const v4u *>(tdirect + (size_t)(jq >> log_s) * u);
@@ -395,7 +486,7 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
         // ---- read-out
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
-            Fr29 v = E::ld(&lds[lidx[k]]);
+            Fr29 v = lay.ldp(lidx[k]);
             if (!LAST) v = f29_mul(v, twr[k]);
             if (LAST && MUL) v = f29_mul(v, ld29(&scale_s[oidx[k] % 3u]));
             if (LAST && !MUL) v = f29_weak_reduce(v);   // weak bound (<= 21 r) -> < 2 r before packing, no multiply
@@ -775,7 +866,8 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
             }
             // the specialised full-tile kernel: every pass of a transform larger than the tile
             if (ctx->ntt_tile_kernel && P >= 2 && LT == 10 && m + cb == 10 && m >= 2 && (last || tdirect) && N <= (1ull << 28)) {
-                const size_t shmem_t = sizeof(Fr29L) * 1024 + sizeof(Fr29P) * (((size_t)1 << (m - 1)) + 3);
+                const bool planes = ctx->ntt_lds_planes != 0;
+                const size_t shmem_t = planes ? TileLayoutPlanes::bytes(m) : TileLayout48::bytes(m);
                 // one persistent workgroup per slot (measured against equal shares — ceil(tiles / rounds) workgroups, every one walking the same number
                 // of tiles: 2^22 0.62 vs 0.575 ms, profiles/r04_ntt_experiments.log: fewer workgroups than slots leave a third of the CUs one short)
                 const uint32_t slots = (uint32_t)ctx->num_cus * 3;
@@ -783,9 +875,14 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
                 const bool mul = first ? in_scale3 != nullptr : (last && out_scale3 != nullptr);
                 const uint32_t in_len32 = (uint32_t)(first ? in_len : N);
                 prof_begin(ctx, "ntt_pass_kernel");
-#define H2_NTT_TILE(KIND, MUL)                                                                                                                \
-    hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL>), dim3(grid_t, gc), dim3(256), shmem_t, ctx->stream, cols, log_n, m, log_s, cb, (const Fr29L *)tw->t1, \
+#define H2_NTT_TILE_(KIND, MUL, LAY)                                                                                                               \
+    hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL, LAY>), dim3(grid_t, gc), dim3(256), shmem_t, ctx->stream, cols, log_n, m, log_s, cb, (const Fr29L *)tw->t1, \
                        (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc)
+#define H2_NTT_TILE(KIND, MUL)                                 \
+    do {                                                       \
+        if (planes) H2_NTT_TILE_(KIND, MUL, TileLayoutPlanes); \
+        else H2_NTT_TILE_(KIND, MUL, TileLayout48);            \
+    } while (0)
                 if (first) {
                     if (mul) H2_NTT_TILE(0, true);
                     else H2_NTT_TILE(0, false);
@@ -796,6 +893,7 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
                     else H2_NTT_TILE(2, false);
                 }
 #undef H2_NTT_TILE
+#undef H2_NTT_TILE_
                 prof_end(ctx);
                 H2_HIPCHK(hipGetLastError());
                 in_scratch = to_scratch;

@@ -784,16 +784,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             if (h2hip_init(ctx->device, nullptr, own) != H2HIP_OK) return nullptr;
             c = *own;
         }
-        c->ntt_tile_bits = ctx->ntt_tile_bits;
-        c->ntt_min_col_bits = ctx->ntt_min_col_bits;
-        c->ntt_full_table = ctx->ntt_full_table;
-        c->ntt_tile_kernel = ctx->ntt_tile_kernel;
-        c->ntt_w8 = ctx->ntt_w8;
-        c->msm_chunk = ctx->msm_chunk;
-        c->msm_seg = ctx->msm_seg;
-        c->profiling = ctx->profiling;
-        c->prof_filter = ctx->prof_filter;
-        c->prof_ref = ctx->prof_ref;
+        inherit_knobs(c, ctx);
         return c;
     };
     bool side_busy = false;   // work is queued on the side stream that the main stream has not waited for yet

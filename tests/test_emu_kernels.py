@@ -569,12 +569,14 @@ def test_full_range_field_inputs(ctx):
     F.check_eval_and_division(ctx, [1, 9, 2049])
 
 
-@pytest.mark.parametrize("tile_bits,tile_kernel", [(10, 1), (10, 0)])
-def test_ntt_full_tile_kernels(ctx, tile_bits, tile_kernel):
-    """ntt_tile_kernel (r04): the specialised full-tile pass kernel (the default) and the generic pass kernel instead (ntt_tile_kernel = 0)
-    — forward, inverse with its fused divisor, coset extension with zero padding and back, bit-exact"""
+@pytest.mark.parametrize("tile_bits,tile_kernel,lds_planes", [(10, 1, 1), (10, 1, 0), (10, 0, 1)])
+def test_ntt_full_tile_kernels(ctx, tile_bits, tile_kernel, lds_planes):
+    """ntt_tile_kernel (r04): the specialised full-tile pass kernel (the default) with its r06 LDS layout (limb planes at a swizzled index, skewed
+    stage twiddles: ntt_lds_planes = 1) and r05's 48-byte elements, and the generic pass kernel instead (ntt_tile_kernel = 0) — forward, inverse
+    with its fused divisor, coset extension with zero padding and back, bit-exact"""
     ctx.set_param("ntt_tile_bits", tile_bits)
     ctx.set_param("ntt_tile_kernel", tile_kernel)
+    ctx.set_param("ntt_lds_planes", lds_planes)
     try:
         for log_n in (11, 12, 13, 14, 16):
             a = rand_fr(1 << log_n, 70 + log_n)
@@ -593,6 +595,7 @@ def test_ntt_full_tile_kernels(ctx, tile_bits, tile_kernel):
     finally:
         ctx.set_param("ntt_tile_bits", 10)
         ctx.set_param("ntt_tile_kernel", 1)
+        ctx.set_param("ntt_lds_planes", 1)
 
 
 @pytest.mark.parametrize("w8", [1, 2])
