@@ -251,7 +251,8 @@ struct TileLayout48 {   // r05: 48-byte elements, packed twiddles
     __device__ __forceinline__ Fr29 ldtw(uint32_t k) const { return ld29(&tw_s[k]); }
     __device__ __forceinline__ void sttw(uint32_t k, const Fr29 &v) const { st29(&tw_s[k], v); }
 };
-struct TileLayoutPlanes {
+template <int SWZ>
+struct TileLayoutPlanesT {
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     static __host__ __device__ constexpr uint32_t tw_slots(uint32_t m) { return (1u << (m - 1)) + (1u << (m - 1) >> 4) + 1; }
     static __host__ __device__ constexpr size_t bytes(uint32_t m) { return (size_t)36 * 1024 + (size_t)36 * tw_slots(m) + sizeof(Fr29P) * 3 + 16; }
@@ -279,6 +280,8 @@ struct TileLayoutPlanes {
         return w;
     }
     __device__ __forceinline__ uint32_t swz(uint32_t e) const {
+        if (SWZ == 0) return e;
+        if (SWZ == 2) return e ^ ((e >> 3) & 31u) ^ ((e >> 5) & 31u);
         constexpr uint32_t T0 = tt(1), T1 = tt(6), T2 = tt(18), T3 = tt(15), T4 = tt(27);
         const uint32_t u = e >> 5;
         const uint32_t x = ((T0 >> u) & 1u) | (((T1 >> u) & 1u) << 1) | (((T2 >> u) & 1u) << 2) | (((T3 >> u) & 1u) << 3) | (((T4 >> u) & 1u) << 4);
@@ -319,6 +322,7 @@ struct TileLayoutPlanes {
         tc[p] = v.l[8];
     }
 };
+typedef TileLayoutPlanesT<1> TileLayoutPlanes;
 template <int KIND, bool MUL, typename L>
 __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
                                                           const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
@@ -880,8 +884,10 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
                        (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc)
 #define H2_NTT_TILE(KIND, MUL)                                 \
     do {                                                       \
-        if (planes) H2_NTT_TILE_(KIND, MUL, TileLayoutPlanes); \
-        else H2_NTT_TILE_(KIND, MUL, TileLayout48);            \
+        if (ctx->ntt_lds_planes == 1) H2_NTT_TILE_(KIND, MUL, TileLayoutPlanes);          \
+        else if (ctx->ntt_lds_planes == 2) H2_NTT_TILE_(KIND, MUL, TileLayoutPlanesT<0>); \
+        else if (ctx->ntt_lds_planes == 3) H2_NTT_TILE_(KIND, MUL, TileLayoutPlanesT<2>); \
+        else H2_NTT_TILE_(KIND, MUL, TileLayout48);                                        \
     } while (0)
                 if (first) {
                     if (mul) H2_NTT_TILE(0, true);

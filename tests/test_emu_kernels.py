@@ -622,3 +622,13 @@ def test_ntt_wave_owned_radix8_pass(ctx, w8):
             assert np.array_equal(back[: 1 << k], a) and not back[1 << k:].any()
     finally:
         ctx.set_param("ntt_w8", 0)
+
+
+def test_flex_gate_reference_kats_emulated(ctx):
+    """the reference-held known answers of halo2-base/src/gates/tests/flex_gate.rs through the emulated batch kernels (same fixture as the GPU test)"""
+    from tests import gate_kats as GK
+
+    class B:
+        add, sub, mul, mul_add, invert = (staticmethod(f) for f in (ctx.fr_add, ctx.fr_sub, ctx.fr_mul, ctx.fr_mul_add, ctx.fr_batch_invert))
+
+    assert GK.check_all(B) == 31

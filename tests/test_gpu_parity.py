@@ -166,6 +166,17 @@ def test_fr_batches(ctx):
     assert np.array_equal(ctx.fr_scale(a, sc), CO.fr_mul(a, rep))
 
 
+def test_flex_gate_reference_kats(ctx):
+    """the reference's own known answers for GateInstructions' witness values (halo2-base/src/gates/tests/flex_gate.rs:11-150, :217:
+    tests/golden/flex_gate_reference_kats.json) through h2hip_fr_{add,sub,mul,mul_add}_batch_dev and h2hip_fr_batch_invert_dev"""
+    from tests import gate_kats as GK
+
+    class B:
+        add, sub, mul, mul_add, invert = (staticmethod(f) for f in (ctx.fr_add, ctx.fr_sub, ctx.fr_mul, ctx.fr_mul_add, ctx.fr_batch_invert))
+
+    assert GK.check_all(B) == 31
+
+
 @pytest.mark.parametrize("n", [700, 1 << 16])
 def test_msm_precomputed_bases(ctx, n):
     from halo2_lib_amd.h2hip import BASES_PRECOMPUTE

@@ -208,3 +208,17 @@ def test_second_g1_implementation_agrees():
     srs = [O.g1_mul(G, pow(tau, i, R)) for i in range(16)]
     p = [rnd.randrange(R) for _ in range(16)]
     assert O.msm_complete(p, srs) == O.g1_mul_complete(G, O.eval_polynomial(p, tau))
+
+
+def test_flex_gate_reference_kats_on_the_oracle():
+    """the reference's own known answers for GateInstructions' witness values (halo2-base/src/gates/tests/flex_gate.rs:11-150, :217) through the
+    oracle's F_r kernels — VERDICT r05 missing 6; the GPU batch kernels take the same fixture in test_gpu_parity.py"""
+    from oracle import c_oracle as CO
+    from tests import gate_kats as GK
+
+    class B:
+        add, sub, mul = staticmethod(CO.fr_add), staticmethod(CO.fr_sub), staticmethod(CO.fr_mul)
+        mul_add = staticmethod(lambda a, b, c: CO.fr_add(CO.fr_mul(a, b), c))
+        invert = staticmethod(CO.fr_batch_invert)
+
+    assert GK.check_all(B) == 31
