@@ -226,6 +226,7 @@ extern "C" {
     pub fn h2hip_comm_info(comm: *const h2hip_comm, world: *mut c_int, rank: *mut c_int, is_rccl: *mut c_int) -> c_int;
     pub fn h2hip_comm_destroy(comm: *mut h2hip_comm);
     pub fn h2hip_comm_allgather_dev(comm: *mut h2hip_comm, ctx: *mut h2hip_ctx, send_dev: *const c_void, bytes: usize, recv_dev: *mut c_void) -> c_int;
+    pub fn h2hip_comm_alltoall_dev(comm: *mut h2hip_comm, ctx: *mut h2hip_ctx, send_dev: *const c_void, bytes: usize, recv_dev: *mut c_void) -> c_int;
     pub fn h2hip_comm_allgather_host(comm: *mut h2hip_comm, ctx: *mut h2hip_ctx, send_host: *const c_void, bytes: usize, recv_host: *mut c_void) -> c_int;
     pub fn h2hip_fr_coset_scale_batch_dev(ctx: *mut h2hip_ctx, outs_dev: *const *mut c_void, ins_dev: *const *const c_void, count: usize, n: usize,
                                           s: *const c_void) -> c_int;

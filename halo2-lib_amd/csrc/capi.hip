@@ -381,6 +381,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "host_poll")) return &ctx->host_poll;
     if (!strcmp(name, "plonk_merge_products")) return &ctx->plonk_merge_products;
     if (!strcmp(name, "plonk_shard_side")) return &ctx->plonk_shard_side;
+    if (!strcmp(name, "plonk_route_rows")) return &ctx->plonk_route_rows;
     if (!strcmp(name, "plonk_early_intt")) return &ctx->plonk_early_intt;
     if (!strcmp(name, "plonk_gate_before_join")) return &ctx->plonk_gate_before_join;
     if (!strcmp(name, "msm_stagger_sorts")) return &ctx->msm_stagger_sorts;

@@ -22,6 +22,9 @@ struct NcclId {
 typedef int (*nccl_get_unique_id_fn)(NcclId *);
 typedef int (*nccl_comm_init_rank_fn)(void **, int, NcclId, int);
 typedef int (*nccl_all_gather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*nccl_send_fn)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_recv_fn)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_group_fn)(void);
 typedef int (*nccl_comm_destroy_fn)(void *);
 typedef const char *(*nccl_get_error_string_fn)(int);
 struct RcclApi {
@@ -29,6 +32,9 @@ struct RcclApi {
     nccl_get_unique_id_fn get_unique_id = nullptr;
     nccl_comm_init_rank_fn comm_init_rank = nullptr;
     nccl_all_gather_fn all_gather = nullptr;
+    nccl_send_fn send = nullptr;   // r06: the all-to-all (rows -> column owners) is a group of point-to-point transfers, one per peer link
+    nccl_recv_fn recv = nullptr;
+    nccl_group_fn group_start = nullptr, group_end = nullptr;
     nccl_comm_destroy_fn comm_destroy = nullptr;
     nccl_get_error_string_fn get_error_string = nullptr;
 };
@@ -50,10 +56,14 @@ static int load_rccl() {
     a.get_unique_id = (nccl_get_unique_id_fn)dlsym(lib, "ncclGetUniqueId");
     a.comm_init_rank = (nccl_comm_init_rank_fn)dlsym(lib, "ncclCommInitRank");
     a.all_gather = (nccl_all_gather_fn)dlsym(lib, "ncclAllGather");
+    a.send = (nccl_send_fn)dlsym(lib, "ncclSend");
+    a.recv = (nccl_recv_fn)dlsym(lib, "ncclRecv");
+    a.group_start = (nccl_group_fn)dlsym(lib, "ncclGroupStart");
+    a.group_end = (nccl_group_fn)dlsym(lib, "ncclGroupEnd");
     a.comm_destroy = (nccl_comm_destroy_fn)dlsym(lib, "ncclCommDestroy");
     a.get_error_string = (nccl_get_error_string_fn)dlsym(lib, "ncclGetErrorString");
-    if (!a.get_unique_id || !a.comm_init_rank || !a.all_gather || !a.comm_destroy) {
-        set_error("h2hip_comm: librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+    if (!a.get_unique_id || !a.comm_init_rank || !a.all_gather || !a.comm_destroy || !a.send || !a.recv || !a.group_start || !a.group_end) {
+        set_error("h2hip_comm: librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd / ncclCommDestroy");
         dlclose(lib);
         return H2HIP_ERR_INVALID;
     }
@@ -107,6 +117,13 @@ int h2::comm_reserve_allgather_dev(h2hip_comm *c, size_t bytes) {
     H2_REQUIRE(c, "NULL argument");
     if (c->nccl || !bytes) return H2HIP_OK;
     return comm_host_stage(c, bytes + bytes * (size_t)c->world);
+}
+// the same for a later h2hip_comm_alltoall_dev(bytes per peer)
+int h2::comm_reserve_alltoall_dev(h2hip_comm *c, size_t bytes) {
+    H2_REQUIRE(c, "NULL argument");
+    if (c->nccl || !bytes) return H2HIP_OK;
+    const size_t mine = bytes * (size_t)c->world;
+    return comm_host_stage(c, mine + mine * (size_t)c->world);
 }
 
 extern "C" {
@@ -182,6 +199,41 @@ int h2hip_comm_allgather_dev(h2hip_comm *comm, h2hip_ctx *ctx, const void *send_
         return H2HIP_ERR_INVALID;
     }
     H2_HIPCHK(hipMemcpyAsync(recv_dev, hr, total, hipMemcpyHostToDevice, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next exchange
+    return H2HIP_OK;
+}
+
+// recv_dev[p * bytes ...] = what rank p put at send_dev[me * bytes ...]: every rank hands every peer a DIFFERENT block (the rows of the columns
+// that peer owns).  RCCL: one group of ncclSend / ncclRecv per peer on the context's stream — xGMI is point to point, every block takes its own
+// link, and a rank receives 1 / world of what the matching all-gather would bring it.  Callback transport (tests): through the all-gather
+// callback over the whole send buffers (world times the traffic: correctness only), staged through pinned host memory.
+int h2hip_comm_alltoall_dev(h2hip_comm *comm, h2hip_ctx *ctx, const void *send_dev, size_t bytes, void *recv_dev) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(comm && ctx && (bytes == 0 || (send_dev && recv_dev)), "NULL argument");
+    if (!bytes) return H2HIP_OK;
+    const size_t W = (size_t)comm->world;
+    if (comm->nccl) {
+        H2_CHK(nccl_check(g_rccl.group_start(), "ncclGroupStart"));
+        int rc = 0;
+        for (size_t p = 0; p < W && rc == 0; ++p) {
+            rc = g_rccl.send((const char *)send_dev + p * bytes, bytes, /* ncclUint8 */ 1, (int)p, comm->nccl, ctx->stream);
+            if (rc == 0) rc = g_rccl.recv((char *)recv_dev + p * bytes, bytes, 1, (int)p, comm->nccl, ctx->stream);
+        }
+        const int rc_end = g_rccl.group_end();   // always closed, whatever a send / recv said
+        H2_CHK(nccl_check(rc, "ncclSend / ncclRecv"));
+        return nccl_check(rc_end, "ncclGroupEnd");
+    }
+    const size_t mine = bytes * W, total = mine * W;
+    H2_CHK(comm_host_stage(comm, mine + total));
+    char *hs = (char *)comm->host_stage, *hr = hs + mine;
+    H2_HIPCHK(hipMemcpyAsync(hs, send_dev, mine, hipMemcpyDeviceToHost, ctx->stream));
+    H2_HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (comm->cb(comm->cb_user, hs, mine, hr) != 0) {
+        set_error("h2hip_comm: the all-gather callback failed");
+        return H2HIP_ERR_INVALID;
+    }
+    for (size_t p = 0; p < W; ++p)   // rank p's block for this rank
+        H2_HIPCHK(hipMemcpyAsync((char *)recv_dev + p * bytes, hr + p * mine + (size_t)comm->rank * bytes, bytes, hipMemcpyHostToDevice, ctx->stream));
     H2_HIPCHK(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next exchange
     return H2HIP_OK;
 }

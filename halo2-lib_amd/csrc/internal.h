@@ -130,6 +130,7 @@ struct h2hip_ctx {
     int kate_coeffs_per_lane = 0;    // multi-point kate division: coefficients per lane (1, 2, 4, 8); 0 = by length
     int plonk_merge_products = 1;    // one permutation set: its factors and the lookups' go through ONE batched inversion / prefix product
     int plonk_shard_side = 1;        // sharded create_proof: the first-round columns' lagrange_to_coeff (+ all-gather) and coset transforms on a side stream next to round 2's commitments
+    int plonk_route_rows = 1;        // r06, sharded create_proof with column-dealt lagrange_to_coeff: the grand products' rows go to the columns' owners by an all-to-all (ncclSend / ncclRecv) instead of to every rank by an all-gather
     int plonk_early_intt = 1;        // round 3: the grand products' lagrange_to_coeff is queued on the side context BEFORE the round's commitments (next to their sorts), only the coset transforms behind the accumulations
     int plonk_gate_before_join = 0;  // the quotient's gate identities start when the FIRST-round columns' cosets are done; the grand products' transforms are joined behind them
     int msm_stagger_sorts = -1;      // batch MSM: lane l's first sort starts when lane l-1's sort is done (the first accumulation starts after ONE sort, not next to NL of them); -1 = auto: with two lanes (from 2^20 points), where it measured -1 % per k = 20 proof; with three lanes it costs 1 - 2.5 % (profiles/r05_early_intt_stagger_ab.log)
@@ -191,6 +192,7 @@ inline void inherit_knobs(h2hip_ctx *c, const h2hip_ctx *p) {
     c->fr_invert_run = p->fr_invert_run;
     c->lookup_big_tile_bits = p->lookup_big_tile_bits;
     c->host_poll = p->host_poll;
+    c->plonk_route_rows = p->plonk_route_rows;
     c->profiling = p->profiling;
     c->prof_filter = p->prof_filter;
     c->prof_ref = p->prof_ref;   // launch spans of all children share the parent's time origin
@@ -271,5 +273,6 @@ void prof_fold_child(h2hip_ctx *parent, h2hip_ctx *child);
 int rng_chacha_fill_dev(h2hip_ctx *ctx, Fr *out_dev, size_t n, const uint8_t seed[32], int rounds, uint64_t first_block, hipStream_t stream);
 // comm.hip: the fallible preparations of a later h2hip_comm_allgather_dev of `bytes` per rank, done ahead of time
 int comm_reserve_allgather_dev(h2hip_comm *comm, size_t bytes);
+int comm_reserve_alltoall_dev(h2hip_comm *c, size_t bytes);
 int msm_reduce_cols(h2hip_ctx *ctx, const h2hip_bases *bases, uint32_t window_bits, const XYZZ29 *buckets, uint32_t ncols, XYZZ *out_dev);
 }  // namespace h2

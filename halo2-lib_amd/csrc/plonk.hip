@@ -766,7 +766,12 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     const bool overlap = !sharded_any && ctx->plonk_tail_overlap != 0;
     // r05, sharded proofs: lagrange_to_coeff (with its all-gather of the coefficient forms when the columns are dealt to the ranks) and the cosets'
     // coeff_to_extended of the FIRST-ROUND columns run on the side context next to round 2's commitments instead of in front of them
-    const bool side_sharded = sharded_any && ctx->plonk_shard_side != 0;
+    // with RCCL and more than one rank the side stream's all-gather and the main stream's host exchanges would use ONE communicator from
+    // two streams at once — a pattern no run has exercised (no box shows more than one device: profiles/r06_rccl_cpx_refusal.log); until one does, the
+    // side stream carries collectives only over the callback transport (which blocks the host anyway) or when plonk_shard_side = 2 forces it
+    int comm_world = 1, comm_rccl = 0;
+    if (sharded_any) h2hip_comm_info(pk->comm, &comm_world, nullptr, &comm_rccl);
+    const bool side_sharded = sharded_any && (ctx->plonk_shard_side == 2 || (ctx->plonk_shard_side == 1 && !(comm_rccl && comm_world > 1)));
     if ((overlap || side_sharded) && !pk->side_ev) H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
     if (overlap && !pk->side_ev1) H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev1, hipEventDisableTiming));
     // (r04 also computed the random polynomial's COMMITMENT ahead — its scalars depend on nothing once the generator is counter-mode — as one
@@ -1035,15 +1040,23 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         const size_t a = std::min<size_t>(pk->shard_offset, u), b = std::min<size_t>(pk->shard_offset + pk->shard_len, u), m = b - a;
         size_t max_m = 0;
         for (auto &rg : rank_ranges) max_m = std::max<size_t>(max_m, std::min<size_t>(rg.first + rg.second, u) - std::min<size_t>(rg.first, u));
-        const size_t row_stride = max_m + 1, slot_elems = nseg * row_stride;
+        // r06 (built): when lagrange_to_coeff is dealt by column, a product column's rows are only ever needed in full by the rank that
+        // transforms it (commitments read a rank's own rows, everything later the coefficient forms) — so the rows go STRAIGHT to the column's owner
+        // (column j -> rank j mod N, the order to_coeff deals in) by an all-to-all (grouped ncclSend / ncclRecv: h2hip_comm_alltoall_dev) instead
+        // of to everybody by an all-gather: a rank receives 1 / N of the bytes, each block over its own xGMI link.
+        const uint32_t NW = pk->shard_world;
+        const bool route = pk->shard_ntt && ctx->plonk_route_rows != 0;
+        const size_t row_stride = max_m + 1, slot_cols = (nseg + NW - 1) / NW, blk_elems = slot_cols * row_stride;
+        const size_t slot_elems = route ? blk_elems * NW : nseg * row_stride;
         Fr *num = nullptr, *den = nullptr, *sendb = nullptr, *recvb = nullptr;
         std::vector<Fr *> zcol(nseg);
         if (nseg) {
             H2_CHK(sc.take(nseg * std::max<size_t>(m, 1), &num));
             H2_CHK(sc.take(nseg * std::max<size_t>(m, 1), &den));
             H2_CHK(sc.take(slot_elems, &sendb));
-            H2_CHK(sc.take(slot_elems * pk->shard_world, &recvb));
-            H2_CHK(comm_reserve_allgather_dev(pk->comm, sizeof(Fr) * slot_elems));
+            H2_CHK(sc.take(route ? slot_elems : slot_elems * pk->shard_world, &recvb));
+            if (route) H2_CHK(comm_reserve_alltoall_dev(pk->comm, sizeof(Fr) * blk_elems));
+            else H2_CHK(comm_reserve_allgather_dev(pk->comm, sizeof(Fr) * slot_elems));
         }
         for (uint32_t si = 0; si < S; ++si) {
             H2_CHK(sc.take(n, &perm_z[si]));
@@ -1092,14 +1105,22 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
                 const Fr start = j < S ? fe_mul(chain, before) : before;
                 if (j < S) chain = fe_mul(chain, whole);
                 H2_CHK(h2hip_fr_scale_dev(ctx, zcol[j] + a, &start, m + 1));
-                H2_HIPCHK(hipMemcpyAsync(sendb + j * row_stride, zcol[j] + a, sizeof(Fr) * (m + 1), hipMemcpyDeviceToDevice, st));
+                Fr *slot = route ? sendb + (j % NW) * blk_elems + (j / NW) * row_stride : sendb + j * row_stride;   // routed: block of the column's owner
+                H2_HIPCHK(hipMemcpyAsync(slot, zcol[j] + a, sizeof(Fr) * (m + 1), hipMemcpyDeviceToDevice, st));
             }
-            H2_CHK(h2hip_comm_allgather_dev(pk->comm, ctx, sendb, sizeof(Fr) * slot_elems, recvb));
+            if (route) H2_CHK(h2hip_comm_alltoall_dev(pk->comm, ctx, sendb, sizeof(Fr) * blk_elems, recvb));
+            else H2_CHK(h2hip_comm_allgather_dev(pk->comm, ctx, sendb, sizeof(Fr) * slot_elems, recvb));
             for (uint32_t r = 0; r < pk->shard_world; ++r) {
                 if (r == pk->shard_rank) continue;
                 const size_t ar = std::min<size_t>(rank_ranges[r].first, u), br = std::min<size_t>(rank_ranges[r].first + rank_ranges[r].second, u);
                 if (rank_ranges[r].second == 0) continue;
-                std::vector<Fr *> dst(nseg);
+                std::vector<Fr *> dst;
+                if (route) {   // rank r's rows of the columns THIS rank transforms
+                    for (size_t j = pk->shard_rank; j < nseg; j += NW) dst.push_back(zcol[j] + ar);
+                    if (!dst.empty()) H2_CHK(fr_scatter_rows(ctx, dst.data(), dst.size(), recvb + (size_t)r * blk_elems, row_stride, br - ar + 1));
+                    continue;
+                }
+                dst.resize(nseg);
                 for (size_t j = 0; j < nseg; ++j) dst[j] = zcol[j] + ar;
                 H2_CHK(fr_scatter_rows(ctx, dst.data(), nseg, recvb + (size_t)r * slot_elems, row_stride, br - ar + 1));
             }

@@ -123,6 +123,7 @@ _PROTOS = {
     "h2hip_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "h2hip_comm_destroy": (None, [_vp]),
     "h2hip_comm_allgather_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "h2hip_comm_alltoall_dev": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_comm_allgather_host": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "h2hip_fr_coset_scale_batch_dev": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _sz, _sz, _vp]),
     "h2hip_fr_coset_gather_dev": (_int, [_vp, _vp, _vp, C.POINTER(_u32), _u32, _u32, _sz]),

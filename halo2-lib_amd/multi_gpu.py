@@ -208,6 +208,10 @@ class Comm:
     def allgather_dev(self, send_dptr: int, nbytes: int, recv_dptr: int):
         self.ctx._chk(self.ctx.lib.h2hip_comm_allgather_dev(self.handle, self.ctx.handle, send_dptr, nbytes, recv_dptr))
 
+    def alltoall_dev(self, send_dptr: int, nbytes_per_peer: int, recv_dptr: int):
+        """recv[p] = rank p's send[me] (blocks of nbytes_per_peer): grouped ncclSend / ncclRecv, or the callback transport"""
+        self.ctx._chk(self.ctx.lib.h2hip_comm_alltoall_dev(self.handle, self.ctx.handle, send_dptr, nbytes_per_peer, recv_dptr))
+
     def destroy(self):
         if self.handle:
             self.ctx.lib.h2hip_comm_destroy(self.handle)

@@ -432,6 +432,10 @@ void h2hip_comm_destroy(h2hip_comm *comm);
  * host buffers (the 96-byte commitment partials of a round; RCCL: staged through device memory) */
 int h2hip_comm_allgather_dev(h2hip_comm *comm, h2hip_ctx *ctx, const void *send_dev, size_t bytes, void *recv_dev);
 int h2hip_comm_allgather_host(h2hip_comm *comm, h2hip_ctx *ctx, const void *send_host, size_t bytes, void *recv_host);
+/* all-to-all over device buffers: recv[p * bytes ...] = the block rank p put at its send[me * bytes ...] (RCCL: one group of ncclSend / ncclRecv
+ * per peer on the context's stream — point-to-point xGMI links, 1 / world of the matching all-gather's inbound traffic; callback transport:
+ * through the all-gather callback).  The sharded prover routes the grand products' rows to the ranks that own the columns' lagrange_to_coeff. */
+int h2hip_comm_alltoall_dev(h2hip_comm *comm, h2hip_ctx *ctx, const void *send_dev, size_t bytes, void *recv_dev);
 
 /* Sharded create_proof: all ranks run the same h2hip_plonk_create_proof call on the same inputs (same circuit, same RNG stream) and emit
  * identical proof bytes.

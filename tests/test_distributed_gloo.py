@@ -129,7 +129,21 @@ def _worker_prover(rank, world, port, q):
             np.array_equal(ctx.download(d, (1 << log_n, 4)), CO.best_fft(cols[j], log_n, w)) for j, d in owned.items())
         for d in owned.values():
             ctx.free(d)
-        q.put((rank, ok_proof, ok_ntt, ok_owned, sharded.hex()[:32]))
+        # r06: the all-to-all primitive (callback transport here; grouped ncclSend / ncclRecv under RCCL): recv[p] = rank p's send[me]
+        from halo2_lib_amd.multi_gpu import Comm
+
+        comm = Comm(ctx)
+        blk = 5
+        send = np.array([[1000 * rank + 10 * p + i for i in range(blk)] for p in range(world)], dtype=np.uint64)
+        d_send, d_recv = ctx.to_device(send), ctx.malloc(8 * blk * world)
+        comm.alltoall_dev(d_send, 8 * blk, d_recv)
+        ctx.sync()
+        got_a2a = ctx.download(d_recv, (world, blk))
+        ok_a2a = np.array_equal(got_a2a, np.array([[1000 * p + 10 * rank + i for i in range(blk)] for p in range(world)], dtype=np.uint64))
+        ctx.free(d_send)
+        ctx.free(d_recv)
+        comm.destroy()
+        q.put((rank, ok_proof, ok_ntt, ok_owned and ok_a2a, sharded.hex()[:32]))
         pk.free()
         kzg.free()
         ctx.close()
@@ -188,6 +202,11 @@ def _worker_scenarios(rank, world, port, q):
             g, gl = ctx.bases_download(kzg.g), ctx.bases_download(kzg.g_lagrange)
             sk = shard_proving_key(pk, g, gl, precompute=False, shard_ntt_columns=True)   # every stage that can be sharded
             out[name] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
+            # r06: with lagrange_to_coeff dealt by column the grand products' rows travel to the columns' owners by an ALL-TO-ALL
+            # (h2hip_comm_alltoall_dev; default) — and by r05's all-gather to every rank with plonk_route_rows = 0: same bytes either way
+            ctx.set_param("plonk_route_rows", 0)
+            out[name + "_allgather_rows"] = PL.create_proof(pk, circ.advice, circ.instances, PreDrawnRng(budget, 9)) == single
+            ctx.set_param("plonk_route_rows", 1)
             if name == "multi":
                 # the exchange schedule libh2hip reports for that proof (bench.py --gpus N prints it): 13 host exchanges with every stage sharded,
                 # the status-only go-aheads at their places, the SHPLONK carry slots at a fixed 64 x 32 bytes
@@ -262,5 +281,6 @@ def test_sharded_create_proof_scenarios(world):
         o = res[r]
         assert o["multi"] and o["single"] and o["msm_only"] and o["multi_unsharded_again"] and o["single_unsharded_again"], (r, o)
         assert o["after_fail"] and o["after_rng"] and o.get("ragged", True) and o["sched"], (r, o)
+        assert o["multi_allgather_rows"] and o.get("single_allgather_rows", True), (r, o)   # r06: rows routed by all-to-all (default) == rows all-gathered
         assert o["fail"] == (-1 if r == world - 1 else -5), (r, o)     # H2HIP_ERR_INVALID where the witness is wrong, H2HIP_ERR_PEER elsewhere
         assert o["rng"] == -1, (r, o)                                   # every rank sees the mismatch in the hello exchange
