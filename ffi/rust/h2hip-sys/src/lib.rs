@@ -266,5 +266,4 @@ extern "C" {
     pub fn h2hip_bench_modmul(ctx: *mut h2hip_ctx, blocks: u32, iters: u32, chains: u32, elapsed_ms: *mut f64, modmuls: *mut f64) -> c_int;
     pub fn h2hip_bench_gather(ctx: *mut h2hip_ctx, kind: u32, table_bytes: usize, lanes: u32, per_lane: u32, elapsed_ms: *mut f64, useful_bytes: *mut f64) -> c_int;
     pub fn h2hip_bench_modmul29(ctx: *mut h2hip_ctx, blocks: u32, iters: u32, chains: u32, elapsed_ms: *mut f64, modmuls: *mut f64) -> c_int;
-    pub fn h2hip_bench_modmul52(ctx: *mut h2hip_ctx, blocks: u32, iters: u32, chains: u32, elapsed_ms: *mut f64, modmuls: *mut f64, check_limbs: *mut u64) -> c_int;
 }

@@ -370,8 +370,6 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "ntt_tile_bits")) return &ctx->ntt_tile_bits;
     if (!strcmp(name, "ntt_debug_skip")) return &ctx->ntt_debug_skip;
     if (!strcmp(name, "ntt_tile_kernel")) return &ctx->ntt_tile_kernel;
-    if (!strcmp(name, "ntt_w8")) return &ctx->ntt_w8;
-    if (!strcmp(name, "ntt_lds_planes")) return &ctx->ntt_lds_planes;
     if (!strcmp(name, "plonk_warm_keygen")) return &ctx->plonk_warm_keygen;
     if (!strcmp(name, "plonk_tail_overlap")) return &ctx->plonk_tail_overlap;
     if (!strcmp(name, "plonk_side_on_lanes")) return &ctx->plonk_side_on_lanes;

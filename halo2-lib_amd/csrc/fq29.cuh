@@ -319,6 +319,25 @@ H2_HD Fe<PS> f29_pack_canonical(const F29<P> &t) {
     return out;
 }
 
+// N value below 2^256 (e.g. < 2 p) -> saturated limbs of the SAME integer, not reduced: for buffers only this library reads back (the NTT's
+// inter-pass scratch: the next pass splits it again, bounds in ntt.hip) — f29_pack_canonical without the trial subtraction (~36 instructions)
+template <class PS, class P>
+H2_HD Fe<PS> f29_pack_weak(const F29<P> &t) {
+    Fe<PS> out;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const int lo_limb = (32 * w) / 29, off = 32 * w - 29 * lo_limb;
+        H2_ASSERT29(lo_limb == 8 || t.l[lo_limb] <= MASK29);
+        uint64_t v = (uint64_t)t.l[lo_limb] >> off;
+        int have = 29 - off;
+        if (lo_limb + 1 < 9) v |= (uint64_t)t.l[lo_limb + 1] << have;
+        if (have + 29 < 32 && lo_limb + 2 < 9) v |= (uint64_t)t.l[lo_limb + 2] << (have + 29);
+        out.l[w] = (uint32_t)v;
+    }
+    H2_ASSERT29(t.l[8] < (1u << 24));   // the value fits 256 bits
+    return out;
+}
+
 H2_HD Fq29 f29_from_sat(const Fq &s) {
     Fq29 k;
 #pragma unroll

@@ -80,9 +80,7 @@ struct h2hip_ctx {
     int ntt_tile_bits = 10;
     int ntt_min_col_bits = 2;    // log2 of the minimum number of adjacent columns per tile (coalescing vs number of passes)
     int ntt_full_table = 1;      // first pass reads a full omega^e table instead of composing two table entries
-    int ntt_w8 = 0;              // r05: 1 / 2 = transforms of 2^12+ points on the wave-owned radix-8 pass (ntt_w8_kernel) at three / two waves per SIMD — bit-exact, measured 8-12 % slower; 0: the tile / generic pass kernels
     int ntt_tile_kernel = 1;     // 1 (default): full 1024-element tiles go through ntt_tile_kernel (r04: no exposed global-memory latency); 0: the generic pass kernel
-    int ntt_lds_planes = 1;      // r06: the tile kernel's LDS layout — 1: three limb planes at a swizzled index + skewed stage twiddles (TileLayoutPlanes, ntt.hip); 0: r05's 48-byte elements
     int ntt_debug_skip = 0;      // diagnostics only: 1 = skip butterflies, 2 = skip inter-pass twiddles (wrong results)
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
@@ -184,8 +182,6 @@ inline void inherit_knobs(h2hip_ctx *c, const h2hip_ctx *p) {
     c->ntt_min_col_bits = p->ntt_min_col_bits;
     c->ntt_full_table = p->ntt_full_table;
     c->ntt_tile_kernel = p->ntt_tile_kernel;
-    c->ntt_lds_planes = p->ntt_lds_planes;
-    c->ntt_w8 = p->ntt_w8;
     c->quotient_29 = p->quotient_29;
     c->kate_29 = p->kate_29;
     c->kate_coeffs_per_lane = p->kate_coeffs_per_lane;

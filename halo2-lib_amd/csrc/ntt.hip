@@ -230,29 +230,17 @@ __device__ __forceinline__ void st29(Fr29P *p, const Fr29 &v) {
 //   * rounds, fills and read-outs whose lanes step through elements at a stride of 4 / 8 (cb + st < 4, the bit-reversed fill, the first pass's
 //     u-contiguous read-out with cb = 2): 2- to 4-way on the 16-byte accesses;
 //   * the packed 36-byte stage twiddles read at power-of-two index strides: up to 4-way on nine 4-byte reads per twiddle.
-// Layout 1 (default) stores an element as three PLANES — limbs 0-3 (16 B), limbs 4-7 (16 B), limb 8 (4 B), 36 KiB per tile instead of 48 — at
+// MEASURED (profiles/r06_ntt_lds_layout_pmc.log, _times.log, _proof_ab.log): SQ_LDS_BANK_CONFLICT 8.78e6 -> 3.5e5 per pass launch (ratio 0.42 ->
+// 0.03), SQ_LDS_IDX_ACTIVE 2.10e7 -> 1.11e7 — and the pass time moves by -2 ... -4 % at 2^22 .. 2^24 and +1 ... +3 % at 2^19 .. 2^21, whole
+// proofs unchanged: the LDS was never what this kernel waited for (its LDS pipe is ~5 % busy; it is VALU-issue bound at 313 executed lane
+// instructions per algorithmic product).  The 48-byte layout and two other variants (planes without a swizzle, a two-shift swizzle: within 1 % of
+// this one everywhere) were A/B'd in the same process and removed.
+// The layout stores an element as three PLANES — limbs 0-3 (16 B), limbs 4-7 (16 B), limb 8 (4 B), 36 KiB per tile instead of 48 — at
 // the swizzled index e ^ X[e >> 5], X a fixed GF(2)-linear map of the upper five index bits into the lower five (found by hill climbing over the
 // model on all (m, cb, pass kind) the planner produces: 0.37 -> 0.06 conflict cycles per LDS cycle on the data), and the stage twiddles in the
 // same three planes at the skewed index k + (k >> 4) (0 conflicts).  Modelled LDS-array cycles per tile: 59.8 k -> 29.9 k.  Linear: swz(a ^ b)
 // = swz(a) ^ swz(b), so a round's four rows e0 + j * stride cost one swizzle and three wave-uniform XORs.
-struct TileLayout48 {   // r05: 48-byte elements, packed twiddles
-    static constexpr uint32_t kTwSlots(uint32_t half) { return half; }
-    static __host__ __device__ constexpr size_t bytes(uint32_t m) { return sizeof(Fr29L) * 1024 + sizeof(Fr29P) * (((size_t)1 << (m - 1)) + 3); }
-    Fr29L *lds;
-    Fr29P *tw_s, *scale_s;
-    __device__ __forceinline__ void init(void *raw, uint32_t m) {
-        lds = reinterpret_cast<Fr29L *>(raw);
-        tw_s = reinterpret_cast<Fr29P *>(lds + 1024);
-        scale_s = tw_s + (1u << (m - 1));
-    }
-    __device__ __forceinline__ uint32_t swz(uint32_t e) const { return e; }
-    __device__ __forceinline__ Fr29 ldp(uint32_t p) const { return lds[p].v; }
-    __device__ __forceinline__ void stp(uint32_t p, const Fr29 &v) const { lds[p].v = v; }
-    __device__ __forceinline__ Fr29 ldtw(uint32_t k) const { return ld29(&tw_s[k]); }
-    __device__ __forceinline__ void sttw(uint32_t k, const Fr29 &v) const { st29(&tw_s[k], v); }
-};
-template <int SWZ>
-struct TileLayoutPlanesT {
+struct TileLayoutPlanes {
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     static __host__ __device__ constexpr uint32_t tw_slots(uint32_t m) { return (1u << (m - 1)) + (1u << (m - 1) >> 4) + 1; }
     static __host__ __device__ constexpr size_t bytes(uint32_t m) { return (size_t)36 * 1024 + (size_t)36 * tw_slots(m) + sizeof(Fr29P) * 3 + 16; }
@@ -280,8 +268,6 @@ struct TileLayoutPlanesT {
         return w;
     }
     __device__ __forceinline__ uint32_t swz(uint32_t e) const {
-        if (SWZ == 0) return e;
-        if (SWZ == 2) return e ^ ((e >> 3) & 31u) ^ ((e >> 5) & 31u);
         constexpr uint32_t T0 = tt(1), T1 = tt(6), T2 = tt(18), T3 = tt(15), T4 = tt(27);
         const uint32_t u = e >> 5;
         const uint32_t x = ((T0 >> u) & 1u) | (((T1 >> u) & 1u) << 1) | (((T2 >> u) & 1u) << 2) | (((T3 >> u) & 1u) << 3) | (((T4 >> u) & 1u) << 4);
@@ -322,7 +308,6 @@ struct TileLayoutPlanesT {
         tc[p] = v.l[8];
     }
 };
-typedef TileLayoutPlanesT<1> TileLayoutPlanes;
 template <int KIND, bool MUL, typename L>
 __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, uint32_t cb,
                                                           const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits,
@@ -494,7 +479,9 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
             if (!LAST) v = f29_mul(v, twr[k]);
             if (LAST && MUL) v = f29_mul(v, ld29(&scale_s[oidx[k] % 3u]));
             if (LAST && !MUL) v = f29_weak_reduce(v);   // weak bound (<= 21 r) -> < 2 r before packing, no multiply
-            const Fr o = f29_pack_canonical<FrP>(v);
+            // a pass that another pass of this transform reads back leaves the product (N, < 1.2 r) unreduced in the scratch buffer: the next fill splits
+            // it again and its butterflies' bound moves from 21 r to 21.2 r (< 32 r: f29_weak_reduce); only the LAST pass writes canonical elements
+            const Fr o = LAST ? f29_pack_canonical<FrP>(v) : f29_pack_weak<FrP>(v);
             v4u *yp = reinterpret_cast<v4u *>(y + oidx[k]);
             v4u lo, hi;
             lo.x = o.l[0]; lo.y = o.l[1]; lo.z = o.l[2]; lo.w = o.l[3];
@@ -508,202 +495,6 @@ __global__ __launch_bounds__(256, 3) void ntt_tile_kernel(NttCols cols, uint32_t
     }
 }
 
-// ---------------------------------------------------------------------------------------------- wave-owned radix-8 pass (r05)
-// One WAVE owns a 512-element sub-transform of a pass — R = 2^m rows (m = 6 .. 9) of 2^(9-m) adjacent columns, eight elements per lane IN
-// REGISTERS — and walks it in steps of three stages: an in-register radix-8 DFT whose five non-trivial twiddles are the wave-uniform powers of
-// w_8 (kernel arguments: scalar registers), eight products by the lane's inter-step twiddles w_R^(..) (one table in LDS, shared by the
-// workgroup's four waves), and an exchange of the 64 x 8 elements through the wave's OWN 8.5 KB LDS buffer, plane by plane (limbs 0-3, 4-7, 8) —
-// no __syncthreads anywhere in the tile loop, no LDS element storage, global loads straight into the first step's register layout and stores
-// straight out of the last one's.  What the r05 probe (tools/probes/w8_probe.hip) measured for this inner structure: 0.77 of the 9 x 29-bit
-// product peak, against ~0.50 (executed products) for the block-barrier radix-4 LDS rounds of ntt_tile_kernel above.
-// MEASURED AS A WHOLE KERNEL (profiles/r05_ntt_w8_ab.log): bit-exact, and 8 - 12 % SLOWER than ntt_tile_kernel (2^22 0.63-0.65 vs 0.583 ms, the k = 21
-// proof 53.6-54.0 vs 52.0-52.7 ms).  PMC: half the LDS instructions and a third of the bank conflicts, as designed — but 8 % more VALU instructions
-// (every in-register stage normalises both outputs where the radix-4 round's lazy sums feed a wide product) and waves parked on memory 30 % of
-// their time against 17 % (228 registers at two waves per SIMD leave none for a prefetched tile; at three waves 43-88 registers spill).  It stays
-// selectable (ntt_w8 = 1 / 2: three / two waves per SIMD; default 0) and tested; the tile kernel remains the product path.
-//
-// Index algebra.  Row t = t1 * 2^(m-3) + t2 * R3 + t3 (t1, t2: 3 bits; t3: m3 = m - 6 bits; R3 = 2^m3), output u = u1 + 8 u2 + 64 u3:
-//   step 1   A[u1; t2, t3] = sum_t1 x[t1, t2, t3] w_8^(t1 u1)                      registers = t1, lane = (t2 | t3, c)
-//   twiddle  A *= w_R^(R3 t2 u1)
-//   step 2   C[u1, u2; t3] = sum_t2 A[u1; t2, t3] w_8^(t2 u2)                      registers = t2, lane = (u1 | t3, c)
-//   twiddle  C *= w_R^(t3 (u1 + 8 u2))                                             (m3 > 0)
-//   step 3   X[u1, u2, u3] = sum_t3 C[u1, u2; t3] w_R3^(t3 u3)                     registers = (u2's top 3 - m3 bits, t3), lane = (c, u1, u2's low m3 bits)
-// The DFTs are decimation-in-time on bit-reversed register indices (the loads / exchanges place element t in register bitrev(t)); a value's bound
-// grows by at most 2 r per stage and every twiddle product brings it back below 1.1 r (fq29.cuh's rules: documented per line below).
-// The lane order of the LAST layout follows the pass's output pattern: later passes write runs contiguous in the column index (c lowest in the
-// lane), the first pass writes runs contiguous in u (u1 lowest).
-struct W8Twiddles {
-    uint32_t w[4][9];   // w_8^0 .. w_8^3 of this transform in R' form (w_8 = omega^(N/8))
-};
-template <int K>
-__device__ __forceinline__ Fr29 w8_const(const W8Twiddles &t) {
-    Fr29 r;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r.l[i] = t.w[K][i];
-    return r;
-}
-// one butterfly of stage S (half = 2^S) of the in-register DIT network: registers e0 = BLK * 2^(S+1) + I and e0 + 2^S, twiddle w_(2^(S+1))^I
-// = w_8^(I * 4 / 2^S).  Inputs of the network: N, < 2 r.  Stage 0: no product, outputs < 4 r.  Stage 1: the trivial butterfly subtracts with
-// K = 4 (b < 4 r), outputs < 8 r; products give t < 1.03 r.  Stage 2: the trivial butterfly weak-reduces b (< 8 r -> < 2 r) first; outputs < 10 r.
-template <int S, int I, int BLK>
-__device__ __forceinline__ void w8_butterfly(Fr29 (&a)[8], const W8Twiddles &t) {
-    constexpr int h = 1 << S, e0 = BLK * 2 * h + I, e1 = e0 + h, K = I * (4 >> S);
-    const Fr29 x = a[e0];
-    if constexpr (S == 0) {
-        const Fr29 y = a[e1];
-        a[e0] = f29_norm(f29_add(x, y));
-        a[e1] = f29_sub<2>(x, y);
-    } else if constexpr (K == 0) {
-        const Fr29 y = S == 1 ? a[e1] : f29_weak_reduce(a[e1]);
-        a[e0] = f29_norm(f29_add(x, y));
-        if constexpr (S == 1) a[e1] = f29_sub<4>(x, y);
-        else a[e1] = f29_sub<2>(x, y);
-    } else {
-        const Fr29 y = f29_mul(a[e1], w8_const<K>(t));
-        a[e0] = f29_norm(f29_add(x, y));
-        a[e1] = f29_sub<2>(x, y);
-    }
-}
-// the first `stages` (wave-uniform, 1 .. 3) stages: a DFT of size 2^stages over the low register bits, the higher register bits are independent columns
-__device__ __forceinline__ void w8_dft(Fr29 (&a)[8], const W8Twiddles &t, uint32_t stages) {
-    w8_butterfly<0, 0, 0>(a, t); w8_butterfly<0, 0, 1>(a, t); w8_butterfly<0, 0, 2>(a, t); w8_butterfly<0, 0, 3>(a, t);
-    if (stages < 2) return;
-    w8_butterfly<1, 0, 0>(a, t); w8_butterfly<1, 1, 0>(a, t); w8_butterfly<1, 0, 1>(a, t); w8_butterfly<1, 1, 1>(a, t);
-    if (stages < 3) return;
-    w8_butterfly<2, 0, 0>(a, t); w8_butterfly<2, 1, 0>(a, t); w8_butterfly<2, 2, 0>(a, t); w8_butterfly<2, 3, 0>(a, t);
-}
-typedef uint32_t w8_v4u __attribute__((ext_vector_type(4)));
-// v[r] *= tw[idx(r)] for r = 0 .. 7 (static_for: a `#pragma unroll` loop of this size is left rolled by the compiler, which then keeps v[] in scratch memory)
-template <int R, class IDX>
-__device__ __forceinline__ void w8_twiddle_all(Fr29 (&v)[8], const Fr29P *tw, IDX idx) {
-    static_for<8>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        v[r] = f29_mul(v[r], ld29(&tw[idx(r)]));
-    });
-}
-// the wave's 64 x 8 elements change owners: lane `lane` writes v[r] to slot wslot(r) and then holds what it finds in slots r * 68 + lane, one
-// 16-byte plane at a time through the wave's own buffer (8 rows of 64 + 4 chunks)
-template <class WS>
-__device__ __forceinline__ void w8_exchange(Fr29 (&v)[8], w8_v4u *xb, uint32_t lane, WS wslot) {
-#pragma unroll
-    for (int plane = 0; plane < 3; ++plane) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            w8_v4u c;
-            if (plane == 0) c = w8_v4u{v[r].l[0], v[r].l[1], v[r].l[2], v[r].l[3]};
-            else if (plane == 1) c = w8_v4u{v[r].l[4], v[r].l[5], v[r].l[6], v[r].l[7]};
-            else c = w8_v4u{v[r].l[8], 0u, 0u, 0u};
-            xb[wslot(r)] = c;
-        }
-        H2_WAVE_SYNC();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const w8_v4u c = xb[r * 68 + lane];
-            if (plane == 0) { v[r].l[0] = c.x; v[r].l[1] = c.y; v[r].l[2] = c.z; v[r].l[3] = c.w; }
-            else if (plane == 1) { v[r].l[4] = c.x; v[r].l[5] = c.y; v[r].l[6] = c.z; v[r].l[7] = c.w; }
-            else v[r].l[8] = c.x;
-        }
-        H2_WAVE_SYNC();
-    }
-}
-__device__ __forceinline__ uint32_t bitrev3(uint32_t x) { return ((x & 1u) << 2) | (x & 2u) | ((x >> 2) & 1u); }
-
-// WPS: waves per SIMD the build is sized for — 3 (168 registers: the loads and table gathers in flight spill ~45 of them) or 2 (no spills)
-template <int KIND, bool MUL, int WPS>
-__global__ __launch_bounds__(256, WPS) void ntt_w8_kernel(NttCols cols, uint32_t log_n, uint32_t m, uint32_t log_s, const Fr29L *__restrict__ t1,
-                                                        const Fr29L *__restrict__ t2, uint32_t lo_bits, const Fr29L *__restrict__ tdirect, uint32_t in_len,
-                                                        NttScale sc, W8Twiddles w8) {
-    constexpr bool FIRST = KIND == 0, LAST = KIND == 2;
-    HIP_DYNAMIC_SHARED(uint4, lds_w8_raw)
-    const uint32_t R = 1u << m, m3 = m - 6, cwb = 9 - m, Cw = 1u << cwb, R3 = 1u << m3;
-    Fr29P *tw_s = reinterpret_cast<Fr29P *>(lds_w8_raw);                       // w_R^k, k < R
-    Fr29P *scale_s = tw_s + R;                                               // the three scales (R' form)
-    w8_v4u *xbuf = reinterpret_cast<w8_v4u *>(scale_s + 4);                  // 4 waves x (8 x 68) chunks (scale_s + 4: a 16-byte aligned offset for every R)
-    const Fr *__restrict__ x = cols.x[blockIdx.y];
-    Fr *__restrict__ y = cols.y[blockIdx.y];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t k = tid; k < R; k += 256) st29(&tw_s[k], tw_lookup(t1, t2, lo_bits, (uint64_t)k << (log_n - m)));
-    if (MUL && tid < 3) st29(&scale_s[tid], fr29_from_sat(FIRST ? sc.in3[tid] : sc.out3[tid]));
-    __syncthreads();   // the only block barrier: the tables
-    w8_v4u *xb = xbuf + wave * (8 * 68);
-    const uint32_t rows_stride = 1u << (log_n - m);
-    const uint32_t ntiles = 1u << (log_n - 9);                               // wave tiles of 512 elements
-    const uint32_t smask = (1u << log_s) - 1;
-    // a zero-padded coset transform (in_len <= N / 4): rows from R / 4 on, i.e. registers t1 >= 2 of EVERY lane, are zero (see ntt_tile_kernel)
-    const bool quarter = FIRST && in_len <= ((1u << log_n) >> 2);
-    // lane fields.  Steps 1 / 2: lane = (hi3 << 3) | low3 with low3 = (t3 << cwb) | c and hi3 = t2 (step 1) / u1 (step 2).
-    const uint32_t low3 = lane & 7u, hi3 = lane >> 3;
-    const uint32_t c12 = low3 & (Cw - 1), t3 = low3 >> cwb;
-    for (uint32_t wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
-        const uint32_t j0 = wt << cwb;
-        Fr29 v[8];
-        // ---- load: element (t1, t2 = hi3, t3, c) into register bitrev3(t1)
-        static_for<8>([&](auto ac) {
-            constexpr uint32_t a = (uint32_t)decltype(ac)::value, reg = ((a & 1u) << 2) | (a & 2u) | (a >> 2);
-            const uint32_t t = (a << (m - 3)) | (hi3 << m3) | t3;
-            const uint32_t idx = j0 + c12 + t * rows_stride;
-            if (FIRST && (idx >= in_len || (quarter && a >= 2))) {
-                v[reg] = Fr29::zero();
-            } else {
-                Fr29 e = f29_split<R29P>(x[idx]);
-                if (FIRST && MUL) e = f29_mul(e, ld29(&scale_s[idx % 3u]));
-                v[reg] = e;
-            }
-        });
-        // ---- step 1 over t1, twiddle w_R^(R3 t2 u1), exchange: (register u1, lane t2 | low3) -> (register bitrev3(t2), lane u1 | low3)
-        w8_dft(v, w8, 3);
-        w8_twiddle_all<0>(v, tw_s, [&](int u1) { return (hi3 * (uint32_t)u1) << m3; });
-        {
-            const uint32_t row = bitrev3(hi3) * 68;
-            w8_exchange(v, xb, lane, [&](int u1) { return row + ((uint32_t)u1 << 3) + low3; });
-        }
-        // ---- step 2 over t2 (now: hi3 = u1, register = u2 after the DFT)
-        w8_dft(v, w8, 3);
-        uint32_t u1, u2lo = 0, cc;
-        if (m3) {
-            // twiddle w_R^(t3 (u1 + 8 u2)), exchange to the last layout: register (x = u2 >> m3, bitrev_m3(t3)), lane (c, u1, u2 & (R3 - 1)) in the pass's order
-            w8_twiddle_all<0>(v, tw_s, [&](int u2) { return t3 * (hi3 + 8u * (uint32_t)u2); });
-            const uint32_t t3r = m3 == 3 ? bitrev3(t3) : m3 == 2 ? (((t3 & 1u) << 1) | (t3 >> 1)) : t3;
-            w8_exchange(v, xb, lane, [&](int u2) {
-                const uint32_t xh = (uint32_t)u2 >> m3, lo = (uint32_t)u2 & (R3 - 1);
-                const uint32_t dl = FIRST ? (hi3 | (lo << 3) | (c12 << (3 + m3))) : (c12 | (hi3 << cwb) | (lo << (cwb + 3)));
-                return ((xh << m3) | t3r) * 68 + dl;
-            });
-            w8_dft(v, w8, m3);
-            if (FIRST) {
-                u1 = lane & 7u;
-                u2lo = (lane >> 3) & (R3 - 1);
-                cc = lane >> (3 + m3);
-            } else {
-                cc = lane & (Cw - 1);
-                u1 = (lane >> cwb) & 7u;
-                u2lo = lane >> (cwb + 3);
-            }
-        } else {   // m = 6: two steps; the output leaves the second layout (lane = u1 | c: eight adjacent columns per lane group)
-            u1 = hi3;
-            cc = low3;
-        }
-        // ---- output: u = u1 + 8 u2 + 64 u3 from register (x, u3) [m3 > 0] or u2 [m3 = 0]
-        const uint32_t j = j0 + cc, q = j & smask, jq = j - q;
-        {
-            static_for<8>([&](auto rc) {
-                constexpr uint32_t r = (uint32_t)decltype(rc)::value;
-                const uint32_t u = m3 ? (u1 + 8u * (((r >> m3) << m3) | u2lo) + 64u * (r & (R3 - 1))) : (u1 + 8u * r);
-                const uint32_t oidx = FIRST ? (j << m) + u : (jq << m) + q + (u << log_s);
-                Fr29 e = v[r];
-                if (!LAST) {   // omega^(jq * u): jq is a multiple of s; the direct table holds omega^(s * t) (the composed lookup where no table exists)
-                    const Fr29 w = tdirect ? tdirect[(size_t)(jq >> log_s) * u].v : tw_lookup(t1, t2, lo_bits, (uint64_t)jq * u);
-                    e = f29_mul(e, w);
-                }
-                if (LAST && MUL) e = f29_mul(e, ld29(&scale_s[oidx % 3u]));
-                if (LAST && !MUL) e = f29_weak_reduce(e);   // (< 12 r -> < 2 r before packing, no multiply)
-                y[oidx] = f29_pack_canonical<FrP>(e);
-            });
-        }
-    }
-}
-
-// direct inter-pass twiddle table for a pass with stride 2^log_s: out[t] = omega^(t << log_s), t < count
 __global__ void ntt_direct_twiddle_kernel(Fr29L *out, Fr omega, uint32_t log_s, uint32_t count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) out[i].v = fr29_from_sat(fe_pow_u64(omega, (uint64_t)i << log_s));
@@ -799,17 +590,6 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
     plan(LT);
     TwiddleSet *tw = nullptr;
     H2_CHK(get_twiddles(ctx, log_n, omega, &tw));
-    // r05, ntt_w8 = 1 / 2 (default 0: measured slower): transforms of 2^12 points and more through the wave-owned radix-8 pass (ntt_w8_kernel), ceil(log_n / 9) passes of 6 .. 9 bits
-    const bool w8 = ctx->ntt_w8 != 0 && log_n >= 12 && log_n <= 28;
-    W8Twiddles w8tw;
-    if (w8) {
-        P = (log_n + 8) / 9;
-        for (uint32_t i = 0; i < P; ++i) mlist[i] = log_n / P + (i < log_n % P ? 1 : 0);
-        for (uint32_t k = 0; k < 4; ++k) {
-            const Fr29 wk = fr29_from_sat(fe_pow_u64(omega, (uint64_t)k << (log_n - 3)));   // w_8^k, w_8 = omega^(N / 8)
-            for (int l = 0; l < 9; ++l) w8tw.w[k][l] = wk.l[l];
-        }
-    }
     const size_t group = ncols < NTT_BATCH ? ncols : NTT_BATCH;
     Fr *scratch = nullptr;
     if (P > 1) H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_NTT, sizeof(Fr) * N * group, (void **)&scratch));
@@ -836,42 +616,9 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
             const uint32_t grid = tiles < (uint32_t)ctx->num_cus * 3 ? tiles : (uint32_t)ctx->num_cus * 3;
             const Fr29L *tdirect = nullptr;
             if (i + 1 < P) H2_CHK(get_direct_table(ctx, tw, log_s, &tdirect));
-            if (w8) {
-                const uint32_t wave_tiles = 1u << (log_n - 9), wgs = wave_tiles / 4, slots = (uint32_t)ctx->num_cus * (ctx->ntt_w8 == 2 ? 2 : 3);
-                const uint32_t grid_w = wgs < slots ? wgs : slots;
-                const size_t shmem_w = sizeof(Fr29P) * (((size_t)1 << m) + 4) + 16 * (size_t)4 * 8 * 68;
-                const bool mul = first ? in_scale3 != nullptr : (last && out_scale3 != nullptr);
-                const uint32_t in_len32 = (uint32_t)(first ? in_len : N);
-                prof_begin(ctx, "ntt_pass_kernel");
-#define H2_NTT_W8_(KIND, MUL, WPS)                                                                                                                \
-    hipLaunchKernelGGL((ntt_w8_kernel<KIND, MUL, WPS>), dim3(grid_w, gc), dim3(256), shmem_w, ctx->stream, cols, log_n, m, log_s, (const Fr29L *)tw->t1, \
-                       (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc, w8tw)
-#define H2_NTT_W8(KIND, MUL)                       \
-    do {                                           \
-        if (ctx->ntt_w8 == 2) H2_NTT_W8_(KIND, MUL, 2); \
-        else H2_NTT_W8_(KIND, MUL, 3);             \
-    } while (0)
-                if (first) {
-                    if (mul) H2_NTT_W8(0, true);
-                    else H2_NTT_W8(0, false);
-                } else if (!last) {
-                    H2_NTT_W8(1, false);
-                } else {
-                    if (mul) H2_NTT_W8(2, true);
-                    else H2_NTT_W8(2, false);
-                }
-#undef H2_NTT_W8
-#undef H2_NTT_W8_
-                prof_end(ctx);
-                H2_HIPCHK(hipGetLastError());
-                in_scratch = to_scratch;
-                log_s += m;
-                continue;
-            }
             // the specialised full-tile kernel: every pass of a transform larger than the tile
             if (ctx->ntt_tile_kernel && P >= 2 && LT == 10 && m + cb == 10 && m >= 2 && (last || tdirect) && N <= (1ull << 28)) {
-                const bool planes = ctx->ntt_lds_planes != 0;
-                const size_t shmem_t = planes ? TileLayoutPlanes::bytes(m) : TileLayout48::bytes(m);
+                const size_t shmem_t = TileLayoutPlanes::bytes(m);
                 // one persistent workgroup per slot (measured against equal shares — ceil(tiles / rounds) workgroups, every one walking the same number
                 // of tiles: 2^22 0.62 vs 0.575 ms, profiles/r04_ntt_experiments.log: fewer workgroups than slots leave a third of the CUs one short)
                 const uint32_t slots = (uint32_t)ctx->num_cus * 3;
@@ -879,16 +626,9 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
                 const bool mul = first ? in_scale3 != nullptr : (last && out_scale3 != nullptr);
                 const uint32_t in_len32 = (uint32_t)(first ? in_len : N);
                 prof_begin(ctx, "ntt_pass_kernel");
-#define H2_NTT_TILE_(KIND, MUL, LAY)                                                                                                               \
-    hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL, LAY>), dim3(grid_t, gc), dim3(256), shmem_t, ctx->stream, cols, log_n, m, log_s, cb, (const Fr29L *)tw->t1, \
+#define H2_NTT_TILE(KIND, MUL)                                                                                                                                    \
+    hipLaunchKernelGGL((ntt_tile_kernel<KIND, MUL, TileLayoutPlanes>), dim3(grid_t, gc), dim3(256), shmem_t, ctx->stream, cols, log_n, m, log_s, cb, (const Fr29L *)tw->t1, \
                        (const Fr29L *)tw->t2, tw->lo_bits, tdirect, in_len32, sc)
-#define H2_NTT_TILE(KIND, MUL)                                 \
-    do {                                                       \
-        if (ctx->ntt_lds_planes == 1) H2_NTT_TILE_(KIND, MUL, TileLayoutPlanes);          \
-        else if (ctx->ntt_lds_planes == 2) H2_NTT_TILE_(KIND, MUL, TileLayoutPlanesT<0>); \
-        else if (ctx->ntt_lds_planes == 3) H2_NTT_TILE_(KIND, MUL, TileLayoutPlanesT<2>); \
-        else H2_NTT_TILE_(KIND, MUL, TileLayout48);                                        \
-    } while (0)
                 if (first) {
                     if (mul) H2_NTT_TILE(0, true);
                     else H2_NTT_TILE(0, false);
@@ -899,7 +639,6 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
                     else H2_NTT_TILE(2, false);
                 }
 #undef H2_NTT_TILE
-#undef H2_NTT_TILE_
                 prof_end(ctx);
                 H2_HIPCHK(hipGetLastError());
                 in_scratch = to_scratch;

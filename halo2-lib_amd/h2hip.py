@@ -144,7 +144,6 @@ _PROTOS = {
     "h2hip_blake2b": (_int, [_vp, C.c_uint, _vp, _sz, _vp]),
     "h2hip_bench_gather": (_int, [_vp, _u32, _sz, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "h2hip_bench_modmul29": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "h2hip_bench_modmul52": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "h2hip_bench_modmul": (_int, [_vp, _u32, _u32, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 # symbols added by later translation units register themselves here (see fr_ops section below)
@@ -517,13 +516,6 @@ class Context:
         finally:
             for d in (da, db, dc):
                 self.free(d)
-
-    def bench_modmul52(self, blocks: int = 4096, iters: int = 512, chains: int = 1):
-        """(elapsed_ms, modmuls, final 52-bit limbs of lane 0) of the FP64-FMA 5 x 52-bit multiplier probe"""
-        ms, mm = C.c_double(), C.c_double()
-        chk = (C.c_uint64 * 5)()
-        self._chk(self.lib.h2hip_bench_modmul52(self.handle, blocks, iters, chains, C.byref(ms), C.byref(mm), chk))
-        return ms.value, mm.value, [int(v) for v in chk]
 
     def bench_modmul(self, blocks: int = 4096, iters: int = 512, chains: int = 1, unsaturated: bool = False):
         """returns (elapsed_ms, modmuls) of the multiplier probe kernel (saturated 8x32 or unsaturated 9x29 limbs)"""

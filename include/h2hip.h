@@ -545,9 +545,6 @@ int h2hip_bench_modmul(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t
 int h2hip_bench_gather(h2hip_ctx *ctx, uint32_t kind, size_t table_bytes, uint32_t lanes, uint32_t per_lane, double *elapsed_ms, double *useful_bytes);
 /* the same probe on the unsaturated 9 x 29-bit representation the MSM / NTT kernels multiply in (chains: 1 or 2) */
 int h2hip_bench_modmul29(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls);
-/* and on 5 x 52-bit limbs held as doubles, products by v_fma_f64 hi / lo pairs (chains: 1 or 2); check_limbs
- * (optional, 5 x u64): lane 0's final value, x_{t+1} = x_t * y * 2^-260 mod r from the fixed x_0 = y documented at the kernel */
-int h2hip_bench_modmul52(h2hip_ctx *ctx, uint32_t blocks, uint32_t iters, uint32_t chains, double *elapsed_ms, double *modmuls, uint64_t *check_limbs);
 
 #ifdef __cplusplus
 }

@@ -569,14 +569,13 @@ def test_full_range_field_inputs(ctx):
     F.check_eval_and_division(ctx, [1, 9, 2049])
 
 
-@pytest.mark.parametrize("tile_bits,tile_kernel,lds_planes", [(10, 1, 1), (10, 1, 0), (10, 0, 1)])
-def test_ntt_full_tile_kernels(ctx, tile_bits, tile_kernel, lds_planes):
-    """ntt_tile_kernel (r04): the specialised full-tile pass kernel (the default) with its r06 LDS layout (limb planes at a swizzled index, skewed
-    stage twiddles: ntt_lds_planes = 1) and r05's 48-byte elements, and the generic pass kernel instead (ntt_tile_kernel = 0) — forward, inverse
-    with its fused divisor, coset extension with zero padding and back, bit-exact"""
+@pytest.mark.parametrize("tile_bits,tile_kernel", [(10, 1), (10, 0)])
+def test_ntt_full_tile_kernels(ctx, tile_bits, tile_kernel):
+    """ntt_tile_kernel (r04): the specialised full-tile pass kernel (the default; r06: its tile in LDS as limb planes at a swizzled index with skewed
+    stage twiddles) and the generic pass kernel instead (ntt_tile_kernel = 0) — forward, inverse with its fused divisor, coset extension with zero
+    padding and back, bit-exact"""
     ctx.set_param("ntt_tile_bits", tile_bits)
     ctx.set_param("ntt_tile_kernel", tile_kernel)
-    ctx.set_param("ntt_lds_planes", lds_planes)
     try:
         for log_n in (11, 12, 13, 14, 16):
             a = rand_fr(1 << log_n, 70 + log_n)
@@ -595,33 +594,6 @@ def test_ntt_full_tile_kernels(ctx, tile_bits, tile_kernel, lds_planes):
     finally:
         ctx.set_param("ntt_tile_bits", 10)
         ctx.set_param("ntt_tile_kernel", 1)
-        ctx.set_param("ntt_lds_planes", 1)
-
-
-@pytest.mark.parametrize("w8", [1, 2])
-def test_ntt_wave_owned_radix8_pass(ctx, w8):
-    """ntt_w8_kernel (r05; selectable, not the default): every pass width 6 .. 9 in two- and three-pass plans, the fused coset scalings, the zero-row
-    skip of padded coset transforms (in_len <= N / 4), full-range inputs — bit-exact against the oracle and round trips"""
-    from tests.util import full_range_fr
-
-    ctx.set_param("ntt_w8", w8)
-    try:
-        for log_n in ((12, 13, 15, 18) if w8 == 1 else (14, 16, 17, 19)):
-            a = full_range_fr(1 << log_n, 170 + log_n)
-            w, winv, div = domain_consts(log_n)
-            got = ctx.best_fft(a, w, log_n)
-            assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=4)), log_n
-            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a), log_n
-        for k, ek in (((10, 12), (13, 15)) if w8 == 1 else ((11, 14), (12, 14))):
-            a = full_range_fr(1 << k, k)
-            we, weinv, ediv = domain_consts(ek)
-            z, zinv = fr([O.ZETA]), fr([O.ZETA * O.ZETA % R])
-            ext = ctx.coeff_to_extended(a, k, ek, we, z)
-            assert np.array_equal(ext, CO.coeff_to_extended(a, k, ek, we, z, threads=4)), (k, ek)
-            back = ctx.extended_to_coeff(ext, ek, weinv, ediv, zinv)
-            assert np.array_equal(back[: 1 << k], a) and not back[1 << k:].any()
-    finally:
-        ctx.set_param("ntt_w8", 0)
 
 
 def test_flex_gate_reference_kats_emulated(ctx):

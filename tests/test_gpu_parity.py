@@ -28,28 +28,6 @@ def test_ntt_bit_exact(ctx, log_n):
     assert np.array_equal(ctx.ifft(got, winv, log_n, div), a)
 
 
-@pytest.mark.parametrize("w8", [1, 2])
-def test_ntt_wave_owned_radix8_pass_gpu(ctx, w8):
-    """ntt_w8_kernel (r05, selectable): the wave-owned radix-8 pass at three / two waves per SIMD, 2^14 .. 2^22 and the prover's coset transforms"""
-    ctx.set_param("ntt_w8", w8)
-    try:
-        for log_n in (14, 19, 21, 22):
-            a = rand_fr(1 << log_n, 300 + log_n)
-            w, winv, div = domain_consts(log_n)
-            got = ctx.best_fft(a, w, log_n)
-            assert np.array_equal(got, CO.best_fft(a, log_n, w, threads=NT)), log_n
-            assert np.array_equal(ctx.ifft(got, winv, log_n, div), a), log_n
-        for k, ek in ((17, 19), (19, 21)):
-            a = rand_fr(1 << k, k)
-            we, weinv, ediv = domain_consts(ek)
-            z, zinv = fr([O.ZETA]), fr([O.ZETA * O.ZETA % R])
-            ext = ctx.coeff_to_extended(a, k, ek, we, z)
-            assert np.array_equal(ext, CO.coeff_to_extended(a, k, ek, we, z, threads=NT)), (k, ek)
-            assert np.array_equal(ctx.extended_to_coeff(ext, ek, weinv, ediv, zinv)[: 1 << k], a)
-    finally:
-        ctx.set_param("ntt_w8", 0)
-
-
 def test_ntt_22_properties(ctx):
     # config #3 size: linearity + Horner spot checks (size-independent properties)
     log_n = 22
@@ -510,27 +488,6 @@ def test_msm_g2(ctx):
     from tests.test_emu_kernels import _g2_msm_checks
 
     _g2_msm_checks(ctx, [1, 37, 300, 5000])
-
-
-@pytest.mark.gpu
-def test_fp64_fma_multiplier_probe_is_a_correct_montgomery_product():
-    """the 5 x 52-bit FP64-FMA multiplier microbenchmark (h2hip_bench_modmul52) computes what it claims —
-    x_{t+1} = x_t * y * 2^-260 mod r — so that its measured rate is the rate of a real 254-bit Montgomery product"""
-    ctx = H.Context()
-    try:
-        y = sum(v << (52 * i) for i, v in enumerate([0x9e3779b97f4a7, 0x3c6ef372fe94f, 0x54ff53a5f1d36, 0x10e527fade682, 0x1f83d9abfb41]))
-        rinv = pow(1 << 260, -1, R)
-        for iters in (1, 2, 37):
-            ms, n, limbs = ctx.bench_modmul52(1, iters, 1)
-            got = sum(v << (52 * i) for i, v in enumerate(limbs))
-            want = y
-            for _ in range(iters):
-                want = want * y * rinv % R
-            assert got % R == want and got < 4 * R and all(v < (1 << 53) for v in limbs), (iters, hex(got), hex(want))
-        ms, n, _ = ctx.bench_modmul52(4096, 64, 2)
-        assert n == 4096 * 256 * 64 * 2 and ms > 0
-    finally:
-        ctx.close()
 
 
 @pytest.mark.gpu

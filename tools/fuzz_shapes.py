@@ -39,7 +39,6 @@ while time.time() - t0 < budget:
                  # r05: host round trips through the mapped flag, the table-entry format (read when the SRS is set up), one-pass grand products,
                  # the wave-owned NTT pass (2^12+ points only)
                  "host_poll": rnd.choice([1, 1, 0]), "msm_table_split": rnd.choice([1, 1, 0]), "plonk_merge_products": rnd.choice([1, 1, 0]),
-                 "ntt_w8": rnd.choice([0, 0, 1, 2]),
                  # r05, last: the grand products' lagrange_to_coeff in front of round 3's commitments; the lanes' first sorts one behind the other
                  "plonk_early_intt": rnd.choice([1, 1, 0]), "msm_stagger_sorts": rnd.choice([-1, 0, 1])}
         for name, val in knobs.items():

@@ -13,7 +13,7 @@ element read as 4 x ds_read2_b32 + 1 x ds_read_b32.  The model walks one tile of
 access class, the LDS-array cycles and how many of them are conflict cycles — the ratio the PMC pair SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 measures for the whole kernel.
 
-    python tools/ntt_lds_model.py                 # the 2^22 transform's three passes, r05 layout against the r06 layout
+    python tools/ntt_lds_model.py [coset]         # the 2^22 transform's three passes (or a k = 19 coset transform's): r05 layout, planes only, the r06 layout
 """
 import sys
 
@@ -78,6 +78,12 @@ def model(m, cb, kind, layout, quarter=False):
         acc.add(cls, cycles([None if e is None else parts(e)[2] for e in es], G32, 32, 1))
 
     def tw_read(cls, ks):
+        if layout.get("planes"):   # the twiddle planes: 16 / 16 / 4 bytes per entry behind the data planes
+            ps = [twp(k, m) for k in ks]
+            acc.add(cls, cycles([TW0 + 16 * q for q in ps], G128, 64, 4))
+            acc.add(cls, cycles([TW0 + 4096 + 16 * q for q in ps], G128, 64, 4))
+            acc.add(cls, cycles([TW0 + 8192 + 4 * q for q in ps], G32, 32, 1))
+            return
         for w in range(9):      # read2_b32 = two b32 accesses; 9 dword accesses in all
             acc.add(cls, cycles([TW0 + 36 * twp(k, m) + 4 * w for k in ks], G32, 32, 1))
 
@@ -156,19 +162,25 @@ def report(title, d):
 R05 = dict(swz=lambda e: e, tw=lambda k, m: k)
 
 
+ROWS_R06 = (1, 6, 18, 15, 27)   # TileLayoutPlanes::swz in csrc/ntt.hip: bit b of X[e >> 5] = parity((e >> 5) & ROWS_R06[b])
+
+
 def swz_r06(e):
-    # r06: the element's low four index bits (its 16-byte slot class mod 16) are XORed with the next index bits, two by two, so that lanes whose
-    # indices differ only above bit 3 still fall into different slots
-    return e ^ ((e >> 4) & 15) ^ (((e >> 8) & 3) << 2)
+    up, x = e >> 5, 0
+    for b, r in enumerate(ROWS_R06):
+        x |= (bin(up & r).count("1") & 1) << b
+    return e ^ x
 
 
-R06 = dict(swz=swz_r06, tw=lambda k, m: bitrev(k, m - 1))
+# r06 (shipped): three limb planes at the swizzled index, stage twiddles in the same planes at the skewed index k + (k >> 4)
+R06 = dict(swz=swz_r06, tw=lambda k, m: k + (k >> 4), planes=True)
+R06_NO_SWZ = dict(swz=lambda e: e, tw=lambda k, m: k + (k >> 4), planes=True)
 
 if __name__ == "__main__":
     passes = [(8, 2, 0, False), (7, 3, 1, False), (7, 3, 2, False)]
     if len(sys.argv) > 1 and sys.argv[1] == "coset":
         passes = [(7, 3, 0, True), (7, 3, 1, False), (7, 3, 2, False)]
-    for name, lay in (("r05 layout", R05), ("r06 layout", R06)):
+    for name, lay in (("r05 layout", R05), ("r06 planes, no swizzle", R06_NO_SWZ), ("r06 layout", R06)):
         T = Cc = 0
         for m, cb, kind, q in passes:
             t, c = report("%s  m=%d cb=%d kind=%d%s" % (name, m, cb, kind, " quarter" if q else ""), model(m, cb, kind, lay, q))
