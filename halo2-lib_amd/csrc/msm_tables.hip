@@ -135,11 +135,17 @@ int msm_prepare_bases(h2hip_ctx *ctx, h2hip_bases *b, bool precompute) {
         W = (255 + c - 1) / c;
         H2_REQUIRE((uint64_t)b->n * W < (1ull << 31), "precomputed table too large for 31-bit indices");
     }
-    const bool split = ctx->msm_table_split != 0;
-    const size_t entry_bytes = split ? sizeof(TableEntry29) : sizeof(G1Affine);
+    bool split = ctx->msm_table_split != 0;
     G1Affine *t29 = nullptr;   // (typed as the packed format; the split format is addressed through TableEntry29 *)
-    hipError_t e = hipMalloc((void **)&t29, entry_bytes * (size_t)(n ? n : 1) * W);
+    hipError_t e = hipMalloc((void **)&t29, (split ? sizeof(TableEntry29) : sizeof(G1Affine)) * (size_t)(n ? n : 1) * W);
+    if (e != hipSuccess && split) {   // the 128-byte pre-split entries double the table; when they do not fit (several keys / contexts
+        (void)hipGetLastError();      // in flight, a smaller part), the 64-byte packed format msm_accum_kernel<false> reads is tried before giving up
+        split = false;
+        t29 = nullptr;
+        e = hipMalloc((void **)&t29, sizeof(G1Affine) * (size_t)(n ? n : 1) * W);
+    }
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         set_error("hipMalloc for %zu bases x %u windows failed: %s", b->n, W, hipGetErrorString(e));
         return H2HIP_ERR_NOMEM;
     }
