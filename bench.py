@@ -538,9 +538,9 @@ def main():
         proofs_per_step = 1 if (world == 1 or sharded) else world
         alg_bytes = 96.0 * msm_n
         traffic_prof = None
-        pmc_path = os.path.join(ROOT, "profiles", "r05_create_proof_k19_pmc_hbm.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r06_create_proof_k19_pmc_hbm.json")
         if not os.path.exists(pmc_path):
-            pmc_path = os.path.join(ROOT, "profiles", "r04_create_proof_k19_pmc_hbm.json")
+            pmc_path = os.path.join(ROOT, "profiles", "r05_create_proof_k19_pmc_hbm.json")
         if os.path.exists(pmc_path) and k == 19 and world == 1:
             import hashlib
             import subprocess
