@@ -61,7 +61,11 @@ struct DigitCols {
 };
 // (the first workgroup also writes the sort's two sentinels — counts[nsort] = 0 and offsets[nsort + 1] = ~0, read by the scan and by the
 // accumulation's boundary walk — which were two tiny memset launches per MSM on the lane's critical path)
-__global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_t n, uint32_t c, uint32_t W, uint32_t *__restrict__ digits,
+// r06: a digit travels as a 16-BIT CODE — 0 = no entry, 1 .. B = +d, B + 1 .. 2B - 1 = -d (a negative digit is at most B - 1: v = B stays positive),
+// 2B - 1 = 65535 at c = 16 — so the digits array, written once and read by the histogram and by the scatter, moves half the bytes
+typedef uint16_t digit_t;
+__device__ __forceinline__ uint32_t digit_bucket(uint32_t code, uint32_t B) { return code > B ? code - B : code; }   // 1-based bucket of a non-zero code
+__global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_t n, uint32_t c, uint32_t W, digit_t *__restrict__ digits,
                                                          uint32_t *__restrict__ counts_tail, uint32_t *__restrict__ offsets_tail) {
     H2_SORT_PRIORITY();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(DigitCols cols, uint32_
         uint32_t neg = v > B ? 1u : 0u;
         uint32_t d = neg ? (1u << c) - v : v;
         carry = neg;
-        digits[(size_t)w * n + i] = d | (neg << 31);
+        digits[(size_t)w * n + i] = (digit_t)((neg && d) ? B + d : d);   // (v = 2^c: digit 0 with a carry — no entry)
     }
 }
 
@@ -114,7 +118,7 @@ __device__ __forceinline__ void block_to_window_chunk(uint32_t L, uint32_t G, ui
 }
 
 // ------------------------------------------------------------------ 2. per-(window, chunk) LDS histogram
-__global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
+__global__ __launch_bounds__(1024) void msm_hist_kernel(const digit_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
                                                         uint32_t G, uint32_t chunk, uint32_t *__restrict__ bhist) {
     H2_SORT_PRIORITY();
     HIP_DYNAMIC_SHARED(uint32_t, hist)   // B counters
@@ -124,16 +128,16 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t *__restri
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    const uint32_t *dw = digits + (size_t)w * n;
+    const digit_t *dw = digits + (size_t)w * n;
     // eight independent loads in flight per lane, then the LDS atomics: one load -> one atomic per iteration left the kernel latency-bound
     const uint32_t T = blockDim.x;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 8 * T) {
         uint32_t d[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) d[k] = i + k * T < hi ? dw[i + k * T] & 0x7fffffffu : 0u;
+        for (uint32_t k = 0; k < 8; ++k) d[k] = i + k * T < hi ? (uint32_t)dw[i + k * T] : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k)
-            if (d[k]) atomicAdd(&hist[d[k] - 1], 1u);
+            if (d[k]) atomicAdd(&hist[digit_bucket(d[k], B) - 1], 1u);
     }
     __syncthreads();
     uint32_t *out = bhist + ((size_t)w * G + g) * B;
@@ -245,7 +249,7 @@ int exclusive_scan_u32(h2hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint32
 // one (window, sub-range) segment run together on one XCD (1 workgroup per CU because of the LDS cursors), and the
 // segment's slice of the sorted array (n*4/S bytes) fits that XCD's 4 MiB L2, so the 4-byte writes combine there
 // instead of each costing a 64-byte HBM write.
-__global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
+__global__ __launch_bounds__(1024) void msm_scatter_kernel(const digit_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
                                                            uint32_t G, uint32_t chunk, uint32_t S, uint32_t table_stride, uint32_t Wcol,
                                                            const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ bhist,
                                                            uint32_t *__restrict__ sval) {
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     for (uint32_t b = threadIdx.x; b < Bs; b += blockDim.x) cursor[b] = offsets[w * B + b0 + b] + bh[b];
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    const uint32_t *dw = digits + (size_t)w * n;
+    const digit_t *dw = digits + (size_t)w * n;
     const uint32_t idx_base = (w % Wcol) * table_stride;   // precomputed bases: window w of a column reads table level w
     // eight entries per lane and round: the loads, then the returning LDS atomics, then the stores — each group independent, so the
     // latencies of a group overlap instead of adding up per entry
@@ -268,15 +272,15 @@ __global__ __launch_bounds__(1024) void msm_scatter_kernel(const uint32_t *__res
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 8 * T) {
         uint32_t dv[8], pos[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) dv[k] = i + k * T < hi ? dw[i + k * T] : 0u;
+        for (uint32_t k = 0; k < 8; ++k) dv[k] = i + k * T < hi ? (uint32_t)dw[i + k * T] : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t d = dv[k] & 0x7fffffffu, b = d - 1 - b0;   // d == 0 wraps to a huge b: skipped like another sub-range's entry
+            const uint32_t d = digit_bucket(dv[k], B), b = d - 1 - b0;   // code 0 wraps to a huge b: skipped like another sub-range's entry
             pos[k] = (d && b < Bs) ? atomicAdd(&cursor[b], 1u) : KEY_INVALID;
         }
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k)
-            if (pos[k] != KEY_INVALID) sval[pos[k]] = (idx_base + i + k * T) | (dv[k] & 0x80000000u);
+            if (pos[k] != KEY_INVALID) sval[pos[k]] = (idx_base + i + k * T) | (dv[k] > B ? 0x80000000u : 0u);
     }
 }
 
@@ -926,9 +930,10 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     // at k >= 20 — a bucket-major sort with one bucket set per column (msm_fold_windows: the wave-level merge of its 16x longer runs cost more
     // than the presum it saved) and a column's windows dealt to two lanes; all three were removed in r04, their A/B logs are
     // profiles/r03_msm_sort_ab.log, r03_msm_reorder.log, r02_msm_fold_windows_ab.log, r03_msm_split_windows_ab.log.
-    uint32_t *digits, *bhist, *counts, *offsets, *sval, *pkey[2];
+    digit_t *digits;
+    uint32_t *bhist, *counts, *offsets, *sval, *pkey[2];
     XYZZ29 *buckets, *pval[2];
-    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_DIGITS, sizeof(uint32_t) * emax, (void **)&digits));
+    H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_DIGITS, sizeof(digit_t) * emax, (void **)&digits));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_CURSOR, sizeof(uint32_t) * (size_t)W * G * B, (void **)&bhist));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_COUNTS, sizeof(uint32_t) * ((size_t)nkeys + 1), (void **)&counts));
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_OFFSETS, sizeof(uint32_t) * ((size_t)nkeys + 2), (void **)&offsets));
@@ -967,7 +972,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         ctx->msm_lds_attr_set = true;
     }
     prof_begin(ctx, "msm_hist_kernel");
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * B, st, (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * B, st, (const digit_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
     prof_end(ctx);
     prof_begin(ctx, "msm_hist_scan_kernel");
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, bhist, W, B, G, counts);
@@ -983,7 +988,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     if (S > B) S = B;
     const uint32_t scatter_grid = sort_grid_size(W * S, G);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(scatter_grid), dim3(sort_threads), ctx->msm_scatter_full_lds ? sizeof(uint32_t) * MAX_LDS_BUCKETS : sizeof(uint32_t) * (B / S), st,   // full 128 KiB: one workgroup per CU keeps a segment's writes on one XCD
-                       (const uint32_t *)digits, (uint32_t)n, W, B, G, chunk, S, precomp ? (uint32_t)bases->n : 0u, Wcol, (const uint32_t *)offsets,
+                       (const digit_t *)digits, (uint32_t)n, W, B, G, chunk, S, precomp ? (uint32_t)bases->n : 0u, Wcol, (const uint32_t *)offsets,
                        (const uint32_t *)bhist, sval);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
