@@ -85,7 +85,8 @@ struct h2hip_ctx {
     int msm_quad_tails = 1;      // 1: bucket reduction / fold on quad-lane point arithmetic (quad29.cuh)
     int msm_sort_threads = 1024; // workgroup size of the LDS histogram / scatter kernels (256, 512 or 1024)
     int msm_scatter_split = 0;   // bucket sub-ranges per window in the scatter (0 = auto, power of two)
-    int msm_scatter_full_lds = 1;   // 1: the scatter declares the full 128 KiB of LDS (one workgroup per CU: one segment per XCD at a time); 0: only its cursors
+    int msm_scatter_full_lds = 0;   // 1: the scatter declares the full 128 KiB of LDS (one workgroup per CU: one segment per XCD at a time; the default until r06); 0: only its cursors — a scatter workgroup then fits into the slot a retiring accumulation workgroup leaves: whole proofs -1 ... -2 % at k = 17 / 19, -0.5 % at k = 21 (profiles/r06_scatter_lds_ab.log)
+    int msm_hist_packed = 1;        // r06: the LDS histogram as 16-bit counter pairs when a chunk holds < 2^16 scalars (half the LDS: fits beside running accumulations)
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]
     // per-kernel timing (h2hip_profile_*): HIP events on `stream` around each launch when enabled
     bool profiling = false;
@@ -174,6 +175,7 @@ inline void inherit_knobs(h2hip_ctx *c, const h2hip_ctx *p) {
     c->msm_seg = p->msm_seg;
     c->msm_scatter_split = p->msm_scatter_split;
     c->msm_scatter_full_lds = p->msm_scatter_full_lds;
+    c->msm_hist_packed = p->msm_hist_packed;
     c->msm_sort_threads = p->msm_sort_threads;
     c->msm_quad_tails = p->msm_quad_tails;
     c->msm_quad_seg_max = p->msm_quad_seg_max;

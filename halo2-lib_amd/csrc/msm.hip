@@ -118,14 +118,20 @@ __device__ __forceinline__ void block_to_window_chunk(uint32_t L, uint32_t G, ui
 }
 
 // ------------------------------------------------------------------ 2. per-(window, chunk) LDS histogram
+// PACKED (r06): two 16-bit counters per LDS word (a chunk holds < 2^16 scalars, so no counter can carry into its neighbour): the histogram of a
+// c = 15 window is 32 KiB instead of 64 — small enough for the slot ONE retiring accumulation workgroup leaves on a CU (160 - 2 x 36 KiB, its
+// registers), where the 64 KiB histogram had to wait for a CU without any accumulation workgroup (one timed k = 19 proof: 105 us per launch
+// against 16 us alone, profiles/r06_bench_proof_k19_kernels.md).
+template <bool PACKED>
 __global__ __launch_bounds__(1024) void msm_hist_kernel(const digit_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
                                                         uint32_t G, uint32_t chunk, uint32_t *__restrict__ bhist) {
     H2_SORT_PRIORITY();
-    HIP_DYNAMIC_SHARED(uint32_t, hist)   // B counters
+    HIP_DYNAMIC_SHARED(uint32_t, hist)   // B counters (PACKED: B / 2 words)
     uint32_t w, g;
     block_to_window_chunk(blockIdx.x, G, W, w, g);
     if (w >= W) return;
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
+    const uint32_t words = PACKED ? (B + 1) >> 1 : B;
+    for (uint32_t b = threadIdx.x; b < words; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const digit_t *dw = digits + (size_t)w * n;
@@ -137,11 +143,15 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const digit_t *__restric
         for (uint32_t k = 0; k < 8; ++k) d[k] = i + k * T < hi ? (uint32_t)dw[i + k * T] : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k)
-            if (d[k]) atomicAdd(&hist[digit_bucket(d[k], B) - 1], 1u);
+            if (d[k]) {
+                const uint32_t b = digit_bucket(d[k], B) - 1;
+                if (PACKED) atomicAdd(&hist[b >> 1], 1u << (16u * (b & 1u)));
+                else atomicAdd(&hist[b], 1u);
+            }
     }
     __syncthreads();
     uint32_t *out = bhist + ((size_t)w * G + g) * B;
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) out[b] = hist[b];
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) out[b] = PACKED ? (hist[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu : hist[b];
 }
 
 // ------------------------------------------------------------------ 3. prefix over chunks per (window, bucket)
@@ -967,12 +977,17 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     prof_end(ctx);
     const uint32_t sort_threads = (uint32_t)ctx->msm_sort_threads;
     if (!ctx->msm_lds_attr_set) {   // dynamic LDS above 64 KiB has to be enabled per kernel (and device) once
-        H2_HIPCHK(hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
+        H2_HIPCHK(hipFuncSetAttribute((const void *)msm_hist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
+        H2_HIPCHK(hipFuncSetAttribute((const void *)msm_hist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
         H2_HIPCHK(hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(uint32_t) * MAX_LDS_BUCKETS)));
         ctx->msm_lds_attr_set = true;
     }
     prof_begin(ctx, "msm_hist_kernel");
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * B, st, (const digit_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
+    const bool hist_packed = ctx->msm_hist_packed != 0 && chunk < 65536u && B >= 2;   // (a counter holds at most `chunk`)
+    if (hist_packed)
+        hipLaunchKernelGGL(msm_hist_kernel<true>, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * ((B + 1) / 2), st, (const digit_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
+    else
+        hipLaunchKernelGGL(msm_hist_kernel<false>, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * B, st, (const digit_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
     prof_end(ctx);
     prof_begin(ctx, "msm_hist_scan_kernel");
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, bhist, W, B, G, counts);
