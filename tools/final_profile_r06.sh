@@ -46,6 +46,7 @@ rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/p19 $OUT/p21
 timeout 300 python tools/ntt_r04.py ntt_tile_kernel=1:0:1 > $OUT/ntt_times.log 2>&1
 bash tools/ntt_pmc.sh > $OUT/ntt_pmc.log 2>&1
 bash tools/accum_pmc.sh > $OUT/accum_pmc.log 2>&1
+bash tools/quotient_pmc.sh > $OUT/quotient_pmc.md 2>&1
 timeout 300 python tools/msm_r03.py 19,20 > $OUT/msm_breakdown.log 2>&1
 timeout 900 python tools/config_sweep.py all 5 > $OUT/config_sweep.md 2> $OUT/config_sweep.err
 timeout 300 python tools/fuzz_shapes.py 150 4 > $OUT/fuzz_small.log 2>&1
