@@ -42,4 +42,22 @@ H2_HD Fr fe_x32(Fr a) {   // 32 a (the factor a data x data product needs, folde
 }
 H2_HD Fr r29_store(const Fr29 &v) { return f29_pack_canonical<FrP>(v); }   // v N and < 2 r
 
+// Table element of the power tables (NTT twiddles, ntt.hip): 9 limbs padded to 48 B so that it moves as 16-byte accesses
+struct alignas(16) Fr29L {
+    Fr29 v;
+    uint32_t pad[3];
+};
+// omega^e from the two-level table of a (log_n, omega) pair (ntt.hip: get_twiddles / ntt_pow_table): omega^e = T2[e >> lo_bits] * T1[e & mask], both in
+// R' = 2^261 form, so the result is too.  r06: the row kernels of the permutation argument start their per-lane chain omega^i0 here (one product, two
+// table reads) instead of a ~28-product square-and-multiply in saturated arithmetic — which was a quarter to a half of those kernels' instructions.
+struct OmegaTable {
+    const Fr29L *t1, *t2;
+    uint32_t lo_bits;
+};
+__device__ __forceinline__ Fr29 pow_lookup(const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits, uint64_t e) {
+    const uint32_t lo = (uint32_t)(e & ((1ull << lo_bits) - 1));
+    const uint32_t hi = (uint32_t)(e >> lo_bits);
+    return f29_mul(t2[hi].v, t1[lo].v);
+}
+
 }  // namespace h2

@@ -8,6 +8,8 @@
 
 namespace h2 {
 
+int ntt_pow_table(h2hip_ctx *ctx, uint32_t log_n, const Fr &omega, OmegaTable *out);   // ntt.hip
+
 enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2 };
 
 template <int OP>
@@ -831,16 +833,18 @@ struct PermArgs29 {
     const Fr *z, *z_prev, *l0, *l_last, *l_blind;
     const Fr *cols[PERM_MAX_COLS], *sigmas[PERM_MAX_COLS];
     uint32_t ncols, terms, last_rot_points;
-    Fr29 beta32, delta, y, x0_delta32, xstep;   // R' form (r29_const) of 32 beta, delta, y, 32 beta zeta delta^j0, ext_omega^(grid stride)
+    Fr29 beta32, delta, y, xstep;               // R' form (r29_const) of 32 beta, delta, y, ext_omega^(grid stride)
+    Fr29 x0_delta32;                            // raw split of 32 beta zeta delta^j0 (stored domain): the X term's start = ext_omega^i0 (table, R' form) x this
     Fr29 gamma32;                               // raw split of (32 gamma mod r) in the stored domain
-    Fr ext_omega;
+    OmegaTable pw;                              // ext_omega^e, e < 2^ext_k: the coset transforms' twiddle set (r06: was ~28 saturated products per lane)
 };
 __global__ __launch_bounds__(256, 3) void quotient_permutation29_kernel(Fr *__restrict__ acc, PermArgs29 g, size_t ne, uint32_t step) {
     const size_t stride = (size_t)gridDim.x * blockDim.x, mask = ne - 1;
     const Fr one_sat = Fr::one();
     const Fr29 one = r29_load(one_sat);
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Fr29 xbase = f29_mul(r29_load(fe_pow_u64(g.ext_omega, (uint64_t)i0)), g.x0_delta32);   // 32 beta delta^j0 zeta w_ext^i, < 1.01
+    if (i0 >= ne) return;   // (the table holds ext_omega^e for e < ne only)
+    Fr29 xbase = f29_mul(pow_lookup(g.pw.t1, g.pw.t2, g.pw.lo_bits, (uint64_t)i0), g.x0_delta32);   // 32 beta delta^j0 zeta w_ext^i, < 1.01
     for (size_t i = i0; i < ne; i += stride, xbase = f29_mul(xbase, g.xstep)) {
         const size_t inext = (i + step) & mask;
         const Fr z_sat = g.z[i], ll_sat = g.l_last[i];
@@ -1017,14 +1021,16 @@ __global__ __launch_bounds__(256, 3) void quotient_lookup_batch29_kernel(Fr *__r
 struct PermConsts29 {
     Fr29 beta32, delta, y, xstep;   // R' form of 32 beta, delta, y, ext_omega^(grid stride)
     Fr29 gamma32;                   // raw split of 32 gamma
-    Fr29 x0_delta32[PERM_BATCH];    // R' form of 32 beta zeta delta^(first column of the job's set)
+    Fr29 x0_delta32[PERM_BATCH];    // raw split of 32 beta zeta delta^(first column of the job's set) (the X term = w_ext^i in R' form x this)
+    OmegaTable pw;                  // ext_omega^e, e < 2^ext_k
 };
 __global__ __launch_bounds__(256, 3) void quotient_permutation_batch29_kernel(Fr *__restrict__ acc, PermBatchArgs g, PermConsts29 k29, size_t ne, uint32_t step) {
     const size_t stride = (size_t)gridDim.x * blockDim.x, mask = ne - 1;
     const Fr one_sat = Fr::one();
     const Fr29 one = r29_load(one_sat);
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Fr29 wpow = r29_load(fe_pow_u64(g.ext_omega, (uint64_t)i0));   // w_ext^i in the stored domain
+    if (i0 >= ne) return;   // (the table holds ext_omega^e for e < ne only)
+    Fr29 wpow = pow_lookup(k29.pw.t1, k29.pw.t2, k29.pw.lo_bits, (uint64_t)i0);   // w_ext^i in R' form (the chain stays there: xstep is an R' constant)
     for (size_t i = i0; i < ne; i += stride, wpow = f29_mul(wpow, k29.xstep)) {
         const size_t inext = (i + step) & mask;
         const Fr ll_sat = g.l_last[i];
@@ -1737,6 +1743,8 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z,
     // ~28 products) is amortised, the stride power is one host-side exponentiation
     const uint32_t pgrid = perm_grid(ne);
     g.xstep = fe_pow_u64(g.ext_omega, (uint64_t)pgrid * 256);
+    OmegaTable pw = {nullptr, nullptr, 0};
+    if (ctx->quotient_29) H2_CHK(ntt_pow_table(ctx, ext_k, g.ext_omega, &pw));   // (before the bracket: a new table launches its own profiled kernel)
     prof_begin(ctx, "quotient_permutation_kernel");
     if (ctx->quotient_29) {
         PermArgs29 h;
@@ -1750,10 +1758,10 @@ int h2hip_quotient_permutation_set_dev(h2hip_ctx *ctx, void *acc, const void *z,
         h.beta32 = r29_const(fe_x32(g.beta));
         h.delta = r29_const(g.delta);
         h.y = r29_const(g.y);
-        h.x0_delta32 = r29_const(fe_x32(g.x0_delta));
+        h.x0_delta32 = r29_load(fe_x32(g.x0_delta));
         h.xstep = r29_const(g.xstep);
         h.gamma32 = r29_load(fe_x32(g.gamma));
-        h.ext_omega = g.ext_omega;
+        h.pw = pw;
         hipLaunchKernelGGL(quotient_permutation29_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, h, ne, step);
     } else {
         hipLaunchKernelGGL(quotient_permutation_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);
@@ -1873,6 +1881,8 @@ int h2hip_quotient_permutation_sets_dev(h2hip_ctx *ctx, void *acc, const void *c
         set_x0[s2] = fe_mul(beta_zeta, dpow);
         for (uint32_t c = 0; c < chunk_len; ++c) dpow = fe_mul(dpow, g.delta);
     }
+    OmegaTable pw = {nullptr, nullptr, 0};
+    if (ctx->quotient_29) H2_CHK(ntt_pow_table(ctx, ext_k, g.ext_omega, &pw));
     for (size_t j0 = 0; j0 < items.size(); j0 += PERM_BATCH) {
         g.njobs = (uint32_t)(items.size() - j0 < PERM_BATCH ? items.size() - j0 : PERM_BATCH);
         for (uint32_t j = 0; j < g.njobs; ++j) {
@@ -1900,7 +1910,8 @@ int h2hip_quotient_permutation_sets_dev(h2hip_ctx *ctx, void *acc, const void *c
             k29.y = r29_const(g.y);
             k29.xstep = r29_const(g.xstep);
             k29.gamma32 = r29_load(fe_x32(g.gamma));
-            for (uint32_t j = 0; j < PERM_BATCH; ++j) k29.x0_delta32[j] = j < g.njobs ? r29_const(fe_x32(g.jobs[j].x0_delta)) : Fr29::zero();
+            for (uint32_t j = 0; j < PERM_BATCH; ++j) k29.x0_delta32[j] = j < g.njobs ? r29_load(fe_x32(g.jobs[j].x0_delta)) : Fr29::zero();
+            k29.pw = pw;
             hipLaunchKernelGGL(quotient_permutation_batch29_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, k29, ne, step);
         } else {
             hipLaunchKernelGGL(quotient_permutation_batch_kernel, dim3(pgrid), dim3(256), 0, ctx->stream, (Fr *)acc, g, ne, step);

@@ -14,7 +14,7 @@
 // the last.  Twiddles come from a two-level table omega^e = T2[e >> lo] * T1[e & mask] built once per
 // (log_n, omega) and cached in the context.
 #include "internal.h"
-#include "fq29.cuh"
+#include "fr29.cuh"
 
 namespace h2 {
 
@@ -31,13 +31,6 @@ namespace h2 {
     } while (0)
 #endif
 
-// LDS / table element: 9 limbs padded to 48 B so that it moves as three 16-byte accesses (ds_read_b128 /
-// global_load_dwordx4); a 12-word stride is bank-conflict free for 16-lane b128 groups
-struct alignas(16) Fr29L {
-    Fr29 v;
-    uint32_t pad[3];
-};
-
 struct NttScale {
     Fr in3[3];
     Fr out3[3];
@@ -51,11 +44,7 @@ __global__ void ntt_twiddle_kernel(Fr29L *t1, Fr29L *t2, Fr omega, uint32_t lo_b
     if (i < hi_count) t2[i].v = fr29_from_sat(fe_pow_u64(omega, (uint64_t)i << lo_bits));
 }
 
-__device__ __forceinline__ Fr29 tw_lookup(const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits, uint64_t e) {
-    uint32_t lo = (uint32_t)(e & ((1ull << lo_bits) - 1));
-    uint32_t hi = (uint32_t)(e >> lo_bits);
-    return f29_mul(t2[hi].v, t1[lo].v);
-}
+__device__ __forceinline__ Fr29 tw_lookup(const Fr29L *__restrict__ t1, const Fr29L *__restrict__ t2, uint32_t lo_bits, uint64_t e) { return pow_lookup(t1, t2, lo_bits, e); }
 
 __device__ __forceinline__ uint32_t bitrev_m(uint32_t x, uint32_t m) { return m ? (__brev(x) >> (32 - m)) : 0; }
 
@@ -529,6 +518,16 @@ static int get_twiddles(h2hip_ctx *ctx, uint32_t log_n, const Fr &omega, Twiddle
     }
     ctx->twiddles.push_back(t);
     *out = &ctx->twiddles.back();
+    return H2HIP_OK;
+}
+
+// the (log_n, omega) power table for kernels outside this file (fr29.cuh: pow_lookup); cached like every twiddle set of the context
+int ntt_pow_table(h2hip_ctx *ctx, uint32_t log_n, const Fr &omega, OmegaTable *out) {
+    TwiddleSet *tw = nullptr;
+    H2_CHK(get_twiddles(ctx, log_n, omega, &tw));
+    out->t1 = (const Fr29L *)tw->t1;
+    out->t2 = (const Fr29L *)tw->t2;
+    out->lo_bits = tw->lo_bits;
     return H2HIP_OK;
 }
 

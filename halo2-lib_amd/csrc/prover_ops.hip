@@ -8,6 +8,8 @@
 
 namespace h2 {
 
+int ntt_pow_table(h2hip_ctx *ctx, uint32_t log_n, const Fr &omega, OmegaTable *out);   // ntt.hip
+
 constexpr int PP_MAX_COLS = 8;
 struct PermProductArgs {
     const Fr *cols[PP_MAX_COLS], *sigmas[PP_MAX_COLS];
@@ -75,16 +77,18 @@ __global__ __launch_bounds__(256) void perm_product_terms_batch_kernel(Fr *__res
 // the same factors on unsaturated limbs (fr29.cuh): every factor is formed 32-fold — 32 v from the split, 32 gamma and 32 beta from the constants, the
 // X term's chain started at 32 beta delta^j0 omega^i — which is what a product of two stored-domain values needs; products start from 1
 struct PermProductConsts29 {
-    Fr29 beta32, delta, xstep, x0_32;   // R' form of 32 beta, delta, omega^(grid stride), 32 beta delta^(first column of the launch)
+    Fr29 beta32, delta, xstep;          // R' form of 32 beta, delta, omega^(grid stride)
+    Fr29 x0_32;                         // raw split of 32 beta delta^(first column of the launch) (omega^row0 included): the chain's start = omega^i0 (table, R' form) x this
     Fr29 gamma32, one;                  // raw splits of 32 gamma and of 1
-    Fr omega;
+    OmegaTable pw;                        // omega^e, e < rows (r06: replaces a per-lane square-and-multiply of ~28 saturated products — more than the
+                                        // four rows a lane then processes cost)
 };
 __global__ __launch_bounds__(256) void perm_product_terms_batch29_kernel(Fr *__restrict__ num, Fr *__restrict__ den, PermProductBatchArgs g, PermProductConsts29 k29,
                                                                          size_t rows) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i0 >= rows) return;
-    Fr29 xbase = f29_mul(r29_load(fe_pow_u64(k29.omega, (uint64_t)i0)), k29.x0_32);
+    Fr29 xbase = f29_mul(pow_lookup(k29.pw.t1, k29.pw.t2, k29.pw.lo_bits, (uint64_t)i0), k29.x0_32);
     for (size_t i = i0; i < rows; i += stride, xbase = f29_mul(xbase, k29.xstep)) {
         Fr29 xterm = xbase;
         for (uint32_t c0 = 0, set = 0; c0 < g.ncols; c0 += g.chunk, ++set) {
@@ -270,6 +274,12 @@ int h2hip_permutation_product_terms_rows_dev(h2hip_ctx *ctx, void *num_dev, void
     g.beta = ld(beta); g.gamma = ld(gamma); g.delta = ld(delta); g.omega = ld(omega);
     const uint32_t grid = grid_rows(ctx, rows, rows >= ((size_t)1 << 16) ? 4 : 1);   // long columns: four rows per lane amortise the omega^i start-up
     g.xstep = fe_pow_u64(g.omega, (uint64_t)grid * 256);
+    OmegaTable pw = {nullptr, nullptr, 0};
+    if (ctx->quotient_29) {
+        uint32_t log_rows = 0;
+        while (((size_t)1 << log_rows) < rows) ++log_rows;
+        H2_CHK(ntt_pow_table(ctx, log_rows, g.omega, &pw));
+    }
     const uint32_t per_launch = PP_BATCH_COLS / chunk_len * chunk_len;   // whole sets
     Fr x0 = fe_mul(g.beta, fe_pow_u64(g.omega, (uint64_t)row0));
     for (uint32_t c0 = 0; c0 < num_columns; c0 += per_launch) {
@@ -287,10 +297,10 @@ int h2hip_permutation_product_terms_rows_dev(h2hip_ctx *ctx, void *num_dev, void
             k29.beta32 = r29_const(fe_x32(g.beta));
             k29.delta = r29_const(g.delta);
             k29.xstep = r29_const(g.xstep);
-            k29.x0_32 = r29_const(fe_x32(g.x0));
+            k29.x0_32 = r29_load(fe_x32(g.x0));
             k29.gamma32 = r29_load(fe_x32(g.gamma));
             k29.one = r29_load(Fr::one());
-            k29.omega = g.omega;
+            k29.pw = pw;
             hipLaunchKernelGGL(perm_product_terms_batch29_kernel, dim3(grid), dim3(256), 0, ctx->stream, (Fr *)num_dev + first_set * rows,
                                (Fr *)den_dev + first_set * rows, g, k29, rows);
         } else {
