@@ -315,7 +315,7 @@ struct PowTable {
 };
 // stage 1: each workgroup evaluates its 256*EVAL_J coefficients relative to its first one:
 // lane Horner over EVAL_J coefficients, then a tree with x^(EVAL_J * 2^l)
-constexpr uint32_t EVAL_J = 8;
+constexpr uint32_t EVAL_J = 32;   // (r06: 8 -> 32: the 8-level workgroup tree costs a product per level on every lane, as much as 8 Horner steps; PMC: 446 -> see profiles/r06_quotient_pmc.md)
 __global__ __launch_bounds__(256) void fr_eval_tile_kernel(const Fr *__restrict__ coeffs, size_t n, Fr x, PowTable pw, Fr *__restrict__ tile_val) {
     __shared__ Fr sh[256];
     const uint32_t tid = threadIdx.x;
