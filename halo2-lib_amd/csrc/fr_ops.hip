@@ -191,23 +191,27 @@ __global__ __launch_bounds__(256, 3) void ntt_round_probe_kernel(Fr *__restrict_
 // Montgomery's trick over strided runs: lane t owns a[t], a[t+T], a[t+2T], ... (coalesced), one inversion
 // (division steps, modinv.cuh) per lane.  [UPSTREAM ff::BatchInvert / halo2 batch_invert_assigned; denominators come from
 // reference halo2-base/src/gates/flex_gate/mod.rs:677-681,791-795]
-__global__ __launch_bounds__(256) void fr_batch_invert_kernel(Fr *__restrict__ a, Fr *__restrict__ scratch, size_t n) {
+// (r06) src -> dst: out of place when they differ — the grand products invert their denominators straight out of the factor array instead of
+// copying it first (a 32 MiB device copy per proof at k = 19, on the critical path between the factors and the prefix products)
+__global__ __launch_bounds__(256) void fr_batch_invert_kernel(const Fr *__restrict__ src, Fr *__restrict__ dst, Fr *__restrict__ scratch, size_t n) {
     const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     Fr acc = Fr::one();
     size_t last = t;
     for (size_t i = t; i < n; i += T) {
-        Fr v = a[i];
+        Fr v = src[i];
         scratch[i] = acc;
         if (!v.is_zero()) acc = fe_mul(acc, v);
         last = i;
     }
     Fr inv = fe_inv(acc);
     for (size_t i = last;; i -= T) {
-        Fr v = a[i];
+        Fr v = src[i];
         if (!v.is_zero()) {
-            a[i] = fe_mul(inv, scratch[i]);
+            dst[i] = fe_mul(inv, scratch[i]);
             inv = fe_mul(inv, v);
+        } else if (dst != src) {
+            dst[i] = v;   // 0 -> 0
         }
         if (i < T) break;
     }
@@ -1202,9 +1206,9 @@ int h2hip_fr_linear_combination_dev(h2hip_ctx *ctx, void *out, const void *const
 }
 
 // ------------------------------------------------------------------ K4 / K5
-int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a, size_t n) {
-    H2_DEVICE_GUARD(ctx);
-    H2_REQUIRE(ctx && (n == 0 || a), "NULL argument");
+}  // extern "C"
+namespace h2 {
+int fr_batch_invert_to(h2hip_ctx *ctx, const Fr *src, Fr *dst, size_t n) {   // dst == src: in place
     if (!n) return H2HIP_OK;
     Fr *scratch = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP1, sizeof(Fr) * n, (void **)&scratch));
@@ -1218,10 +1222,17 @@ int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a, size_t n) {
     size_t lanes = (n + per_lane - 1) / per_lane;
     uint32_t blocks = (uint32_t)((lanes + 255) / 256);
     prof_begin(ctx, "fr_batch_invert_kernel");
-    hipLaunchKernelGGL(fr_batch_invert_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (Fr *)a, scratch, n);
+    hipLaunchKernelGGL(fr_batch_invert_kernel, dim3(blocks), dim3(256), 0, ctx->stream, src, dst, scratch, n);
     prof_end(ctx);
     H2_HIPCHK(hipGetLastError());
     return H2HIP_OK;
+}
+}  // namespace h2
+extern "C" {
+int h2hip_fr_batch_invert_dev(h2hip_ctx *ctx, void *a, size_t n) {
+    H2_DEVICE_GUARD(ctx);
+    H2_REQUIRE(ctx && (n == 0 || a), "NULL argument");
+    return fr_batch_invert_to(ctx, (const Fr *)a, (Fr *)a, n);
 }
 
 // inclusive prefix products of `segments` independent runs of n elements, `seg_stride` elements apart (in -> out, same layout)
@@ -1273,8 +1284,7 @@ int h2hip_fr_grand_product_dev(h2hip_ctx *ctx, void *z, const void *num, const v
     if (!n) return H2HIP_OK;
     Fr *t = nullptr;
     H2_CHK(ws_reserve(ctx, h2hip_ctx::WS_TMP0, sizeof(Fr) * n, (void **)&t));
-    H2_HIPCHK(hipMemcpyAsync(t, den, sizeof(Fr) * n, hipMemcpyDeviceToDevice, ctx->stream));
-    H2_CHK(h2hip_fr_batch_invert_dev(ctx, t, n));
+    H2_CHK(fr_batch_invert_to(ctx, (const Fr *)den, t, n));
     H2_CHK(binop(ctx, OP_MUL, t, t, num, n));
     return prefix_product_inplace(ctx, t, zz + 1, n);
 }
@@ -1299,8 +1309,7 @@ int h2hip_fr_grand_products_dev(h2hip_ctx *ctx, void *const *z, const void *num,
         H2_HIPCHK(hipGetLastError());
         return H2HIP_OK;
     }
-    H2_HIPCHK(hipMemcpyAsync(t, den, sizeof(Fr) * total, hipMemcpyDeviceToDevice, ctx->stream));
-    H2_CHK(h2hip_fr_batch_invert_dev(ctx, t, total));
+    H2_CHK(fr_batch_invert_to(ctx, (const Fr *)den, t, total));   // (out of place: no copy of the denominators first)
     prof_begin(ctx, "fr_ratio_rows_kernel");
     hipLaunchKernelGGL(fr_ratio_rows_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, r, (const Fr *)num, (const Fr *)t, total, seg_len,
                        chained ? 1 : 0);
