@@ -931,7 +931,8 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     // competing for one 4 MiB L2).
     uint32_t chunk = (uint32_t)((n + 31) / 32);
     if (chunk < 4096) chunk = 4096;
-    if (chunk > 65536) chunk = 65536;
+    const uint32_t chunk_cap = ctx->msm_hist_packed ? 65535u : 65536u;   // (r06) a packed histogram counter holds at most 65535: 2^21 points sort as 33 chunks
+    if (chunk > chunk_cap) chunk = chunk_cap;
     const uint32_t G = (uint32_t)((n + chunk - 1) / chunk);
     const uint32_t sort_grid = sort_grid_size(W, G);
 
