@@ -350,6 +350,7 @@ void h2hip_destroy(h2hip_ctx *ctx) {
         }
     if (ctx->fork_ev) hipEventDestroy(ctx->fork_ev);
     if (ctx->fork_ev2) hipEventDestroy(ctx->fork_ev2);
+    if (ctx->fork_ev3) hipEventDestroy(ctx->fork_ev3);
     for (auto e : ctx->timer_ev)
         if (e) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -380,6 +381,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "plonk_merge_products")) return &ctx->plonk_merge_products;
     if (!strcmp(name, "plonk_shard_side")) return &ctx->plonk_shard_side;
     if (!strcmp(name, "plonk_route_rows")) return &ctx->plonk_route_rows;
+    if (!strcmp(name, "plonk_lazy_upload")) return &ctx->plonk_lazy_upload;
     if (!strcmp(name, "plonk_early_intt")) return &ctx->plonk_early_intt;
     if (!strcmp(name, "plonk_gate_before_join")) return &ctx->plonk_gate_before_join;
     if (!strcmp(name, "msm_stagger_sorts")) return &ctx->msm_stagger_sorts;
@@ -814,6 +816,8 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
         for (int l = 0; l < NL; ++l) H2_HIPCHK(hipStreamWaitEvent(ctx->lane[l]->stream, ctx->fork_ev2, 0));
         return H2HIP_OK;
     };
+    std::function<int(size_t)> col_hook;   // columns that arrive one by one (msm_col_hook, internal.h)
+    col_hook.swap(ctx->msm_col_hook);
     const size_t ngroups = groups.size();
     // (r05, last: the lanes' streams created with the lowest / the highest HIP priority — either way 7 - 10 % slower at k = 17 / 19, profiles/r05_lane_priority_ab.log; removed)
     // (r05 built and measured a third schedule — the sorts of a round of columns queued on ALL lanes before any of their accumulations, so that no
@@ -821,8 +825,15 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     // equal — profiles/r05_msm_sort_first_ab.log; removed)
     for (size_t g = 0; g < ngroups; ++g) {
         const size_t j0 = groups[g].first, gsize = groups[g].second;
-        if (mid_hook && j0 + gsize > mid_after) H2_LANES_RC(run_mid());
         h2hip_ctx *c = ctx->lane[g % NL];
+        if (col_hook)   // the group's columns are produced now, on the caller's stream (before the mid hook: what it queues may read them)
+            for (size_t j = j0; j < j0 + gsize; ++j) H2_LANES_RC(col_hook(j));
+        if (mid_hook && j0 + gsize > mid_after) H2_LANES_RC(run_mid());
+        if (col_hook) {   // the lane waits for them
+            if (!ctx->fork_ev3) H2_LANES(hipEventCreateWithFlags(&ctx->fork_ev3, hipEventDisableTiming));
+            H2_LANES(hipEventRecord(ctx->fork_ev3, ctx->stream));
+            H2_LANES(hipStreamWaitEvent(c->stream, ctx->fork_ev3, 0));
+        }
         const h2hip_bases *gb = bases_of(j0);
         if ((ctx->msm_stagger_sorts > 0 || (ctx->msm_stagger_sorts < 0 && NL == 2)) && precomp && fuse == 1 && g < (size_t)NL) {   // the first round of columns: lane g sorts behind lane g - 1's sort
             if (g > 0 && ctx->lane[g - 1]->sorted_ev) H2_LANES(hipStreamWaitEvent(c->stream, ctx->lane[g - 1]->sorted_ev, 0));

@@ -117,6 +117,12 @@ struct h2hip_ctx {
     // host synchronisations allowed — makes the lanes wait for that stream, and goes on with the remaining columns.  Consumed by the batch call.
     std::function<int()> msm_mid_hook;
     size_t msm_mid_after = 0;
+    // (r06) a batch MSM whose columns ARRIVE one by one: called with j right before column j's group is queued on its lane; the caller queues what
+    // produces column j on this context's stream (create_proof: the host-to-device copy of advice column j — pageable, so it blocks the host while
+    // the GPU already works on the columns before it), the lane then waits for that stream.  Consumed by the batch call.
+    std::function<int(size_t)> msm_col_hook;
+    hipEvent_t fork_ev3 = nullptr;
+    int plonk_lazy_upload = 1;       // create_proof with host-resident advice and >= 2 advice columns: column j >= 1 is uploaded inside round 1's commitment batch, right before its MSM is queued
     hipEvent_t fork_ev2 = nullptr;
     std::function<int(hipEvent_t ev)> msm_tail_hook;
     hipEvent_t tail_ev = nullptr;

@@ -877,13 +877,18 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
         H2_HIPCHK(hipStreamSynchronize(st));
     }
     // ---- advice columns: witness rows from the caller, blinding rows from the RNG
+    const bool lazy_upload = !advice_on_device && overlap && ctx->plonk_lazy_upload != 0 && sh.num_advice_total >= 2 &&
+                             (sh.lookups.empty() || ctx->plonk_permute_in_commit != 0);
     {
         TailRun tails;
         tails_reserve(tails, sh.num_advice_total, n - u, n - u);
         for (uint32_t c = 0; c < sh.num_advice_total; ++c) {
             H2_REQUIRE(advice[c], "NULL advice column");
             H2_CHK(sc.take(n, &adv[c]));
-            H2_HIPCHK(hipMemcpyAsync(adv[c], advice[c], sizeof(Fr) * u, advice_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+            // r06: host-resident columns behind the first are uploaded INSIDE round 1's commitment batch (msm_col_hook below), each right before its
+            // MSM is queued: the pageable copy blocks the host, not the GPU, which is working on the columns before it by then
+            if (!(lazy_upload && c >= 1))
+                H2_HIPCHK(hipMemcpyAsync(adv[c], advice[c], sizeof(Fr) * u, advice_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
             const Fr *tail = draw(n - u);
             H2_CHK(tails_add(tails, adv[c] + u, tail));
         }
@@ -1010,8 +1015,15 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
             }
             side_arm([&]() -> int { return side_transforms(r1_src, r1_coef, r1_cos); }, true);
         }
+        if (lazy_upload) {
+            const uint32_t A = sh.num_advice_total;
+            ctx->msm_col_hook = [&, A](size_t j) -> int {
+                if (j >= 1 && j < A) H2_HIPCHK(hipMemcpyAsync(adv[j], advice[j], sizeof(Fr) * u, hipMemcpyHostToDevice, st));
+                return H2HIP_OK;
+            };
+        }
         H2_CHK(commit_points(pk->g_lagrange, cols, n, pts));
-        H2_REQUIRE(!ctx->msm_mid_hook, "internal: the commitment round did not run the lookup permutation");
+        H2_REQUIRE(!ctx->msm_mid_hook && !ctx->msm_col_hook, "internal: the commitment round did not run the lookup permutation / the advice uploads");
         H2_CHK(side_fire_if_pending());
         for (size_t i = 0; i < adv.size(); ++i) H2_CHK(tr.write_point(pts[i]));
         const Fr theta = tr.squeeze_challenge();
@@ -1973,6 +1985,7 @@ int h2hip_plonk_keygen(h2hip_ctx *ctx, const h2hip_base_circuit_params *params, 
             pk->transcript_repr = saved;
             ctx->msm_tail_hook = nullptr;   // both hooks capture create_proof_impl's frame: never leave one on the context
             ctx->msm_mid_hook = nullptr;
+            ctx->msm_col_hook = nullptr;
             if (pk->side) hipStreamSynchronize(pk->side->stream);
             for (h2hip_ctx *l : ctx->lane)
                 if (l) hipStreamSynchronize(l->stream);
@@ -2128,6 +2141,7 @@ int h2hip_plonk_create_proof(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     int rc = create_proof_impl(ctx, pk, advice, advice_on_device != 0, instances_host, instance_lens, rng, rng_user, proof, stage_ms);
     ctx->msm_tail_hook = nullptr;   // (never leave a hook of this proof behind: it captures the proof's frame)
     ctx->msm_mid_hook = nullptr;
+    ctx->msm_col_hook = nullptr;
     if (pk->side && ctx->profiling && ctx->prof_filter.empty()) prof_fold_child(ctx, pk->side);   // (the lanes' timers are folded when the table is read)
     if (rc != H2HIP_OK) {
         if (pk->copy_stream) hipStreamSynchronize(pk->copy_stream);
