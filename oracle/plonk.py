@@ -27,6 +27,7 @@ protocol: ordering, transcript, challenges, SHPLONK.  Vectors: (n,4) uint64; sca
 from __future__ import annotations
 
 import hashlib
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
@@ -268,6 +269,22 @@ def transcript_repr_for(shape: Shape, fixed_commitments, permutation_commitments
     return fr_from_uniform_bytes(h.digest())
 
 
+class _LazyCosets:
+    """list-like: item i = coeff_to_extended(polys[i]), computed at every access and never cached (H2_ORACLE_LOWMEM=1)"""
+
+    def __init__(self, dom, polys, threads):
+        self.dom, self.polys, self.threads = dom, polys, threads
+
+    def __len__(self):
+        return len(self.polys)
+
+    def __getitem__(self, i):
+        return self.dom.coeff_to_extended(self.polys[i], self.threads)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self.polys)))
+
+
 def keygen(params: Params, shape: Shape, fixed_values: List[np.ndarray], assembly: PermutationAssembly, threads=1) -> ProvingKey:
     """keygen_vk + keygen_pk for the shape: fixed_values = Lagrange values of ALL fixed columns in Shape order (table, constants,
     selector columns), each (n,4)."""
@@ -276,10 +293,17 @@ def keygen(params: Params, shape: Shape, fixed_values: List[np.ndarray], assembl
     n, bf = shape.n, shape.blinding_factors
     fixed_values = [np.ascontiguousarray(v, dtype=np.uint64).reshape(n, 4) for v in fixed_values]
     fixed_polys = [dom.lagrange_to_coeff(v, threads) for v in fixed_values]
-    fixed_cosets = [dom.coeff_to_extended(p, threads) for p in fixed_polys]
     sig_vals = assembly.sigma_values()
     sig_polys = [dom.lagrange_to_coeff(v, threads) for v in sig_vals]
-    sig_cosets = [dom.coeff_to_extended(p, threads) for p in sig_polys]
+    if os.environ.get("H2_ORACLE_LOWMEM") == "1":
+        # r06 (tests/golden/make_proof_goldens.py for bench_msm.config:13, k = 23 with 6 + 1 advice columns): the proving key's extended-domain forms —
+        # 1 GiB per column at k = 23, 17 columns — are recomputed from the coefficient forms whenever create_proof indexes them instead of being held
+        # for the key's lifetime (same values, hence the same proof bytes: checked against a committed digest in tests/test_oracle.py)
+        fixed_cosets = _LazyCosets(dom, fixed_polys, threads)
+        sig_cosets = _LazyCosets(dom, sig_polys, threads)
+    else:
+        fixed_cosets = [dom.coeff_to_extended(p, threads) for p in fixed_polys]
+        sig_cosets = [dom.coeff_to_extended(p, threads) for p in sig_polys]
     fixed_comm = [params.commit_lagrange(v, threads) for v in fixed_values]
     perm_comm = [params.commit_lagrange(v, threads) for v in sig_vals]
     one, zero = fr1(1)[0], fr1(0)[0]

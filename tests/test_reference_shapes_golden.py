@@ -99,6 +99,28 @@ def test_oracle_reproduces_a_golden_entry():
     assert (len(proof), _sha(proof)) == (e["proof_len"], e["proof_sha256"])
 
 
+def test_oracle_low_memory_mode_reproduces_a_golden_entry(monkeypatch):
+    """H2_ORACLE_LOWMEM=1 (the proving key's extended forms recomputed at every use: what lets the k = 23, 6 + 1-column shape of
+    bench_msm.config:13 fit the generator's memory) gives the committed digest of a shape generated WITHOUT it (k = 13: 68 + 12 columns)"""
+    from oracle import plonk as P
+    from halo2_lib_amd import testing as T
+    from tests.golden import make_proof_goldens as M
+    from tests.util import PreDrawnRng
+
+    monkeypatch.setenv("H2_ORACLE_LOWMEM", "1")
+    e = _doc()["shapes"]["ecdsa-13"]
+    sh = P.Shape(13, 68, 12, 1, 0, 12)
+    params = P.Params.setup(13, M.TOXIC_S, threads=8)
+    circ = T.build_circuit(sh, M.CIRCUIT_SEED + 13, M.OracleBackend)
+    asm = P.PermutationAssembly(sh)
+    for l, r in circ.copies:
+        asm.copy(l, r)
+    pk = P.keygen(params, sh, circ.fixed, asm, 8)
+    assert isinstance(pk.fixed_cosets, P._LazyCosets) and hex(pk.vk.transcript_repr) == e["transcript_repr"]
+    proof = P.create_proof(params, pk, circ.advice, [], PreDrawnRng(M.rng_budget(sh), M.RNG_SEED + 13), 8)
+    assert (len(proof), _sha(proof)) == (e["proof_len"], e["proof_sha256"])
+
+
 class _GpuBackend:
     def __init__(self, ctx):
         self.mul, self.add = ctx.fr_mul, ctx.fr_add
