@@ -153,7 +153,8 @@ def test_sharded_path_single_rank_rccl_gpu(shape):
 
 @pytest.mark.gpu
 def test_rccl_transport_allgather_gpu():
-    """h2hip_comm over RCCL (one rank): device and host all-gathers return the rank's own payload; the library reports itself as RCCL"""
+    """h2hip_comm over RCCL (one rank): device and host all-gathers and the all-to-all (grouped ncclSend / ncclRecv) return the rank's own payload;
+    the library reports itself as RCCL"""
     ctx = H.Context()
     try:
         comm, _ = _rccl_comm(ctx)
@@ -164,6 +165,11 @@ def test_rccl_transport_allgather_gpu():
         d_a, d_b = ctx.to_device(a), ctx.malloc(a.nbytes)
         ctx._chk(ctx.lib.h2hip_comm_allgather_dev(comm, ctx.handle, d_a, a.nbytes, d_b))
         assert np.array_equal(ctx.download(d_b, a.shape), a)
+        # r06: the all-to-all — one group of ncclSend / ncclRecv per peer (here: to itself) on the context's stream
+        d_c = ctx.malloc(a.nbytes)
+        ctx._chk(ctx.lib.h2hip_comm_alltoall_dev(comm, ctx.handle, d_a, a.nbytes, d_c))
+        assert np.array_equal(ctx.download(d_c, a.shape), a)
+        ctx.free(d_c)
         send = bytes(range(200))
         recv = C.create_string_buffer(200)
         ctx._chk(ctx.lib.h2hip_comm_allgather_host(comm, ctx.handle, send, 200, recv))
