@@ -427,6 +427,11 @@ def create_proof(params: Params, pk: ProvingKey, advice: List[np.ndarray], insta
     t_last = [_time.perf_counter()]
 
     def lap(name):
+        if os.environ.get("H2_ORACLE_TRACE") == "1":   # (the golden generator's large shapes: which step holds how much memory)
+            import resource
+            print("  oracle create_proof: %-28s %6.1f s, peak rss %.1f GB" % (name, _time.perf_counter() - t_last[0], resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576), flush=True)
+            if timings is None:
+                t_last[0] = _time.perf_counter()
         if timings is not None:
             now = _time.perf_counter()
             timings[name] = timings.get(name, 0.0) + now - t_last[0]

@@ -120,7 +120,12 @@ def main():
         asm = P.PermutationAssembly(sh)
         for l, r in circ.copies:
             asm.copy(l, r)
+        if os.environ.get("H2_ORACLE_TRACE") == "1":
+            import resource
+            print("  %s: SRS + circuit + permutation assembly %.1f s, peak rss %.1f GB" % (name, time.time() - t0, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576), flush=True)
         pk = P.keygen(params, sh, circ.fixed, asm, threads)
+        if os.environ.get("H2_ORACLE_TRACE") == "1":
+            print("  %s: keygen done %.1f s, peak rss %.1f GB" % (name, time.time() - t0, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576), flush=True)
         inst = [O.limbs_to_ints(v, O.R_MOD) for v in circ.instances]
         proof = P.create_proof(params, pk, circ.advice, inst, PreDrawnRng(rng_budget(sh), RNG_SEED + k), threads)
         assert P.verify_proof(params, pk.vk, inst, proof), name
