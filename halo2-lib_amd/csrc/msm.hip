@@ -922,8 +922,15 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         // Measured at 2^19 / 17 windows (tools/msm_r03.py): 34 entries per lane = 4096 waves 0.72 ms; 32 = 4352 waves 0.81 ms; 64 = 2176 waves
         // 0.98 ms; ONE exact round of two waves per SIMD (68 entries = 2048 waves) 0.72 ms although its wave-level merge is a single
         // addition per lane — with one round the kernel ends with its slowest wave, shorter lanes in several rounds balance themselves.
+        // r06, re-measured in whole proofs with the sort kernels running beside the accumulations (profiles/r06_msm_chunk_ab.log): shorter lanes — more,
+        // shorter accumulation workgroups, whose retiring gives the next column's sort its slots sooner — win up to 2^20 points: 24 entries per lane
+        // -0.7 ... -1.3 % at k = 19, -1.6 % at k = 18, -3 % at k = 17 (four fused columns), -4 % at k = 16; 2^20 points: 32 (-1.5 ... -3 %; 48: +3 %); from 2^21
+        // points the longest lanes stay best (56 / 48 / 32: +1 % / neutral / +1.3 %)
         uint64_t k = emax / 262144;
         K1 = k < 8 ? 8u : k > 64 ? 64u : (uint32_t)k;
+        if (emax >= 25000000ull) K1 = 64;
+        else if (emax >= 12000000ull) K1 = 32;
+        else if (emax >= 4000000ull) K1 = 24;
     }
     // chunking of the counting sort: about 32 chunks per window, 4Ki..64Ki scalars each.  32 = the CUs of an XCD: the (window, chunk)
     // workgroups of one window run together on the window's XCD, one per CU (tried: chunks sized for ONE round over the whole chip,
