@@ -232,12 +232,13 @@ __device__ __forceinline__ void st29(Fr29P *p, const Fr29 &v) {
 struct TileLayoutPlanes {
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     static __host__ __device__ constexpr uint32_t tw_slots(uint32_t m) { return (1u << (m - 1)) + (1u << (m - 1) >> 4) + 1; }
-    static __host__ __device__ constexpr size_t bytes(uint32_t m) { return (size_t)36 * 1024 + (size_t)36 * tw_slots(m) + sizeof(Fr29P) * 3 + 16; }
+    static __host__ __device__ constexpr uint32_t tw_stride(uint32_t m) { return (tw_slots(m) + 3u) & ~3u; }   // keeps every plane 16-byte aligned
+    static __host__ __device__ constexpr size_t bytes(uint32_t m) { return (size_t)36 * 1024 + (size_t)36 * tw_stride(m) + sizeof(Fr29P) * 3 + 16; }
     v4u *pa, *pb, *ta, *tb;
     uint32_t *pc, *tc;
     Fr29P *scale_s;
     __device__ __forceinline__ void init(void *raw, uint32_t m) {
-        const uint32_t ts = (tw_slots(m) + 3u) & ~3u;   // keeps every plane 16-byte aligned
+        const uint32_t ts = tw_stride(m);   // (bytes() sizes the planes with the same stride: the emulated build under AddressSanitizer caught a version that did not)
         pa = reinterpret_cast<v4u *>(raw);
         pb = pa + 1024;
         ta = pb + 1024;
