@@ -394,6 +394,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_quad_tails")) return &ctx->msm_quad_tails;
     if (!strcmp(name, "msm_scatter_split")) return &ctx->msm_scatter_split;
     if (!strcmp(name, "msm_hist_packed")) return &ctx->msm_hist_packed;
+    if (!strcmp(name, "msm_chunk_lone")) return &ctx->msm_chunk_lone;
     if (!strcmp(name, "msm_scatter_full_lds")) return &ctx->msm_scatter_full_lds;
     if (!strcmp(name, "msm_sort_threads")) return &ctx->msm_sort_threads;
     if (!strcmp(name, "msm_fuse_cols")) return &ctx->msm_fuse_cols;
@@ -731,6 +732,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
             h2hip_ctx *c = nullptr;
             H2_CHK(h2hip_init(ctx->device, nullptr, &c));
             c->msm_window_bits = ctx->msm_window_bits;
+            c->is_lane = true;
             ctx->lane[l] = c;
             H2_HIPCHK(hipEventCreate(&ctx->lane_ev[l]));
         }
