@@ -939,25 +939,11 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     // workgroups of one window run together on the window's XCD, one per CU (tried: chunks sized for ONE round over the whole chip,
     // W * G <= CUs — 2^19: scatter 0.081 -> 0.145 ms, 2^20: 0.154 -> 0.242 ms: half of every XCD's CUs idle and three windows' slices
     // competing for one 4 MiB L2).
-    // r06: ... and how MANY chunks decides the sort's last round: the histogram / scatter workgroups (1024 lanes; 32 - 64 KiB of LDS since r06) fit two to a
-    // CU = 512 slots, and 17 windows x 32 chunks = 544 workgroups are 1.06 rounds — a second round of 32 workgroups with the chip idle behind it.  The
-    // chunk count is taken from 24 .. 32 so that windows x chunks fills whole rounds: 30 at 17 windows (510 workgroups; also 68 fused windows: 2040 of
-    // 2048), 32 at 16.  A synchronous 2^19-point MSM 1.198 -> 1.092 ms, 2^20 1.965 -> 1.832, the k = 19 proof -1 % (profiles/r06_sort_groups_ab.log).
-    uint32_t sort_groups = ctx->msm_sort_groups > 0 ? (uint32_t)ctx->msm_sort_groups : 32u;
-    if (ctx->msm_sort_groups == 0) {
-        const uint32_t slots = 2u * (uint32_t)ctx->num_cus;
-        // (from 2^21 points a chunk's 65535-scalar cap asks for more than 32 chunks: the search starts there — 64 at 2^21 points and 16 windows)
-        const uint32_t gneed = (uint32_t)((n + 65534) / 65535), gmin = gneed > 24 ? gneed : 24, gmax = gneed > 24 ? 2 * gneed + 8 : 32;
-        double best = -1.0;
-        for (uint32_t g = gmin; g <= gmax; ++g) {
-            const uint32_t wgs = W * g, rounds = (wgs + slots - 1) / slots;
-            const double util = (double)wgs / ((double)rounds * slots);
-            if (util > best + 1e-9) {   // ties: fewer, larger chunks
-                best = util;
-                sort_groups = g;
-            }
-        }
-    }
+    // (r06 tried choosing the chunk count so that windows x chunks fills whole rounds of the chip's 2 x CUs sort-workgroup slots — 30 at 17 windows: 510
+    // workgroups instead of 544 — on the theory that the 32 left-over workgroups cost a round: warm, a synchronous 2^19-point MSM is 1.08 ms either way
+    // and whole proofs do not move (profiles/r06_sort_groups_ab.log; the first sweep's 1.20 -> 1.09 ms was the tool's cold first measurement).  The
+    // knob stays: msm_sort_groups, 0 = 32.)
+    const uint32_t sort_groups = ctx->msm_sort_groups > 0 ? (uint32_t)ctx->msm_sort_groups : 32u;
     uint32_t chunk = (uint32_t)((n + sort_groups - 1) / sort_groups);
     if (chunk < 4096) chunk = 4096;
     const uint32_t chunk_cap = ctx->msm_hist_packed ? 65535u : 65536u;   // (r06) a packed histogram counter holds at most 65535: 2^21 points sort as 33 chunks
