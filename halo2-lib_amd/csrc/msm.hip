@@ -929,7 +929,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
         uint64_t k = emax / 262144;
         K1 = k < 8 ? 8u : k > 64 ? 64u : (uint32_t)k;
         const bool lone = !ctx->is_lane && ctx->msm_chunk_lone != 0;   // a lone MSM (SHPLONK's W, W'): no other column's sort waits for its slots
-        if (lone) {   // r05's rule stays: alone, 34 entries per lane are 5 % faster than 24 at 2^19 points (sync MSM 1.20 vs 1.24 ms)
+        if (lone) {   // r05's rule stays: alone, 34 entries per lane are 1 - 3 % faster than 24 at 2^19 points (warm: sync MSM 1.09 - 1.12 vs 1.12 - 1.13 ms, accumulation 0.70 vs 0.72 - 0.78)
             if (ctx->msm_chunk_lone > 0) K1 = (uint32_t)ctx->msm_chunk_lone;
         } else if (emax >= 25000000ull) K1 = 64;
         else if (emax >= 12000000ull) K1 = 32;
