@@ -396,6 +396,7 @@ static int *param_slot(h2hip_ctx *ctx, const char *name) {
     if (!strcmp(name, "msm_hist_packed")) return &ctx->msm_hist_packed;
     if (!strcmp(name, "msm_chunk_lone")) return &ctx->msm_chunk_lone;
     if (!strcmp(name, "msm_sort_groups")) return &ctx->msm_sort_groups;
+    if (!strcmp(name, "msm_hist_split")) return &ctx->msm_hist_split;
     if (!strcmp(name, "msm_scatter_full_lds")) return &ctx->msm_scatter_full_lds;
     if (!strcmp(name, "msm_sort_threads")) return &ctx->msm_sort_threads;
     if (!strcmp(name, "msm_fuse_cols")) return &ctx->msm_fuse_cols;

@@ -124,13 +124,16 @@ __device__ __forceinline__ void block_to_window_chunk(uint32_t L, uint32_t G, ui
 // against 16 us alone, profiles/r06_bench_proof_k19_kernels.md).
 template <bool PACKED>
 __global__ __launch_bounds__(1024) void msm_hist_kernel(const digit_t *__restrict__ digits, uint32_t n, uint32_t W, uint32_t B,
-                                                        uint32_t G, uint32_t chunk, uint32_t *__restrict__ bhist) {
+                                                        uint32_t G, uint32_t chunk, uint32_t S, uint32_t *__restrict__ bhist) {
     H2_SORT_PRIORITY();
-    HIP_DYNAMIC_SHARED(uint32_t, hist)   // B counters (PACKED: B / 2 words)
-    uint32_t w, g;
-    block_to_window_chunk(blockIdx.x, G, W, w, g);
-    if (w >= W) return;
-    const uint32_t words = PACKED ? (B + 1) >> 1 : B;
+    HIP_DYNAMIC_SHARED(uint32_t, hist)   // B / S counters (PACKED: half as many words)
+    // S > 1 (r06): a workgroup counts one bucket SUB-RANGE of its (window, chunk) — the chunk's digits are read S times (2 bytes each), the histogram
+    // is 1 / S the size: at c = 16 two sub-ranges of 32 KiB each fit the slot a retiring accumulation workgroup leaves, the whole 64 KiB did not
+    uint32_t seg, g;
+    block_to_window_chunk(blockIdx.x, G, W * S, seg, g);
+    if (seg >= W * S) return;
+    const uint32_t w = seg / S, h = seg - w * S, Bs = B / S, b0 = h * Bs;
+    const uint32_t words = PACKED ? (Bs + 1) >> 1 : Bs;
     for (uint32_t b = threadIdx.x; b < words; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     uint32_t lo = g * chunk, hi = lo + chunk < n ? lo + chunk : n;
@@ -142,16 +145,17 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const digit_t *__restric
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) d[k] = i + k * T < hi ? (uint32_t)dw[i + k * T] : 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k)
-            if (d[k]) {
-                const uint32_t b = digit_bucket(d[k], B) - 1;
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t b = digit_bucket(d[k], B) - 1 - b0;   // code 0 wraps to a huge b: skipped like another sub-range's digit
+            if (d[k] && b < Bs) {
                 if (PACKED) atomicAdd(&hist[b >> 1], 1u << (16u * (b & 1u)));
                 else atomicAdd(&hist[b], 1u);
             }
+        }
     }
     __syncthreads();
-    uint32_t *out = bhist + ((size_t)w * G + g) * B;
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) out[b] = PACKED ? (hist[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu : hist[b];
+    uint32_t *out = bhist + ((size_t)w * G + g) * B + b0;
+    for (uint32_t b = threadIdx.x; b < Bs; b += blockDim.x) out[b] = PACKED ? (hist[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu : hist[b];
 }
 
 // ------------------------------------------------------------------ 3. prefix over chunks per (window, bucket)
@@ -949,7 +953,6 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     const uint32_t chunk_cap = ctx->msm_hist_packed ? 65535u : 65536u;   // (r06) a packed histogram counter holds at most 65535: 2^21 points sort as 33 chunks
     if (chunk > chunk_cap) chunk = chunk_cap;
     const uint32_t G = (uint32_t)((n + chunk - 1) / chunk);
-    const uint32_t sort_grid = sort_grid_size(W, G);
 
     // The one-pass LDS-histogram counting sort is the only sort.  r03 also built a two-level sort with only coalesced writes (0.124 -> 0.087 ms
     // at 2^19 on uniform scalars) that lost inside the proofs — 5-9 % slower accumulation on its entry order, 15-20 % behind on 0/1-heavy columns
@@ -1000,10 +1003,15 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     }
     prof_begin(ctx, "msm_hist_kernel");
     const bool hist_packed = ctx->msm_hist_packed != 0 && chunk < 65536u && B >= 2;   // (a counter holds at most `chunk`)
+    uint32_t HS = ctx->msm_hist_split > 0 ? (uint32_t)ctx->msm_hist_split : 1u;          // bucket sub-ranges per window: the histogram's LDS footprint within 32 KiB
+    if (ctx->msm_hist_split == 0)
+        while (HS < 8 && HS * 2 <= B && (hist_packed ? 2u : 4u) * (B / HS) > 32768u) HS *= 2;
+    if (HS > B) HS = B;
+    const uint32_t hist_grid = sort_grid_size(W * HS, G);
     if (hist_packed)
-        hipLaunchKernelGGL(msm_hist_kernel<true>, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * ((B + 1) / 2), st, (const digit_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
+        hipLaunchKernelGGL(msm_hist_kernel<true>, dim3(hist_grid), dim3(sort_threads), sizeof(uint32_t) * ((B / HS + 1) / 2), st, (const digit_t *)digits, (uint32_t)n, W, B, G, chunk, HS, bhist);
     else
-        hipLaunchKernelGGL(msm_hist_kernel<false>, dim3(sort_grid), dim3(sort_threads), sizeof(uint32_t) * B, st, (const digit_t *)digits, (uint32_t)n, W, B, G, chunk, bhist);
+        hipLaunchKernelGGL(msm_hist_kernel<false>, dim3(hist_grid), dim3(sort_threads), sizeof(uint32_t) * (B / HS), st, (const digit_t *)digits, (uint32_t)n, W, B, G, chunk, HS, bhist);
     prof_end(ctx);
     prof_begin(ctx, "msm_hist_scan_kernel");
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, st, bhist, W, B, G, counts);

@@ -556,6 +556,27 @@ def test_msm_sort_degenerate_inputs(ctx):
         b.free()
 
 
+def test_msm_sort_variants_r06(ctx):
+    """r06's sort: the LDS histogram as 16-bit counter pairs or plain words, over 1 / 2 / 4 bucket sub-ranges per window, the scatter with its cursors
+    only or the whole LDS, other chunk counts — the same point as the oracle's for uniform, all-equal (one bucket takes a whole chunk) and 0 / 1 scalars"""
+    n = 20000
+    bases = CO.known_dlog_bases(n, fr([5]), fr([13]))
+    b = ctx.bases_upload(bases)
+    cols = [rand_fr(n, 191), np.repeat(fr([R - 7]), n, axis=0), np.concatenate([np.repeat(fr([1]), n // 2, axis=0), np.repeat(fr([0]), n - n // 2, axis=0)])]
+    want = [CO.best_multiexp(s, bases, threads=8) for s in cols]
+    names = ("msm_hist_packed", "msm_hist_split", "msm_scatter_full_lds", "msm_sort_groups")
+    try:
+        for vals in ((1, 0, 0, 0), (1, 2, 0, 0), (1, 4, 1, 0), (0, 2, 0, 3), (0, 1, 1, 5), (1, 1, 0, 2)):
+            for nm, v in zip(names, vals):
+                ctx.set_param(nm, v)
+            for s, w in zip(cols, want):
+                assert np.array_equal(ctx.msm(b, s, H.POINT_AFFINE), w), vals
+    finally:
+        for nm, v in zip(names, (1, 0, 0, 0)):
+            ctx.set_param(nm, v)
+        b.free()
+
+
 def test_full_range_field_inputs(ctx):
     """limb patterns from the whole of [0, r) plus the edge patterns through every kernel family (tests/full_range_checks.py); the GPU suite
     runs the same checks at BASELINE sizes"""
