@@ -88,7 +88,7 @@ struct h2hip_ctx {
     int msm_scatter_full_lds = 0;   // 1: the scatter declares the full 128 KiB of LDS (one workgroup per CU: one segment per XCD at a time; the default until r06); 0: only its cursors — a scatter workgroup then fits into the slot a retiring accumulation workgroup leaves: whole proofs -1 ... -2 % at k = 17 / 19, -0.5 % at k = 21 (profiles/r06_scatter_lds_ab.log)
     bool is_lane = false;           // a batch lane (child context of h2hip_msm_g1_batch_dev): its MSMs run beside other lanes' kernels
     int msm_chunk_lone = -1;        // entries per lane of a LONE MSM (not on a batch lane): -1 = r05's rule (emax / 2^18 in 8 .. 64: nothing waits for its workgroups' slots, and alone the longer lanes are 1 - 3 % faster), 0 = the batch rule, else the value
-    int msm_hist_split = 0;         // bucket sub-ranges per window in the histogram kernel (0 = auto: as many as keep its LDS within 32 KiB; 1 = r05's whole-window histogram)
+    int msm_hist_split = 0;         // bucket sub-ranges per window in the histogram kernel (0 / 1 = the whole window; r06 measured 2 and 4: no gain)
     int msm_sort_groups = 0;        // chunks per window of the counting sort (0 = 32; r06 measured 15 .. 30 and a whole-rounds rule: no gain)
     int msm_hist_packed = 1;        // r06: the LDS histogram as 16-bit counter pairs when a chunk holds < 2^16 scalars (half the LDS: fits beside running accumulations)
     uint32_t pos_t = 0, pos_rf = 0, pos_rp = 0;   // Poseidon spec resident in ws[WS_POSEIDON]

@@ -1003,9 +1003,9 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     }
     prof_begin(ctx, "msm_hist_kernel");
     const bool hist_packed = ctx->msm_hist_packed != 0 && chunk < 65536u && B >= 2;   // (a counter holds at most `chunk`)
-    uint32_t HS = ctx->msm_hist_split > 0 ? (uint32_t)ctx->msm_hist_split : 1u;          // bucket sub-ranges per window: the histogram's LDS footprint within 32 KiB
-    if (ctx->msm_hist_split == 0)
-        while (HS < 8 && HS * 2 <= B && (hist_packed ? 2u : 4u) * (B / HS) > 32768u) HS *= 2;
+    // bucket sub-ranges per window (msm_hist_split, default 1): two 32 KiB sub-ranges at c = 16 would fit one retiring accumulation workgroup's slot where
+    // the 64 KiB window needs two — measured: k = 21 / 22 proofs unchanged, k = 20 +0.5 %, a synchronous 2^20-point MSM +4 % (profiles/r06_hist_split_ab.log)
+    uint32_t HS = ctx->msm_hist_split > 0 ? (uint32_t)ctx->msm_hist_split : 1u;
     if (HS > B) HS = B;
     const uint32_t hist_grid = sort_grid_size(W * HS, G);
     if (hist_packed)
