@@ -72,10 +72,16 @@ int h2hip_sync(h2hip_ctx *ctx);
  * "plonk_early_intt" (1: the grand products' lagrange_to_coeff is queued on the side context in front of their commitment round),
  * "plonk_gate_before_join" (0; 1: the quotient's gate identities start before the grand products' transforms are joined — measured neutral),
  * "msm_stagger_sorts" (-1 = auto: two-lane batches; 1 / 0: a batch's lanes start their first sorts one behind the other / together),
- * "ntt_w8" (0; 1 / 2: transforms of 2^12+ points on the wave-owned radix-8 pass at three / two waves per SIMD — bit-exact, measured 8-12 % slower);
+ * r06: "msm_hist_packed" (1: the sort's LDS histogram as 16-bit counter pairs whenever a chunk holds < 2^16 scalars), "msm_scatter_full_lds"
+ * (0: the scatter declares its cursors only, so that it fits beside running accumulations), "msm_hist_split" (0 / 1 = the whole window per
+ * histogram workgroup; n = n bucket sub-ranges), "msm_sort_groups" (0 = auto), "msm_chunk_lone" (-1 = auto: a lone MSM keeps the longer
+ * entries-per-lane rule, batch lanes the shorter one), "plonk_lazy_upload" (1: host-resident advice columns 1.. are uploaded inside round 1's
+ * commitment batch, each right before its MSM is queued), "plonk_route_rows" (1: sharded proofs route the grand products' rows to the column
+ * owners by h2hip_comm_alltoall_dev instead of all-gathering them; same proof bytes);
  * profiling aid: "ntt_debug_skip" (produces wrong results).  The variants r01-r03 measured slower (two-level sort, bucket-major sort,
  * split streams, split windows, accumulation builds 2/5/6/7, radix-8 and wave-local NTT passes) were removed in r04, r05's (two-wave
- * accumulation, sort-first batches, split lone commitments) in r05; their A/B logs stay under profiles/. */
+ * accumulation, sort-first batches, split lone commitments) in r05, r05's wave-owned radix-8 NTT pass ("ntt_w8") and the 48-byte NTT tile
+ * layout in r06 (tools/probes/); their A/B logs stay under profiles/. */
 int h2hip_set_param(h2hip_ctx *ctx, const char *name, int value);
 int h2hip_get_param(h2hip_ctx *ctx, const char *name, int *value);
 
