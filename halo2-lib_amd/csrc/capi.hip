@@ -724,11 +724,11 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     int NL = ctx->msm_lanes;
     if (NL <= 0) NL = n >= ((size_t)1 << 20) ? 2 : 3;   // (2^18 / 2^19 were on 2 lanes until the window model moved them to c = 15: 3 lanes now win by 2 %, k = 18 / 19 proofs;
                                                         //  r04: 2^21 on 2 lanes 60.3 ms per k = 21 proof against 62.2 on one and 61.0 on three — the next column's sort
-                                                        //  runs beside the accumulation: profiles/r04_msm_lanes_large.log)
+                                                        //  runs beside the accumulation: profiles/archive/r04_msm_lanes_large.log)
     if (NL > 4) NL = 4;
     // (a third context exists even where only two lanes carry columns: the prover's side transforms run on the LAST lane's context, and with two
     // lanes a context of their own ended up behind the grand products on a shared hardware queue — k = 21: the products waited 3.5 ms for
-    // the transforms they were meant to run beside, profiles/r04_timeline_k21.md)
+    // the transforms they were meant to run beside, profiles/archive/r04_timeline_k21.md)
     for (int l = 0; l < (NL < 3 ? 3 : NL); ++l) {
         if (!ctx->lane[l]) {
             h2hip_ctx *c = nullptr;
@@ -805,7 +805,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     }
     // (two other schedules were built, measured slower and removed in r04: every accumulation on one stream with all sorts / merges on a
     // second, higher-priority one — 2^19 1.00 vs 0.95 ms per MSM, tools/batch_ab.py in r02 — and a column's windows dealt to two lanes —
-    // the k = 19 proof 15.7-15.8 vs 14.7 ms, profiles/r03_msm_split_windows_ab.log)
+    // the k = 19 proof 15.7-15.8 vs 14.7 ms, profiles/archive/r03_msm_split_windows_ab.log)
     // late columns (msm_mid_hook, internal.h): the hook runs once, before the first group that holds a column >= msm_mid_after
     std::function<int()> mid_hook;
     mid_hook.swap(ctx->msm_mid_hook);
@@ -869,7 +869,7 @@ static int msm_batch_impl(h2hip_ctx *ctx, const h2hip_bases *bases, const h2hip_
     // the accumulations are queued and joined: what follows on this stream is the reduction's tail.  The hook runs HERE, before the tail is
     // queued: the device is still hundreds of microseconds of accumulation behind the host at this point, so the hook's few launches do not
     // delay the reduction — and a wait on the event must be issued before more work follows it on this stream (r04 timeline,
-    // profiles/r04_timeline_k19.md: issued after the tail and the result copy had been queued, the side transforms started 20 us after that
+    // profiles/archive/r04_timeline_k19.md: issued after the tail and the result copy had been queued, the side transforms started 20 us after that
     // copy FINISHED — the runtime resolved the cross-stream wait against what the stream held at the time of the wait, not of the record)
     int hook_rc = H2HIP_OK;
     if (ctx->msm_tail_hook) {

@@ -1507,7 +1507,7 @@ static int kate_division_sets_run(h2hip_ctx *ctx, const KateSet *sets, size_t ns
 }
 static int kate_division_sets_pick(h2hip_ctx *ctx, const KateSet *sets, size_t nsets, size_t n) {
     uint32_t j = ctx->kate_coeffs_per_lane;
-    if (j != 1 && j != 2 && j != 4 && j != 8) j = n >= ((size_t)1 << 20) ? 8 : n >= ((size_t)1 << 18) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;   // (2^19: 4 and 8 within noise, 4 ahead by 0.04 ms per proof; 2^21: 8 ahead by 0.4 ms — profiles/r04_kate_tile_ab.log)
+    if (j != 1 && j != 2 && j != 4 && j != 8) j = n >= ((size_t)1 << 20) ? 8 : n >= ((size_t)1 << 18) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;   // (2^19: 4 and 8 within noise, 4 ahead by 0.04 ms per proof; 2^21: 8 ahead by 0.4 ms — profiles/archive/r04_kate_tile_ab.log)
     if (j == 8) return kate_division_sets_run<8>(ctx, sets, nsets, n);
     if (j == 4) return kate_division_sets_run<4>(ctx, sets, nsets, n);
     if (j == 2) return kate_division_sets_run<2>(ctx, sets, nsets, n);

@@ -520,7 +520,7 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
 }
 
 // r04: the accumulator's emptiness is a flag (not 36 zeroed registers tested every step) and the next bucket's end offset is requested one
-// boundary ahead: SQ_INSTS_VALU per 2^20-point launch 6.417e8 -> 6.322e8 (-1.5 %), time within noise (profiles/r04_accum_flag_ab.log) — the
+// boundary ahead: SQ_INSTS_VALU per 2^20-point launch 6.417e8 -> 6.322e8 (-1.5 %), time within noise (profiles/archive/r04_accum_flag_ab.log) — the
 // loop is VALU-bound at ~2440 instructions per step, 1467 of them multiplies, ~560 the nine reductions' carries and quotient digits.
 // r05: two waves per SIMD once more, this time WITH room made for the other lanes' sorts beside it (205 registers without spills, 72 KiB of LDS for
 // its two workgroups per CU, the scatter on 64 KiB and 512-lane workgroups so that a histogram / scatter workgroup fits next to it): the k = 19
@@ -532,7 +532,7 @@ __device__ __forceinline__ void msm_accum_body(const uint32_t *__restrict__ sval
 // r05, last: the addition's ten products issued as five side-by-side pairs (two dependency chains per lane, pinned with scheduling barriers) at two / three
 // waves per SIMD: 0.702 / 0.680 against 0.690 ms, proofs equal — tools/probes/valu_rate.hip shows why: a dependent v_mad_u64_u32 chain issues as fast as
 // independent ones (every 4 cycles per SIMD, like every instruction here except plain 32-bit adds / ands at 2).  profiles/r05_accum_pair_valu_rate.log; removed.
-// three waves per SIMD (168 registers per lane); measured and left behind (profiles/r03_msm_tune_*.log, r03_knob_ab.log): two waves per
+// three waves per SIMD (168 registers per lane); measured and left behind (profiles/archive/r03_msm_tune_*.log, r03_knob_ab.log): two waves per
 // SIMD by launch bounds or by register padding (2 % slower / equal in isolation, nothing end to end), four (spills), the next table entry
 // requested one addition ahead (5 % slower: the gather is not what the kernel waits for), plain instead of non-temporal table loads
 template <bool SPLIT>
@@ -878,7 +878,7 @@ bool buckets_prezeroed(h2hip_ctx *ctx, int which, const void *buf, size_t bytes)
 }
 // `on`: the stream the zero-fill is queued on (default: the context's own clean stream).  HIP serves all streams through four hardware queues:
 // a fill that waits for the reduction blocks whatever is queued BEHIND it on a stream sharing its queue — the batch MSM therefore queues its fill
-// after the tail hook's work and on its first lane's stream, which that work never uses (r04: profiles/r04_timeline_k19.md)
+// after the tail hook's work and on its first lane's stream, which that work never uses (r04: profiles/archive/r04_timeline_k19.md)
 int buckets_clean_after_use(h2hip_ctx *ctx, int which, void *buf, size_t bytes, hipStream_t on) {
     if (!ctx->clean_stream) {
         H2_HIPCHK(hipStreamCreateWithFlags(&ctx->clean_stream, hipStreamNonBlocking));
@@ -958,7 +958,7 @@ int msm_run_cols(h2hip_ctx *ctx, const h2hip_bases *bases, const Fr *const *scal
     // at 2^19 on uniform scalars) that lost inside the proofs — 5-9 % slower accumulation on its entry order, 15-20 % behind on 0/1-heavy columns
     // at k >= 20 — a bucket-major sort with one bucket set per column (msm_fold_windows: the wave-level merge of its 16x longer runs cost more
     // than the presum it saved) and a column's windows dealt to two lanes; all three were removed in r04, their A/B logs are
-    // profiles/r03_msm_sort_ab.log, r03_msm_reorder.log, r02_msm_fold_windows_ab.log, r03_msm_split_windows_ab.log.
+    // profiles/archive/r03_msm_sort_ab.log, r03_msm_reorder.log, r02_msm_fold_windows_ab.log, r03_msm_split_windows_ab.log.
     digit_t *digits;
     uint32_t *bhist, *counts, *offsets, *sval, *pkey[2];
     XYZZ29 *buckets, *pval[2];

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(NttCols cols, uint32_t lo
 // inter-pass twiddles; OUT_MUL: fused ifft divisor / zeta^-i scaling).
 // LDS: the 1024-element tile as 48-byte elements (three 16-byte accesses per element), the stage twiddles and the three scales behind it as
 // bare 36-byte elements, so that a pass with m = 8 (128 twiddles) still fits three workgroups into a CU's 160 KiB (with 48-byte twiddles it
-// took 55.7 KiB and only two fitted).  Measured and left behind in r04 (profiles/r04_ntt_experiments.log): a 2048-element build on 36-byte
+// took 55.7 KiB and only two fitted).  Measured and left behind in r04 (profiles/archive/r04_ntt_experiments.log): a 2048-element build on 36-byte
 // elements with 512 lanes, at most 128 registers and no register prefetch — four waves per SIMD instead of three — ran at the same speed
 // (2^22 0.60 vs 0.61 ms), as did start delays that put a CU's workgroups out of phase.
 struct Fr29P {   // packed LDS element
@@ -620,7 +620,7 @@ int ntt_run_batch(h2hip_ctx *ctx, Fr *const *a, const Fr *const *in_override, si
             if (ctx->ntt_tile_kernel && P >= 2 && LT == 10 && m + cb == 10 && m >= 2 && (last || tdirect) && N <= (1ull << 28)) {
                 const size_t shmem_t = TileLayoutPlanes::bytes(m);
                 // one persistent workgroup per slot (measured against equal shares — ceil(tiles / rounds) workgroups, every one walking the same number
-                // of tiles: 2^22 0.62 vs 0.575 ms, profiles/r04_ntt_experiments.log: fewer workgroups than slots leave a third of the CUs one short)
+                // of tiles: 2^22 0.62 vs 0.575 ms, profiles/archive/r04_ntt_experiments.log: fewer workgroups than slots leave a third of the CUs one short)
                 const uint32_t slots = (uint32_t)ctx->num_cus * 3;
                 const uint32_t grid_t = tiles < slots ? tiles : slots;
                 const bool mul = first ? in_scale3 != nullptr : (last && out_scale3 != nullptr);

@@ -775,7 +775,7 @@ static int create_proof_impl(h2hip_ctx *ctx, h2hip_plonk_pk *pk, const void *con
     if ((overlap || side_sharded) && !pk->side_ev) H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev, hipEventDisableTiming));
     if (overlap && !pk->side_ev1) H2_HIPCHK(hipEventCreateWithFlags(&pk->side_ev1, hipEventDisableTiming));
     // (r04 also computed the random polynomial's COMMITMENT ahead — its scalars depend on nothing once the generator is counter-mode — as one
-    // MSM on a second side context behind round 1's accumulations: 14.72-14.99 vs 14.71-14.98 ms, profiles/r04_tail_overlap_ab.log.  The
+    // MSM on a second side context behind round 1's accumulations: 14.72-14.99 vs 14.71-14.98 ms, profiles/archive/r04_tail_overlap_ab.log.  The
     // chip is busy with something ~97 % of the time; only work moved into LOW-occupancy stretches gains, and that MSM is not such work.  Removed.)
     // Which contexts run the side work.  The device serves its streams through a handful of hardware queues (4 by default: with more,
     // measured, everything gets slower), and the batch MSM's lanes already hold as many: a further stream shares a queue with one of them.

@@ -365,7 +365,7 @@ def test_create_proof_gpu_k21_pairing_shape():
 @pytest.mark.gpu
 def test_create_proof_gpu_random_shapes():
     """tools/fuzz_shapes.py for 25 s with a fixed seed: randomly drawn shapes (narrow / wide, with and without lookups, instances, precomputed
-    bases), proof bytes equal to the oracle prover's for every one (a longer run: profiles/r03_fuzz_shapes.log)"""
+    bases), proof bytes equal to the oracle prover's for every one (a longer run: profiles/archive/r03_fuzz_shapes.log)"""
     import subprocess, sys, os
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # r05 GPU call 2: host round trips through the host-mapped flag (host_poll) A/B on whole proofs, the zero-row skip of the coset transforms' first pass
-# (NTT times against profiles/r04_ntt_times.log), the NTT parity tests on the GPU, and the kernel trace / timeline of ONE TIMED bench proof
+# (NTT times against profiles/archive/r04_ntt_times.log), the NTT parity tests on the GPU, and the kernel trace / timeline of ONE TIMED bench proof
 # (advice resident, device RNG, no stage laps: the r04 account was taken from tools/prove_time.py's lapped proof)
 set -u
 O=$PWD/gpurun_out/r05c02; mkdir -p $O; REPO=$PWD

@@ -20,7 +20,7 @@ import json, os
 out = os.path.join(os.getcwd(), "gpurun_out", "final")
 d = json.load(open(os.path.join(out, "pmc_hbm.json")))
 k = [n for n in d if n.startswith("msm_accum_kernel")][0]
-json.dump({"kernel": k, **d[k]}, open(os.path.join(out, "pmc_accum.json"), "w"), indent=1)   # -> profiles/r03_create_proof_k19_pmc_hbm.json (+ the "how" note)
+json.dump({"kernel": k, **d[k]}, open(os.path.join(out, "pmc_accum.json"), "w"), indent=1)   # -> profiles/archive/r03_create_proof_k19_pmc_hbm.json (+ the "how" note)
 PY
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
 head -c 600 $OUT/bench.json; echo; head -12 $OUT/kernel_trace.md; head -8 $OUT/pmc_hbm.md

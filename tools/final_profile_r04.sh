@@ -1,5 +1,5 @@
 #!/bin/bash
-# r04 evidence run (on the GPU box, from the repo root); everything lands under gpurun_out/final/ and is copied to profiles/r04_* by hand:
+# r04 evidence run (on the GPU box, from the repo root); everything lands under gpurun_out/final/ and is copied to profiles/archive/r04_* by hand:
 #   pytest_gpu.log            the whole -m gpu suite + smoke()
 #   bench.json                `python bench.py` with default flags (the driver's command without --steps / --warmup), incl. the in-run PMC traffic
 #   kernel_trace.md           rocprofv3 --kernel-trace --stats of the same command's timed workload (k = 19 create_proof x 20)
@@ -34,7 +34,7 @@ try:
     json.dump({"kernel": k, **d[k], "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python bench.py --pmc-child --steps 4 --warmup 1` "
                "(tools/final_profile_r04.sh); bytes = (2 * FETCH_SIZE_KB + WRITE_SIZE_KB) * 1024: FETCH_SIZE tallies 128-byte requests as 64 B on gfx950 "
                "(MI355X_MICROARCH.md, profiles/archive/r02_hbm_counter_calibration.md); mean over the run's launches (keygen's and the proofs' 2^19-point MSMs); every kernel "
-               "of the run: profiles/r04_bench_pmc_hbm.md"}, open(os.path.join(out, "pmc_accum.json"), "w"), indent=1)
+               "of the run: profiles/archive/r04_bench_pmc_hbm.md"}, open(os.path.join(out, "pmc_accum.json"), "w"), indent=1)
 except Exception as e:
     print("pmc_accum:", e)
 PY
