@@ -40,7 +40,11 @@ while time.time() - t0 < budget:
                  # the wave-owned NTT pass (2^12+ points only)
                  "host_poll": rnd.choice([1, 1, 0]), "msm_table_split": rnd.choice([1, 1, 0]), "plonk_merge_products": rnd.choice([1, 1, 0]),
                  # r05, last: the grand products' lagrange_to_coeff in front of round 3's commitments; the lanes' first sorts one behind the other
-                 "plonk_early_intt": rnd.choice([1, 1, 0]), "msm_stagger_sorts": rnd.choice([-1, 0, 1])}
+                 "plonk_early_intt": rnd.choice([1, 1, 0]), "msm_stagger_sorts": rnd.choice([-1, 0, 1]),
+                 # r06: the sort's histogram / scatter variants, the entries-per-lane rules, host advice uploaded inside round 1's commitment batch
+                 "msm_hist_packed": rnd.choice([1, 1, 0]), "msm_scatter_full_lds": rnd.choice([0, 0, 1]), "msm_hist_split": rnd.choice([0, 1, 2, 4]),
+                 "msm_sort_groups": rnd.choice([0, 0, 8, 30]), "msm_chunk_lone": rnd.choice([-1, -1, 0, 1]), "msm_chunk": rnd.choice([0, 0, 8, 24, 64]),
+                 "plonk_lazy_upload": rnd.choice([1, 1, 0])}
         for name, val in knobs.items():
             ctx.set_param(name, val)
     try:
